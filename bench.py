@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- effective TFLOP/s of the native rtc_compute path on BASELINE.json's headline workload.
+
+Workload at N=1 (config.workload): configs[1] = test/sgemm-ops-full.txt, the 17 square fp32 sgemms 64^3..12288^3, run
+through be=hip's native door (hip_sgemm -> kernels/gemm_conv_f32.hip).  One "step" = one pass over all 17 ops
+(8.66 TFLOP).  Inputs are the reference's deterministic gen_data mode-5 tensors, generated on the device and resident
+in HBM before the timed region.  flops = 2*M*N*K (src/latex-util.H:116-120).
+  --workload alexnet   BASELINE configs[2]: AlexNet-ng conv layers at batch 256 (hip_conv), same accounting.
+N>1 (launched by torch.distributed.run, one process per GPU): the path shards on the batch axis with no data-path
+collective -- every rank runs the same per-GPU workload on its own shard (sgemm: its own M-shard of an N-times-taller
+problem; conv: its own images), weights (sgemm b / conv filts+biases) are broadcast once from rank 0 over RCCL before
+the timed region.  value = all ranks' flops / max-over-ranks time ("scaling": "weak").
+"""
+from __future__ import annotations
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def alexnet_b256_ops(batch: int = 256):
+    from boda_amd.op import parse_op
+    layers = [(3, 227, 96, 11, 4, 0), (96, 27, 256, 5, 1, 2), (256, 13, 384, 3, 1, 1), (384, 13, 384, 3, 1, 1),
+              (384, 13, 256, 3, 1, 1), (256, 6, 4096, 6, 1, 0), (4096, 1, 4096, 1, 1, 0), (4096, 1, 1000, 1, 1, 0)]
+    ops = []
+    for C, H, OC, K, S, P in layers:
+        O = (H + 2 * P - K) // S + 1
+        ops.append(parse_op(f"(str_vals=(type=Convolution),nda_vals=(biases=(dims=(out_chan={OC})),filts=(dims=(out_chan={OC},in_chan={C},y={K},x={K})),"
+                            f"in=(dims=(img={batch},chan={C},y={H},x={H})),in_pad=(tn=none,dims=(y={P},x={P})),kern_sz=(tn=none,dims=(y={K},x={K})),"
+                            f"out=(dims=(img={batch},chan={OC},y={O},x={O})),out_chans=(tn=uint32_t,v={OC}),stride=(tn=none,dims=(y={S},x={S}))))"))
+    return ops
+
+
+def sgemm_full_ops():
+    from boda_amd.op import read_ops
+    return read_ops(os.path.join(ROOT, "tests", "golden", "ops", "sgemm-ops-full.txt"))
+
+
+def cpu_baseline(workload: str, budget_s: float = 20.0) -> dict:
+    """The CPU oracle (a port: the reference has no CPU path) timed on this host's cores on a bounded sample."""
+    from oracle import boda_oracle as bo
+    import numpy as np
+    if workload == "sgemm-ops-full":
+        sizes, flops, t_tot = [], 0.0, 0.0
+        for n in (1024, 1536, 2048, 3072, 4096):
+            a = bo.gen_sgemm_a(n, n, 5); b = bo.gen_sgemm_b(n, n, 5)
+            t = time.perf_counter(); bo.sgemm(a, b); dt = time.perf_counter() - t
+            sizes.append(n); flops += 2.0 * n ** 3; t_tot += dt
+            if t_tot > budget_s:
+                break
+        return {"value": flops / t_tot / 1e12, "unit": "TFLOP/s", "cores": bo.num_threads(), "kind": "port",
+                "sample": f"oracle/boda_oracle.c bo_sgemm (OpenMP, fp32 fmaf) on sgemm-ops-full sizes {sizes}, {t_tot:.1f} s"}
+    ops = alexnet_b256_ops(batch=4)
+    flops, t_tot = 0.0, 0.0
+    for op in ops:
+        t = time.perf_counter(); bo.run_op(op, 5); dt = time.perf_counter() - t
+        flops += op.flops(); t_tot += dt
+    return {"value": flops / t_tot / 1e12, "unit": "TFLOP/s", "cores": bo.num_threads(), "kind": "port",
+            "sample": f"oracle/boda_oracle.c bo_conv_fwd (OpenMP) on the 8 AlexNet-ng conv layers at batch 4 (incl. data gen), {t_tot:.1f} s"}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="sgemm-ops-full", choices=["sgemm-ops-full", "alexnet"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-op", action="store_true", help="also print a per-op table to stderr")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            print(f"bench.py: --gpus {a.gpus} needs torch.distributed.run --nproc-per-node {a.gpus}", file=sys.stderr); return 2
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+    torch.cuda.set_device(local_rank)
+
+    from boda_amd import gen_data as gd
+    from boda_amd.cnn_op import NATIVE_ARGS, OpTune, add_codegen_annotations
+    from boda_amd.rtc import RtcArg, RtcFuncCall, RtcFuncInfo, make_rtc
+
+    rtc = make_rtc("(be=hip)", local_rank)
+    rtc.init()
+    rtc.compile(gd.func_infos())
+    ops = sgemm_full_ops() if a.workload == "sgemm-ops-full" else alexnet_b256_ops()
+    weight_args = {"sgemm": ("b",), "Convolution": ("filts", "biases")}
+
+    calls = []  # (op, RtcFuncCall)
+    for i, op in enumerate(ops):
+        anno = add_codegen_annotations(op, OpTune())
+        fn = anno.get_func_name(); gen_fn = f"{fn}__{i}"
+        rtc.compile([RtcFuncInfo(gen_fn, "", [x for x, _ in NATIVE_ARGS[fn]], anno)])
+        am = {}
+        for an, io in NATIVE_ARGS[fn]:
+            if io == "REF":
+                am[an] = RtcArg.ref(anno.get_dims(an)); continue
+            vn = f"op{i}_{an}"
+            rtc.create_var_with_dims(vn, anno.get_dims(an))
+            am[an] = RtcArg.var(vn)
+            if io == "IN":
+                rtc.run(gd.gen_call(op.get_type(), an, vn, anno.get_dims(an), 5, 0.0))
+        calls.append((op, RtcFuncCall(gen_fn, am)))
+    rtc.finish_and_sync()
+    if dist is not None:  # one-time weight broadcast from rank 0 over RCCL/xGMI (off the timed path)
+        for (op, rfc) in calls:
+            for an in weight_args[op.get_type()]:
+                dist.broadcast(rtc.torch_view(rfc.arg_map[an].n), src=0)
+        torch.cuda.synchronize()
+
+    def step():
+        return [rtc.run(rfc) for (_, rfc) in calls]
+
+    for _ in range(a.warmup):
+        step()
+    rtc.finish_and_sync(); rtc.release_per_call_id_data()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ids = [step() for _ in range(a.steps)]
+    rtc.finish_and_sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+
+    # per-kernel durations from the backend's HIP events (recorded on the stream the kernels run on)
+    per_op_ms = np.array([[rtc.get_dur(i, i) for i in st] for st in ids])  # steps x ops
+    flops_per_op = np.array([op.flops() for op, _ in calls], dtype=np.float64)
+    bytes_per_op = np.array([op.algo_bytes() for op, _ in calls], dtype=np.float64)
+    step_flops = float(flops_per_op.sum())
+    kern_ms_per_step = float(per_op_ms.sum(axis=1).mean())
+    value = step_flops * a.steps * world / elapsed / 1e12
+
+    if rank == 0:
+        avg_ms = per_op_ms.mean(axis=0)
+        achieved = step_flops / (kern_ms_per_step * 1e-3) / 1e12
+        li = rtc.last_launch(); info = rtc.get_device_info()
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(a.workload, {}).get("hbm_bytes_per_step")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "effective TFLOP/s (2*M*N*K / time), whole job", "value": round(value, 3), "unit": "TFLOP/s",
+            "per_gpu": round(value / world, 3), "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (reference gen_data mode 5, generated on device)",
+            "config": {"workload": ("test/sgemm-ops-full.txt: 17 fp32 sgemms 64^3..12288^3 via hip_sgemm" if a.workload == "sgemm-ops-full"
+                                    else "alexnet_ng_conv per-layer conv-ops, batch 256, via hip_conv"),
+                       "ops": len(calls), "tflop_per_step": round(step_flops / 1e12, 4), "parallelism": f"batch-shard x{world}, weights broadcast once (RCCL)",
+                       "device": rtc.get_plat_tag(), "arch": info["arch"], "cus": info["num_cus"]},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "kernel": li["kernel"], "kernel_ms_per_step": round(kern_ms_per_step, 4),
+                         "note": "achieved = sum(2MNK) / sum(HIP-event kernel durations) over the timed steps"},
+            "per_op": [{"flops": float(f), "ms": round(float(m), 5), "tflops": round(float(f / (m * 1e-3) / 1e12), 2),
+                        "gbs": round(float(b / (m * 1e-3) / 1e9), 1)} for f, b, m in zip(flops_per_op, bytes_per_op, avg_ms)],
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.workload)
+        if a.per_op:
+            for (op, _), r in zip(calls, out["per_op"]):
+                print(f"  {op.get_type():12s} {r['flops']/1e9:10.2f} GF {r['ms']:9.4f} ms {r['tflops']:8.2f} TF/s {r['gbs']:9.1f} GB/s", file=sys.stderr)
+        print(json.dumps(out))
+    rtc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,312 @@
+// gemm_conv_f32.hip -- fp32 MFMA contraction kernel for gfx950 (MI355X), specialised at run time by hiprtc.
+//
+//   D[i][j] = sum_k I(k,i) * J(k,j)          (+ bias[i], ReLU for convolutions)
+//
+// One kernel body serves both ops on Boda's hot path; the host picks the operand roles so that the *j* index is the
+// contiguous dimension of the output (coalesced 128-B row stores straight out of the MFMA accumulator layout):
+//   sgemm        i = M, j = N, k = K      I = a[K][M], J = b[K][N], D = c[M][N]
+//                (contract of test/rtc/cublas_sgemm.cucl:1-4; semantics test/rtc/sgemm.cucl:17-43)
+//   Convolution  i = out_chan, j = pel=(img,oy,ox), k = (in_chan,ky,kx)
+//                I = filts[out_chan][k] (OIHW), J = im2col view of in (NCHW) gathered on the fly -- never materialised,
+//                D = out[img][out_chan][oy][ox]   (contract of test/rtc/cudnn_conv.cucl:1-7;
+//                semantics test/rtc/conv.cucl:24-44 + bias/ReLU epilogue src/cnn_codegen.cc:35-42)
+// This replaces the reference's sgemm / conv / k1conv / tconv / ipconv CUCL variants (src/cnn_codegen.cc:165-823) and
+// their separate layout-transform passes (xpose_filts, k1conv_xpose_in, tconv_xpose_in): operands are read in
+// reference layout and re-laid-out only inside LDS.
+//
+// Numerics: v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain in ascending k, so every output is
+// bit-identical to one thread of the reference accumulating fmaf() over k = 0..K-1 (zero-padded k / halo terms add
+// fma(x,0,acc) == acc).
+//
+// Structure per workgroup (WI x WJ waves of 64 lanes):
+//   * BI x BJ output tile, BK-deep K steps, LDS double-buffered as k-major [BK][BI+4] / [BK][BJ+4] float images
+//     (the +4 pad keeps 16-B alignment for ds_write_b128 and de-phases rows); register-staged prefetch of K-tile t+1
+//     is issued before the MFMAs of tile t and written to the other LDS buffer after them: one barrier per K step.
+//   * each wave owns a (TI*32) x (TJ*32) sub-tile = TI*TJ accumulators of 16 VGPRs; A/B operands are single
+//     conflict-free ds_read_b32 (lane l reads row 2*kk+(l>>5), column (l&31)).
+//   * workgroup ids are remapped XCD-aware (block b runs on XCD b%8): each XCD gets a contiguous band of
+//     tiles, walked in groups of GROUP_I tiles along i so neighbouring workgroups share I / J panels in their L2.
+//
+// Compile-time parameters (-D):  KNAME BI BJ BK WI WJ MINW I_MODE J_MODE EPI [KH KW SY SX PY PX RELU]
+//   I_MODE 0 k-major float4 | 1 k-major scalar | 2 i-major (k contiguous) float4 | 3 i-major scalar
+//   J_MODE 0 k-major float4 | 1 k-major scalar | 2 convolution gather from NCHW
+//   EPI    0 plain store    | 1 + bias[i], optional ReLU, NCHW scatter of j=(img,pel)
+
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h> // offline (hipcc) builds only; hiprtc provides the device runtime implicitly
+#endif
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef KNAME
+#define KNAME bodahip_gemm_f32
+#endif
+#ifndef GROUP_I
+#define GROUP_I 8
+#endif
+#ifndef KH
+#define KH 1
+#define KW 1
+#define SY 1
+#define SX 1
+#define PY 0
+#define PX 0
+#endif
+#ifndef RELU
+#define RELU 0
+#endif
+
+struct gemm_args_t {
+  float const *I; float const *J; float *D; float const *bias;
+  int Mi, Nj, K;          // extents of i, j, k
+  int ldI, ldJ, ldD;      // row pitches (elements) of I, J (k-major: per k row; i-major: per i row) and of D per i
+  int C, H, W, OH, OW;    // convolution geometry (J_MODE 2 / EPI 1)
+  int tiles_i, tiles_j;
+};
+
+namespace {
+constexpr int kNT = WI * WJ * 64;
+constexpr int kTI = BI / (WI * 32);
+constexpr int kTJ = BJ / (WJ * 32);
+constexpr int kPAD = 4;
+constexpr int kLDI = BI + kPAD;
+constexpr int kLDJ = BJ + kPAD;
+constexpr int kITile = BK * kLDI;
+constexpr int kJTile = BK * kLDJ;
+static_assert(BI % (WI * 32) == 0 && BJ % (WJ * 32) == 0, "tile must be a multiple of 32 per wave");
+static_assert(BK % 4 == 0, "BK must be a multiple of 4");
+static_assert((BK * BI) % (4 * kNT) == 0 && (BK * BJ) % (4 * kNT) == 0, "tile must split evenly over the threads");
+#if J_MODE == 2
+static_assert(kNT % BJ == 0 || BJ % kNT == 0, "gather needs a fixed j column per thread");
+#endif
+constexpr int kNI = BK * BI / kNT; // staged floats per thread, operand I
+constexpr int kNJ = BK * BJ / kNT; // staged floats per thread, operand J
+
+// ---------------------------------------------------------------------------------------------------------------
+// global -> registers
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE, int BX, int NR>
+__device__ __forceinline__ void load_kmajor_or_imajor(float (&r)[NR], float const *__restrict__ P, int ld, int x0, int X, int k0, int K, int tid) {
+  if constexpr (MODE == 0) { // k-major rows of BX floats, float4 along x
+    constexpr int VPR = BX / 4;
+#pragma unroll
+    for (int p = 0; p < NR / 4; ++p) {
+      int const v = tid + p * kNT, row = v / VPR, c4 = v % VPR;
+      int const k = k0 + row, x = x0 + 4 * c4;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (k < K && x < X) val = *reinterpret_cast<f32x4 const *>(P + (long)k * ld + x);
+      r[4 * p + 0] = val[0]; r[4 * p + 1] = val[1]; r[4 * p + 2] = val[2]; r[4 * p + 3] = val[3];
+    }
+  } else if constexpr (MODE == 1) { // k-major scalar
+#pragma unroll
+    for (int p = 0; p < NR; ++p) {
+      int const e = tid + p * kNT, row = e / BX, c = e % BX;
+      int const k = k0 + row, x = x0 + c;
+      r[p] = (k < K && x < X) ? P[(long)k * ld + x] : 0.f;
+    }
+  } else if constexpr (MODE == 2) { // x-major rows, k contiguous, float4 along k
+    constexpr int VPR = BK / 4;
+#pragma unroll
+    for (int p = 0; p < NR / 4; ++p) {
+      int const v = tid + p * kNT, xr = v / VPR, k4 = v % VPR;
+      int const x = x0 + xr, k = k0 + 4 * k4;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (x < X && k < K) val = *reinterpret_cast<f32x4 const *>(P + (long)x * ld + k);
+      r[4 * p + 0] = val[0]; r[4 * p + 1] = val[1]; r[4 * p + 2] = val[2]; r[4 * p + 3] = val[3];
+    }
+  } else { // MODE 3: x-major scalar
+#pragma unroll
+    for (int p = 0; p < NR; ++p) {
+      int const e = tid + p * kNT, xr = e / BK, kk = e % BK;
+      int const x = x0 + xr, k = k0 + kk;
+      r[p] = (x < X && k < K) ? P[(long)x * ld + k] : 0.f;
+    }
+  }
+}
+
+// registers -> LDS image [BK][LD] (k-major)
+template <int MODE, int BX, int LD, int NR>
+__device__ __forceinline__ void store_tile(float const (&r)[NR], float *__restrict__ S, int tid) {
+  if constexpr (MODE == 0) {
+    constexpr int VPR = BX / 4;
+#pragma unroll
+    for (int p = 0; p < NR / 4; ++p) {
+      int const v = tid + p * kNT, row = v / VPR, c4 = v % VPR;
+      f32x4 val = {r[4 * p + 0], r[4 * p + 1], r[4 * p + 2], r[4 * p + 3]};
+      *reinterpret_cast<f32x4 *>(S + row * LD + 4 * c4) = val;
+    }
+  } else if constexpr (MODE == 1) {
+#pragma unroll
+    for (int p = 0; p < NR; ++p) { int const e = tid + p * kNT; S[(e / BX) * LD + (e % BX)] = r[p]; }
+  } else if constexpr (MODE == 2) {
+    constexpr int VPR = BK / 4;
+#pragma unroll
+    for (int p = 0; p < NR / 4; ++p) {
+      int const v = tid + p * kNT, xr = v / VPR, k4 = v % VPR;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) S[(4 * k4 + e) * LD + xr] = r[4 * p + e];
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < NR; ++p) { int const e = tid + p * kNT; S[(e % BK) * LD + (e / BK)] = r[p]; }
+  }
+}
+
+#if J_MODE == 2
+// per-thread constants of the im2col gather: this thread always serves output position (pel) column jj
+struct gather_t { long base; int iy0, ix0; bool jv; };
+constexpr int kRowsPerPass = (kNT >= BJ) ? (kNT / BJ) : 1;
+constexpr int kColsPerThr = (kNT >= BJ) ? 1 : (BJ / kNT);
+static_assert(kColsPerThr == 1, "BJ > threads is not supported by the gather (pick BJ <= WI*WJ*64)");
+__device__ __forceinline__ void load_gather(float (&r)[kNJ], float const *__restrict__ in, gather_t const &g, gemm_args_t const &p, int k0, int tid) {
+  constexpr int KHW = KH * KW;
+  int const row0 = tid / BJ;
+#pragma unroll
+  for (int q = 0; q < kNJ; ++q) {
+    int const kg = k0 + row0 + q * kRowsPerPass;
+    int const ic = kg / KHW, rem = kg - ic * KHW, ky = rem / KW, kx = rem - ky * KW;
+    int const iy = g.iy0 + ky, ix = g.ix0 + kx;
+    bool const ok = g.jv && (kg < p.K) && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+    long const off = g.base + ((long)ic * p.H + ky) * p.W + kx;
+    r[q] = ok ? in[off] : 0.f;
+  }
+}
+__device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__restrict__ S, int tid) {
+  int const row0 = tid / BJ, jj = tid % BJ;
+#pragma unroll
+  for (int q = 0; q < kNJ; ++q) S[(row0 + q * kRowsPerPass) * kLDJ + jj] = r[q];
+}
+#endif
+} // namespace
+
+extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * (kITile + kJTile)];
+  int const tid = threadIdx.x;
+  int const lane = tid & 63;
+  int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int const wi = wave / WJ, wj = wave % WJ;
+
+  // ---- XCD-aware workgroup -> tile map (bijective for any grid size) ------------------------------------------
+  int tile_i, tile_j;
+  {
+    int const nb = p.tiles_i * p.tiles_j, bid = blockIdx.x;
+    int const q = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    int const nid = ((xcd < rr) ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    int const group_sz = GROUP_I * p.tiles_j, gid = nid / group_sz, first_i = gid * GROUP_I;
+    int const gsz = min(p.tiles_i - first_i, GROUP_I), in_g = nid - gid * group_sz;
+    tile_i = first_i + in_g % gsz; tile_j = in_g / gsz;
+  }
+  int const i0 = tile_i * BI, j0 = tile_j * BJ;
+
+  float *const Is0 = smem, *const Is1 = smem + kITile;
+  float *const Js0 = smem + 2 * kITile, *const Js1 = smem + 2 * kITile + kJTile;
+
+#if J_MODE == 2
+  gather_t g;
+  {
+    int const OHW = p.OH * p.OW;
+    int const jg = j0 + (tid % BJ);
+    g.jv = jg < p.Nj;
+    int const img = jg / OHW, pel = jg - img * OHW, oy = pel / p.OW, ox = pel - oy * p.OW;
+    g.iy0 = oy * SY - PY; g.ix0 = ox * SX - PX;
+    g.base = ((long)img * p.C * p.H + g.iy0) * p.W + g.ix0;
+  }
+#endif
+
+  f32x16 acc[kTI][kTJ];
+#pragma unroll
+  for (int a = 0; a < kTI; ++a)
+#pragma unroll
+    for (int b = 0; b < kTJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float ri[kNI], rj[kNJ];
+  int const nkt = (p.K + BK - 1) / BK;
+
+  load_kmajor_or_imajor<I_MODE, BI, kNI>(ri, p.I, p.ldI, i0, p.Mi, 0, p.K, tid);
+#if J_MODE == 2
+  load_gather(rj, p.J, g, p, 0, tid);
+#else
+  load_kmajor_or_imajor<J_MODE, BJ, kNJ>(rj, p.J, p.ldJ, j0, p.Nj, 0, p.K, tid);
+#endif
+  store_tile<I_MODE, BI, kLDI, kNI>(ri, Is0, tid);
+#if J_MODE == 2
+  store_gather(rj, Js0, tid);
+#else
+  store_tile<J_MODE, BJ, kLDJ, kNJ>(rj, Js0, tid);
+#endif
+  __syncthreads();
+
+  int const a_off = wi * (kTI * 32) + (lane & 31) + (lane >> 5) * kLDI;
+  int const b_off = wj * (kTJ * 32) + (lane & 31) + (lane >> 5) * kLDJ;
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    bool const more = (kt + 1) < nkt;
+    float const *const Ic = ((kt & 1) ? Is1 : Is0) + a_off;
+    float const *const Jc = ((kt & 1) ? Js1 : Js0) + b_off;
+    if (more) { // prefetch K-tile kt+1 into registers; the loads fly under the MFMAs below
+      load_kmajor_or_imajor<I_MODE, BI, kNI>(ri, p.I, p.ldI, i0, p.Mi, (kt + 1) * BK, p.K, tid);
+#if J_MODE == 2
+      load_gather(rj, p.J, g, p, (kt + 1) * BK, tid);
+#else
+      load_kmajor_or_imajor<J_MODE, BJ, kNJ>(rj, p.J, p.ldJ, j0, p.Nj, (kt + 1) * BK, p.K, tid);
+#endif
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[kTI], b[kTJ];
+#pragma unroll
+      for (int t = 0; t < kTI; ++t) a[t] = Ic[kk * 2 * kLDI + t * 32];
+#pragma unroll
+      for (int t = 0; t < kTJ; ++t) b[t] = Jc[kk * 2 * kLDJ + t * 32];
+#pragma unroll
+      for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < kTJ; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+    }
+    if (more) {
+      store_tile<I_MODE, BI, kLDI, kNI>(ri, (kt & 1) ? Is0 : Is1, tid);
+#if J_MODE == 2
+      store_gather(rj, (kt & 1) ? Js0 : Js1, tid);
+#else
+      store_tile<J_MODE, BJ, kLDJ, kNJ>(rj, (kt & 1) ? Js0 : Js1, tid);
+#endif
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: MFMA C/D layout: column j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5) -----------------
+#pragma unroll
+  for (int tb = 0; tb < kTJ; ++tb) {
+    int const jg = j0 + wj * (kTJ * 32) + tb * 32 + (lane & 31);
+    if (jg >= p.Nj) continue;
+#if EPI == 1
+    int const OHW = p.OH * p.OW;
+    int const img = jg / OHW, pel = jg - img * OHW;
+    long const joff = (long)img * p.Mi * OHW + pel;
+    long const istride = OHW;
+#else
+    long const joff = jg;
+    long const istride = p.ldD;
+#endif
+#pragma unroll
+    for (int ta = 0; ta < kTI; ++ta) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int const ig = i0 + wi * (kTI * 32) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (ig < p.Mi) {
+          float v = acc[ta][tb][r];
+#if EPI == 1
+          v = v + p.bias[ig];
+#if RELU
+          v = (v > 0.f) ? v : 0.f;
+#endif
+#endif
+          p.D[joff + (long)ig * istride] = v;
+        }
+      }
+    }
+  }
+}

@@ -1,0 +1,262 @@
+// native_kernels.cc -- host side of the hand-written kernels: variant/tile selection, hiprtc specialisation, launch.
+// See native_kernels.h for the contract and the reference precedent.
+#include "native_kernels.h"
+#include <algorithm>
+#include <cstdlib>
+#include <sstream>
+
+namespace bodahip {
+
+// kernel template sources, embedded at build time from kernels/*.hip (see build.py: kernels_embed.inc)
+#include "kernels_embed.inc"
+
+struct gemm_args_t { // must match kernels/gemm_conv_f32.hip
+  float const *I; float const *J; float *D; float const *bias;
+  int Mi, Nj, K;
+  int ldI, ldJ, ldD;
+  int C, H, W, OH, OW;
+  int tiles_i, tiles_j;
+};
+
+struct kernel_t { hipModule_t mod = nullptr; hipFunction_t func = nullptr; };
+
+struct native_kernels_t::impl_t {
+  std::map<string, kernel_t> kernels; // key = option string
+  std::map<string, string> tune;
+};
+
+native_kernels_t::native_kernels_t(native_host_t *host_) : impl(new impl_t), host(host_) {
+  if (char const *e = getenv("BODAHIP_SGEMM_TILE")) impl->tune["sgemm_tile"] = e;
+  if (char const *e = getenv("BODAHIP_CONV_TILE")) impl->tune["conv_tile"] = e;
+}
+native_kernels_t::~native_kernels_t() {
+  for (auto &kv : impl->kernels) { if (kv.second.mod) (void)hipModuleUnload(kv.second.mod); }
+  delete impl;
+}
+uint32_t native_kernels_t::num_specialisations() const { return (uint32_t)impl->kernels.size(); }
+
+bool native_kernels_t::is_native_func_name(string const &fn) {
+  return fn == "hip_sgemm" || fn == "hip_conv" || fn == "cublas_sgemm" || fn == "cudnn_conv" || startswith(fn, "hip_");
+}
+void native_kernels_t::check_compile_time(rtc_func_info_t const &fi) {
+  string const &fn = fi.op.get_func_name();
+  if (fn == "hip_sgemm" || fn == "cublas_sgemm") return;
+  if (fn == "hip_conv" || fn == "cudnn_conv") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
+  rt_err("unknown/unhandled native hip function: " + fn);
+}
+void native_kernels_t::set_tune(string const &key, string const &val) {
+  if (key != "sgemm_tile" && key != "conv_tile") rt_err("set_tune: unknown key '" + key + "'");
+  if (val.empty()) impl->tune.erase(key); else { impl->tune[key] = val; }
+}
+
+static bool parse_tile(string const &s, tile_cfg_t &c) {
+  int v[6] = {0, 0, 0, 0, 0, 0}; int n = 0; string cur;
+  for (size_t i = 0; i <= s.size(); ++i) {
+    if (i == s.size() || s[i] == 'x' || s[i] == ':') { if (cur.empty() || n >= 6) return false; v[n++] = atoi(cur.c_str()); cur.clear(); }
+    else if (s[i] >= '0' && s[i] <= '9') cur.push_back(s[i]); else return false;
+  }
+  if (n < 5) return false;
+  c.BI = v[0]; c.BJ = v[1]; c.BK = v[2]; c.WI = v[3]; c.WJ = v[4]; c.MINW = (n >= 6) ? v[5] : 1;
+  return true;
+}
+// the static_asserts of the kernel, checked on the host so that a bad tune is an unsup_err, not a compile failure
+static void check_cfg(tile_cfg_t const &c, bool gather) {
+  int const nt = c.threads();
+  bool ok = c.BI > 0 && c.BJ > 0 && c.BK > 0 && c.WI > 0 && c.WJ > 0 && nt <= 1024 && (c.BI % (c.WI * 32) == 0) && (c.BJ % (c.WJ * 32) == 0) &&
+            (c.BK % 4 == 0) && ((c.BK * c.BI) % (4 * nt) == 0) && ((c.BK * c.BJ) % (4 * nt) == 0);
+  if (gather) ok = ok && (nt % c.BJ == 0);
+  int const accs = (c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32));
+  ok = ok && accs * 16 <= 256;
+  uint64_t const lds = 2ull * c.BK * (c.BI + 4 + c.BJ + 4) * 4;
+  ok = ok && lds <= 160 * 1024;
+  if (!ok) unsup_err("native kernel: unsupported tile configuration " + c.str());
+}
+
+static int pick_bi(int Mi) { // minimise padded extent; ties -> larger tile
+  int best = 32; long best_pad = -1;
+  for (int bi : {32, 64, 96, 128}) { long const padded = ((Mi + bi - 1) / bi) * (long)bi; if (best_pad < 0 || padded <= best_pad) { best = bi; best_pad = padded; } }
+  return best;
+}
+
+static tile_cfg_t choose_cfg(int Mi, int Nj, int num_cus) {
+  tile_cfg_t c;
+  int const bi = pick_bi(Mi);
+  if (bi == 128) { c.BI = 128; c.BJ = 128; c.WI = 2; c.WJ = 2; c.MINW = 2; }
+  else if (bi == 96) { c.BI = 96; c.BJ = 128; c.WI = 1; c.WJ = 2; c.MINW = 2; }
+  else if (bi == 64) { c.BI = 64; c.BJ = 128; c.WI = 1; c.WJ = 2; c.MINW = 2; }
+  else { c.BI = 32; c.BJ = 128; c.WI = 1; c.WJ = 2; c.MINW = 2; }
+  c.BK = 16;
+  // not enough tiles to occupy the chip: shrink the j tile (more, smaller workgroups)
+  long tiles = (long)((Mi + c.BI - 1) / c.BI) * ((Nj + c.BJ - 1) / c.BJ);
+  if (tiles < num_cus && c.BJ == 128) {
+    c.BJ = 64; c.WJ = 1; if (c.BI == 128) { c.WI = 2; } // 128x64: 2 waves of 64x64 ; else 1 wave
+    tiles = (long)((Mi + c.BI - 1) / c.BI) * ((Nj + c.BJ - 1) / c.BJ);
+    if (tiles < num_cus && c.BI == 128) { c.BI = 64; c.WI = 1; }
+  }
+  return c;
+}
+
+static vect_string cfg_defs(tile_cfg_t const &c) {
+  return {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI),
+          "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW)};
+}
+
+static vect_string cfg_defs(tile_cfg_t const &c);
+struct plan_t;
+static kernel_t &get_kernel(native_kernels_t::impl_t *impl, native_host_t *host, plan_t const &p);
+static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t const &c) {
+  void *params[] = {&a};
+  uint32_t const grid = (uint32_t)a.tiles_i * (uint32_t)a.tiles_j;
+  hip_err_chk(hipModuleLaunchKernel(k.func, grid, 1, 1, (uint32_t)c.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(native)");
+}
+
+
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; };
+
+static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string const &tile) {
+  (void)K;
+  plan_t p; p.kname = "bodahip_sgemm_f32";
+  p.cfg = choose_cfg((int)M, (int)N, num_cus);
+  if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad sgemm_tile '" + tile + "'"); }
+  check_cfg(p.cfg, false);
+  p.defs = cfg_defs(p.cfg);
+  p.defs.push_back(string("-DI_MODE=") + ((M % 4 == 0) ? "0" : "1"));
+  p.defs.push_back(string("-DJ_MODE=") + ((N % 4 == 0) ? "0" : "1"));
+  p.defs.push_back("-DEPI=0");
+  return p;
+}
+static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile) {
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  plan_t p; p.kname = "bodahip_conv_f32";
+  p.cfg = choose_cfg(g.OC, (int)Nj, num_cus);
+  if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad conv_tile '" + tile + "'"); }
+  check_cfg(p.cfg, true);
+  p.defs = cfg_defs(p.cfg);
+  p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0) ? "2" : "3"));
+  p.defs.push_back("-DJ_MODE=2"); p.defs.push_back("-DEPI=1");
+  p.defs.push_back("-DKH=" + std::to_string(g.KH)); p.defs.push_back("-DKW=" + std::to_string(g.KW));
+  p.defs.push_back("-DSY=" + std::to_string(g.SY)); p.defs.push_back("-DSX=" + std::to_string(g.SX));
+  p.defs.push_back("-DPY=" + std::to_string(g.PY)); p.defs.push_back("-DPX=" + std::to_string(g.PX));
+  p.defs.push_back(string("-DRELU=") + (g.relu ? "1" : "0"));
+  return p;
+}
+static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
+  vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
+  return hiprtc_compile(k_src_gemm_conv_f32, p.kname, arch, opts, log, true);
+}
+
+static string tune_of(native_kernels_t::impl_t *impl, char const *key) { auto t = impl->tune.find(key); return (t == impl->tune.end()) ? string() : t->second; }
+
+void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K) {
+  if (!M || !N) return;
+  if (!K) { hip_err_chk(hipMemsetAsync(c, 0, (size_t)M * N * 4, host->nh_stream()), "hipMemsetAsync"); return; }
+  if (M > 0x7fffffffu || N > 0x7fffffffu || K > 0x7fffffffu) unsup_err("hip_sgemm: dims exceed int32");
+  plan_t const p = plan_sgemm(M, N, K, host->nh_num_cus(), tune_of(impl, "sgemm_tile"));
+  tile_cfg_t const &cfg = p.cfg;
+  kernel_t &k = get_kernel(impl, host, p);
+  gemm_args_t ga; memset(&ga, 0, sizeof(ga));
+  ga.I = a; ga.J = b; ga.D = c; ga.bias = nullptr;
+  ga.Mi = (int)M; ga.Nj = (int)N; ga.K = (int)K; ga.ldI = (int)M; ga.ldJ = (int)N; ga.ldD = (int)N;
+  ga.tiles_i = (int)((M + cfg.BI - 1) / cfg.BI); ga.tiles_j = (int)((N + cfg.BJ - 1) / cfg.BJ);
+  launch(host, k, ga, cfg);
+  last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)ga.tiles_i * ga.tiles_j; last_launch.block = cfg.threads();
+  last_launch.flops = 2.0 * M * N * K; last_launch.algo_bytes = 4.0 * ((double)K * M + (double)K * N + (double)M * N);
+}
+
+void native_kernels_t::conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g) {
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  if (!Nj || !g.OC) return;
+  if (Nj > 0x7fffffffl || Kt > 0x7fffffffl) unsup_err("hip_conv: dims exceed int32");
+  plan_t const p = plan_conv(g, host->nh_num_cus(), tune_of(impl, "conv_tile"));
+  tile_cfg_t const &cfg = p.cfg;
+  kernel_t &k = get_kernel(impl, host, p);
+  gemm_args_t ga; memset(&ga, 0, sizeof(ga));
+  ga.I = filts; ga.J = in; ga.D = out; ga.bias = biases;
+  ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.ldI = (int)Kt; ga.ldJ = 0; ga.ldD = g.OH * g.OW;
+  ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
+  ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
+  launch(host, k, ga, cfg);
+  last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)ga.tiles_i * ga.tiles_j; last_launch.block = cfg.threads();
+  last_launch.flops = 2.0 * Nj * g.OC * Kt;
+  last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
+}
+
+static conv_geom_t geom_from_dims(dims_t const &f, dims_t const &in, dims_t const &out, dims_t const &stride, dims_t const &in_pad, bool relu) {
+  conv_geom_t g;
+  g.B = in.dsz("img"); g.C = in.dsz("chan"); g.H = in.dsz("y"); g.W = in.dsz("x");
+  g.OC = f.dsz("out_chan"); g.KH = f.dsz("y"); g.KW = f.dsz("x");
+  g.SY = stride.dsz("y"); g.SX = stride.dsz("x"); g.PY = in_pad.dsz("y"); g.PX = in_pad.dsz("x");
+  g.OH = out.dsz("y"); g.OW = out.dsz("x"); g.relu = relu;
+  return g;
+}
+
+// AOT: compile (into the on-disk code-object cache) the specialisation that run() would pick for `op`.  No device needed.
+size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile) {
+  string const &t = op.get_type();
+  plan_t p; string log;
+  if (t == "sgemm") { dims_t const &a = op.get_dims("a"), &b = op.get_dims("b"); p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, tile); }
+  else if (t == "Convolution") {
+    bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
+    p = plan_conv(geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims("out"), op.get_dims("stride"), op.get_dims("in_pad"), relu), num_cus, tile);
+  } else rt_err("prebuild: op type '" + t + "' has no native kernel");
+  return compile_plan(p, arch, &log).size();
+}
+
+static kernel_t &get_kernel(native_kernels_t::impl_t *impl, native_host_t *host, plan_t const &p) {
+  string key = p.kname; for (auto const &d : p.defs) key += " " + d;
+  auto it = impl->kernels.find(key);
+  if (it != impl->kernels.end()) return it->second;
+  string log;
+  std::vector<char> code = compile_plan(p, host->nh_arch(), &log);
+  kernel_t k;
+  hip_err_chk(hipModuleLoadData(&k.mod, code.data()), "hipModuleLoadData(native)");
+  hip_err_chk(hipModuleGetFunction(&k.func, k.mod, p.kname.c_str()), "hipModuleGetFunction(native)");
+  return impl->kernels.emplace(key, k).first->second;
+}
+
+static string var_of(map_str_rtc_arg_t const &am, string const &an) {
+  auto i = am.find(an);
+  if (i == am.end()) rt_err("native hip function: arg '" + an + "' not found in arg_map for call.");
+  if (!i->second.is_valid() || !i->second.is_var()) rt_err("native hip function: arg '" + an + "' must be a var");
+  return i->second.n;
+}
+static void need_float(dims_t const &d, char const *an) {
+  if (d.tn != "float") unsup_err(string("native hip kernels: arg '") + an + "' has type " + d.tn + "; only float storage is supported");
+}
+
+void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &am) {
+  string const &fn = fi.op.get_func_name();
+  if (fn == "hip_sgemm" || fn == "cublas_sgemm") {
+    string const an = var_of(am, "a"), bn = var_of(am, "b"), cn = var_of(am, "c");
+    dims_t const a = host->nh_var_dims(an), b = host->nh_var_dims(bn), c = host->nh_var_dims(cn);
+    need_float(a, "a"); need_float(b, "b"); need_float(c, "c");
+    uint32_t const M = a.dsz("M"), K = a.dsz("K"), N = b.dsz("N");
+    // same consistency checks as culibs_wrap_t::sgemm (src/culibs-wrap.cc:218-225); a is K:M, b is K:N, c is M:N
+    assert_st(a.sz() == 2 && b.sz() == 2 && c.sz() == 2);
+    assert_st(a.names(0) == "K" && a.names(1) == "M" && b.names(0) == "K" && b.names(1) == "N" && c.names(0) == "M" && c.names(1) == "N");
+    assert_st(b.dsz("K") == K); assert_st(c.dsz("M") == M); assert_st(c.dsz("N") == N);
+    sgemm((float const *)host->nh_var_ptr(an), (float const *)host->nh_var_ptr(bn), (float *)host->nh_var_ptr(cn), M, N, K);
+    return;
+  }
+  if (fn == "hip_conv" || fn == "cudnn_conv") {
+    string const fnm = var_of(am, "filts"), bnm = var_of(am, "biases"), inm = var_of(am, "in"), onm = var_of(am, "out");
+    dims_t const f = host->nh_var_dims(fnm), bi = host->nh_var_dims(bnm), in = host->nh_var_dims(inm), out = host->nh_var_dims(onm);
+    need_float(f, "filts"); need_float(bi, "biases"); need_float(in, "in"); need_float(out, "out");
+    auto si = am.find("stride"), pi = am.find("in_pad");
+    if (si == am.end() || pi == am.end()) rt_err("hip_conv: 'stride' and 'in_pad' REF args are required");
+    dims_t const stride = si->second.get_dims(host->nh_rtc()), in_pad = pi->second.get_dims(host->nh_rtc());
+    assert_st(stride.sz() == 2); assert_st(in_pad.sz() == 2);
+    assert_st(f.sz() == 4 && in.sz() == 4 && out.sz() == 4 && bi.sz() == 1);
+    conv_geom_t g = geom_from_dims(f, in, out, stride, in_pad, fi.op.get_u32("conv_has_relu") != 0);
+    if (f.dsz("in_chan") != (uint32_t)g.C) rt_err("hip_conv: filts.in_chan != in.chan");
+    if (bi.dsz("out_chan") != (uint32_t)g.OC || out.dsz("chan") != (uint32_t)g.OC || out.dsz("img") != (uint32_t)g.B) rt_err("hip_conv: inconsistent biases/out dims");
+    if (!g.SY || !g.SX) rt_err("hip_conv: zero stride");
+    // out = (in + 2*pad - k)/stride + 1, floor (src/conv_util.cc:167-173)
+    if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW) rt_err("hip_conv: out dims do not match in/filts/stride/in_pad");
+    conv((float const *)host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), (float const *)host->nh_var_ptr(inm), (float *)host->nh_var_ptr(onm), g);
+    return;
+  }
+  rt_err("unknown/unhandled native hip function: " + fn);
+}
+
+} // namespace bodahip

@@ -1,0 +1,66 @@
+// native_kernels.h -- the native side door of the hip backend: hand-written MFMA kernels bound by op func_name.
+//
+// Precedent in the reference: nvrtc_compute_t::run() routes functions whose op.func_name starts with cublas_ / cudnn_
+// to a vendor library (src/nvrtc_util.cc:369-372, src/culibs-wrap.cc:66-247) while every tensor stays in reference
+// layout (src/cnn_op.cc:47-48,142,339-340).  This backend does the same for
+//     hip_sgemm  (alias cublas_sgemm)   args a:K:M  b:K:N  c:M:N                      test/rtc/cublas_sgemm.cucl:1-4
+//     hip_conv   (alias cudnn_conv)     args filts biases in stride(REF) in_pad(REF) out   test/rtc/cudnn_conv.cucl:1-7
+// and lands them on kernels/gemm_conv_f32.hip, specialised with hiprtc per shape class at first use.
+#pragma once
+#include "rtc_types.h"
+#include <hip/hip_runtime.h>
+
+namespace bodahip {
+
+void hip_err_chk(hipError_t e, char const *what);
+std::vector<char> hiprtc_compile(string const &src, string const &name, string const &arch, vect_string const &opts, string *log_out, bool use_cache);
+string cucl_prelude();
+string default_cache_dir();
+
+// what the native kernels need from their backend
+struct native_host_t {
+  virtual ~native_host_t() {}
+  virtual hipStream_t nh_stream() = 0;
+  virtual string const &nh_arch() = 0;
+  virtual int nh_num_cus() = 0;
+  virtual void *nh_var_ptr(string const &vn) = 0;
+  virtual dims_t nh_var_dims(string const &vn) = 0;
+  virtual rtc_compute_t &nh_rtc() = 0;
+};
+
+// blocking of one specialisation (the op_tune_t analogue for the native kernels: MNb/MNt/Kb of src/cnn_op.H:18-20
+// become workgroup tile / waves / K step)
+struct tile_cfg_t {
+  int BI = 128, BJ = 128, BK = 16, WI = 2, WJ = 2, MINW = 2;
+  int threads() const { return WI * WJ * 64; }
+  string str() const { return std::to_string(BI) + "x" + std::to_string(BJ) + "x" + std::to_string(BK) + "_w" + std::to_string(WI) + "x" + std::to_string(WJ); }
+};
+
+struct conv_geom_t { int B, C, H, W, OC, KH, KW, SY, SX, PY, PX, OH, OW; bool relu; };
+
+struct launch_info_t { string kernel; tile_cfg_t cfg; uint32_t grid = 0, block = 0; double flops = 0, algo_bytes = 0; };
+
+struct native_kernels_t {
+  explicit native_kernels_t(native_host_t *host_);
+  ~native_kernels_t();
+  static bool is_native_func_name(string const &fn);
+  void check_compile_time(rtc_func_info_t const &fi);
+  void run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &arg_map);
+
+  // direct entry points on raw device pointers (used by run() and by the C ABI's fast paths)
+  void sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K);
+  void conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g);
+
+  // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW]"
+  void set_tune(string const &key, string const &val);
+  static size_t prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile);
+  launch_info_t last_launch;
+  uint32_t num_specialisations() const;
+  struct impl_t;
+
+ private:
+  impl_t *impl;
+  native_host_t *host;
+};
+
+} // namespace bodahip

@@ -1,0 +1,118 @@
+/* bodahip.h -- C ABI of libbodahip.so: the MI355X-native rtc_compute backend (be=hip) for Boda.
+ *
+ * Every entry point below is the flat-C form of one member of the reference's backend interface
+ * `struct rtc_compute_t` (src/rtc_compute.H:35-97); the comment on each names the member it replaces.  A Boda checkout
+ * binds them from a ~100-line `hip_compute_t : rtc_compute_t` adapter; tests bind them with ctypes.
+ * Plain pointers and sizes only -- no C++ or torch types cross this boundary.
+ *
+ * Errors: the reference throws rt_err (fatal) or unsup_err ("this configuration is unsupported", which callers such
+ * as ops-prof catch and record, src/rtc_prof.cc:287-296).  Here every call returns
+ *     BODAHIP_OK (0) | BODAHIP_UNSUPPORTED (1) | BODAHIP_ERROR (2)
+ * and bodahip_last_error() returns the message of the last failing call on this thread.
+ *
+ * Threading: one host thread per context, one in-order stream; bodahip_finish_and_sync() is the only barrier
+ * (H2D copies are asynchronous on that stream, D2H copies are synchronous) -- as in the reference's backends.
+ */
+#ifndef BODAHIP_H_
+#define BODAHIP_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BODAHIP_OK 0
+#define BODAHIP_UNSUPPORTED 1
+#define BODAHIP_ERROR 2
+#define BODAHIP_ABI_VERSION 1
+
+typedef struct bodahip_ctx bodahip_ctx;
+
+/* dims_t (src/boda_base.H:498-690): row-major named dims + element type name ("float","uint32_t","none",...) */
+typedef struct bodahip_dims {
+  const char *tn;
+  uint32_t ndims;
+  const uint32_t *sizes;
+  const char *const *names;
+} bodahip_dims;
+
+/* rtc_arg_t (src/rtc_compute.H:103-115).  kind 0: `var` names a device var (its pointer is passed to the kernel).
+ * kind 1: a value: `dims` + `data`; data != NULL -> dims.bytes_sz() raw bytes are passed BY VALUE; data == NULL -> a
+ * null pointer is passed (REF / optional args: the information is the dims, e.g. stride = dims (y=4,x=4)). */
+typedef struct bodahip_arg {
+  const char *name;
+  int32_t kind;
+  const char *var;
+  bodahip_dims dims;
+  const void *data;
+} bodahip_arg;
+
+/* rtc_func_info_t (src/rtc_compute.H:23-28).  `op` is the (annotated) op_base_t as one lexp line
+ * "(str_vals=(func_name=...,type=...),nda_vals=(...))"; op.func_name selects the native kernels
+ * (hip_sgemm / hip_conv, aliases cublas_sgemm / cudnn_conv). */
+typedef struct bodahip_func_info {
+  const char *func_name;
+  const char *func_src;
+  uint32_t n_args;
+  const char *const *arg_names;
+  const char *op;
+} bodahip_func_info;
+
+/* rtc_compile_opts_t (src/rtc_compute.H:9-21) */
+typedef struct bodahip_compile_opts {
+  uint32_t show_compile_log, enable_lineinfo, show_func_attrs, show_rtc_calls;
+} bodahip_compile_opts;
+
+int bodahip_abi_version(void);
+const char *bodahip_last_error(void);
+
+/* construction: NESI would create the backend from "(be=hip)"; device_ordinal selects the GPU (one process per GPU) */
+int bodahip_create(bodahip_ctx **out, int device_ordinal);
+void bodahip_destroy(bodahip_ctx *ctx);
+int bodahip_set_gen_src(bodahip_ctx *ctx, uint32_t gen_src, const char *gen_src_output_dir); /* fields gen_src, gen_src_output_dir (:39-40) */
+
+int bodahip_init(bodahip_ctx *ctx);                                            /* rtc_compute_t::init() (:45) */
+int bodahip_get_plat_tag(bodahip_ctx *ctx, char *buf, size_t buf_sz);           /* ::get_plat_tag() (:46) -> "hip:<device name>" */
+int bodahip_create_var(bodahip_ctx *ctx, const char *vn, const bodahip_dims *dims); /* ::create_var_with_dims() (:48); zero-filled */
+int bodahip_create_view(bodahip_ctx *ctx, const char *vn, const bodahip_dims *dims, const char *src_vn); /* ::create_var_with_dims_as_reshaped_view_of_var() (:49) */
+int bodahip_release_var(bodahip_ctx *ctx, const char *vn);                     /* ::release_var() (:50) */
+/* ::get_var_dims() (:51).  sizes[]/names_buf are caller storage: *ndims_inout is capacity in, count out; names are
+ * written NUL-separated into names_buf; tn into tn_buf. */
+int bodahip_get_var_dims(bodahip_ctx *ctx, const char *vn, char *tn_buf, size_t tn_buf_sz, uint32_t *ndims_inout, uint32_t *sizes,
+                         char *names_buf, size_t names_buf_sz);
+int bodahip_set_var_to_zero(bodahip_ctx *ctx, const char *vn);                 /* ::set_var_to_zero() (:52) */
+int bodahip_compile(bodahip_ctx *ctx, uint32_t n_funcs, const bodahip_func_info *funcs, const bodahip_compile_opts *opts); /* ::compile() (:55) */
+int bodahip_release_func(bodahip_ctx *ctx, const char *func_name);             /* ::release_func() (:56) */
+int bodahip_release_all_funcs(bodahip_ctx *ctx);                               /* ::release_all_funcs() (:62) */
+int bodahip_run(bodahip_ctx *ctx, const char *rtc_func_name, uint32_t n_args, const bodahip_arg *args, uint32_t tpb, uint32_t blks,
+                uint32_t *call_id_out);                                        /* ::run(rtc_func_call_t) (:59) */
+int bodahip_finish_and_sync(bodahip_ctx *ctx);                                 /* ::finish_and_sync() (:60) */
+int bodahip_release_per_call_id_data(bodahip_ctx *ctx);                        /* ::release_per_call_id_data() (:61) */
+int bodahip_get_dur(bodahip_ctx *ctx, uint32_t b, uint32_t e, float *ms_out);  /* ::get_dur() (:70), milliseconds */
+int bodahip_profile_start(bodahip_ctx *ctx);                                   /* ::profile_start() (:72) */
+int bodahip_profile_stop(bodahip_ctx *ctx);                                    /* ::profile_stop() (:73) */
+int bodahip_copy_to_var(bodahip_ctx *ctx, const char *vn, const bodahip_dims *dims, const void *host_data);   /* ::copy_nda_to_var() (:80); dims must equal the var's */
+int bodahip_copy_from_var(bodahip_ctx *ctx, void *host_data, const bodahip_dims *dims, const char *vn);       /* ::copy_var_to_nda() (:78) */
+int bodahip_get_raw_ptr(bodahip_ctx *ctx, const char *vn, void **dev_ptr_out); /* ::get_var_raw_native_pointer() (:79) */
+
+/* ---- additions with no counterpart in the reference interface (plumbing / tooling) ---- */
+int bodahip_get_stream(bodahip_ctx *ctx, void **hip_stream_out);   /* the backend's hipStream_t, for event timing / interop */
+int bodahip_get_device_info(bodahip_ctx *ctx, char *arch_buf, size_t arch_buf_sz, int *num_cus_out, int *clock_khz_out);
+/* tile override for the native kernels (the op_tune_t MNt/MNb/Kb analogue): key "sgemm_tile"|"conv_tile",
+ * value "BIxBJxBKxWIxWJ[xMINW]" or "" to restore the heuristic */
+int bodahip_set_tune(bodahip_ctx *ctx, const char *key, const char *value);
+int bodahip_last_launch(bodahip_ctx *ctx, char *kernel_buf, size_t kernel_buf_sz, char *cfg_buf, size_t cfg_buf_sz, uint32_t *grid, uint32_t *block,
+                        double *flops, double *algo_bytes);
+/* device-less hiprtc compile of CUCL-dialect source (prelude prepended iff add_prelude) or of a named native kernel
+ * template ("gemm_conv_f32"; src = "-D..." option string); returns code-object size.  Works without a GPU. */
+int bodahip_compile_offline(const char *src_or_opts, const char *native_template_or_null, const char *arch, int add_prelude, int use_cache,
+                            size_t *code_size_out, char *log_buf, size_t log_buf_sz);
+
+/* AOT: compile, into the on-disk code-object cache the runtime reads, the native-kernel specialisation run() would pick
+ * for the op described by `op_lexp` (sgemm / Convolution line) on a device of `arch` with `num_cus` CUs.  No GPU needed. */
+int bodahip_prebuild(const char *op_lexp, const char *arch, int num_cus, const char *tile, size_t *code_size_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BODAHIP_H_ */
