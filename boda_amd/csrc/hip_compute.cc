@@ -170,7 +170,7 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
     native.reset(new native_kernels_t(this));
     init_done = true;
   }
-  string get_plat_tag() override { assert_st(init_done); return "hip:" + string(props.name); }
+  string get_plat_tag() override { assert_st(init_done); string const dn = props.name; return "hip:" + (dn.empty() ? arch : dn); }
 
   // ---- vars
   void create_var_with_dims(string const &vn, dims_t const &dims) override {

@@ -45,7 +45,9 @@ class OpsBackend:
     def __init__(self, rtc: HipCompute, compile_opts: Optional[RtcCompileOpts] = None):
         self.rtc = rtc
         self.compile_opts = compile_opts or RtcCompileOpts()
-        self.rtc.compile(gd.func_infos(), self.compile_opts)
+        if not getattr(rtc, "_gen_data_compiled", False):  # one generator module per backend instance
+            self.rtc.compile(gd.func_infos(), self.compile_opts)
+            rtc._gen_data_compiled = True
         self._fn_ix = 0
         self._gen_fns: Dict[str, str] = {}  # annotated-op text -> generated function name (rtc_func_sigs_map analogue)
 

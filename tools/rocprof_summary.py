@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (ROCm 7.2, rocpd sqlite output) run into text: per-kernel stats (== --stats) and, when the run
+collected PMC counters, per-kernel / per-grid counter sums.   usage: rocprof_summary.py results.db [--by-grid]"""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def main():
+    db = sys.argv[1]
+    by_grid = "--by-grid" in sys.argv
+    c = sqlite3.connect(db)
+    print(f"# rocprofv3 summary of {db}")
+    print("## kernel stats (ns)  [name, calls, total_ns, avg_ns, min_ns, max_ns, pct]")
+    rows = list(c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc"))
+    tot = sum(r[2] for r in rows) or 1
+    for n, k, s, a, mn, mx in rows:
+        print(f"{n:44s} {k:6d} {s:14.0f} {a:14.1f} {mn:12.0f} {mx:12.0f} {100.0*s/tot:7.2f}%")
+    if by_grid:
+        print("## per (kernel, grid, workgroup) [calls, avg_ns, min_ns, vgpr, accum_vgpr, sgpr, lds]")
+        for r in c.execute("select name, grid_x, workgroup_x, count(*), avg(duration), min(duration), max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size) "
+                           "from kernels group by name, grid_x, workgroup_x order by name, grid_x"):
+            print(f"{r[0]:36s} grid {r[1]:9d} wg {r[2]:4d} calls {r[3]:4d} avg {r[4]:13.1f} min {r[5]:12.0f} vgpr {r[6]} agpr {r[7]} sgpr {r[8]} lds {r[9]}")
+    try:
+        pm = list(c.execute("select kernel_name, grid_size, counter_name, count(*), sum(value), avg(value) from counters_collection group by kernel_name, grid_size, counter_name order by kernel_name, grid_size"))
+    except sqlite3.Error:
+        pm = []
+    if pm:
+        print("## PMC counters per (kernel, grid): [counter, dispatches, sum, avg]")
+        for kn, g, cn, n, s, a in pm:
+            print(f"{kn:36s} grid {g:9d} {cn:28s} n {n:4d} sum {s:18.2f} avg {a:16.2f}")
+
+
+if __name__ == "__main__":
+    main()
