@@ -14,23 +14,33 @@
 // their separate layout-transform passes (xpose_filts, k1conv_xpose_in, tconv_xpose_in): operands are read in
 // reference layout and re-laid-out only inside LDS.
 //
-// Numerics: v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain in ascending k, so every output is
+// Numerics: v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain in ascending k, so (without SPLITK) every output is
 // bit-identical to one thread of the reference accumulating fmaf() over k = 0..K-1 (zero-padded k / halo terms add
-// fma(x,0,acc) == acc).
+// fma(x,0,acc) == acc).  With SPLITK the K range is cut into slices that are summed in ascending order afterwards
+// (fp32 re-association; inside the reference's 2e-4 tolerance, src/rtc_prof.cc:161).
 //
 // Structure per workgroup (WI x WJ waves of 64 lanes):
 //   * BI x BJ output tile, BK-deep K steps, LDS double-buffered as k-major [BK][BI+4] / [BK][BJ+4] float images
 //     (the +4 pad keeps 16-B alignment for ds_write_b128 and de-phases rows); register-staged prefetch of K-tile t+1
 //     is issued before the MFMAs of tile t and written to the other LDS buffer after them: one barrier per K step.
+//     All global loads are branch-free (out-of-range lanes read element 0 and are zeroed by a select) so the compiler
+//     can schedule them among the MFMAs.
 //   * each wave owns a (TI*32) x (TJ*32) sub-tile = TI*TJ accumulators of 16 VGPRs; A/B operands are single
 //     conflict-free ds_read_b32 (lane l reads row 2*kk+(l>>5), column (l&31)).
+//   * the im2col gather assigns each thread one fixed output position (column j) and wave-uniform k rows, so the
+//     (in_chan,ky,kx) decode runs on the scalar unit and each element costs ~9 VALU ops.
 //   * workgroup ids are remapped XCD-aware (block b runs on XCD b%8): each XCD gets a contiguous band of
 //     tiles, walked in groups of GROUP_I tiles along i so neighbouring workgroups share I / J panels in their L2.
 //
-// Compile-time parameters (-D):  KNAME BI BJ BK WI WJ MINW I_MODE J_MODE EPI [KH KW SY SX PY PX RELU]
+// Compile-time parameters (-D):  KNAME BI BJ BK WI WJ MINW I_MODE J_MODE EPI [KH KW SY SX PY PX RELU SPLITK]
 //   I_MODE 0 k-major float4 | 1 k-major scalar | 2 i-major (k contiguous) float4 | 3 i-major scalar
-//   J_MODE 0 k-major float4 | 1 k-major scalar | 2 convolution gather from NCHW
+//   J_MODE 0 k-major float4 | 1 k-major scalar | 2 convolution gather from NCHW | 3 j-major (k contiguous) float4 | 4 j-major scalar
+//          (3/4: convolutions whose output is 1x1 with no padding -- the reference's "ipconv" case, src/cnn_op.cc:49-50 --
+//           where the im2col row of image j is simply the contiguous image: J(k,j) = in[j*K + k])
 //   EPI    0 plain store    | 1 + bias[i], optional ReLU, NCHW scatter of j=(img,pel)
+//   SPLITK 0|1: with 1 the grid is tiles x p.splitk; slice s accumulates K-tiles [s*kt_per, (s+1)*kt_per) and stores its raw
+//          partial tile to slab s of p.ws (same indexing as D); bodahip_splitk_reduce then sums the slabs in ascending s and
+//          applies the epilogue.  Used when a problem has too few output tiles to occupy 256 CUs (e.g. AlexNet fc6-fc8).
 
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h> // offline (hipcc) builds only; hiprtc provides the device runtime implicitly
@@ -56,15 +66,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef RELU
 #define RELU 0
 #endif
+#ifndef SPLITK
+#define SPLITK 0
+#endif
 
 struct gemm_args_t {
   float const *I; float const *J; float *D; float const *bias;
   int Mi, Nj, K;          // extents of i, j, k
-  int ldI, ldJ, ldD;      // row pitches (elements) of I, J (k-major: per k row; i-major: per i row) and of D per i
+  int ldI, ldJ, ldD;      // row pitches (elements) of I, J (k-major: per k row; i/j-major: per i/j row) and of D per i
   int C, H, W, OH, OW;    // convolution geometry (J_MODE 2 / EPI 1)
   int tiles_i, tiles_j;
+  int splitk, kt_per;     // SPLITK: number of K slices, K-tiles per slice
+  float *ws; long ws_slab; // SPLITK: partial-sum slabs, ws_slab elements apart
 };
 
+#ifndef REDUCE_ONLY
 namespace {
 constexpr int kNT = WI * WJ * 64;
 constexpr int kTI = BI / (WI * 32);
@@ -77,50 +93,51 @@ constexpr int kJTile = BK * kLDJ;
 static_assert(BI % (WI * 32) == 0 && BJ % (WJ * 32) == 0, "tile must be a multiple of 32 per wave");
 static_assert(BK % 4 == 0, "BK must be a multiple of 4");
 static_assert((BK * BI) % (4 * kNT) == 0 && (BK * BJ) % (4 * kNT) == 0, "tile must split evenly over the threads");
-#if J_MODE == 2
-static_assert(kNT % BJ == 0 || BJ % kNT == 0, "gather needs a fixed j column per thread");
-#endif
 constexpr int kNI = BK * BI / kNT; // staged floats per thread, operand I
 constexpr int kNJ = BK * BJ / kNT; // staged floats per thread, operand J
 
 // ---------------------------------------------------------------------------------------------------------------
-// global -> registers
+// global -> registers.  MODE 0/1: k-major rows of BX floats (x contiguous); MODE 2/3: x-major rows, k contiguous.
 // ---------------------------------------------------------------------------------------------------------------
 template <int MODE, int BX, int NR>
-__device__ __forceinline__ void load_kmajor_or_imajor(float (&r)[NR], float const *__restrict__ P, int ld, int x0, int X, int k0, int K, int tid) {
-  if constexpr (MODE == 0) { // k-major rows of BX floats, float4 along x
+__device__ __forceinline__ void load_tile(float (&r)[NR], float const *__restrict__ P, int ld, int x0, int X, int k0, int K, int tid) {
+  if constexpr (MODE == 0) {
     constexpr int VPR = BX / 4;
 #pragma unroll
     for (int p = 0; p < NR / 4; ++p) {
       int const v = tid + p * kNT, row = v / VPR, c4 = v % VPR;
       int const k = k0 + row, x = x0 + 4 * c4;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (k < K && x < X) val = *reinterpret_cast<f32x4 const *>(P + (long)k * ld + x);
-      r[4 * p + 0] = val[0]; r[4 * p + 1] = val[1]; r[4 * p + 2] = val[2]; r[4 * p + 3] = val[3];
+      bool const ok = (k < K) && (x < X); // branch-free: out-of-range lanes read element 0 and are zeroed
+      f32x4 const val = *reinterpret_cast<f32x4 const *>(P + (ok ? ((long)k * ld + x) : 0l));
+      r[4 * p + 0] = ok ? val[0] : 0.f; r[4 * p + 1] = ok ? val[1] : 0.f; r[4 * p + 2] = ok ? val[2] : 0.f; r[4 * p + 3] = ok ? val[3] : 0.f;
     }
-  } else if constexpr (MODE == 1) { // k-major scalar
+  } else if constexpr (MODE == 1) {
 #pragma unroll
     for (int p = 0; p < NR; ++p) {
       int const e = tid + p * kNT, row = e / BX, c = e % BX;
       int const k = k0 + row, x = x0 + c;
-      r[p] = (k < K && x < X) ? P[(long)k * ld + x] : 0.f;
+      bool const ok = (k < K) && (x < X);
+      float const val = P[ok ? ((long)k * ld + x) : 0l];
+      r[p] = ok ? val : 0.f;
     }
-  } else if constexpr (MODE == 2) { // x-major rows, k contiguous, float4 along k
+  } else if constexpr (MODE == 2) {
     constexpr int VPR = BK / 4;
 #pragma unroll
     for (int p = 0; p < NR / 4; ++p) {
       int const v = tid + p * kNT, xr = v / VPR, k4 = v % VPR;
       int const x = x0 + xr, k = k0 + 4 * k4;
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (x < X && k < K) val = *reinterpret_cast<f32x4 const *>(P + (long)x * ld + k);
-      r[4 * p + 0] = val[0]; r[4 * p + 1] = val[1]; r[4 * p + 2] = val[2]; r[4 * p + 3] = val[3];
+      bool const ok = (x < X) && (k < K);
+      f32x4 const val = *reinterpret_cast<f32x4 const *>(P + (ok ? ((long)x * ld + k) : 0l));
+      r[4 * p + 0] = ok ? val[0] : 0.f; r[4 * p + 1] = ok ? val[1] : 0.f; r[4 * p + 2] = ok ? val[2] : 0.f; r[4 * p + 3] = ok ? val[3] : 0.f;
     }
-  } else { // MODE 3: x-major scalar
+  } else {
 #pragma unroll
     for (int p = 0; p < NR; ++p) {
       int const e = tid + p * kNT, xr = e / BK, kk = e % BK;
       int const x = x0 + xr, k = k0 + kk;
-      r[p] = (x < X && k < K) ? P[(long)x * ld + k] : 0.f;
+      bool const ok = (x < X) && (k < K);
+      float const val = P[ok ? ((long)x * ld + k) : 0l];
+      r[p] = ok ? val : 0.f;
     }
   }
 }
@@ -154,22 +171,24 @@ __device__ __forceinline__ void store_tile(float const (&r)[NR], float *__restri
 }
 
 #if J_MODE == 2
-// per-thread constants of the im2col gather: this thread always serves output position (pel) column jj
-struct gather_t { long base; int iy0, ix0; bool jv; };
-constexpr int kRowsPerPass = (kNT >= BJ) ? (kNT / BJ) : 1;
-constexpr int kColsPerThr = (kNT >= BJ) ? 1 : (BJ / kNT);
-static_assert(kColsPerThr == 1, "BJ > threads is not supported by the gather (pick BJ <= WI*WJ*64)");
+// per-thread constants of the im2col gather: this thread always serves output position (pel) column jj.
+// Offsets are 32-bit element indices (the host guarantees the input tensor has < 2^31 elements).
+struct gather_t { int base; int iy0, ix0; bool jv; };
+static_assert(BJ % 64 == 0 && kNT % BJ == 0, "gather: a wave must sit inside one k row (BJ multiple of 64, BJ <= threads)");
+constexpr int kRowsPerPass = kNT / BJ;
 __device__ __forceinline__ void load_gather(float (&r)[kNJ], float const *__restrict__ in, gather_t const &g, gemm_args_t const &p, int k0, int tid) {
   constexpr int KHW = KH * KW;
-  int const row0 = tid / BJ;
+  // the k row is wave-uniform: decode (in_chan, ky, kx) once per wave on the scalar unit
+  int const row0 = __builtin_amdgcn_readfirstlane(tid / BJ);
 #pragma unroll
   for (int q = 0; q < kNJ; ++q) {
     int const kg = k0 + row0 + q * kRowsPerPass;
     int const ic = kg / KHW, rem = kg - ic * KHW, ky = rem / KW, kx = rem - ky * KW;
+    int const koff = (ic * p.H + ky) * p.W + kx;
     int const iy = g.iy0 + ky, ix = g.ix0 + kx;
     bool const ok = g.jv && (kg < p.K) && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
-    long const off = g.base + ((long)ic * p.H + ky) * p.W + kx;
-    r[q] = ok ? in[off] : 0.f;
+    float const v = in[ok ? (g.base + koff) : 0]; // branch-free: masked lanes read element 0
+    r[q] = ok ? v : 0.f;
   }
 }
 __device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__restrict__ S, int tid) {
@@ -177,7 +196,31 @@ __device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__res
 #pragma unroll
   for (int q = 0; q < kNJ; ++q) S[(row0 + q * kRowsPerPass) * kLDJ + jj] = r[q];
 }
+#define GATHER_ARG , g
+#define GATHER_PARM , gather_t const &g
+#else
+#define GATHER_ARG
+#define GATHER_PARM
 #endif
+
+__device__ __forceinline__ void load_J(float (&rj)[kNJ], gemm_args_t const &p, int j0, int k0, int tid GATHER_PARM) {
+#if J_MODE == 2
+  load_gather(rj, p.J, g, p, k0, tid);
+#elif J_MODE == 3 || J_MODE == 4
+  load_tile<J_MODE - 1, BJ, kNJ>(rj, p.J, p.ldJ, j0, p.Nj, k0, p.K, tid);
+#else
+  load_tile<J_MODE, BJ, kNJ>(rj, p.J, p.ldJ, j0, p.Nj, k0, p.K, tid);
+#endif
+}
+__device__ __forceinline__ void store_J(float const (&rj)[kNJ], float *__restrict__ S, int tid) {
+#if J_MODE == 2
+  store_gather(rj, S, tid);
+#elif J_MODE == 3 || J_MODE == 4
+  store_tile<J_MODE - 1, BJ, kLDJ, kNJ>(rj, S, tid);
+#else
+  store_tile<J_MODE, BJ, kLDJ, kNJ>(rj, S, tid);
+#endif
+}
 } // namespace
 
 extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p) {
@@ -188,9 +231,14 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   int const wi = wave / WJ, wj = wave % WJ;
 
   // ---- XCD-aware workgroup -> tile map (bijective for any grid size) ------------------------------------------
+#if SPLITK
+  int const bid = blockIdx.x / p.splitk, slice = blockIdx.x % p.splitk;
+#else
+  int const bid = blockIdx.x;
+#endif
   int tile_i, tile_j;
   {
-    int const nb = p.tiles_i * p.tiles_j, bid = blockIdx.x;
+    int const nb = p.tiles_i * p.tiles_j;
     int const q = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
     int const nid = ((xcd < rr) ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
     int const group_sz = GROUP_I * p.tiles_j, gid = nid / group_sz, first_i = gid * GROUP_I;
@@ -210,7 +258,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     g.jv = jg < p.Nj;
     int const img = jg / OHW, pel = jg - img * OHW, oy = pel / p.OW, ox = pel - oy * p.OW;
     g.iy0 = oy * SY - PY; g.ix0 = ox * SX - PX;
-    g.base = ((long)img * p.C * p.H + g.iy0) * p.W + g.ix0;
+    g.base = (img * p.C * p.H + g.iy0) * p.W + g.ix0;
   }
 #endif
 
@@ -223,20 +271,19 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   float ri[kNI], rj[kNJ];
-  int const nkt = (p.K + BK - 1) / BK;
+  int const nkt_all = (p.K + BK - 1) / BK;
+#if SPLITK
+  int const kt_begin = slice * p.kt_per;
+  int const nkt = max(0, min(nkt_all, kt_begin + p.kt_per) - kt_begin);
+#else
+  int const kt_begin = 0;
+  int const nkt = nkt_all;
+#endif
 
-  load_kmajor_or_imajor<I_MODE, BI, kNI>(ri, p.I, p.ldI, i0, p.Mi, 0, p.K, tid);
-#if J_MODE == 2
-  load_gather(rj, p.J, g, p, 0, tid);
-#else
-  load_kmajor_or_imajor<J_MODE, BJ, kNJ>(rj, p.J, p.ldJ, j0, p.Nj, 0, p.K, tid);
-#endif
+  load_tile<I_MODE, BI, kNI>(ri, p.I, p.ldI, i0, p.Mi, kt_begin * BK, p.K, tid);
+  load_J(rj, p, j0, kt_begin * BK, tid GATHER_ARG);
   store_tile<I_MODE, BI, kLDI, kNI>(ri, Is0, tid);
-#if J_MODE == 2
-  store_gather(rj, Js0, tid);
-#else
-  store_tile<J_MODE, BJ, kLDJ, kNJ>(rj, Js0, tid);
-#endif
+  store_J(rj, Js0, tid);
   __syncthreads();
 
   int const a_off = wi * (kTI * 32) + (lane & 31) + (lane >> 5) * kLDI;
@@ -247,12 +294,8 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     float const *const Ic = ((kt & 1) ? Is1 : Is0) + a_off;
     float const *const Jc = ((kt & 1) ? Js1 : Js0) + b_off;
     if (more) { // prefetch K-tile kt+1 into registers; the loads fly under the MFMAs below
-      load_kmajor_or_imajor<I_MODE, BI, kNI>(ri, p.I, p.ldI, i0, p.Mi, (kt + 1) * BK, p.K, tid);
-#if J_MODE == 2
-      load_gather(rj, p.J, g, p, (kt + 1) * BK, tid);
-#else
-      load_kmajor_or_imajor<J_MODE, BJ, kNJ>(rj, p.J, p.ldJ, j0, p.Nj, (kt + 1) * BK, p.K, tid);
-#endif
+      load_tile<I_MODE, BI, kNI>(ri, p.I, p.ldI, i0, p.Mi, (kt_begin + kt + 1) * BK, p.K, tid);
+      load_J(rj, p, j0, (kt_begin + kt + 1) * BK, tid GATHER_ARG);
     }
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
@@ -268,16 +311,17 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     }
     if (more) {
       store_tile<I_MODE, BI, kLDI, kNI>(ri, (kt & 1) ? Is0 : Is1, tid);
-#if J_MODE == 2
-      store_gather(rj, (kt & 1) ? Js0 : Js1, tid);
-#else
-      store_tile<J_MODE, BJ, kLDJ, kNJ>(rj, (kt & 1) ? Js0 : Js1, tid);
-#endif
+      store_J(rj, (kt & 1) ? Js0 : Js1, tid);
     }
     __syncthreads();
   }
 
   // ---- epilogue: MFMA C/D layout: column j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5) -----------------
+#if SPLITK
+  float *const Dp = p.ws + (long)slice * p.ws_slab;
+#else
+  float *const Dp = p.D;
+#endif
 #pragma unroll
   for (int tb = 0; tb < kTJ; ++tb) {
     int const jg = j0 + wj * (kTJ * 32) + tb * 32 + (lane & 31);
@@ -298,15 +342,55 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
         int const ig = i0 + wi * (kTI * 32) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (ig < p.Mi) {
           float v = acc[ta][tb][r];
-#if EPI == 1
+#if EPI == 1 && !SPLITK
           v = v + p.bias[ig];
 #if RELU
           v = (v > 0.f) ? v : 0.f;
 #endif
 #endif
-          p.D[joff + (long)ig * istride] = v;
+          Dp[joff + (long)ig * istride] = v;
         }
       }
     }
   }
 }
+#endif // !REDUCE_ONLY
+
+#ifdef REDUCE_ONLY
+// Second pass of SPLITK: D[e] = epilogue( sum_{s ascending} ws[s][e] ).  Memory-bound: float4 per lane, grid-stride.
+//   RED_EPI 0: plain   1: + bias[(e / chan_stride) % n_chan], optional ReLU (RED_RELU)
+extern "C" __global__ __launch_bounds__(256) void KNAME(float const *__restrict__ ws, long ws_slab, int splitk, float *__restrict__ D, long n,
+                                                        float const *__restrict__ bias, int chan_stride, int n_chan) {
+  long const stride = (long)gridDim.x * blockDim.x * 4;
+  for (long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < n; e += stride) {
+    if (e + 3 < n) {
+      f32x4 s = *reinterpret_cast<f32x4 const *>(ws + e);
+      for (int k = 1; k < splitk; ++k) { f32x4 const t = *reinterpret_cast<f32x4 const *>(ws + (long)k * ws_slab + e); s += t; }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = s[c];
+#if RED_EPI == 1
+        v += bias[((e + c) / chan_stride) % n_chan];
+#if RED_RELU
+        v = (v > 0.f) ? v : 0.f;
+#endif
+#endif
+        s[c] = v;
+      }
+      *reinterpret_cast<f32x4 *>(D + e) = s;
+    } else {
+      for (long ee = e; ee < n; ++ee) {
+        float v = ws[ee];
+        for (int k = 1; k < splitk; ++k) v += ws[(long)k * ws_slab + ee];
+#if RED_EPI == 1
+        v += bias[(ee / chan_stride) % n_chan];
+#if RED_RELU
+        v = (v > 0.f) ? v : 0.f;
+#endif
+#endif
+        D[ee] = v;
+      }
+    }
+  }
+}
+#endif

@@ -16,6 +16,8 @@ struct gemm_args_t { // must match kernels/gemm_conv_f32.hip
   int ldI, ldJ, ldD;
   int C, H, W, OH, OW;
   int tiles_i, tiles_j;
+  int splitk, kt_per;
+  float *ws; long ws_slab;
 };
 
 struct kernel_t { hipModule_t mod = nullptr; hipFunction_t func = nullptr; };
@@ -23,6 +25,7 @@ struct kernel_t { hipModule_t mod = nullptr; hipFunction_t func = nullptr; };
 struct native_kernels_t::impl_t {
   std::map<string, kernel_t> kernels; // key = option string
   std::map<string, string> tune;
+  void *ws = nullptr; size_t ws_bytes = 0; // split-K partial-sum slabs (grow-only scratch, like the reference's cudnn scratch var)
 };
 
 native_kernels_t::native_kernels_t(native_host_t *host_) : impl(new impl_t), host(host_) {
@@ -31,6 +34,7 @@ native_kernels_t::native_kernels_t(native_host_t *host_) : impl(new impl_t), hos
 }
 native_kernels_t::~native_kernels_t() {
   for (auto &kv : impl->kernels) { if (kv.second.mod) (void)hipModuleUnload(kv.second.mod); }
+  if (impl->ws) (void)hipFree(impl->ws);
   delete impl;
 }
 uint32_t native_kernels_t::num_specialisations() const { return (uint32_t)impl->kernels.size(); }
@@ -49,14 +53,15 @@ void native_kernels_t::set_tune(string const &key, string const &val) {
   if (val.empty()) impl->tune.erase(key); else { impl->tune[key] = val; }
 }
 
+// "BIxBJxBKxWIxWJ[xMINW[xSPLITK]]"
 static bool parse_tile(string const &s, tile_cfg_t &c) {
-  int v[6] = {0, 0, 0, 0, 0, 0}; int n = 0; string cur;
+  int v[7] = {0, 0, 0, 0, 0, 0, 0}; int n = 0; string cur;
   for (size_t i = 0; i <= s.size(); ++i) {
-    if (i == s.size() || s[i] == 'x' || s[i] == ':') { if (cur.empty() || n >= 6) return false; v[n++] = atoi(cur.c_str()); cur.clear(); }
+    if (i == s.size() || s[i] == 'x' || s[i] == ':') { if (cur.empty() || n >= 7) return false; v[n++] = atoi(cur.c_str()); cur.clear(); }
     else if (s[i] >= '0' && s[i] <= '9') cur.push_back(s[i]); else return false;
   }
   if (n < 5) return false;
-  c.BI = v[0]; c.BJ = v[1]; c.BK = v[2]; c.WI = v[3]; c.WJ = v[4]; c.MINW = (n >= 6) ? v[5] : 1;
+  c.BI = v[0]; c.BJ = v[1]; c.BK = v[2]; c.WI = v[3]; c.WJ = v[4]; c.MINW = (n >= 6) ? v[5] : 1; c.SPLITK = (n >= 7) ? v[6] : 1;
   return true;
 }
 // the static_asserts of the kernel, checked on the host so that a bad tune is an unsup_err, not a compile failure
@@ -64,7 +69,8 @@ static void check_cfg(tile_cfg_t const &c, bool gather) {
   int const nt = c.threads();
   bool ok = c.BI > 0 && c.BJ > 0 && c.BK > 0 && c.WI > 0 && c.WJ > 0 && nt <= 1024 && (c.BI % (c.WI * 32) == 0) && (c.BJ % (c.WJ * 32) == 0) &&
             (c.BK % 4 == 0) && ((c.BK * c.BI) % (4 * nt) == 0) && ((c.BK * c.BJ) % (4 * nt) == 0);
-  if (gather) ok = ok && (nt % c.BJ == 0);
+  if (gather) ok = ok && (nt % c.BJ == 0) && (c.BJ % 64 == 0);
+  ok = ok && c.SPLITK >= 1 && c.SPLITK <= 64 && c.MINW >= 1;
   int const accs = (c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32));
   ok = ok && accs * 16 <= 256;
   uint64_t const lds = 2ull * c.BK * (c.BI + 4 + c.BJ + 4) * 4;
@@ -78,21 +84,29 @@ static int pick_bi(int Mi) { // minimise padded extent; ties -> larger tile
   return best;
 }
 
-static tile_cfg_t choose_cfg(int Mi, int Nj, int num_cus) {
+// Tile / split-K heuristic.  Goal: >= ~1 four-wave workgroup per CU with the largest per-wave tile (64x64 feeds the
+// MFMA pipe with the fewest LDS reads); problems with too few output tiles get 32x32 per-wave tiles (64x64 workgroups)
+// and, if still too few, the K loop is split across workgroups (deterministic slab reduction afterwards).
+static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus) {
   tile_cfg_t c;
   int const bi = pick_bi(Mi);
-  if (bi == 128) { c.BI = 128; c.BJ = 128; c.WI = 2; c.WJ = 2; c.MINW = 2; }
-  else if (bi == 96) { c.BI = 96; c.BJ = 128; c.WI = 1; c.WJ = 2; c.MINW = 2; }
-  else if (bi == 64) { c.BI = 64; c.BJ = 128; c.WI = 1; c.WJ = 2; c.MINW = 2; }
-  else { c.BI = 32; c.BJ = 128; c.WI = 1; c.WJ = 2; c.MINW = 2; }
-  c.BK = 16;
-  // not enough tiles to occupy the chip: shrink the j tile (more, smaller workgroups)
-  long tiles = (long)((Mi + c.BI - 1) / c.BI) * ((Nj + c.BJ - 1) / c.BJ);
-  if (tiles < num_cus && c.BJ == 128) {
-    c.BJ = 64; c.WJ = 1; if (c.BI == 128) { c.WI = 2; } // 128x64: 2 waves of 64x64 ; else 1 wave
-    tiles = (long)((Mi + c.BI - 1) / c.BI) * ((Nj + c.BJ - 1) / c.BJ);
-    if (tiles < num_cus && c.BI == 128) { c.BI = 64; c.WI = 1; }
-  }
+  if (bi == 128) { c.BI = 128; c.BJ = 128; c.WI = 2; c.WJ = 2; }
+  else if (bi == 96) { c.BI = 96; c.BJ = 128; c.WI = 1; c.WJ = 2; }
+  else if (bi == 64) { c.BI = 64; c.BJ = 128; c.WI = 1; c.WJ = 2; }
+  else { c.BI = 32; c.BJ = 128; c.WI = 1; c.WJ = 2; }
+  c.BK = 16; c.MINW = 2; c.SPLITK = 1;
+  auto ntiles = [&](tile_cfg_t const &t) { return (long)((Mi + t.BI - 1) / t.BI) * ((Nj + t.BJ - 1) / t.BJ); };
+  long const tiles = ntiles(c);
+  if (tiles >= num_cus) return c;
+  double const flops = 2.0 * Mi * (double)Nj * K;
+  if (Mi > 32) {
+    tile_cfg_t c2 = c; c2.BI = 64; c2.BJ = 64; c2.WI = 2; c2.WJ = 2;
+    if (ntiles(c2) >= num_cus / 2 || flops < 2.7e8) return c2; // enough workgroups, or too small to matter (launch-bound)
+  } else if (flops < 2.7e8) return c;
+  int const nkt = (K + c.BK - 1) / c.BK;
+  long s = (2l * num_cus + tiles - 1) / tiles;
+  s = std::min<long>(s, std::min<long>(32, nkt / 2));
+  if (s >= 2) c.SPLITK = (int)s;
   return c;
 }
 
@@ -100,40 +114,42 @@ static vect_string cfg_defs(tile_cfg_t const &c) {
   return {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI),
           "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW)};
 }
-
-static vect_string cfg_defs(tile_cfg_t const &c);
 struct plan_t;
 static kernel_t &get_kernel(native_kernels_t::impl_t *impl, native_host_t *host, plan_t const &p);
 static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t const &c) {
   void *params[] = {&a};
-  uint32_t const grid = (uint32_t)a.tiles_i * (uint32_t)a.tiles_j;
+  uint32_t const grid = (uint32_t)a.tiles_i * (uint32_t)a.tiles_j * (uint32_t)std::max(1, a.splitk);
   hip_err_chk(hipModuleLaunchKernel(k.func, grid, 1, 1, (uint32_t)c.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(native)");
 }
 
-
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false; };
 
 static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string const &tile) {
   (void)K;
   plan_t p; p.kname = "bodahip_sgemm_f32";
-  p.cfg = choose_cfg((int)M, (int)N, num_cus);
+  p.cfg = choose_cfg((int)M, (int)N, (int)K, num_cus);
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad sgemm_tile '" + tile + "'"); }
   check_cfg(p.cfg, false);
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((M % 4 == 0) ? "0" : "1"));
   p.defs.push_back(string("-DJ_MODE=") + ((N % 4 == 0) ? "0" : "1"));
   p.defs.push_back("-DEPI=0");
+  if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
   return p;
 }
 static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile) {
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   plan_t p; p.kname = "bodahip_conv_f32";
-  p.cfg = choose_cfg(g.OC, (int)Nj, num_cus);
+  p.cfg = choose_cfg(g.OC, (int)Nj, (int)Kt, num_cus);
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad conv_tile '" + tile + "'"); }
-  check_cfg(p.cfg, true);
+  // output 1x1, no padding, kernel == whole input ("ipconv" case): the im2col row of image j is the contiguous image
+  p.ipconv = (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W);
+  check_cfg(p.cfg, !p.ipconv);
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0) ? "2" : "3"));
-  p.defs.push_back("-DJ_MODE=2"); p.defs.push_back("-DEPI=1");
+  p.defs.push_back(p.ipconv ? (string("-DJ_MODE=") + ((Kt % 4 == 0) ? "3" : "4")) : string("-DJ_MODE=2"));
+  p.defs.push_back("-DEPI=1");
+  if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
   p.defs.push_back("-DKH=" + std::to_string(g.KH)); p.defs.push_back("-DKW=" + std::to_string(g.KW));
   p.defs.push_back("-DSY=" + std::to_string(g.SY)); p.defs.push_back("-DSX=" + std::to_string(g.SX));
   p.defs.push_back("-DPY=" + std::to_string(g.PY)); p.defs.push_back("-DPX=" + std::to_string(g.PX));
@@ -143,6 +159,34 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile) {
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
   return hiprtc_compile(k_src_gemm_conv_f32, p.kname, arch, opts, log, true);
+}
+
+static void setup_splitk(native_kernels_t::impl_t *impl, native_host_t *host, gemm_args_t &ga, tile_cfg_t const &cfg, size_t out_elems) {
+  ga.splitk = cfg.SPLITK; ga.kt_per = 0; ga.ws = nullptr; ga.ws_slab = 0;
+  if (cfg.SPLITK <= 1) { ga.splitk = 1; return; }
+  int const nkt = (ga.K + cfg.BK - 1) / cfg.BK;
+  ga.kt_per = (nkt + cfg.SPLITK - 1) / cfg.SPLITK;
+  size_t const slab = (out_elems + 3) & ~size_t(3);
+  size_t const need = slab * (size_t)cfg.SPLITK * sizeof(float);
+  if (impl->ws_bytes < need) {
+    if (impl->ws) { hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize"); hip_err_chk(hipFree(impl->ws), "hipFree"); impl->ws = nullptr; impl->ws_bytes = 0; }
+    hip_err_chk(hipMalloc(&impl->ws, need), "hipMalloc(split-k scratch)"); impl->ws_bytes = need;
+  }
+  ga.ws = (float *)impl->ws; ga.ws_slab = (long)slab;
+}
+
+static kernel_t &get_reduce_kernel(native_kernels_t::impl_t *impl, native_host_t *host, bool epi, bool relu) {
+  plan_t p; p.kname = "bodahip_splitk_reduce";
+  p.defs = {"-DREDUCE_ONLY=1", string("-DRED_EPI=") + (epi ? "1" : "0"), string("-DRED_RELU=") + (relu ? "1" : "0")};
+  return get_kernel(impl, host, p);
+}
+static void reduce_splitk(native_kernels_t::impl_t *impl, native_host_t *host, gemm_args_t const &ga, long n, bool epi, bool relu, int chan_stride, int n_chan) {
+  kernel_t &k = get_reduce_kernel(impl, host, epi, relu);
+  float const *ws = ga.ws; long ws_slab = ga.ws_slab; int splitk = ga.splitk; float *D = ga.D; float const *bias = ga.bias;
+  void *params[] = {&ws, &ws_slab, &splitk, &D, &n, &bias, &chan_stride, &n_chan};
+  long const groups = (n / 4 + 255) / 256;
+  uint32_t const grid = (uint32_t)std::max<long>(1, std::min<long>(groups, 2048));
+  hip_err_chk(hipModuleLaunchKernel(k.func, grid, 1, 1, 256, 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(splitk_reduce)");
 }
 
 static string tune_of(native_kernels_t::impl_t *impl, char const *key) { auto t = impl->tune.find(key); return (t == impl->tune.end()) ? string() : t->second; }
@@ -158,8 +202,10 @@ void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t 
   ga.I = a; ga.J = b; ga.D = c; ga.bias = nullptr;
   ga.Mi = (int)M; ga.Nj = (int)N; ga.K = (int)K; ga.ldI = (int)M; ga.ldJ = (int)N; ga.ldD = (int)N;
   ga.tiles_i = (int)((M + cfg.BI - 1) / cfg.BI); ga.tiles_j = (int)((N + cfg.BJ - 1) / cfg.BJ);
+  setup_splitk(impl, host, ga, cfg, (size_t)M * N);
   launch(host, k, ga, cfg);
-  last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)ga.tiles_i * ga.tiles_j; last_launch.block = cfg.threads();
+  if (cfg.SPLITK > 1) reduce_splitk(impl, host, ga, (long)M * N, false, false, 1, 1);
+  last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)ga.tiles_i * ga.tiles_j * cfg.SPLITK; last_launch.block = cfg.threads();
   last_launch.flops = 2.0 * M * N * K; last_launch.algo_bytes = 4.0 * ((double)K * M + (double)K * N + (double)M * N);
 }
 
@@ -171,12 +217,15 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
   gemm_args_t ga; memset(&ga, 0, sizeof(ga));
+  if (!p.ipconv && (long)g.B * g.C * g.H * g.W > 0x7fffffffl) unsup_err("hip_conv: input tensors of >= 2^31 elements are not supported by the gather");
   ga.I = filts; ga.J = in; ga.D = out; ga.bias = biases;
-  ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.ldI = (int)Kt; ga.ldJ = 0; ga.ldD = g.OH * g.OW;
+  ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.ldI = (int)Kt; ga.ldJ = p.ipconv ? (int)Kt : 0; ga.ldD = g.OH * g.OW;
   ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
   ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
+  setup_splitk(impl, host, ga, cfg, (size_t)Nj * g.OC);
   launch(host, k, ga, cfg);
-  last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)ga.tiles_i * ga.tiles_j; last_launch.block = cfg.threads();
+  if (cfg.SPLITK > 1) reduce_splitk(impl, host, ga, Nj * g.OC, true, g.relu, g.OH * g.OW, g.OC);
+  last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)ga.tiles_i * ga.tiles_j * cfg.SPLITK; last_launch.block = cfg.threads();
   last_launch.flops = 2.0 * Nj * g.OC * Kt;
   last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
 }
@@ -199,7 +248,14 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
     p = plan_conv(geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims("out"), op.get_dims("stride"), op.get_dims("in_pad"), relu), num_cus, tile);
   } else rt_err("prebuild: op type '" + t + "' has no native kernel");
-  return compile_plan(p, arch, &log).size();
+  size_t const n = compile_plan(p, arch, &log).size();
+  if (p.cfg.SPLITK > 1) { // the matching second-pass kernel
+    plan_t r; r.kname = "bodahip_splitk_reduce"; bool const epi = (t == "Convolution");
+    bool const relu = epi && (op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true);
+    r.defs = {"-DREDUCE_ONLY=1", string("-DRED_EPI=") + (epi ? "1" : "0"), string("-DRED_RELU=") + (relu ? "1" : "0")};
+    compile_plan(r, arch, &log);
+  }
+  return n;
 }
 
 static kernel_t &get_kernel(native_kernels_t::impl_t *impl, native_host_t *host, plan_t const &p) {
