@@ -23,8 +23,9 @@
 //   * BI x BJ output tile, BK-deep K steps, LDS double-buffered as k-major [BK][BI+4] / [BK][BJ+4] float images
 //     (the +4 pad keeps 16-B alignment for ds_write_b128 and de-phases rows); register-staged prefetch of K-tile t+1
 //     is issued before the MFMAs of tile t and written to the other LDS buffer after them: one barrier per K step.
-//     All global loads are branch-free (out-of-range lanes read element 0 and are zeroed by a select) so the compiler
-//     can schedule them among the MFMAs.
+//     All global loads are buffer loads through a wave-uniform resource descriptor: out-of-range lanes (tile edges, conv
+//     halo / zero padding, K tail) are given an offset beyond num_records and the hardware returns 0 -- no branches, no
+//     selects on the loaded value, 32-bit offsets only, so the loads stay in flight until the LDS write after the MFMAs.
 //   * each wave owns a (TI*32) x (TJ*32) sub-tile = TI*TJ accumulators of 16 VGPRs; A/B operands are single
 //     conflict-free ds_read_b32 (lane l reads row 2*kk+(l>>5), column (l&31)).
 //   * the im2col gather assigns each thread one fixed output position (column j) and wave-uniform k rows, so the
@@ -78,6 +79,7 @@ struct gemm_args_t {
   int tiles_i, tiles_j;
   int splitk, kt_per;     // SPLITK: number of K slices, K-tiles per slice
   float *ws; long ws_slab; // SPLITK: partial-sum slabs, ws_slab elements apart
+  unsigned I_bytes, J_bytes; // sizes of the I / J tensors (buffer-descriptor num_records; host guarantees <= 2^31)
 };
 
 #ifndef REDUCE_ONLY
@@ -99,26 +101,29 @@ constexpr int kNJ = BK * BJ / kNT; // staged floats per thread, operand J
 // ---------------------------------------------------------------------------------------------------------------
 // global -> registers.  MODE 0/1: k-major rows of BX floats (x contiguous); MODE 2/3: x-major rows, k contiguous.
 // ---------------------------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int kOOB = (int)0x80000000; // byte offset beyond any num_records (tensors are <= 2^31 bytes): hardware returns 0
+__device__ __forceinline__ rsrc_t make_rsrc(float const *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)bytes, 0x00020000); }
+__device__ __forceinline__ f32x4 bload4(rsrc_t r, int byte_off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0)); }
+__device__ __forceinline__ float bload1(rsrc_t r, int byte_off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0)); }
+
 template <int MODE, int BX, int NR>
-__device__ __forceinline__ void load_tile(float (&r)[NR], float const *__restrict__ P, int ld, int x0, int X, int k0, int K, int tid) {
+__device__ __forceinline__ void load_tile(float (&r)[NR], rsrc_t P, int ld, int x0, int X, int k0, int K, int tid) {
   if constexpr (MODE == 0) {
     constexpr int VPR = BX / 4;
 #pragma unroll
     for (int p = 0; p < NR / 4; ++p) {
       int const v = tid + p * kNT, row = v / VPR, c4 = v % VPR;
       int const k = k0 + row, x = x0 + 4 * c4;
-      bool const ok = (k < K) && (x < X); // branch-free: out-of-range lanes read element 0 and are zeroed
-      f32x4 const val = *reinterpret_cast<f32x4 const *>(P + (ok ? ((long)k * ld + x) : 0l));
-      r[4 * p + 0] = ok ? val[0] : 0.f; r[4 * p + 1] = ok ? val[1] : 0.f; r[4 * p + 2] = ok ? val[2] : 0.f; r[4 * p + 3] = ok ? val[3] : 0.f;
+      f32x4 const val = bload4(P, ((k < K) && (x < X)) ? ((k * ld + x) * 4) : kOOB);
+      r[4 * p + 0] = val[0]; r[4 * p + 1] = val[1]; r[4 * p + 2] = val[2]; r[4 * p + 3] = val[3];
     }
   } else if constexpr (MODE == 1) {
 #pragma unroll
     for (int p = 0; p < NR; ++p) {
       int const e = tid + p * kNT, row = e / BX, c = e % BX;
       int const k = k0 + row, x = x0 + c;
-      bool const ok = (k < K) && (x < X);
-      float const val = P[ok ? ((long)k * ld + x) : 0l];
-      r[p] = ok ? val : 0.f;
+      r[p] = bload1(P, ((k < K) && (x < X)) ? ((k * ld + x) * 4) : kOOB);
     }
   } else if constexpr (MODE == 2) {
     constexpr int VPR = BK / 4;
@@ -126,18 +131,15 @@ __device__ __forceinline__ void load_tile(float (&r)[NR], float const *__restric
     for (int p = 0; p < NR / 4; ++p) {
       int const v = tid + p * kNT, xr = v / VPR, k4 = v % VPR;
       int const x = x0 + xr, k = k0 + 4 * k4;
-      bool const ok = (x < X) && (k < K);
-      f32x4 const val = *reinterpret_cast<f32x4 const *>(P + (ok ? ((long)x * ld + k) : 0l));
-      r[4 * p + 0] = ok ? val[0] : 0.f; r[4 * p + 1] = ok ? val[1] : 0.f; r[4 * p + 2] = ok ? val[2] : 0.f; r[4 * p + 3] = ok ? val[3] : 0.f;
+      f32x4 const val = bload4(P, ((x < X) && (k < K)) ? ((x * ld + k) * 4) : kOOB);
+      r[4 * p + 0] = val[0]; r[4 * p + 1] = val[1]; r[4 * p + 2] = val[2]; r[4 * p + 3] = val[3];
     }
   } else {
 #pragma unroll
     for (int p = 0; p < NR; ++p) {
       int const e = tid + p * kNT, xr = e / BK, kk = e % BK;
       int const x = x0 + xr, k = k0 + kk;
-      bool const ok = (x < X) && (k < K);
-      float const val = P[ok ? ((long)x * ld + k) : 0l];
-      r[p] = ok ? val : 0.f;
+      r[p] = bload1(P, ((x < X) && (k < K)) ? ((x * ld + k) * 4) : kOOB);
     }
   }
 }
@@ -172,11 +174,11 @@ __device__ __forceinline__ void store_tile(float const (&r)[NR], float *__restri
 
 #if J_MODE == 2
 // per-thread constants of the im2col gather: this thread always serves output position (pel) column jj.
-// Offsets are 32-bit element indices (the host guarantees the input tensor has < 2^31 elements).
+// Offsets are 32-bit (the host guarantees the input tensor is <= 2^31 bytes).
 struct gather_t { int base; int iy0, ix0; bool jv; };
 static_assert(BJ % 64 == 0 && kNT % BJ == 0, "gather: a wave must sit inside one k row (BJ multiple of 64, BJ <= threads)");
 constexpr int kRowsPerPass = kNT / BJ;
-__device__ __forceinline__ void load_gather(float (&r)[kNJ], float const *__restrict__ in, gather_t const &g, gemm_args_t const &p, int k0, int tid) {
+__device__ __forceinline__ void load_gather(float (&r)[kNJ], rsrc_t in, gather_t const &g, gemm_args_t const &p, int k0, int tid) {
   constexpr int KHW = KH * KW;
   // the k row is wave-uniform: decode (in_chan, ky, kx) once per wave on the scalar unit
   int const row0 = __builtin_amdgcn_readfirstlane(tid / BJ);
@@ -187,8 +189,7 @@ __device__ __forceinline__ void load_gather(float (&r)[kNJ], float const *__rest
     int const koff = (ic * p.H + ky) * p.W + kx;
     int const iy = g.iy0 + ky, ix = g.ix0 + kx;
     bool const ok = g.jv && (kg < p.K) && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
-    float const v = in[ok ? (g.base + koff) : 0]; // branch-free: masked lanes read element 0
-    r[q] = ok ? v : 0.f;
+    r[q] = bload1(in, ok ? ((g.base + koff) * 4) : kOOB); // masked lanes: out-of-range offset -> hardware returns 0
   }
 }
 __device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__restrict__ S, int tid) {
@@ -203,13 +204,13 @@ __device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__res
 #define GATHER_PARM
 #endif
 
-__device__ __forceinline__ void load_J(float (&rj)[kNJ], gemm_args_t const &p, int j0, int k0, int tid GATHER_PARM) {
+__device__ __forceinline__ void load_J(float (&rj)[kNJ], rsrc_t J, gemm_args_t const &p, int j0, int k0, int tid GATHER_PARM) {
 #if J_MODE == 2
-  load_gather(rj, p.J, g, p, k0, tid);
+  load_gather(rj, J, g, p, k0, tid);
 #elif J_MODE == 3 || J_MODE == 4
-  load_tile<J_MODE - 1, BJ, kNJ>(rj, p.J, p.ldJ, j0, p.Nj, k0, p.K, tid);
+  load_tile<J_MODE - 1, BJ, kNJ>(rj, J, p.ldJ, j0, p.Nj, k0, p.K, tid);
 #else
-  load_tile<J_MODE, BJ, kNJ>(rj, p.J, p.ldJ, j0, p.Nj, k0, p.K, tid);
+  load_tile<J_MODE, BJ, kNJ>(rj, J, p.ldJ, j0, p.Nj, k0, p.K, tid);
 #endif
 }
 __device__ __forceinline__ void store_J(float const (&rj)[kNJ], float *__restrict__ S, int tid) {
@@ -280,8 +281,9 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   int const nkt = nkt_all;
 #endif
 
-  load_tile<I_MODE, BI, kNI>(ri, p.I, p.ldI, i0, p.Mi, kt_begin * BK, p.K, tid);
-  load_J(rj, p, j0, kt_begin * BK, tid GATHER_ARG);
+  rsrc_t const rI = make_rsrc(p.I, p.I_bytes), rJ = make_rsrc(p.J, p.J_bytes); // built from kernel args only: provably wave-uniform
+  load_tile<I_MODE, BI, kNI>(ri, rI, p.ldI, i0, p.Mi, kt_begin * BK, p.K, tid);
+  load_J(rj, rJ, p, j0, kt_begin * BK, tid GATHER_ARG);
   store_tile<I_MODE, BI, kLDI, kNI>(ri, Is0, tid);
   store_J(rj, Js0, tid);
   __syncthreads();
@@ -294,8 +296,8 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     float const *const Ic = ((kt & 1) ? Is1 : Is0) + a_off;
     float const *const Jc = ((kt & 1) ? Js1 : Js0) + b_off;
     if (more) { // prefetch K-tile kt+1 into registers; the loads fly under the MFMAs below
-      load_tile<I_MODE, BI, kNI>(ri, p.I, p.ldI, i0, p.Mi, (kt_begin + kt + 1) * BK, p.K, tid);
-      load_J(rj, p, j0, (kt_begin + kt + 1) * BK, tid GATHER_ARG);
+      load_tile<I_MODE, BI, kNI>(ri, rI, p.ldI, i0, p.Mi, (kt_begin + kt + 1) * BK, p.K, tid);
+      load_J(rj, rJ, p, j0, (kt_begin + kt + 1) * BK, tid GATHER_ARG);
     }
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {

@@ -18,6 +18,7 @@ struct gemm_args_t { // must match kernels/gemm_conv_f32.hip
   int tiles_i, tiles_j;
   int splitk, kt_per;
   float *ws; long ws_slab;
+  unsigned I_bytes, J_bytes;
 };
 
 struct kernel_t { hipModule_t mod = nullptr; hipFunction_t func = nullptr; };
@@ -86,7 +87,7 @@ static int pick_bi(int Mi) { // minimise padded extent; ties -> larger tile
 
 // Tile / split-K heuristic.  Goal: >= ~1 four-wave workgroup per CU with the largest per-wave tile (64x64 feeds the
 // MFMA pipe with the fewest LDS reads); problems with too few output tiles get 32x32 per-wave tiles (64x64 workgroups)
-// and, if still too few, the K loop is split across workgroups (deterministic slab reduction afterwards).
+// (the K loop can additionally be split across workgroups, with a deterministic slab reduction, as an explicit tune).
 static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus) {
   tile_cfg_t c;
   int const bi = pick_bi(Mi);
@@ -103,10 +104,10 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus) {
     tile_cfg_t c2 = c; c2.BI = 64; c2.BJ = 64; c2.WI = 2; c2.WJ = 2;
     if (ntiles(c2) >= num_cus / 2 || flops < 2.7e8) return c2; // enough workgroups, or too small to matter (launch-bound)
   } else if (flops < 2.7e8) return c;
-  int const nkt = (K + c.BK - 1) / c.BK;
-  long s = (2l * num_cus + tiles - 1) / tiles;
-  s = std::min<long>(s, std::min<long>(32, nkt / 2));
-  if (s >= 2) c.SPLITK = (int)s;
+  // Splitting K would fill the chip for these shapes, but it re-associates the fp32 sum: the reference's golden digests
+  // (tolerance 2e-4 on max(1,|v|)) are only met robustly by the ascending-k chain, so SPLITK is an explicit tune
+  // ("...xMINWxS"), never the default.  Default: 64x64 workgroups of four 32x32 wave tiles.
+  if (Mi > 32) { tile_cfg_t c2 = c; c2.BI = 64; c2.BJ = 64; c2.WI = 2; c2.WJ = 2; return c2; }
   return c;
 }
 
@@ -201,6 +202,8 @@ void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t 
   gemm_args_t ga; memset(&ga, 0, sizeof(ga));
   ga.I = a; ga.J = b; ga.D = c; ga.bias = nullptr;
   ga.Mi = (int)M; ga.Nj = (int)N; ga.K = (int)K; ga.ldI = (int)M; ga.ldJ = (int)N; ga.ldD = (int)N;
+  if ((uint64_t)K * M * 4 > 0x80000000ull || (uint64_t)K * N * 4 > 0x80000000ull) unsup_err("hip_sgemm: operands larger than 2 GiB are not supported (32-bit buffer offsets)");
+  ga.I_bytes = (unsigned)((uint64_t)K * M * 4); ga.J_bytes = (unsigned)((uint64_t)K * N * 4);
   ga.tiles_i = (int)((M + cfg.BI - 1) / cfg.BI); ga.tiles_j = (int)((N + cfg.BJ - 1) / cfg.BJ);
   setup_splitk(impl, host, ga, cfg, (size_t)M * N);
   launch(host, k, ga, cfg);
@@ -217,10 +220,12 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
   gemm_args_t ga; memset(&ga, 0, sizeof(ga));
-  if (!p.ipconv && (long)g.B * g.C * g.H * g.W > 0x7fffffffl) unsup_err("hip_conv: input tensors of >= 2^31 elements are not supported by the gather");
+  uint64_t const in_bytes = (uint64_t)g.B * g.C * g.H * g.W * 4, f_bytes = (uint64_t)g.OC * Kt * 4;
+  if (in_bytes > 0x80000000ull || f_bytes > 0x80000000ull) unsup_err("hip_conv: in / filts larger than 2 GiB are not supported (32-bit buffer offsets)");
   ga.I = filts; ga.J = in; ga.D = out; ga.bias = biases;
   ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.ldI = (int)Kt; ga.ldJ = p.ipconv ? (int)Kt : 0; ga.ldD = g.OH * g.OW;
   ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
+  ga.I_bytes = (unsigned)f_bytes; ga.J_bytes = (unsigned)in_bytes;
   ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
   setup_splitk(impl, host, ga, cfg, (size_t)Nj * g.OC);
   launch(host, k, ga, cfg);

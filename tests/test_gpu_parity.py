@@ -21,11 +21,18 @@ from oracle import boda_oracle as bo
 MRD = 2e-4
 
 
+MRD_REASSOC = 2e-3  # the reference's bound for kernels that re-associate the sum (cuDNN Winograd, src/rtc_prof.cc:317-319)
+
+
 def _assert_matches_oracle(want, got, launch):
-    """bit-exact unless the launch split the K loop (then fp32 re-association: reference tolerance applies)."""
+    """Default kernels keep the reference's ascending-k fp32 fma chain: bit-exact (and hence < 2e-4).  The explicit
+    split-K tune re-associates the sum; it is held to the reference's own bound for re-associating kernels, 2e-3."""
     sd = SsdsDiff.of(want, got)
-    assert not sd.has_nan() and sd.mrd < MRD, sd.basic_str()
-    if "_s" not in launch["cfg"]:
+    assert not sd.has_nan()
+    if "_s" in launch["cfg"]:
+        assert sd.mrd < MRD_REASSOC, sd.basic_str()
+    else:
+        assert sd.mrd < MRD, sd.basic_str()
         assert np.array_equal(want, got), (launch["cfg"], sd.basic_str())
 
 

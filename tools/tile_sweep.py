@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Time one op (or a named workload) under several native-kernel tiles.  usage:
+   tile_sweep.py --workload alexnet|sgemm --ops 1,2 --tiles 128x128x16x2x2x2,128x128x32x2x2x2 [--iters 5]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from boda_amd.cnn_op import OpTune, add_codegen_annotations
+from boda_amd.ops_prof import OpsBackend, profile_rcg_call
+from boda_amd.rtc import make_rtc
+import bench
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="alexnet")
+ap.add_argument("--ops", default="")
+ap.add_argument("--tiles", default="")
+ap.add_argument("--iters", type=int, default=5)
+a = ap.parse_args()
+ops = bench.alexnet_b256_ops() if a.workload == "alexnet" else bench.sgemm_full_ops()
+sel = [int(x) for x in a.ops.split(",")] if a.ops else list(range(len(ops)))
+tiles = [""] + [t for t in a.tiles.split(",") if t]
+rtc = make_rtc(); rtc.init(); be = OpsBackend(rtc)
+for i in sel:
+    op = ops[i]
+    for t in tiles:
+        try:
+            anno = add_codegen_annotations(op, OpTune(hip_tile=t))
+            _, prc = profile_rcg_call(be, anno, 5, run_iter=a.iters, want_outs=False, tile=t)
+            best = min(prc.all_secs[1:]) if len(prc.all_secs) > 1 else prc.all_secs[0]
+            print(f"op {i:2d} tile {t or 'auto':>24s} [{prc.launch['cfg']:>22s}] grid {prc.launch['grid']:6d}  {best*1e3:9.4f} ms  {op.flops()/best/1e12:7.2f} TF/s", flush=True)
+        except Exception as e:
+            print(f"op {i:2d} tile {t:>24s} ERR {type(e).__name__}: {str(e)[:100]}", flush=True)
