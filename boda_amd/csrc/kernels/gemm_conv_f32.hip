@@ -28,8 +28,8 @@
 //     selects on the loaded value, 32-bit offsets only, so the loads stay in flight until the LDS write after the MFMAs.
 //   * each wave owns a (TI*32) x (TJ*32) sub-tile = TI*TJ accumulators of 16 VGPRs; A/B operands are single
 //     conflict-free ds_read_b32 (lane l reads row 2*kk+(l>>5), column (l&31)).
-//   * the im2col gather assigns each thread one fixed output position (column j) and wave-uniform k rows, so the
-//     (in_chan,ky,kx) decode runs on the scalar unit and each element costs ~9 VALU ops.
+//   * the im2col gather assigns each thread one fixed output position (column j) and wave-uniform k rows; the
+//     (in_chan,ky,kx) decode is a host-built table read through the scalar cache, so an element costs ~6 VALU ops.
 //   * workgroup ids are remapped XCD-aware (block b runs on XCD b%8): each XCD gets a contiguous band of
 //     tiles, walked in groups of GROUP_I tiles along i so neighbouring workgroups share I / J panels in their L2.
 //
@@ -70,6 +70,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SPLITK
 #define SPLITK 0
 #endif
+#ifndef SETPRIO
+#define SETPRIO 0
+#endif
 
 struct gemm_args_t {
   float const *I; float const *J; float *D; float const *bias;
@@ -80,6 +83,8 @@ struct gemm_args_t {
   int splitk, kt_per;     // SPLITK: number of K slices, K-tiles per slice
   float *ws; long ws_slab; // SPLITK: partial-sum slabs, ws_slab elements apart
   unsigned I_bytes, J_bytes; // sizes of the I / J tensors (buffer-descriptor num_records; host guarantees <= 2^31)
+  int const *ktab; int ktab_n; // J_MODE 2: per-k gather tables, three arrays of ktab_n ints: element offset of (in_chan,ky,kx)
+                               // inside one image | ky | kx ; rows k >= K carry ky = 2^30 (fail the row-range test)
 };
 
 #ifndef REDUCE_ONLY
@@ -173,29 +178,38 @@ __device__ __forceinline__ void store_tile(float const (&r)[NR], float *__restri
 }
 
 #if J_MODE == 2
-// per-thread constants of the im2col gather: this thread always serves output position (pel) column jj.
+// im2col gather.  Each thread serves one fixed output position (column jj of the tile); each wave serves kNJ consecutive
+// k rows per K step.  Everything that depends only on k -- the (in_chan,ky,kx) decode and the element offset inside an
+// image -- comes from a small host-built table read through the scalar cache (one s_load per wave per K step), so a
+// gathered element costs ~6 VALU ops: 2 adds + 2 unsigned compares (halo / zero padding), offset add, select.
 // Offsets are 32-bit (the host guarantees the input tensor is <= 2^31 bytes).
-struct gather_t { int base; int iy0, ix0; bool jv; };
+struct gather_t { int base; int iy0, ix0; };
 static_assert(BJ % 64 == 0 && kNT % BJ == 0, "gather: a wave must sit inside one k row (BJ multiple of 64, BJ <= threads)");
-constexpr int kRowsPerPass = kNT / BJ;
+static_assert(kNJ % 4 == 0, "gather: rows per wave must be a multiple of 4 (vector scalar loads)");
 __device__ __forceinline__ void load_gather(float (&r)[kNJ], rsrc_t in, gather_t const &g, gemm_args_t const &p, int k0, int tid) {
-  constexpr int KHW = KH * KW;
-  // the k row is wave-uniform: decode (in_chan, ky, kx) once per wave on the scalar unit
-  int const row0 = __builtin_amdgcn_readfirstlane(tid / BJ);
+  int const row0 = __builtin_amdgcn_readfirstlane(tid / BJ); // wave-uniform
+  int const kb = k0 + row0 * kNJ;                           // multiple of 4: 16-B aligned table rows
+  // constant address space + wave-uniform address => s_load_dwordx4 through the scalar cache (the table is never written by a kernel)
+  typedef int4 const __attribute__((address_space(4))) *ctab_t;
+  ctab_t const t_off = (ctab_t)(p.ktab + kb), t_ky = (ctab_t)(p.ktab + p.ktab_n + kb), t_kx = (ctab_t)(p.ktab + 2 * p.ktab_n + kb);
 #pragma unroll
-  for (int q = 0; q < kNJ; ++q) {
-    int const kg = k0 + row0 + q * kRowsPerPass;
-    int const ic = kg / KHW, rem = kg - ic * KHW, ky = rem / KW, kx = rem - ky * KW;
-    int const koff = (ic * p.H + ky) * p.W + kx;
-    int const iy = g.iy0 + ky, ix = g.ix0 + kx;
-    bool const ok = g.jv && (kg < p.K) && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
-    r[q] = bload1(in, ok ? ((g.base + koff) * 4) : kOOB); // masked lanes: out-of-range offset -> hardware returns 0
+  for (int q4 = 0; q4 < kNJ / 4; ++q4) {
+    int4 const ko = t_off[q4], ky = t_ky[q4], kx = t_kx[q4]; // s_load_dwordx4 each (scalar cache)
+    int const kov[4] = {ko.x, ko.y, ko.z, ko.w}, kyv[4] = {ky.x, ky.y, ky.z, ky.w}, kxv[4] = {kx.x, kx.y, kx.z, kx.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int const iy = g.iy0 + kyv[e], ix = g.ix0 + kxv[e];
+      int off = (g.base + kov[e]) * 4;
+      asm volatile("" : "+v"(off)); // keep the offset unconditional: the select below must stay a v_cndmask, not a branch
+      bool const ok = ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+      r[q4 * 4 + e] = bload1(in, ok ? off : kOOB); // masked lanes: out-of-range offset -> hardware returns 0
+    }
   }
 }
 __device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__restrict__ S, int tid) {
   int const row0 = tid / BJ, jj = tid % BJ;
 #pragma unroll
-  for (int q = 0; q < kNJ; ++q) S[(row0 + q * kRowsPerPass) * kLDJ + jj] = r[q];
+  for (int q = 0; q < kNJ; ++q) S[(row0 * kNJ + q) * kLDJ + jj] = r[q];
 }
 #define GATHER_ARG , g
 #define GATHER_PARM , gather_t const &g
@@ -256,10 +270,10 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   {
     int const OHW = p.OH * p.OW;
     int const jg = j0 + (tid % BJ);
-    g.jv = jg < p.Nj;
     int const img = jg / OHW, pel = jg - img * OHW, oy = pel / p.OW, ox = pel - oy * p.OW;
-    g.iy0 = oy * SY - PY; g.ix0 = ox * SX - PX;
-    g.base = (img * p.C * p.H + g.iy0) * p.W + g.ix0;
+    g.iy0 = (jg < p.Nj) ? (oy * SY - PY) : (1 << 29); // columns past the end fail the row-range test for every k
+    g.ix0 = ox * SX - PX;
+    g.base = (img * p.C * p.H + (oy * SY - PY)) * p.W + g.ix0;
   }
 #endif
 
@@ -299,6 +313,9 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
       load_tile<I_MODE, BI, kNI>(ri, rI, p.ldI, i0, p.Mi, (kt_begin + kt + 1) * BK, p.K, tid);
       load_J(rj, rJ, p, j0, (kt_begin + kt + 1) * BK, tid GATHER_ARG);
     }
+#if SETPRIO
+    __builtin_amdgcn_s_setprio(1); // co-resident waves of other workgroups are in their load phase: favour the MFMA issuer
+#endif
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       float a[kTI], b[kTJ];
@@ -311,6 +328,9 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #pragma unroll
         for (int tb = 0; tb < kTJ; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
     }
+#if SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (more) {
       store_tile<I_MODE, BI, kLDI, kNI>(ri, (kt & 1) ? Is0 : Is1, tid);
       store_J(rj, (kt & 1) ? Js0 : Js1, tid);

@@ -19,6 +19,7 @@ struct gemm_args_t { // must match kernels/gemm_conv_f32.hip
   int splitk, kt_per;
   float *ws; long ws_slab;
   unsigned I_bytes, J_bytes;
+  void const *ktab; int ktab_n;
 };
 
 struct kernel_t { hipModule_t mod = nullptr; hipFunction_t func = nullptr; };
@@ -27,6 +28,7 @@ struct native_kernels_t::impl_t {
   std::map<string, kernel_t> kernels; // key = option string
   std::map<string, string> tune;
   void *ws = nullptr; size_t ws_bytes = 0; // split-K partial-sum slabs (grow-only scratch, like the reference's cudnn scratch var)
+  std::map<string, void *> ktabs;           // im2col gather tables, one per (C,H,W,KH,KW) (device memory)
 };
 
 native_kernels_t::native_kernels_t(native_host_t *host_) : impl(new impl_t), host(host_) {
@@ -36,6 +38,7 @@ native_kernels_t::native_kernels_t(native_host_t *host_) : impl(new impl_t), hos
 native_kernels_t::~native_kernels_t() {
   for (auto &kv : impl->kernels) { if (kv.second.mod) (void)hipModuleUnload(kv.second.mod); }
   if (impl->ws) (void)hipFree(impl->ws);
+  for (auto &kv : impl->ktabs) (void)hipFree(kv.second);
   delete impl;
 }
 uint32_t native_kernels_t::num_specialisations() const { return (uint32_t)impl->kernels.size(); }
@@ -112,6 +115,12 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus) {
 }
 
 static vect_string cfg_defs(tile_cfg_t const &c) {
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { // experiment hook: extra -D options for the native kernels
+    vect_string r = {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI),
+                     "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW)};
+    std::istringstream is(e); string tok; while (is >> tok) r.push_back(tok);
+    return r;
+  }
   return {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI),
           "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW)};
 }
@@ -190,6 +199,29 @@ static void reduce_splitk(native_kernels_t::impl_t *impl, native_host_t *host, g
   hip_err_chk(hipModuleLaunchKernel(k.func, grid, 1, 1, 256, 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(splitk_reduce)");
 }
 
+// per-k tables of the im2col gather (three arrays of n ints): offset of (in_chan,ky,kx) inside one image | ky | kx.
+// Rows k >= K carry ky = 2^30 so that they fail the kernel's row-range test (zero contribution); n is padded so that any
+// K-tile read stays inside the table.
+struct ktab_t { void *d; int n; };
+static ktab_t get_ktab(native_kernels_t::impl_t *impl, native_host_t *host, conv_geom_t const &g) {
+  string const key = std::to_string(g.C) + "," + std::to_string(g.H) + "," + std::to_string(g.W) + "," + std::to_string(g.KH) + "," + std::to_string(g.KW);
+  long const K = (long)g.C * g.KH * g.KW, n = ((K + 255) / 256 + 1) * 256;
+  auto it = impl->ktabs.find(key);
+  if (it != impl->ktabs.end()) return ktab_t{it->second, (int)n};
+  std::vector<int> h((size_t)n * 3);
+  for (long k = 0; k < n; ++k) {
+    if (k < K) { long const ic = k / (g.KH * g.KW), rem = k % (g.KH * g.KW), ky = rem / g.KW, kx = rem % g.KW;
+      h[k] = (int)((ic * g.H + ky) * g.W + kx); h[n + k] = (int)ky; h[2 * n + k] = (int)kx; }
+    else { h[k] = 0; h[n + k] = 1 << 30; h[2 * n + k] = 0; }
+  }
+  void *d = nullptr;
+  hip_err_chk(hipMalloc(&d, h.size() * sizeof(int)), "hipMalloc(ktab)");
+  hip_err_chk(hipMemcpyAsync(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, host->nh_stream()), "hipMemcpyAsync(ktab)");
+  hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize");
+  impl->ktabs.emplace(key, d);
+  return ktab_t{d, (int)n};
+}
+
 static string tune_of(native_kernels_t::impl_t *impl, char const *key) { auto t = impl->tune.find(key); return (t == impl->tune.end()) ? string() : t->second; }
 
 void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K) {
@@ -226,6 +258,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.ldI = (int)Kt; ga.ldJ = p.ipconv ? (int)Kt : 0; ga.ldD = g.OH * g.OW;
   ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
   ga.I_bytes = (unsigned)f_bytes; ga.J_bytes = (unsigned)in_bytes;
+  if (!p.ipconv) { ktab_t const kt = get_ktab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
   ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
   setup_splitk(impl, host, ga, cfg, (size_t)Nj * g.OC);
   launch(host, k, ga, cfg);
