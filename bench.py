@@ -87,10 +87,17 @@ def main() -> int:
         if world == 1 and a.gpus > 1:
             print(f"bench.py: --gpus {a.gpus} needs torch.distributed.run --nproc-per-node {a.gpus}", file=sys.stderr); return 2
     dist = None
+    # test hook only: BENCH_SAME_GPU=1 runs all ranks on GPU 0 over gloo (exercises the N>1 code path on a 1-GPU box)
+    same_gpu = os.environ.get("BENCH_SAME_GPU") == "1"
+    if same_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
     torch.cuda.set_device(local_rank)
 
     from boda_amd import gen_data as gd
@@ -101,7 +108,7 @@ def main() -> int:
     rtc.init()
     rtc.compile(gd.func_infos())
     ops = sgemm_full_ops() if a.workload == "sgemm-ops-full" else alexnet_b256_ops()
-    weight_args = {"sgemm": ("b",), "Convolution": ("filts", "biases")}
+    from boda_amd.shard import WEIGHT_ARGS as weight_args, BATCH_DIM
 
     calls = []  # (op, RtcFuncCall)
     for i, op in enumerate(ops):
@@ -116,7 +123,14 @@ def main() -> int:
             rtc.create_var_with_dims(vn, anno.get_dims(an))
             am[an] = RtcArg.var(vn)
             if io == "IN":
-                rtc.run(gd.gen_call(op.get_type(), an, vn, anno.get_dims(an), 5, 0.0))
+                # rank r owns batch chunk r of a world-times-larger global problem: generate that slice of the global
+                # pattern; weights are generated on rank 0 only and broadcast below (other ranks start from zeros)
+                dn = BATCH_DIM[op.get_type()][0]
+                is_w = an in weight_args[op.get_type()]
+                if is_w and rank != 0:
+                    continue
+                per = anno.get_dims(an).dsz(dn) if (not is_w and anno.get_dims(an).has(dn)) else 0
+                rtc.run(gd.gen_call(op.get_type(), an, vn, anno.get_dims(an), 5, 0.0, shard_off=rank * per, shard_glob=world * per))
         calls.append((op, RtcFuncCall(gen_fn, am)))
     rtc.finish_and_sync()
     if dist is not None:  # one-time weight broadcast from rank 0 over RCCL/xGMI (off the timed path)

@@ -28,15 +28,18 @@ CUCL_DEVICE float det_hash_rand( uint32_t const rv ) {
 
 SRC = _UTIL + """
 // a: K:M
-CUCL_GLOBAL_KERNEL void gen_data_sgemm_a( GASQ float * const a, uint32_t const mode, float const vi, uint32_t const K, uint32_t const M ) {
+// m_off / M_glob: this var holds columns [m_off, m_off+M) of a global K:M_glob tensor (batch-axis shard); unsharded: 0 / M
+CUCL_GLOBAL_KERNEL void gen_data_sgemm_a( GASQ float * const a, uint32_t const mode, float const vi, uint32_t const K, uint32_t const M,
+                                          uint32_t const m_off, uint32_t const M_glob ) {
   uint32_t fin_mode = mode; if( fin_mode >= 100 ) { fin_mode = fin_mode / 100; }
   if( GLOB_ID_1D >= K*M ) { return; }
-  uint32_t const k = GLOB_ID_1D / M; uint32_t const m = GLOB_ID_1D % M;
+  uint32_t const k = GLOB_ID_1D / M; uint32_t const m = GLOB_ID_1D % M + m_off;
+  uint32_t const gix = k * M_glob + m; // flat index in the global tensor
   float val = vi;
   if( fin_mode == 2 ) { val += m; }
   if( fin_mode == 3 ) { val += k; }
-  else if( fin_mode == 4 ) { if( (m==M/2) && (k==K/2) ) { val += 1.0f; } }
-  else if( fin_mode == 5 ) { val += det_hash_rand( GLOB_ID_1D + 12738732 ); }
+  else if( fin_mode == 4 ) { if( (m==M_glob/2) && (k==K/2) ) { val += 1.0f; } }
+  else if( fin_mode == 5 ) { val += det_hash_rand( gix + 12738732 ); }
   else if( fin_mode == 6 ) { val += m*1000 + k; }
   a[GLOB_ID_1D] = val;
 }
@@ -53,15 +56,16 @@ CUCL_GLOBAL_KERNEL void gen_data_sgemm_b( GASQ float * const b, uint32_t const m
   b[GLOB_ID_1D] = val;
 }
 // 4-D tensors ?:?:y:x (Convolution in / filts) and the 1-D biases; hc = per-tensor hash constant
+// ix_off: flat-index offset of this var inside the global tensor (img-axis shard of `in`: img0*chan*y*x); unsharded: 0
 CUCL_GLOBAL_KERNEL void gen_data_Convolution_4d( GASQ float * const t, uint32_t const mode, float const vi, uint32_t const sz,
-                                                 uint32_t const Y, uint32_t const X, uint32_t const hc ) {
+                                                 uint32_t const Y, uint32_t const X, uint32_t const hc, uint32_t const ix_off ) {
   if( GLOB_ID_1D >= sz ) { return; }
   uint32_t const x = GLOB_ID_1D % X; uint32_t const y = ( GLOB_ID_1D / X ) % Y;
   float val = vi;
   if( mode == 2 ) { val += x; }
   if( mode == 3 ) { val += y; }
   else if( mode == 4 ) { if( (x==X/2) && (y==Y/2) ) { val += 1.0f; } }
-  else if( mode == 5 ) { val += det_hash_rand( GLOB_ID_1D + hc ); }
+  else if( mode == 5 ) { val += det_hash_rand( GLOB_ID_1D + ix_off + hc ); }
   t[GLOB_ID_1D] = val;
 }
 CUCL_GLOBAL_KERNEL void gen_data_Convolution_biases( GASQ float * const biases, uint32_t const mode, float const vi, uint32_t const sz ) {
@@ -73,9 +77,9 @@ CUCL_GLOBAL_KERNEL void gen_data_Convolution_biases( GASQ float * const biases, 
 """
 
 FUNCS: Dict[str, List[str]] = {
-    "gen_data_sgemm_a": ["a", "mode", "vi", "K", "M"],
+    "gen_data_sgemm_a": ["a", "mode", "vi", "K", "M", "m_off", "M_glob"],
     "gen_data_sgemm_b": ["b", "mode", "vi", "K", "N"],
-    "gen_data_Convolution_4d": ["t", "mode", "vi", "sz", "Y", "X", "hc"],
+    "gen_data_Convolution_4d": ["t", "mode", "vi", "sz", "Y", "X", "hc", "ix_off"],
     "gen_data_Convolution_biases": ["biases", "mode", "vi", "sz"],
 }
 TPB = 256
@@ -90,18 +94,23 @@ def func_infos() -> List[RtcFuncInfo]:
     return out
 
 
-def gen_call(op_type: str, arg: str, vn: str, dims: Dims, mode: int, vi: float) -> RtcFuncCall:
-    """The call that fills var `vn` (dims `dims`) with the reference's test pattern for (op_type, arg)."""
+def gen_call(op_type: str, arg: str, vn: str, dims: Dims, mode: int, vi: float, shard_off: int = 0, shard_glob: int = 0) -> RtcFuncCall:
+    """The call that fills var `vn` (dims `dims`) with the reference's test pattern for (op_type, arg).
+    Batch-axis shards: for sgemm `a`, shard_off/shard_glob = first global column m and global M; for Convolution `in`,
+    shard_off = first global image (the var then holds the matching slice of the global tensor's pattern)."""
     n = dims.dims_prod()
     u32 = lambda v: RtcArg.scalar(v, "uint32_t")
     base = {"mode": u32(mode), "vi": RtcArg.scalar(vi, "float")}
     if op_type == "sgemm" and arg in ("a", "b"):
         other = "M" if arg == "a" else "N"
         am = {arg: RtcArg.var(vn), **base, "K": u32(dims.dsz("K")), other: u32(dims.dsz(other))}
+        if arg == "a":
+            am["m_off"] = u32(shard_off); am["M_glob"] = u32(shard_glob or dims.dsz("M"))
         fn = "gen_data_sgemm_" + arg
     elif op_type == "Convolution" and arg in ("in", "filts"):
         am = {"t": RtcArg.var(vn), **base, "sz": u32(n), "Y": u32(dims.dsz("y")), "X": u32(dims.dsz("x")),
-              "hc": u32(HASH_CONSTS[(op_type, arg)])}
+              "hc": u32(HASH_CONSTS[(op_type, arg)]),
+              "ix_off": u32((shard_off * (n // dims.dsz("img"))) if arg == "in" else 0)}
         fn = "gen_data_Convolution_4d"
     elif op_type == "Convolution" and arg == "biases":
         am = {"biases": RtcArg.var(vn), **base, "sz": u32(n)}

@@ -162,6 +162,17 @@ def test_gen_data_device_equals_oracle(be):
             elif an == "filts": want = bo.gen_conv_filts(5, 3, 3, 3, mode, 0.25)
             else: want = bo.gen_conv_biases(77, mode, 0.25)
             assert np.array_equal(got.reshape(-1), want.reshape(-1)), (t, an, mode)
+    # batch-axis shards generate the matching slice of the global pattern (multi-GPU path, boda_amd/shard.py)
+    d = Dims.make("float", K=37, M=20)
+    rtc.create_var_with_dims("g", d)
+    rtc.run(gd.gen_call("sgemm", "a", "g", d, 5, 0.0, shard_off=32, shard_glob=52))
+    assert np.array_equal(rtc.copy_var_to_nda("g"), bo.gen_sgemm_a(37, 52, 5)[:, 32:52])
+    rtc.release_var("g")
+    d = Dims.make("float", img=2, chan=3, y=9, x=7)
+    rtc.create_var_with_dims("g", d)
+    rtc.run(gd.gen_call("Convolution", "in", "g", d, 5, 0.0, shard_off=3))
+    assert np.array_equal(rtc.copy_var_to_nda("g"), bo.gen_conv_in(5, 3, 9, 7, 5)[3:5])
+    rtc.release_var("g")
     rtc.release_per_call_id_data()
 
 
