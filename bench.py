@@ -26,10 +26,17 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma
 PEAK_HBM_GBS = 8000.0
 
 
-def alexnet_b256_ops(batch: int = 256):
+ALEXNET_LAYERS = [  # alexnet_ng_conv: (in_chan, in_hw, out_chan, k, stride, pad) -- conv1..5, fc6..8
+    (3, 227, 96, 11, 4, 0), (96, 27, 256, 5, 1, 2), (256, 13, 384, 3, 1, 1), (384, 13, 384, 3, 1, 1),
+    (384, 13, 256, 3, 1, 1), (256, 6, 4096, 6, 1, 0), (4096, 1, 4096, 1, 1, 0), (4096, 1, 1000, 1, 1, 0)]
+NIN_LAYERS = [  # nin_imagenet at 227x227: conv1 cccp1 cccp2 conv2 cccp3 cccp4 conv3 cccp5 cccp6 conv4 cccp7 cccp8
+    (3, 227, 96, 11, 4, 0), (96, 55, 96, 1, 1, 0), (96, 55, 96, 1, 1, 0), (96, 27, 256, 5, 1, 2), (256, 27, 256, 1, 1, 0),
+    (256, 27, 256, 1, 1, 0), (256, 13, 384, 3, 1, 1), (384, 13, 384, 1, 1, 0), (384, 13, 384, 1, 1, 0), (384, 6, 1024, 3, 1, 1),
+    (1024, 6, 1024, 1, 1, 0), (1024, 6, 1000, 1, 1, 0)]
+
+
+def conv_ops(layers, batch: int):
     from boda_amd.op import parse_op
-    layers = [(3, 227, 96, 11, 4, 0), (96, 27, 256, 5, 1, 2), (256, 13, 384, 3, 1, 1), (384, 13, 384, 3, 1, 1),
-              (384, 13, 256, 3, 1, 1), (256, 6, 4096, 6, 1, 0), (4096, 1, 4096, 1, 1, 0), (4096, 1, 1000, 1, 1, 0)]
     ops = []
     for C, H, OC, K, S, P in layers:
         O = (H + 2 * P - K) // S + 1
@@ -37,6 +44,14 @@ def alexnet_b256_ops(batch: int = 256):
                             f"in=(dims=(img={batch},chan={C},y={H},x={H})),in_pad=(tn=none,dims=(y={P},x={P})),kern_sz=(tn=none,dims=(y={K},x={K})),"
                             f"out=(dims=(img={batch},chan={OC},y={O},x={O})),out_chans=(tn=uint32_t,v={OC}),stride=(tn=none,dims=(y={S},x={S}))))"))
     return ops
+
+
+def alexnet_b256_ops(batch: int = 256):
+    return conv_ops(ALEXNET_LAYERS, batch)
+
+
+def nin_ops(batch: int = 256):
+    return conv_ops(NIN_LAYERS, batch)
 
 
 def sgemm_full_ops():
@@ -59,15 +74,16 @@ def cpu_baseline(workload: str, budget_s: float = 12.0) -> dict:
         return {"value": flops / t_tot / 1e12, "unit": "TFLOP/s", "cores": bo.num_threads(), "kind": "port",
                 "sample": f"oracle/boda_oracle.c bo_sgemm (OpenMP, fp32 fmaf) on sgemm-ops-full sizes {sizes}, {t_tot:.1f} s"}
     flops, t_tot, batch = 0.0, 0.0, 8
+    layers = ALEXNET_LAYERS if workload == "alexnet" else NIN_LAYERS
     while t_tot < budget_s and batch <= 256:
-        for op in alexnet_b256_ops(batch=batch):
+        for op in conv_ops(layers, batch):
             g = op.conv_geom()
             i = bo.gen_conv_in(g["B"], g["C"], g["H"], g["W"]); f = bo.gen_conv_filts(g["OC"], g["C"], g["KH"], g["KW"]); b = bo.gen_conv_biases(g["OC"])
             t = time.perf_counter(); bo.conv_fwd(i, f, b, (g["SY"], g["SX"]), (g["PY"], g["PX"]), True); dt = time.perf_counter() - t
             flops += op.flops(); t_tot += dt
         batch *= 2
     return {"value": flops / t_tot / 1e12, "unit": "TFLOP/s", "cores": bo.num_threads(), "kind": "port",
-            "sample": f"oracle/boda_oracle.c bo_conv_fwd (OpenMP) on the 8 AlexNet-ng conv layers at batches 8..{batch//2}, {t_tot:.1f} s"}
+            "sample": f"oracle/boda_oracle.c bo_conv_fwd (OpenMP) on the {workload} conv layers at batches 8..{batch//2}, {t_tot:.1f} s"}
 
 
 def main() -> int:
@@ -75,7 +91,8 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sgemm-ops-full", choices=["sgemm-ops-full", "alexnet"])
+    ap.add_argument("--workload", default="sgemm-ops-full", choices=["sgemm-ops-full", "alexnet", "nin"])
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch of the conv workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-op", action="store_true", help="also print a per-op table to stderr")
     a = ap.parse_args()
@@ -107,7 +124,7 @@ def main() -> int:
     rtc = make_rtc("(be=hip)", local_rank)
     rtc.init()
     rtc.compile(gd.func_infos())
-    ops = sgemm_full_ops() if a.workload == "sgemm-ops-full" else alexnet_b256_ops()
+    ops = {"sgemm-ops-full": sgemm_full_ops, "alexnet": lambda: alexnet_b256_ops(a.batch), "nin": lambda: nin_ops(a.batch)}[a.workload]()
     from boda_amd.shard import WEIGHT_ARGS as weight_args, BATCH_DIM
 
     calls = []  # (op, RtcFuncCall)
@@ -183,8 +200,9 @@ def main() -> int:
             "per_gpu": round(value / world, 3), "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (reference gen_data mode 5, generated on device)",
-            "config": {"workload": ("test/sgemm-ops-full.txt: 17 fp32 sgemms 64^3..12288^3 via hip_sgemm" if a.workload == "sgemm-ops-full"
-                                    else "alexnet_ng_conv per-layer conv-ops, batch 256, via hip_conv"),
+            "config": {"workload": {"sgemm-ops-full": "test/sgemm-ops-full.txt: 17 fp32 sgemms 64^3..12288^3 via hip_sgemm",
+                                    "alexnet": f"alexnet_ng_conv per-layer conv-ops, batch {a.batch}/GPU, via hip_conv",
+                                    "nin": f"nin_imagenet per-layer conv-ops, batch {a.batch}/GPU, via hip_conv"}[a.workload],
                        "ops": len(calls), "tflop_per_step": round(step_flops / 1e12, 4), "parallelism": f"batch-shard x{world}, weights broadcast once (RCCL)",
                        "device": rtc.get_plat_tag(), "arch": info["arch"], "cus": info["num_cus"]},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -33,9 +33,11 @@
 //   * workgroup ids are remapped XCD-aware (block b runs on XCD b%8): each XCD gets a contiguous band of
 //     tiles, walked in groups of GROUP_I tiles along i so neighbouring workgroups share I / J panels in their L2.
 //
-// Compile-time parameters (-D):  KNAME BI BJ BK WI WJ MINW I_MODE J_MODE EPI [KH KW SY SX PY PX RELU SPLITK]
+// Compile-time parameters (-D):  KNAME BI BJ BK WI WJ MINW I_MODE J_MODE EPI [KH KW SY SX PY PX RELU SPLITK MT]
 //   I_MODE 0 k-major float4 | 1 k-major scalar | 2 i-major (k contiguous) float4 | 3 i-major scalar
 //   J_MODE 0 k-major float4 | 1 k-major scalar | 2 convolution gather from NCHW | 3 j-major (k contiguous) float4 | 4 j-major scalar
+//          5 1x1 convolution without padding, any stride (the reference's k1conv case, src/cnn_op.cc:51-60): k = in_chan, so
+//            J(k,j) = in[base_j + k*H*W] -- one add per gathered element, no table, no halo tests
 //          (3/4: convolutions whose output is 1x1 with no padding -- the reference's "ipconv" case, src/cnn_op.cc:49-50 --
 //           where the im2col row of image j is simply the contiguous image: J(k,j) = in[j*K + k])
 //   EPI    0 plain store    | 1 + bias[i], optional ReLU, NCHW scatter of j=(img,pel)
@@ -73,6 +75,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SETPRIO
 #define SETPRIO 0
 #endif
+#ifndef MT
+#define MT 32 // MFMA tile: 32 -> v_mfma_f32_32x32x2_f32 (default), 16 -> v_mfma_f32_16x16x4_f32 (4x more, smaller wave tiles for
+#endif        // shapes with too few 32x32 tiles to give every SIMD a wave; same fp32 rate, same ascending-k fma chain)
 
 struct gemm_args_t {
   float const *I; float const *J; float *D; float const *bias;
@@ -90,14 +95,22 @@ struct gemm_args_t {
 #ifndef REDUCE_ONLY
 namespace {
 constexpr int kNT = WI * WJ * 64;
-constexpr int kTI = BI / (WI * 32);
-constexpr int kTJ = BJ / (WJ * 32);
+constexpr int kTI = BI / (WI * MT);
+constexpr int kTJ = BJ / (WJ * MT);
+constexpr int kKS = (MT == 32) ? 2 : 4;   // k consumed per MFMA
+constexpr int kNA = (MT == 32) ? 16 : 4;  // accumulator registers per MFMA tile
+static_assert(MT == 32 || MT == 16, "MT must be 32 or 16");
+#if MT == 32
+typedef f32x16 acc_t;
+#else
+typedef f32x4 acc_t;
+#endif
 constexpr int kPAD = 4;
 constexpr int kLDI = BI + kPAD;
 constexpr int kLDJ = BJ + kPAD;
 constexpr int kITile = BK * kLDI;
 constexpr int kJTile = BK * kLDJ;
-static_assert(BI % (WI * 32) == 0 && BJ % (WJ * 32) == 0, "tile must be a multiple of 32 per wave");
+static_assert(BI % (WI * MT) == 0 && BJ % (WJ * MT) == 0, "tile must be a multiple of the MFMA tile per wave");
 static_assert(BK % 4 == 0, "BK must be a multiple of 4");
 static_assert((BK * BI) % (4 * kNT) == 0 && (BK * BJ) % (4 * kNT) == 0, "tile must split evenly over the threads");
 constexpr int kNI = BK * BI / kNT; // staged floats per thread, operand I
@@ -177,7 +190,29 @@ __device__ __forceinline__ void store_tile(float const (&r)[NR], float *__restri
   }
 }
 
-#if J_MODE == 2
+#if J_MODE == 5
+// 1x1 / pad 0 convolution: thread = one output position, wave = kNJ consecutive input channels per K step.
+struct gather_t { int base4; }; // byte offset of (img, chan 0, oy*SY, ox*SX); columns past the end: 0x80000000 (out of range for every k)
+static_assert(BJ % 64 == 0 && kNT % BJ == 0, "gather: a wave must sit inside one k row (BJ multiple of 64, BJ <= threads)");
+constexpr int kKTail = 0x7ffffff0; // scalar offset for k >= K: base4 + kKTail >= num_records (tensors are < 2^31 - 16 bytes), no 32-bit wrap
+__device__ __forceinline__ void load_gather(float (&r)[kNJ], rsrc_t in, gather_t const &g, gemm_args_t const &p, int k0, int tid) {
+  int const row0 = __builtin_amdgcn_readfirstlane(tid / BJ);
+  int const kb = k0 + row0 * kNJ, hw4 = p.H * p.W * 4;
+#pragma unroll
+  for (int q = 0; q < kNJ; ++q) {
+    int const kg = kb + q;
+    int const soff = (kg < p.K) ? kg * hw4 : kKTail; // scalar unit
+    r[q] = bload1(in, g.base4 + soff);
+  }
+}
+__device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__restrict__ S, int tid) {
+  int const row0 = tid / BJ, jj = tid % BJ;
+#pragma unroll
+  for (int q = 0; q < kNJ; ++q) S[(row0 * kNJ + q) * kLDJ + jj] = r[q];
+}
+#define GATHER_ARG , g
+#define GATHER_PARM , gather_t const &g
+#elif J_MODE == 2
 // im2col gather.  Each thread serves one fixed output position (column jj of the tile); each wave serves kNJ consecutive
 // k rows per K step.  Everything that depends only on k -- the (in_chan,ky,kx) decode and the element offset inside an
 // image -- comes from a small host-built table read through the scalar cache (one s_load per wave per K step), so a
@@ -219,7 +254,7 @@ __device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__res
 #endif
 
 __device__ __forceinline__ void load_J(float (&rj)[kNJ], rsrc_t J, gemm_args_t const &p, int j0, int k0, int tid GATHER_PARM) {
-#if J_MODE == 2
+#if J_MODE == 2 || J_MODE == 5
   load_gather(rj, J, g, p, k0, tid);
 #elif J_MODE == 3 || J_MODE == 4
   load_tile<J_MODE - 1, BJ, kNJ>(rj, J, p.ldJ, j0, p.Nj, k0, p.K, tid);
@@ -228,7 +263,7 @@ __device__ __forceinline__ void load_J(float (&rj)[kNJ], rsrc_t J, gemm_args_t c
 #endif
 }
 __device__ __forceinline__ void store_J(float const (&rj)[kNJ], float *__restrict__ S, int tid) {
-#if J_MODE == 2
+#if J_MODE == 2 || J_MODE == 5
   store_gather(rj, S, tid);
 #elif J_MODE == 3 || J_MODE == 4
   store_tile<J_MODE - 1, BJ, kLDJ, kNJ>(rj, S, tid);
@@ -265,7 +300,15 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   float *const Is0 = smem, *const Is1 = smem + kITile;
   float *const Js0 = smem + 2 * kITile, *const Js1 = smem + 2 * kITile + kJTile;
 
-#if J_MODE == 2
+#if J_MODE == 5
+  gather_t g;
+  {
+    int const OHW = p.OH * p.OW;
+    int const jg = j0 + (tid % BJ);
+    int const img = jg / OHW, pel = jg - img * OHW, oy = pel / p.OW, ox = pel - oy * p.OW;
+    g.base4 = (jg < p.Nj) ? (((img * p.C * p.H + oy * SY) * p.W + ox * SX) * 4) : kOOB;
+  }
+#elif J_MODE == 2
   gather_t g;
   {
     int const OHW = p.OH * p.OW;
@@ -277,13 +320,13 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   }
 #endif
 
-  f32x16 acc[kTI][kTJ];
+  acc_t acc[kTI][kTJ];
 #pragma unroll
   for (int a = 0; a < kTI; ++a)
 #pragma unroll
     for (int b = 0; b < kTJ; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < kNA; ++r) acc[a][b][r] = 0.f;
 
   float ri[kNI], rj[kNJ];
   int const nkt_all = (p.K + BK - 1) / BK;
@@ -302,8 +345,9 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   store_J(rj, Js0, tid);
   __syncthreads();
 
-  int const a_off = wi * (kTI * 32) + (lane & 31) + (lane >> 5) * kLDI;
-  int const b_off = wj * (kTJ * 32) + (lane & 31) + (lane >> 5) * kLDJ;
+  // MFMA operand fetch: lane l holds A[i = l % MT][k = l / MT] and B[k = l / MT][j = l % MT]
+  int const a_off = wi * (kTI * MT) + (lane % MT) + (lane / MT) * kLDI;
+  int const b_off = wj * (kTJ * MT) + (lane % MT) + (lane / MT) * kLDJ;
 
   for (int kt = 0; kt < nkt; ++kt) {
     bool const more = (kt + 1) < nkt;
@@ -317,16 +361,22 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     __builtin_amdgcn_s_setprio(1); // co-resident waves of other workgroups are in their load phase: favour the MFMA issuer
 #endif
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
+    for (int kk = 0; kk < BK / kKS; ++kk) {
       float a[kTI], b[kTJ];
 #pragma unroll
-      for (int t = 0; t < kTI; ++t) a[t] = Ic[kk * 2 * kLDI + t * 32];
+      for (int t = 0; t < kTI; ++t) a[t] = Ic[kk * kKS * kLDI + t * MT];
 #pragma unroll
-      for (int t = 0; t < kTJ; ++t) b[t] = Jc[kk * 2 * kLDJ + t * 32];
+      for (int t = 0; t < kTJ; ++t) b[t] = Jc[kk * kKS * kLDJ + t * MT];
 #pragma unroll
       for (int ta = 0; ta < kTI; ++ta)
 #pragma unroll
-        for (int tb = 0; tb < kTJ; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        for (int tb = 0; tb < kTJ; ++tb) {
+#if MT == 32
+          acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+#else
+          acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+#endif
+        }
     }
 #if SETPRIO
     __builtin_amdgcn_s_setprio(0);
@@ -338,7 +388,8 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     __syncthreads();
   }
 
-  // ---- epilogue: MFMA C/D layout: column j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5) -----------------
+  // ---- epilogue: MFMA C/D layout.  32x32: column j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16
+  //                                16x16: column j = lane&15, row i = 4*(lane>>4) + r,               r < 4
 #if SPLITK
   float *const Dp = p.ws + (long)slice * p.ws_slab;
 #else
@@ -346,7 +397,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #endif
 #pragma unroll
   for (int tb = 0; tb < kTJ; ++tb) {
-    int const jg = j0 + wj * (kTJ * 32) + tb * 32 + (lane & 31);
+    int const jg = j0 + wj * (kTJ * MT) + tb * MT + (lane % MT);
     if (jg >= p.Nj) continue;
 #if EPI == 1
     int const OHW = p.OH * p.OW;
@@ -360,8 +411,12 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #pragma unroll
     for (int ta = 0; ta < kTI; ++ta) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < kNA; ++r) {
+#if MT == 32
         int const ig = i0 + wi * (kTI * 32) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#else
+        int const ig = i0 + wi * (kTI * 16) + ta * 16 + 4 * (lane >> 4) + r;
+#endif
         if (ig < p.Mi) {
           float v = acc[ta][tb][r];
 #if EPI == 1 && !SPLITK

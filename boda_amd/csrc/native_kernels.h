@@ -31,11 +31,11 @@ struct native_host_t {
 // blocking of one specialisation (the op_tune_t analogue for the native kernels: MNb/MNt/Kb of src/cnn_op.H:18-20
 // become workgroup tile / waves / K step)
 struct tile_cfg_t {
-  int BI = 128, BJ = 128, BK = 16, WI = 2, WJ = 2, MINW = 2, SPLITK = 1;
+  int BI = 128, BJ = 128, BK = 16, WI = 2, WJ = 2, MINW = 2, SPLITK = 1, MT = 32;
   int threads() const { return WI * WJ * 64; }
   string str() const {
     return std::to_string(BI) + "x" + std::to_string(BJ) + "x" + std::to_string(BK) + "_w" + std::to_string(WI) + "x" + std::to_string(WJ) +
-           (SPLITK > 1 ? ("_s" + std::to_string(SPLITK)) : string()); }
+           (MT != 32 ? ("_m" + std::to_string(MT)) : string()) + (SPLITK > 1 ? ("_s" + std::to_string(SPLITK)) : string()); }
 };
 
 struct conv_geom_t { int B, C, H, W, OC, KH, KW, SY, SX, PY, PX, OH, OW; bool relu; };
@@ -53,7 +53,7 @@ struct native_kernels_t {
   void sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K);
   void conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g);
 
-  // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK]]"
+  // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"
   void set_tune(string const &key, string const &val);
   static size_t prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile);
   launch_info_t last_launch;

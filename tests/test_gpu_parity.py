@@ -201,13 +201,14 @@ def test_sgemm_vs_oracle_bit_exact(be, M, N, K):
     assert np.array_equal(want, outs["c"]), sd.basic_str()  # same fma chain -> same bits
 
 
-@pytest.mark.parametrize("tile", ["64x64x16x1x1", "128x64x16x2x1", "64x128x16x1x2", "32x128x16x1x2", "96x128x16x1x2", "128x128x32x2x2", "256x128x16x4x2"])
+@pytest.mark.parametrize("tile", ["64x64x16x1x1", "128x64x16x2x1", "64x128x16x1x2", "32x128x16x1x2", "96x128x16x1x2", "128x128x32x2x2", "256x128x16x4x2",
+                                  "32x32x32x2x2x1x1x16", "64x64x64x4x4x1x1x16", "64x64x16x2x2x2x1x16"])
 def test_sgemm_tiles_agree(be, tile):
     op = _sgemm_op(320, 448, 200)
     ref, _ = _run(be, op, 5)
     got, prc = _run(be, op, 5, tune=OpTune(hip_tile=tile))
-    assert prc.launch["cfg"].startswith(tile.rsplit("x", 2)[0])
-    assert np.array_equal(ref["c"], got["c"])
+    assert prc.launch["cfg"].startswith("x".join(tile.split("x")[:3]))
+    assert np.array_equal(ref["c"], got["c"])  # incl. the 16x16x4-MFMA tiles (suffix x16): same ascending-k fma chain
 
 
 def test_sgemm_bad_tile_is_unsupported(be):
@@ -285,7 +286,8 @@ def test_conv_golden_3x3_42(be, golden_dir):
     assert n == 42 and worst < MRD
 
 
-EDGE_CONVS = [  # B, C, H, W, OC, KH, KW, S, P
+EDGE_CONVS = [  # B, C, H, W, OC, KH, KW, S, P   (incl. 1x1 stride 1/2 -> k1 path, 1x1 with padding -> general gather)
+    (2, 19, 11, 11, 40, 1, 1, 1, 0), (3, 64, 14, 14, 128, 1, 1, 2, 0), (2, 8, 7, 7, 16, 1, 1, 1, 1),
     (1, 3, 12, 12, 16, 3, 3, 1, 1), (2, 5, 17, 13, 7, 5, 5, 2, 2), (3, 4, 9, 9, 33, 1, 1, 1, 0), (1, 8, 6, 6, 40, 6, 6, 1, 0),
     (2, 3, 35, 35, 96, 11, 11, 4, 0), (1, 16, 14, 14, 130, 7, 7, 2, 3), (5, 32, 7, 7, 64, 1, 1, 2, 0), (2, 6, 10, 10, 12, 3, 3, 1, 0),
     (1, 1, 5, 5, 1, 5, 5, 1, 2), (4, 20, 8, 8, 100, 3, 3, 1, 1),
@@ -313,7 +315,8 @@ def test_conv_without_relu_and_alias(be):
     assert want.min() < 0 and np.array_equal(want, outs["out"])
 
 
-@pytest.mark.parametrize("tile", ["64x64x16x1x1", "128x64x16x2x1", "32x128x16x1x2", "96x128x16x1x2", "128x128x32x2x2", "128x256x16x2x4"])
+@pytest.mark.parametrize("tile", ["64x64x16x1x1", "128x64x16x2x1", "32x128x16x1x2", "96x128x16x1x2", "128x128x32x2x2", "128x256x16x2x4",
+                                  "64x64x16x2x2x2x1x16", "32x64x32x2x2x1x1x16"])
 def test_conv_tiles_agree(be, tile):
     op = _conv_op(3, 24, 15, 15, 100, 3, 3, 1, 1)
     ref, _ = _run(be, op, 5)
