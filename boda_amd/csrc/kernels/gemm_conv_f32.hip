@@ -75,6 +75,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SETPRIO
 #define SETPRIO 0
 #endif
+#ifndef ABLATE
+#define ABLATE 0 // experiment hook (tools/tile_sweep.py via BODAHIP_EXTRA_DEFS): 1 no epilogue stores | 2 no J loads | 4 no in-loop LDS stores | 8 no I loads
+#endif
 #ifndef MT
 #define MT 32 // MFMA tile: 32 -> v_mfma_f32_32x32x2_f32 (default), 16 -> v_mfma_f32_16x16x4_f32 (4x more, smaller wave tiles for
 #endif        // shapes with too few 32x32 tiles to give every SIMD a wave; same fp32 rate, same ascending-k fma chain)
@@ -354,8 +357,12 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     float const *const Ic = ((kt & 1) ? Is1 : Is0) + a_off;
     float const *const Jc = ((kt & 1) ? Js1 : Js0) + b_off;
     if (more) { // prefetch K-tile kt+1 into registers; the loads fly under the MFMAs below
+#if !(ABLATE & 8)
       load_tile<I_MODE, BI, kNI>(ri, rI, p.ldI, i0, p.Mi, (kt_begin + kt + 1) * BK, p.K, tid);
+#endif
+#if !(ABLATE & 2)
       load_J(rj, rJ, p, j0, (kt_begin + kt + 1) * BK, tid GATHER_ARG);
+#endif
     }
 #if SETPRIO
     __builtin_amdgcn_s_setprio(1); // co-resident waves of other workgroups are in their load phase: favour the MFMA issuer
@@ -381,10 +388,12 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #if SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
+#if !(ABLATE & 4)
     if (more) {
       store_tile<I_MODE, BI, kLDI, kNI>(ri, (kt & 1) ? Is0 : Is1, tid);
       store_J(rj, (kt & 1) ? Js0 : Js1, tid);
     }
+#endif
     __syncthreads();
   }
 
@@ -424,6 +433,9 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #if RELU
           v = (v > 0.f) ? v : 0.f;
 #endif
+#endif
+#if ABLATE & 1
+          if (v == 123.456f) // keeps the accumulators live without storing
 #endif
           Dp[joff + (long)ig * istride] = v;
         }

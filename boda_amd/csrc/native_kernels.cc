@@ -100,20 +100,19 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather) {
   else { c.BI = 32; c.BJ = 128; c.WI = 1; c.WJ = 2; }
   c.BK = 16; c.MINW = 2; c.SPLITK = 1;
   auto ntiles = [&](tile_cfg_t const &t) { return (long)((Mi + t.BI - 1) / t.BI) * ((Nj + t.BJ - 1) / t.BJ); };
+  // fraction of the slowest CU's time that the average CU is busy when `tiles` equal workgroups are dealt to num_cus CUs
+  auto balance = [&](long tiles) { double const per = (double)tiles / num_cus; return per / (double)((tiles + num_cus - 1) / num_cus); };
   long const tiles = ntiles(c);
-  if (tiles >= num_cus) return c;
-  double const flops = 2.0 * Mi * (double)Nj * K;
   if (Mi > 32) {
-    tile_cfg_t c2 = c; c2.BI = 64; c2.BJ = 64; c2.WI = 2; c2.WJ = 2;
-    if (ntiles(c2) >= num_cus / 2 || flops < 2.7e8) return c2; // enough workgroups, or too small to matter (launch-bound)
-  } else if (flops < 2.7e8) return c;
-  // Splitting K would fill the chip for these shapes, but it re-associates the fp32 sum: the reference's golden digests
-  // (tolerance 2e-4 on max(1,|v|)) are only met robustly by the ascending-k chain, so SPLITK is an explicit tune
-  // ("...xMINWxS"), never the default.  Default: 64x64 workgroups of four 32x32 wave tiles.
-  if (Mi > 32) {
-    tile_cfg_t c2 = c; c2.BI = 64; c2.BJ = 64; c2.WI = 2; c2.WJ = 2;
+    tile_cfg_t c2 = c; c2.BI = 64; c2.BJ = 64; c2.WI = 2; c2.WJ = 2; // four 32x32 wave tiles: ~0.87x the per-tile efficiency of 64x64 wave tiles
+    long const tiles2 = ntiles(c2);
+    bool const use_small = (tiles < num_cus) || (balance(tiles) < 0.87 * balance(tiles2));
+    if (!use_small) return c;
+    // Splitting K would fill the chip for tile-starved shapes, but it re-associates the fp32 sum: the reference's golden
+    // digests (tolerance 2e-4 on max(1,|v|)) are only met robustly by the ascending-k chain, so SPLITK is an explicit tune
+    // ("...xMINWxS"), never the default.
     // still fewer than half a workgroup per CU (e.g. AlexNet fc8, 1000x256 outputs): 16x16x4-MFMA wave tiles give 4x the waves
-    if (ntiles(c2) < num_cus / 2 && !gather && 2.0 * Mi * (double)Nj * K >= 2.7e8) { c2.BI = 32; c2.BJ = 32; c2.BK = 32; c2.MT = 16; c2.MINW = 1; }
+    if (tiles2 < num_cus / 2 && !gather && 2.0 * Mi * (double)Nj * K >= 2.7e8) { c2.BI = 32; c2.BJ = 32; c2.BK = 32; c2.MT = 16; c2.MINW = 1; }
     return c2;
   }
   return c;

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""gpurun_out/<dir>/{stats,fetch,write,sq}_<workload>/p_results.db + calib -> profiles/r01_*.txt + profiles/pmc_summary.json"""
+import json, os, sqlite3, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "final")
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+out = os.path.join(ROOT, "profiles")
+os.makedirs(out, exist_ok=True)
+summ = os.path.join(ROOT, "tools", "rocprof_summary.py")
+
+
+def q(db, sql):
+    return list(sqlite3.connect(db).execute(sql))
+
+
+# FETCH_SIZE calibration (known-bytes streaming read, tools/fetch_calib.py)
+cal = q(os.path.join(src, "calib", "c_results.db"), "select avg(value) from counters_collection where counter_name='FETCH_SIZE' and kernel_name like 'calib_stream_read%'")[0][0]
+known = 1 << 30
+factor = known / (cal * 1024.0)
+res = {"_fetch_size_calibration": {"known_bytes": known, "FETCH_SIZE_KB": cal, "bytes_per_reported_byte": round(factor, 4),
+                                   "note": "16 B/lane coalesced stream; FETCH_SIZE under-reports by this factor on gfx950 (guide: exactly 2)"}}
+for w in ("sgemm-ops-full", "alexnet", "nin"):
+    sdb = os.path.join(src, f"stats_{w}", "p_results.db")
+    if not os.path.exists(sdb):
+        continue
+    with open(os.path.join(out, f"{tag}_{w}_kernel_stats.txt"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --workload {w} --steps 5 --warmup 2 --no-cpu-baseline\n")
+        f.write(subprocess.check_output([sys.executable, summ, sdb, "--by-grid"], text=True))
+    kern = "bodahip_sgemm_f32" if w.startswith("sgemm") else "bodahip_conv_f32"
+    rows = {}
+    for cn, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        for g, v in q(os.path.join(src, f"{sub}_{w}", "p_results.db"), f"select grid_size, sum(value) from counters_collection where counter_name='{cn}' and kernel_name='{kern}' group by grid_size"):
+            rows.setdefault(g, {})[cn] = v
+    sq = {}
+    for g, cn, v, dur in q(os.path.join(src, f"sq_{w}", "p_results.db"), f"select grid_size, counter_name, sum(value), sum(end-start) from counters_collection where kernel_name='{kern}' group by grid_size, counter_name"):
+        sq.setdefault(g, {})[cn] = v; sq[g]["_dur_ns"] = dur
+    with open(os.path.join(out, f"{tag}_{w}_pmc.txt"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload {w} --steps 1 --warmup 0   (separate passes: FETCH_SIZE | WRITE_SIZE | SQ set)\n")
+        f.write(f"# HBM bytes = FETCH_SIZE_KB*1024*{factor:.3f} (calibrated, see pmc_summary.json) + WRITE_SIZE_KB*1024 ; summed over launches of the same grid size\n")
+        f.write("# grid(threads)  fetch_MB(corrected)  write_MB  | mfma_busy%  clock_GHz  waves  wave_cycles: wait_inst% wait_any% active%\n")
+        tot_f = tot_w = 0.0
+        for g in sorted(rows):
+            fb = rows[g].get("FETCH_SIZE", 0) * 1024 * factor; wb = rows[g].get("WRITE_SIZE", 0) * 1024
+            tot_f += fb; tot_w += wb
+            s = sq.get(g, {})
+            line = f"{g:12d}  {fb/1e6:14.1f}  {wb/1e6:10.1f}"
+            if s.get("GRBM_GUI_ACTIVE"):
+                cyc = s["GRBM_GUI_ACTIVE"] / 8.0
+                wc = s.get("SQ_WAVE_CYCLES", 0) or 1
+                line += (f"  | {100*s.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/1024/cyc:9.1f}  {cyc/s['_dur_ns']:9.2f}  {int(s.get('SQ_WAVES',0)):6d}"
+                         f"  {100*s.get('SQ_WAIT_INST_ANY',0)/wc:6.1f} {100*s.get('SQ_WAIT_ANY',0)/wc:6.1f} {100*s.get('SQ_ACTIVE_INST_ANY',0)/wc:6.1f}")
+            f.write(line + "\n")
+        f.write(f"# total per step: fetch {tot_f/1e9:.3f} GB (corrected), write {tot_w/1e9:.3f} GB\n")
+    res[w] = {"hbm_bytes_per_step": int(tot_f + tot_w), "fetch_bytes_corrected": int(tot_f), "write_bytes": int(tot_w)}
+json.dump(res, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))

@@ -16,7 +16,7 @@ ap.add_argument("--ops", default="")
 ap.add_argument("--tiles", default="")
 ap.add_argument("--iters", type=int, default=5)
 a = ap.parse_args()
-ops = bench.alexnet_b256_ops() if a.workload == "alexnet" else bench.sgemm_full_ops()
+ops = {"alexnet": bench.alexnet_b256_ops, "nin": bench.nin_ops, "sgemm": bench.sgemm_full_ops}[a.workload]()
 sel = [int(x) for x in a.ops.split(",")] if a.ops else list(range(len(ops)))
 tiles = [""] + [t for t in a.tiles.split(",") if t]
 rtc = make_rtc(); rtc.init(); be = OpsBackend(rtc)
