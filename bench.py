@@ -86,12 +86,71 @@ def cpu_baseline(workload: str, budget_s: float = 12.0) -> dict:
             "sample": f"oracle/boda_oracle.c bo_conv_fwd (OpenMP) on the {workload} conv layers at batches 8..{batch//2}, {t_tot:.1f} s"}
 
 
+def bench_full_net(a, rtc, rank, world, dist, torch) -> int:
+    """BASELINE configs[3]: full-net forward (nin_imagenet / alexnet_ng_conv) through ConvPipeFwd, batch-sharded."""
+    import numpy as np
+    from boda_amd import gen_data as gd
+    from boda_amd.conv_pipe import ConvPipeFwd, alexnet_ng_conv, nin_imagenet
+    from boda_amd.shard import broadcast_weights
+    cp = nin_imagenet(a.batch) if a.workload == "nin-net" else alexnet_ng_conv(a.batch)
+    fwd = ConvPipeFwd(rtc)
+    fwd.init(cp)  # params: deterministic pattern on device (rank 0's are broadcast below)
+    d = cp.nodes["data"]
+    rtc.run(gd.gen_call("Convolution", "in", "data", d, 5, 0.0, shard_off=rank * a.batch))
+    rtc.finish_and_sync(); rtc.release_per_call_id_data()
+    if dist is not None:
+        broadcast_weights([rtc.torch_view(pn) for pn in fwd.op_param_names], src=0)
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        fwd.run_fwd_device_only()
+    if dist is not None:
+        dist.barrier()
+    import gc
+    gc.collect(); gc.disable()  # a generation-2 collection (tens of ms with torch loaded) must not land between two launches
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev_ms = []
+    for _ in range(a.steps):
+        ts = time.perf_counter(); dev_ms.append(fwd.run_fwd_device_only())
+        if os.environ.get("BENCH_DEBUG"):
+            print(f"step wall {1e3*(time.perf_counter()-ts):.3f} ms, device first-to-last {dev_ms[-1]:.3f} ms", file=sys.stderr)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+    flops = float(cp.conv_flops())
+    if rank == 0:
+        conv_ms = sum(ms for _, f, ms, _ in fwd.per_call_ms if f == "hip_conv"); other_ms = sum(ms for _, f, ms, _ in fwd.per_call_ms if f != "hip_conv")
+        value = flops * a.steps * world / elapsed / 1e12
+        out = {"metric": "effective TFLOP/s (conv 2*M*N*K / whole-net forward time), whole job", "value": round(value, 3), "unit": "TFLOP/s",
+               "per_gpu": round(value / world, 3), "images_per_s": round(a.batch * world * a.steps / elapsed, 1), "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic (reference gen_data mode 5 inputs and weights, generated on device)",
+               "config": {"workload": f"{cp.name} full net forward (rtc_fwd counterpart), batch {a.batch}/GPU: {len(fwd.fwd_calls)} calls "
+                                      f"({sum(1 for c in fwd.fwd_calls if c.func == 'hip_conv')} hip_conv + pool/lrn CUCL kernels)",
+                          "parallelism": f"batch-shard x{world}, weights broadcast once (RCCL)", "device": rtc.get_plat_tag()},
+               "roofline": {"bound": "mfma", "achieved": round(flops / (conv_ms * 1e-3) / 1e12, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(flops / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "kernel": "bodahip_conv_f32",
+                            "conv_ms": round(conv_ms, 4), "non_conv_ms": round(other_ms, 4), "device_ms_first_to_last_call": round(float(np.mean(dev_ms)), 4)},
+               "per_call": [{"tag": t_, "func": f, "ms": round(ms, 5)} for t_, f, ms, _ in fwd.per_call_ms]}
+        if a.per_op:
+            for t_, f, ms, fl in fwd.per_call_ms:
+                print(f"  {t_:8s} {f:10s} {ms:9.4f} ms" + (f" {fl/ms/1e9:8.2f} TF/s" if fl else ""), file=sys.stderr)
+        print(json.dumps(out))
+    fwd.release(); rtc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sgemm-ops-full", choices=["sgemm-ops-full", "alexnet", "nin"])
+    ap.add_argument("--workload", default="sgemm-ops-full", choices=["sgemm-ops-full", "alexnet", "nin", "nin-net", "alexnet-net"],
+                    help="*-net: the whole network through the has_conv_fwd_t(mode=rtc) driver (convs + pool/LRN kernels), BASELINE configs[3]")
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch of the conv workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-op", action="store_true", help="also print a per-op table to stderr")
@@ -123,7 +182,9 @@ def main() -> int:
 
     rtc = make_rtc("(be=hip)", local_rank)
     rtc.init()
-    rtc.compile(gd.func_infos())
+    if a.workload.endswith("-net"):
+        return bench_full_net(a, rtc, rank, world, dist, torch)
+    rtc.compile(gd.func_infos()); rtc._gen_data_compiled = True
     ops = {"sgemm-ops-full": sgemm_full_ops, "alexnet": lambda: alexnet_b256_ops(a.batch), "nin": lambda: nin_ops(a.batch)}[a.workload]()
     from boda_amd.shard import WEIGHT_ARGS as weight_args, BATCH_DIM
 
@@ -164,6 +225,8 @@ def main() -> int:
     rtc.finish_and_sync(); rtc.release_per_call_id_data()
     if dist is not None:
         dist.barrier()
+    import gc
+    gc.collect(); gc.disable()  # keep the collector out of the timed region (it is host-side noise, not work of the path)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ids = [step() for _ in range(a.steps)]

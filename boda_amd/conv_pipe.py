@@ -1,0 +1,367 @@
+"""Full-net forward over be=hip: a `conv_pipe_t` (graph) and the `has_conv_fwd_t(mode=rtc)` driver.
+
+Restates the behaviour of the reference's net-level path (not its code):
+  * conv_pipe_t / shape inference      src/conv_util.H:169-243, src/conv_util.cc:167-204,405-505
+      conv out = (in + 2*pad - k)/stride + 1 (floor); pooling uses the Caffe CEIL convention; no kern_sz = global pooling
+  * prototxt -> pipe conventions       src/caffepb.cc:166-326 : each Convolution gets inputs <name>_filts / <name>_biases;
+      Dropout is a no-op at inference; Accuracy / Softmax* layers are ignored; ReLU is in-place
+  * conv_pipe_fwd_t::{init,gen_op,run_fwd}  src/rtc_fwd.cc:263-577 : ops are annotated, a ReLU that immediately follows a
+      conv in place is FUSED into it (conv_has_relu=1, the ReLU emits no call, :486-493,266); one call per remaining op in
+      topological order; params are uploaded once; run_fwd = set inputs -> run all calls -> get outputs; the duration
+      is get_dur(first call, last call); an optional per-call profile (python assignments, :560-572)
+Convolutions run on the native side door (hip_conv); pooling / LRN / un-fused ReLU are this project's own CUCL-dialect
+sources (semantics of test/rtc/{pool,lrn,relu}.cucl) and go through the backend's generic hiprtc path.
+The reference ships no trained weights (nets/ holds prototxts only), so params default to its deterministic
+gen_data mode-5 pattern generated on the device; callers may pass real arrays instead.
+"""
+from __future__ import annotations
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import gen_data as gd
+from .cnn_op import NATIVE_ARGS, OpTune, add_codegen_annotations
+from .op import Dims, Nda, Op, RtErr, UnsupErr
+from .rtc import HipCompute, RtcArg, RtcCompileOpts, RtcFuncCall, RtcFuncInfo
+
+
+# ------------------------------------------------------------------------------------------------
+# graph
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class PipeOp:
+    tag: str
+    type: str                      # Convolution | Pooling | ReLU | LRN | Dropout
+    bot: str
+    top: str
+    out_chans: int = 0
+    kern_sz: Optional[Tuple[int, int]] = None   # (y, x); None for Pooling = global pooling
+    stride: Tuple[int, int] = (1, 1)
+    in_pad: Tuple[int, int] = (0, 0)
+    avg_pool: int = 0
+    lrn: Tuple[int, float, float, float] = (5, 1.0, 0.75, 1.0)  # local_size, alpha, beta, k (src/conv_util.cc:42-48)
+
+    @property
+    def in_place(self) -> bool:
+        return self.bot == self.top
+
+
+class ConvPipe:
+    """Linear-chain-or-DAG of ops over named nodes; ops are kept in topological (definition) order."""
+
+    def __init__(self, name: str, in_node: str, in_dims: Dims):
+        self.name, self.in_node = name, in_node
+        self.nodes: Dict[str, Dims] = {in_node: in_dims}
+        self.ops: List[PipeOp] = []
+        self.params: Dict[str, Dims] = {}
+
+    def add(self, op: PipeOp) -> "ConvPipe":
+        if op.bot not in self.nodes:
+            raise RtErr(f"pipe: op {op.tag} reads unknown node {op.bot!r}")
+        d = self.nodes[op.bot]
+        B, C, H, W = d.dsz("img"), d.dsz("chan"), d.dsz("y"), d.dsz("x")
+        if op.type == "Convolution":
+            kh, kw = op.kern_sz
+            oh = (H + 2 * op.in_pad[0] - kh) // op.stride[0] + 1; ow = (W + 2 * op.in_pad[1] - kw) // op.stride[1] + 1
+            if oh < 1 or ow < 1:
+                raise RtErr(f"pipe: conv {op.tag}: padded input too small")
+            out = Dims.make("float", img=B, chan=op.out_chans, y=oh, x=ow)
+            self.params[op.tag + "_filts"] = Dims.make("float", out_chan=op.out_chans, in_chan=C, y=kh, x=kw)
+            self.params[op.tag + "_biases"] = Dims.make("float", out_chan=op.out_chans)
+        elif op.type == "Pooling":
+            if op.kern_sz is None:   # global pooling
+                op.kern_sz, op.stride, op.in_pad = (H, W), (1, 1), (0, 0)
+            def osz(i, k, s, p):
+                pin = i + 2 * p
+                return 1 if pin < k else -(-(pin - k) // s) + 1
+            out = Dims.make("float", img=B, chan=C, y=osz(H, op.kern_sz[0], op.stride[0], op.in_pad[0]), x=osz(W, op.kern_sz[1], op.stride[1], op.in_pad[1]))
+        elif op.type in ("ReLU", "LRN", "Dropout"):
+            out = d
+        else:
+            raise UnsupErr(f"pipe: op type {op.type!r} has no forward kernel in this backend")
+        if op.top in self.nodes and not op.in_place:
+            raise RtErr(f"pipe: node {op.top!r} written twice")
+        self.nodes[op.top] = out
+        self.ops.append(op)
+        return self
+
+    def conv_op(self, op: PipeOp) -> Op:
+        """The op_base_t line of a Convolution of this pipe (same text form as the ops-prof op lists)."""
+        i, o = self.nodes[op.bot], self.nodes[op.top]
+        none = lambda y, x: Nda(Dims(("y", "x"), (y, x), "none"), "none")
+        return Op({"type": "Convolution"}, {"in": Nda(i), "out": Nda(o), "filts": Nda(self.params[op.tag + "_filts"]),
+                                            "biases": Nda(self.params[op.tag + "_biases"]), "kern_sz": none(*op.kern_sz),
+                                            "stride": none(*op.stride), "in_pad": none(*op.in_pad),
+                                            "out_chans": Nda(None, "uint32_t", (op.out_chans,))})
+
+    def conv_flops(self) -> int:
+        return sum(self.conv_op(o).flops() for o in self.ops if o.type == "Convolution")
+
+    def out_node(self) -> str:
+        return self.ops[-1].top
+
+
+def _conv(p, tag, bot, oc, k, s=1, pad=0):
+    p.add(PipeOp(tag, "Convolution", bot, tag, out_chans=oc, kern_sz=(k, k), stride=(s, s), in_pad=(pad, pad)))
+    p.add(PipeOp("relu_" + tag, "ReLU", tag, tag))
+    return tag
+
+
+def nin_imagenet(batch: int, in_hw: int = 227) -> ConvPipe:
+    """nets/nin_imagenet/train_val.prototxt (TEST phase): conv1 cccp1 cccp2 pool0 conv2 cccp3 cccp4 pool2 conv3 cccp5 cccp6
+    pool3 drop conv4 cccp7 cccp8 pool4(avg 6x6); every conv is followed by an in-place ReLU."""
+    p = ConvPipe("nin_imagenet", "data", Dims.make("float", img=batch, chan=3, y=in_hw, x=in_hw))
+    n = _conv(p, "conv1", "data", 96, 11, 4); n = _conv(p, "cccp1", n, 96, 1); n = _conv(p, "cccp2", n, 96, 1)
+    p.add(PipeOp("pool0", "Pooling", n, "pool0", kern_sz=(3, 3), stride=(2, 2)))
+    n = _conv(p, "conv2", "pool0", 256, 5, 1, 2); n = _conv(p, "cccp3", n, 256, 1); n = _conv(p, "cccp4", n, 256, 1)
+    p.add(PipeOp("pool2", "Pooling", n, "pool2", kern_sz=(3, 3), stride=(2, 2)))
+    n = _conv(p, "conv3", "pool2", 384, 3, 1, 1); n = _conv(p, "cccp5", n, 384, 1); n = _conv(p, "cccp6", n, 384, 1)
+    p.add(PipeOp("pool3", "Pooling", n, "pool3", kern_sz=(3, 3), stride=(2, 2)))
+    p.add(PipeOp("drop", "Dropout", "pool3", "pool3"))
+    n = _conv(p, "conv4", "pool3", 1024, 3, 1, 1); n = _conv(p, "cccp7", n, 1024, 1); n = _conv(p, "cccp8", n, 1000, 1)
+    p.add(PipeOp("pool4", "Pooling", n, "pool4", kern_sz=(6, 6), stride=(1, 1), avg_pool=1))
+    return p
+
+
+def alexnet_ng_conv(batch: int, in_hw: int = 227) -> ConvPipe:
+    """nets/alexnet_ng_conv (fc layers as convolutions, no groups): conv1 norm1 pool1 conv2 norm2 pool2 conv3 conv4 conv5 pool5
+    fc6 drop fc7 drop fc8."""
+    p = ConvPipe("alexnet_ng_conv", "data", Dims.make("float", img=batch, chan=3, y=in_hw, x=in_hw))
+    lrn = (5, 1e-4, 0.75, 1.0)
+    n = _conv(p, "conv1", "data", 96, 11, 4)
+    p.add(PipeOp("norm1", "LRN", n, "norm1", lrn=lrn)); p.add(PipeOp("pool1", "Pooling", "norm1", "pool1", kern_sz=(3, 3), stride=(2, 2)))
+    n = _conv(p, "conv2", "pool1", 256, 5, 1, 2)
+    p.add(PipeOp("norm2", "LRN", n, "norm2", lrn=lrn)); p.add(PipeOp("pool2", "Pooling", "norm2", "pool2", kern_sz=(3, 3), stride=(2, 2)))
+    n = _conv(p, "conv3", "pool2", 384, 3, 1, 1); n = _conv(p, "conv4", n, 384, 3, 1, 1); n = _conv(p, "conv5", n, 256, 3, 1, 1)
+    p.add(PipeOp("pool5", "Pooling", n, "pool5", kern_sz=(3, 3), stride=(2, 2)))
+    n = _conv(p, "fc6", "pool5", 4096, 6); p.add(PipeOp("drop6", "Dropout", n, n))
+    n = _conv(p, "fc7", n, 4096, 1); p.add(PipeOp("drop7", "Dropout", n, n))
+    p.add(PipeOp("fc8", "Convolution", n, "fc8", out_chans=1000, kern_sz=(1, 1)))
+    return p
+
+
+# ------------------------------------------------------------------------------------------------
+# non-conv forward kernels (CUCL dialect, dims as by-value args)
+# ------------------------------------------------------------------------------------------------
+FWD_SRC = """
+// pooling: only in-bounds (non-padding) pixels take part, for max and for average (semantics of test/rtc/pool.cucl)
+CUCL_GLOBAL_KERNEL void fwd_pool( GASQ float const * const in, GASQ float * const out, uint32_t const avg_pool, uint32_t const n_out,
+                                  uint32_t const H, uint32_t const W, uint32_t const OH, uint32_t const OW, uint32_t const KH, uint32_t const KW,
+                                  uint32_t const SY, uint32_t const SX, uint32_t const PY, uint32_t const PX ) {
+  if( GLOB_ID_1D >= n_out ) { return; }
+  uint32_t const ox = GLOB_ID_1D % OW; uint32_t const oy = ( GLOB_ID_1D / OW ) % OH; uint32_t const plane = GLOB_ID_1D / ( OW * OH );
+  GASQ float const * const ip = in + plane * H * W;
+  float out_v = avg_pool ? 0.0f : -FLT_MAX;
+  float avg_pool_sz = 0;
+  for( int32_t kx = 0; kx != (int32_t)KW; ++kx ) {
+    for( int32_t ky = 0; ky != (int32_t)KH; ++ky ) {
+      int const in_y = oy*SY + ky - PY;
+      int const in_x = ox*SX + kx - PX;
+      if( in_y >= 0 && in_x >= 0 && in_x < (int)W && in_y < (int)H ) {
+        float const v = ip[in_y*W + in_x];
+        if( avg_pool ) { out_v += v; avg_pool_sz += 1; } else if( v > out_v ) { out_v = v; }
+      }
+    }
+  }
+  if( avg_pool ) { out_v /= avg_pool_sz; }
+  out[GLOB_ID_1D] = out_v;
+}
+CUCL_GLOBAL_KERNEL void fwd_relu( GASQ float * const inout, uint32_t const n ) {
+  if( GLOB_ID_1D >= n ) { return; }
+  inout[GLOB_ID_1D] = (inout[GLOB_ID_1D] <= 0) ? 0.0f : inout[GLOB_ID_1D];
+}
+// across-channel LRN, running-sum ("match caffe") form (semantics of test/rtc/lrn.cucl); one thread per (img,y,x)
+CUCL_GLOBAL_KERNEL void fwd_lrn( GASQ float const * const in, GASQ float * const out, float const alpha, float const beta, float const k,
+                                 uint32_t const local_size, uint32_t const n_pel, uint32_t const C, uint32_t const HW ) {
+  if( GLOB_ID_1D >= n_pel ) { return; }
+  float ls_buf[16];
+  for( uint32_t i = 0; i != 16; ++i ) { ls_buf[i] = 0.0f; }
+  int32_t const hls = local_size >> 1;
+  uint32_t const base = ( GLOB_ID_1D / HW ) * C * HW + ( GLOB_ID_1D % HW );
+  float ls_sum = 0.0f;
+  float const alpha_over_ls = alpha / (float)local_size;
+  for( int32_t ic = 0; ic < (int32_t)C + hls; ++ic ) {
+    int32_t const lsb_ix = ic % (int32_t)local_size;
+    float const ls_old = ls_buf[lsb_ix];
+    ls_buf[lsb_ix] = (ic < (int32_t)C) ? in[base + ic*HW] : 0.0f;
+    ls_sum += ls_buf[lsb_ix]*ls_buf[lsb_ix]; ls_sum -= ls_old*ls_old;
+    if( ic >= hls ) {
+      float const scale_base = k + ls_sum*alpha_over_ls;
+      out[base + (ic - hls)*HW] = ls_buf[(lsb_ix + local_size - hls) % local_size] * powf( scale_base, -beta );
+    }
+  }
+}
+"""
+FWD_FUNCS = {"fwd_pool": ["in", "out", "avg_pool", "n_out", "H", "W", "OH", "OW", "KH", "KW", "SY", "SX", "PY", "PX"],
+             "fwd_relu": ["inout", "n"],
+             "fwd_lrn": ["in", "out", "alpha", "beta", "k", "local_size", "n_pel", "C", "HW"]}
+_TPB = 256
+_u32 = lambda v: RtcArg.scalar(int(v), "uint32_t")
+_f32 = lambda v: RtcArg.scalar(float(v), "float")
+
+
+@dataclass
+class FwdCall:
+    tag: str
+    rfc: RtcFuncCall
+    func: str
+    flops: int = 0
+    call_id: int = -1
+
+
+class ConvPipeFwd:
+    """`has_conv_fwd_t` with mode=rtc over an rtc backend (src/has_conv_fwd.H:16-25, src/rtc_fwd.cc:43-577)."""
+    mode = "rtc"
+
+    def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False):
+        self.rtc, self.op_tune = rtc, op_tune or OpTune()
+        self.per_call_fn, self.enable_double_run = per_call_fn, enable_double_run
+        self.fwd_calls: List[FwdCall] = []
+        self.op_param_names: List[str] = []
+        self.cp: Optional[ConvPipe] = None
+        self.compute_dur_ms = float("nan")
+        self._vars: List[str] = []
+        self._funcs: List[str] = []
+
+    # -- init: annotate, fuse, create vars, generate calls, upload params
+    def init(self, cp: ConvPipe, op_params: Optional[Dict[str, np.ndarray]] = None, gen_mode: int = 5) -> None:
+        rtc = self.rtc
+        self.cp = cp
+        if not getattr(rtc, "_gen_data_compiled", False):
+            rtc.compile(gd.func_infos()); rtc._gen_data_compiled = True
+        if not getattr(rtc, "_fwd_funcs_compiled", False):
+            infos = [RtcFuncInfo(fn, FWD_SRC if i == 0 else "", args, Op({"type": "fwd", "func_name": fn}, {})) for i, (fn, args) in enumerate(FWD_FUNCS.items())]
+            rtc.compile(infos); rtc._fwd_funcs_compiled = True
+        # ReLU fusion: a ReLU that directly follows a conv, in place on its output (src/rtc_fwd.cc:486-493)
+        fused = set()
+        has_relu: Dict[str, int] = {}
+        for i, op in enumerate(cp.ops):
+            if op.type == "Convolution":
+                nxt = cp.ops[i + 1] if i + 1 < len(cp.ops) else None
+                hr = int(nxt is not None and nxt.type == "ReLU" and nxt.in_place and nxt.bot == op.top)
+                has_relu[op.tag] = hr
+                if hr:
+                    fused.add(nxt.tag)
+        # vars: the source node, then one per op output (in-place ops and Dropout reuse their input var)
+        alias: Dict[str, str] = {}
+        def vn(node: str) -> str:
+            return alias.get(node, node)
+        rtc.create_var_with_dims(cp.in_node, cp.nodes[cp.in_node]); self._vars.append(cp.in_node)
+        for pn, pd in cp.params.items():
+            rtc.create_var_with_dims(pn, pd); self._vars.append(pn); self.op_param_names.append(pn)
+        for op in cp.ops:
+            if op.tag in fused:
+                continue
+            if op.type == "Dropout":           # no-op at inference (src/caffepb.cc:233-238): the top IS the bottom
+                if not op.in_place:
+                    alias[op.top] = vn(op.bot)
+                continue
+            if not op.in_place:
+                rtc.create_var_with_dims(op.top, cp.nodes[op.top]); self._vars.append(op.top)
+            if op.type == "Convolution":
+                cop = cp.conv_op(op)
+                anno = add_codegen_annotations(cop, self.op_tune)
+                anno.nda_vals["conv_has_relu"].v = (has_relu[op.tag],)
+                fn = anno.get_func_name(); gen_fn = f"{fn}__{cp.name}_{op.tag}"
+                rtc.compile([RtcFuncInfo(gen_fn, "", [a for a, _ in NATIVE_ARGS[fn]], anno)]); self._funcs.append(gen_fn)
+                am = {"filts": RtcArg.var(op.tag + "_filts"), "biases": RtcArg.var(op.tag + "_biases"), "in": RtcArg.var(vn(op.bot)),
+                      "stride": RtcArg.ref(anno.get_dims("stride")), "in_pad": RtcArg.ref(anno.get_dims("in_pad")), "out": RtcArg.var(op.top)}
+                self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(gen_fn, am), fn, cop.flops()))
+            elif op.type == "Pooling":
+                i, o = cp.nodes[op.bot], cp.nodes[op.top]
+                n = o.dims_prod()
+                am = {"in": RtcArg.var(vn(op.bot)), "out": RtcArg.var(op.top), "avg_pool": _u32(op.avg_pool), "n_out": _u32(n),
+                      "H": _u32(i.dsz("y")), "W": _u32(i.dsz("x")), "OH": _u32(o.dsz("y")), "OW": _u32(o.dsz("x")),
+                      "KH": _u32(op.kern_sz[0]), "KW": _u32(op.kern_sz[1]), "SY": _u32(op.stride[0]), "SX": _u32(op.stride[1]),
+                      "PY": _u32(op.in_pad[0]), "PX": _u32(op.in_pad[1])}
+                self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall("fwd_pool", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB), "fwd_pool"))
+            elif op.type == "ReLU":
+                n = cp.nodes[op.top].dims_prod()
+                self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall("fwd_relu", {"inout": RtcArg.var(vn(op.bot)), "n": _u32(n)}, tpb=_TPB, blks=(n + _TPB - 1) // _TPB), "fwd_relu"))
+            elif op.type == "LRN":
+                d = cp.nodes[op.bot]; hw = d.dsz("y") * d.dsz("x"); n = d.dsz("img") * hw
+                ls, alpha, beta, k = op.lrn
+                if ls > 16:
+                    raise UnsupErr("fwd_lrn: local_size > 16")
+                am = {"in": RtcArg.var(vn(op.bot)), "out": RtcArg.var(op.top), "alpha": _f32(alpha), "beta": _f32(beta), "k": _f32(k),
+                      "local_size": _u32(ls), "n_pel": _u32(n), "C": _u32(d.dsz("chan")), "HW": _u32(hw)}
+                self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall("fwd_lrn", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB), "fwd_lrn"))
+        self._alias = alias
+        # params: given arrays (copy_ndas_to_vars, src/rtc_fwd.cc:524) or the deterministic on-device pattern
+        for pn in self.op_param_names:
+            if op_params is not None and pn in op_params:
+                rtc.copy_nda_to_var(pn, op_params[pn])
+            else:
+                arg = "filts" if pn.endswith("_filts") else "biases"
+                rtc.run(gd.gen_call("Convolution", arg, pn, cp.params[pn], gen_mode, 0.0))
+        rtc.finish_and_sync()
+        rtc.release_per_call_id_data()
+
+    def var_of(self, node: str) -> str:
+        return self._alias.get(node, node)
+
+    # -- run_fwd: set inputs -> run all calls -> get outputs (src/rtc_fwd.cc:529-577)
+    def run_fwd(self, to_set_vns: Sequence[str], fwd: Dict[str, np.ndarray], to_get_vns: Sequence[str]) -> None:
+        rtc = self.rtc
+        if self.enable_double_run:
+            for c in self.fwd_calls:
+                rtc.run(c.rfc)
+        rtc.finish_and_sync()
+        for v in to_set_vns:
+            rtc.copy_nda_to_var(self.var_of(v), fwd[v])
+        rtc.finish_and_sync()
+        for c in self.fwd_calls:
+            c.call_id = rtc.run(c.rfc)
+        rtc.finish_and_sync()
+        for v in to_get_vns:
+            fwd[v] = rtc.copy_var_to_nda(self.var_of(v))
+        self.compute_dur_ms = rtc.get_dur(self.fwd_calls[0].call_id, self.fwd_calls[-1].call_id) if self.fwd_calls else 0.0
+        self.per_call_ms = [(c.tag, c.func, rtc.get_dur(c.call_id, c.call_id), c.flops) for c in self.fwd_calls]
+        if self.per_call_fn:
+            with open(self.per_call_fn, "w") as f:
+                f.write(f"net.args.runtime={self.compute_dur_ms / 1000.0}\n")
+                for tag, func, ms, _ in self.per_call_ms:
+                    f.write(f"per_layer_time['{tag}']=per_layer_time.get('{tag}',0.0) + {ms / 1000.0} # {func} \n")
+        rtc.release_per_call_id_data()
+
+    def run_fwd_device_only(self) -> float:
+        """Run all calls once with inputs already resident (benchmarks); -> ms first-call-start to last-call-end."""
+        rtc = self.rtc
+        ids = [rtc.run(c.rfc) for c in self.fwd_calls]
+        rtc.finish_and_sync()
+        ms = rtc.get_dur(ids[0], ids[-1])
+        self.per_call_ms = [(c.tag, c.func, rtc.get_dur(i, i), c.flops) for c, i in zip(self.fwd_calls, ids)]
+        rtc.release_per_call_id_data()
+        return ms
+
+    def get_info_log(self) -> str:
+        return "\n".join(f"{c.tag}: {c.func}" for c in self.fwd_calls)
+
+    def release(self) -> None:
+        rtc = self.rtc
+        rtc.finish_and_sync()
+        for f in self._funcs:
+            rtc.release_func(f)
+        for v in self._vars:
+            rtc.release_var(v)
+        self._funcs, self._vars, self.fwd_calls = [], [], []
+
+
+def oracle_forward(cp: ConvPipe, data: np.ndarray, params: Dict[str, np.ndarray], bo) -> Dict[str, np.ndarray]:
+    """Reference-order forward of `cp` with the CPU oracle module `bo` (TESTS ONLY: the caller passes oracle.boda_oracle).
+    Returns every node after its in-place ops (what the device vars hold after run_fwd)."""
+    vals = {cp.in_node: data}
+    for op in cp.ops:
+        x = vals[op.bot]
+        if op.type == "Convolution":
+            vals[op.top] = bo.conv_fwd(x, params[op.tag + "_filts"], params[op.tag + "_biases"], op.stride, op.in_pad, relu=False)
+        elif op.type == "ReLU":
+            vals[op.top] = bo.relu(x)
+        elif op.type == "Pooling":
+            vals[op.top] = bo.pool_fwd(x, op.kern_sz, op.stride, op.in_pad, bool(op.avg_pool))
+        elif op.type == "LRN":
+            vals[op.top] = bo.lrn_fwd(x, *op.lrn)
+        elif op.type == "Dropout":
+            vals[op.top] = x
+    return vals

@@ -139,11 +139,15 @@ class RtcArg:
 
 @dataclass
 class RtcFuncCall:
-    """rtc_func_call_t (src/rtc_compute.H:117-123)."""
+    """rtc_func_call_t (src/rtc_compute.H:117-123).  The marshalled C form is cached on first run(); call invalidate()
+    after mutating arg_map / tpb / blks of a call that has already been run."""
     rtc_func_name: str
     arg_map: Dict[str, RtcArg] = field(default_factory=dict)
     tpb: int = 0
     blks: int = 0
+
+    def invalidate(self) -> None:
+        self.__dict__.pop("_c_form", None)
 
 
 class RtcCompileOpts:
@@ -223,6 +227,12 @@ class HipCompute:
         _chk(_lib.bodahip_release_all_funcs(self._ctx))
 
     def run(self, rfc: RtcFuncCall) -> int:
+        cf = rfc.__dict__.get("_c_form")
+        if cf is not None:  # hot path: one ctypes call, no Python-side allocation
+            fn, n, arr, tpb, blks, _keep = cf
+            cid = C.c_uint32()
+            _chk(_lib.bodahip_run(self._ctx, fn, n, arr, tpb, blks, C.byref(cid)))
+            return int(cid.value)
         n = len(rfc.arg_map)
         arr = (_CArg * max(1, n))()
         keep = []
@@ -241,7 +251,9 @@ class HipCompute:
                     data = buf.ctypes.data
                 arr[i] = _CArg(an.encode(), 1, None, cd, data)
         cid = C.c_uint32()
-        _chk(_lib.bodahip_run(self._ctx, rfc.rtc_func_name.encode(), n, arr, rfc.tpb, rfc.blks, C.byref(cid)))
+        fn = rfc.rtc_func_name.encode()
+        _chk(_lib.bodahip_run(self._ctx, fn, n, arr, rfc.tpb, rfc.blks, C.byref(cid)))
+        rfc.__dict__["_c_form"] = (fn, n, arr, rfc.tpb, rfc.blks, keep)
         return int(cid.value)
 
     def finish_and_sync(self) -> None:

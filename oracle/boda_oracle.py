@@ -49,6 +49,9 @@ _lib.bo_digest_plan.restype = u32
 _lib.bo_digest_plan.argtypes = [u64, _u32p, u32, u64, _u64p, _u64p, u32]
 _lib.bo_digest_f32.argtypes = [_f32p, u64, _u64p, _u64p, u32, C.POINTER(f32), C.POINTER(f32), _f32p]
 _lib.bo_num_threads.restype = C.c_int
+_lib.bo_pool_fwd.argtypes = [_f32p, _f32p] + [u32] * 13
+_lib.bo_relu.argtypes = [_f32p, u64]
+_lib.bo_lrn_fwd.argtypes = [_f32p, _f32p, u32, u32, u32, u32, u32, f32, f32, f32]
 
 
 def num_threads() -> int:
@@ -96,6 +99,31 @@ def conv_fwd(inp, filts, biases, stride=(1, 1), pad=(0, 0), relu=True) -> np.nda
     out = np.empty((B, OC, OH, OW), np.float32)
     _lib.bo_conv_fwd(np.ascontiguousarray(inp), np.ascontiguousarray(filts), np.ascontiguousarray(biases), out,
                      B, Cc, H, W, OC, KH, KW, SY, SX, PY, PX, OH, OW, 1 if relu else 0)
+    return out
+
+
+def pool_out_sz(in_sz: int, k: int, s: int, p: int) -> int:
+    """Caffe ceil convention (src/conv_util.cc:198-204)."""
+    pin = in_sz + 2 * p
+    return 1 if pin < k else -(-(pin - k) // s) + 1
+
+
+def pool_fwd(inp, kern=(3, 3), stride=(2, 2), pad=(0, 0), avg=False) -> np.ndarray:
+    B, Cc, H, W = inp.shape
+    OH, OW = pool_out_sz(H, kern[0], stride[0], pad[0]), pool_out_sz(W, kern[1], stride[1], pad[1])
+    out = np.empty((B, Cc, OH, OW), np.float32)
+    _lib.bo_pool_fwd(np.ascontiguousarray(inp), out, B, Cc, H, W, kern[0], kern[1], stride[0], stride[1], pad[0], pad[1], OH, OW, 1 if avg else 0)
+    return out
+
+
+def relu(x) -> np.ndarray:
+    y = np.ascontiguousarray(x, np.float32).copy(); _lib.bo_relu(y.reshape(-1), y.size); return y
+
+
+def lrn_fwd(inp, local_size=5, alpha=1.0, beta=0.75, k=1.0) -> np.ndarray:
+    B, Cc, H, W = inp.shape
+    out = np.empty_like(inp, dtype=np.float32)
+    _lib.bo_lrn_fwd(np.ascontiguousarray(inp), out, B, Cc, H, W, local_size, alpha, beta, k)
     return out
 
 

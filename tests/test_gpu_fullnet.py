@@ -1,0 +1,93 @@
+"""Full-net forward (`has_conv_fwd_t` mode=rtc over be=hip, boda_amd/conv_pipe.py) against the CPU oracle run in the
+reference's op order.  No trained weights exist in the reference tree (nets/ holds prototxts only), so the reference's
+own full-net goldens (good_tr/{nin,alexnet}/digest-*.boda) are unpinned here; parity is vs the oracle on deterministic
+hash-generated inputs/weights, at the reference's full-net tolerance 5e-4 (src/test_compute.cc:45) -- and bit-exact on
+every node that involves only conv / ReLU / max-pool."""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from boda_amd.conv_pipe import ConvPipe, ConvPipeFwd, PipeOp, alexnet_ng_conv, nin_imagenet, oracle_forward
+from boda_amd.digest import SsdsDiff
+from boda_amd.op import Dims
+from boda_amd.rtc import make_rtc
+from oracle import boda_oracle as bo
+
+FULLNET_MRD = 5e-4
+
+
+@pytest.fixture(scope="module")
+def rtc():
+    r = make_rtc("(be=hip)", 0); r.init()
+    yield r
+    r.finish_and_sync(); r.close()
+
+
+def _params(cp):
+    ps = {}
+    for pn, d in cp.params.items():
+        if pn.endswith("_filts"):
+            k = d.dsz("in_chan") * d.dsz("y") * d.dsz("x")
+            ps[pn] = (bo.gen_conv_filts(*d.sizes) * np.float32(0.6 / np.sqrt(k))).astype(np.float32)
+        else:
+            ps[pn] = (bo.gen_conv_biases(d.sizes[0]) * np.float32(0.05)).astype(np.float32)
+    return ps
+
+
+@pytest.mark.parametrize("net,batch", [("nin", 3), ("alexnet", 2)])
+def test_full_net_forward_matches_oracle(rtc, net, batch, tmp_path):
+    cp = nin_imagenet(batch) if net == "nin" else alexnet_ng_conv(batch)
+    params = _params(cp)
+    d = cp.nodes["data"]
+    data = bo.gen_conv_in(*d.sizes)
+    fwd = ConvPipeFwd(rtc, per_call_fn=str(tmp_path / "per_call.py"))
+    fwd.init(cp, op_params=params)
+    try:
+        # conv+ReLU fusion: no separate relu call after a conv; Dropout emits nothing
+        funcs = [c.func for c in fwd.fwd_calls]
+        assert "fwd_relu" not in funcs and funcs.count("hip_conv") == sum(o.type == "Convolution" for o in cp.ops)
+        nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
+        io = {"data": data}
+        fwd.run_fwd(["data"], io, nodes)
+        want = oracle_forward(cp, data, params, bo)
+        exact_ok = True
+        for op in cp.ops:
+            if op.type in ("ReLU", "Dropout"):
+                continue
+            n = op.top
+            sd = SsdsDiff.of(want[n], io[n])
+            assert not sd.has_nan() and sd.mrd < FULLNET_MRD, (n, sd.basic_str())
+            if op.type == "LRN" or (op.type == "Pooling" and op.avg_pool):
+                exact_ok = False  # powf / fast-math division: ulp-level differences from here on
+            if exact_ok:
+                assert np.array_equal(want[n], io[n]), (n, sd.basic_str())
+        assert io[cp.out_node()].shape[:2] == (batch, 1000)
+        assert fwd.compute_dur_ms > 0
+        prof = open(tmp_path / "per_call.py").read()
+        assert prof.startswith("net.args.runtime=") and "per_layer_time['conv1']" in prof
+        # second run (device-resident inputs) reproduces the same outputs
+        ms = fwd.run_fwd_device_only()
+        assert ms > 0 and np.array_equal(rtc.copy_var_to_nda(fwd.var_of(cp.out_node())), io[cp.out_node()])
+    finally:
+        fwd.release()
+
+
+def test_pool_lrn_relu_kernels_vs_oracle(rtc):
+    cp = ConvPipe("t", "data", Dims.make("float", img=2, chan=7, y=13, x=10))
+    cp.add(PipeOp("p_pad", "Pooling", "data", "p_pad", kern_sz=(3, 3), stride=(2, 2), in_pad=(1, 1)))
+    cp.add(PipeOp("r", "ReLU", "p_pad", "p_pad"))
+    cp.add(PipeOp("n", "LRN", "p_pad", "n", lrn=(5, 1e-2, 0.75, 2.0)))
+    cp.add(PipeOp("g", "Pooling", "n", "g", kern_sz=None, avg_pool=1))  # global average pooling
+    data = bo.gen_conv_in(2, 7, 13, 10)
+    fwd = ConvPipeFwd(rtc); fwd.init(cp)
+    try:
+        io = {"data": data}
+        fwd.run_fwd(["data"], io, ["p_pad", "n", "g"])
+        want = oracle_forward(cp, data, {}, bo)
+        assert np.array_equal(want["p_pad"], io["p_pad"]) and (io["p_pad"] >= 0).all()  # max-pool (ceil sizes, padding) + un-fused ReLU
+        assert io["p_pad"].shape == (2, 7, 7, 6) and io["g"].shape == (2, 7, 1, 1)
+        assert SsdsDiff.of(want["n"], io["n"]).mrd < 1e-5 and SsdsDiff.of(want["g"], io["g"]).mrd < 1e-5
+    finally:
+        fwd.release()
