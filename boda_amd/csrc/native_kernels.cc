@@ -48,8 +48,8 @@ bool native_kernels_t::is_native_func_name(string const &fn) {
 }
 void native_kernels_t::check_compile_time(rtc_func_info_t const &fi) {
   string const &fn = fi.op.get_func_name();
-  if (fn == "hip_sgemm" || fn == "cublas_sgemm") return;
-  if (fn == "hip_conv" || fn == "cudnn_conv") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
+  if (fn == "hip_sgemm" || fn == "cublas_sgemm" || fn == "hip_sgemm_bf16") return;
+  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
   rt_err("unknown/unhandled native hip function: " + fn);
 }
 void native_kernels_t::set_tune(string const &key, string const &val) {
@@ -136,13 +136,31 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(hipModuleLaunchKernel(k.func, grid, 1, 1, (uint32_t)c.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false; };
 
-static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string const &tile) {
+// bf16 variant (kernels/gemm_conv_bf16.hip): BK = 32, 32x32x16 MFMA only, chunked staging
+static void bf16_cfg(tile_cfg_t &c, bool gather) {
+  if (c.MT != 32) { c.MT = 32; c.BI = 64; c.BJ = 64; c.WI = 2; c.WJ = 2; }
+  if (c.BK != 32 && c.BK != 64) c.BK = 32;
+  c.SPLITK = 1;
+  int const nt = c.threads();
+  bool ok = (c.BI % (c.WI * 32) == 0) && (c.BJ % (c.WJ * 32) == 0) && ((c.BI * c.BK / 8) % nt == 0) && ((c.BJ * c.BK / 8) % nt == 0) && nt <= 1024 &&
+            (c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) * 16 <= 256 && 4ull * (c.BK + 8) * (c.BI + c.BJ) <= 160 * 1024;
+  if (gather) ok = ok && (c.BJ % 64 == 0) && (nt % c.BJ == 0);
+  if (!ok) unsup_err("native bf16 kernel: unsupported tile configuration " + c.str());
+}
+
+static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string const &tile, bool bf16 = false) {
   (void)K;
-  plan_t p; p.kname = "bodahip_sgemm_f32";
+  plan_t p; p.kname = bf16 ? "bodahip_sgemm_bf16" : "bodahip_sgemm_f32"; p.bf16 = bf16;
   p.cfg = choose_cfg((int)M, (int)N, (int)K, num_cus, false);
+  if (bf16 && tile.empty()) p.cfg.BK = 32;
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad sgemm_tile '" + tile + "'"); }
+  if (bf16) {
+    bf16_cfg(p.cfg, false);
+    p.defs = cfg_defs(p.cfg); p.defs.push_back("-DI_MODE=0"); p.defs.push_back("-DJ_MODE=0"); p.defs.push_back("-DEPI=0");
+    return p;
+  }
   check_cfg(p.cfg, false);
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((M % 4 == 0) ? "0" : "1"));
@@ -151,14 +169,15 @@ static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string
   if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
   return p;
 }
-static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile) {
+static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false) {
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
-  plan_t p; p.kname = "bodahip_conv_f32";
+  plan_t p; p.kname = bf16 ? "bodahip_conv_bf16" : "bodahip_conv_f32"; p.bf16 = bf16;
   // output 1x1, no padding, kernel == whole input ("ipconv" case): the im2col row of image j is the contiguous image
   p.ipconv = (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W);
   p.cfg = choose_cfg(g.OC, (int)Nj, (int)Kt, num_cus, !p.ipconv);
+  if (bf16 && tile.empty()) p.cfg.BK = 32;
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad conv_tile '" + tile + "'"); }
-  check_cfg(p.cfg, !p.ipconv);
+  if (bf16) bf16_cfg(p.cfg, !p.ipconv); else check_cfg(p.cfg, !p.ipconv);
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0) ? "2" : "3"));
   // 1x1 kernel, no padding (any stride): the reference's k1conv case -- one add per gathered element, no table
@@ -174,7 +193,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile) {
 }
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
-  return hiprtc_compile(k_src_gemm_conv_f32, p.kname, arch, opts, log, true);
+  return hiprtc_compile(p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32, p.kname, arch, opts, log, true);
 }
 
 static void setup_splitk(native_kernels_t::impl_t *impl, native_host_t *host, gemm_args_t &ga, tile_cfg_t const &cfg, size_t out_elems) {
@@ -230,11 +249,11 @@ static ktab_t get_ktab(native_kernels_t::impl_t *impl, native_host_t *host, conv
 
 static string tune_of(native_kernels_t::impl_t *impl, char const *key) { auto t = impl->tune.find(key); return (t == impl->tune.end()) ? string() : t->second; }
 
-void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K) {
+void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16) {
   if (!M || !N) return;
   if (!K) { hip_err_chk(hipMemsetAsync(c, 0, (size_t)M * N * 4, host->nh_stream()), "hipMemsetAsync"); return; }
   if (M > 0x7fffffffu || N > 0x7fffffffu || K > 0x7fffffffu) unsup_err("hip_sgemm: dims exceed int32");
-  plan_t const p = plan_sgemm(M, N, K, host->nh_num_cus(), tune_of(impl, "sgemm_tile"));
+  plan_t const p = plan_sgemm(M, N, K, host->nh_num_cus(), tune_of(impl, "sgemm_tile"), bf16);
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
   gemm_args_t ga; memset(&ga, 0, sizeof(ga));
@@ -250,11 +269,11 @@ void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t 
   last_launch.flops = 2.0 * M * N * K; last_launch.algo_bytes = 4.0 * ((double)K * M + (double)K * N + (double)M * N);
 }
 
-void native_kernels_t::conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g) {
+void native_kernels_t::conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16) {
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   if (!Nj || !g.OC) return;
   if (Nj > 0x7fffffffl || Kt > 0x7fffffffl) unsup_err("hip_conv: dims exceed int32");
-  plan_t const p = plan_conv(g, host->nh_num_cus(), tune_of(impl, "conv_tile"));
+  plan_t const p = plan_conv(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), bf16);
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
   gemm_args_t ga; memset(&ga, 0, sizeof(ga));
@@ -287,10 +306,11 @@ static conv_geom_t geom_from_dims(dims_t const &f, dims_t const &in, dims_t cons
 size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile) {
   string const &t = op.get_type();
   plan_t p; string log;
-  if (t == "sgemm") { dims_t const &a = op.get_dims("a"), &b = op.get_dims("b"); p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, tile); }
+  bool const bf16 = op.has_func_name() && (op.get_func_name() == "hip_sgemm_bf16" || op.get_func_name() == "hip_conv_bf16");
+  if (t == "sgemm") { dims_t const &a = op.get_dims("a"), &b = op.get_dims("b"); p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, tile, bf16); }
   else if (t == "Convolution") {
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
-    p = plan_conv(geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims("out"), op.get_dims("stride"), op.get_dims("in_pad"), relu), num_cus, tile);
+    p = plan_conv(geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims("out"), op.get_dims("stride"), op.get_dims("in_pad"), relu), num_cus, tile, bf16);
   } else rt_err("prebuild: op type '" + t + "' has no native kernel");
   size_t const n = compile_plan(p, arch, &log).size();
   if (p.cfg.SPLITK > 1) { // the matching second-pass kernel
@@ -326,7 +346,8 @@ static void need_float(dims_t const &d, char const *an) {
 
 void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &am) {
   string const &fn = fi.op.get_func_name();
-  if (fn == "hip_sgemm" || fn == "cublas_sgemm") {
+  bool const bf16 = (fn == "hip_sgemm_bf16" || fn == "hip_conv_bf16");
+  if (fn == "hip_sgemm" || fn == "cublas_sgemm" || fn == "hip_sgemm_bf16") {
     string const an = var_of(am, "a"), bn = var_of(am, "b"), cn = var_of(am, "c");
     dims_t const a = host->nh_var_dims(an), b = host->nh_var_dims(bn), c = host->nh_var_dims(cn);
     need_float(a, "a"); need_float(b, "b"); need_float(c, "c");
@@ -335,10 +356,10 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     assert_st(a.sz() == 2 && b.sz() == 2 && c.sz() == 2);
     assert_st(a.names(0) == "K" && a.names(1) == "M" && b.names(0) == "K" && b.names(1) == "N" && c.names(0) == "M" && c.names(1) == "N");
     assert_st(b.dsz("K") == K); assert_st(c.dsz("M") == M); assert_st(c.dsz("N") == N);
-    sgemm((float const *)host->nh_var_ptr(an), (float const *)host->nh_var_ptr(bn), (float *)host->nh_var_ptr(cn), M, N, K);
+    sgemm((float const *)host->nh_var_ptr(an), (float const *)host->nh_var_ptr(bn), (float *)host->nh_var_ptr(cn), M, N, K, bf16);
     return;
   }
-  if (fn == "hip_conv" || fn == "cudnn_conv") {
+  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16") {
     string const fnm = var_of(am, "filts"), bnm = var_of(am, "biases"), inm = var_of(am, "in"), onm = var_of(am, "out");
     dims_t const f = host->nh_var_dims(fnm), bi = host->nh_var_dims(bnm), in = host->nh_var_dims(inm), out = host->nh_var_dims(onm);
     need_float(f, "filts"); need_float(bi, "biases"); need_float(in, "in"); need_float(out, "out");
@@ -353,7 +374,7 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     if (!g.SY || !g.SX) rt_err("hip_conv: zero stride");
     // out = (in + 2*pad - k)/stride + 1, floor (src/conv_util.cc:167-173)
     if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW) rt_err("hip_conv: out dims do not match in/filts/stride/in_pad");
-    conv((float const *)host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), (float const *)host->nh_var_ptr(inm), (float *)host->nh_var_ptr(onm), g);
+    conv((float const *)host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), (float const *)host->nh_var_ptr(inm), (float *)host->nh_var_ptr(onm), g, bf16);
     return;
   }
   rt_err("unknown/unhandled native hip function: " + fn);

@@ -5,6 +5,7 @@
 // layout (src/cnn_op.cc:47-48,142,339-340).  This backend does the same for
 //     hip_sgemm  (alias cublas_sgemm)   args a:K:M  b:K:N  c:M:N                      test/rtc/cublas_sgemm.cucl:1-4
 //     hip_conv   (alias cudnn_conv)     args filts biases in stride(REF) in_pad(REF) out   test/rtc/cudnn_conv.cucl:1-7
+//     hip_sgemm_bf16 / hip_conv_bf16    same contracts; bf16 operands (converted while staging), fp32 accumulate (config 5)
 // and lands them on kernels/gemm_conv_f32.hip, specialised with hiprtc per shape class at first use.
 #pragma once
 #include "rtc_types.h"
@@ -50,8 +51,8 @@ struct native_kernels_t {
   void run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &arg_map);
 
   // direct entry points on raw device pointers (used by run() and by the C ABI's fast paths)
-  void sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K);
-  void conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g);
+  void sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16 = false);
+  void conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16 = false);
 
   // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"
   void set_tune(string const &key, string const &val);

@@ -127,6 +127,13 @@ def lrn_fwd(inp, local_size=5, alpha=1.0, beta=0.75, k=1.0) -> np.ndarray:
     return out
 
 
+def to_bf16(x: np.ndarray) -> np.ndarray:
+    """fp32 -> bf16 (round-to-nearest-even) -> fp32: what v_cvt_pk_bf16_f32 does to the operands of the bf16 kernels."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u >> 16) & 1) + 0x7FFF
+    return ((u + r) & 0xFFFF0000).astype(np.uint32).view(np.float32).reshape(x.shape)
+
+
 def mrd(o1: np.ndarray, o2: np.ndarray) -> float:
     a = np.ascontiguousarray(o1, np.float32).reshape(-1); b = np.ascontiguousarray(o2, np.float32).reshape(-1)
     assert a.size == b.size

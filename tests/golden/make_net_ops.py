@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ops/{googlenet_conv,resnet-50}-conv-ops-b1.txt from the reference's net definitions
+(nets/<net>/train_val.prototxt) with THIS project's prototxt reader + shape inference (boda_amd/prototxt.py).  Run in the
+build container only.  The outputs are data: one op line per Convolution layer, batch 1 (re-batched by the callers);
+layer order and multiplicity preserved (64 GoogLeNet convs incl. the auxiliary heads, 53 ResNet-50 convs + its fc)."""
+import os, sys
+HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(os.path.dirname(HERE)); sys.path.insert(0, ROOT)
+from boda_amd.prototxt import conv_ops
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+for net in ("googlenet_conv", "resnet-50"):
+    ops = conv_ops(open(os.path.join(REF, "nets", net, "train_val.prototxt")).read(), 1)
+    with open(os.path.join(HERE, "ops", f"{net}-conv-ops-b1.txt"), "w") as f:
+        for name, op in ops:
+            f.write(op.to_str() + "\n")
+    print(net, len(ops), "convs", sum(o.flops() for _, o in ops) / 1e9, "GF at batch 1")

@@ -394,3 +394,41 @@ def test_ops_prof_harness_end_to_end(be, golden_dir, tmp_path):
     write_wisdoms(str(p), wout)
     back = read_wisdoms(str(p))
     assert len(back) == 2 and all(any(r.be_plat_tag.startswith("hip:") for t in w.wisdoms for r in t.runs.values()) for w in back)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bf16-operand kernels (BASELINE config 5).  The reference has no bf16 path: parity is UNPINNED for them by construction.
+# Stated bounds: (1) vs the oracle fed the same bf16-rounded operands (only the fp32 summation order differs: the 16-deep
+# MFMA is not a sequential chain): max-rel-diff < 5e-4 (measured worst 2.3e-4 at K=2048);  (2) vs the exact fp32 oracle:
+# normalised RMS error < 1e-2
+# (bf16 has 8 mantissa bits: ~2^-9 relative rounding per operand).
+# ---------------------------------------------------------------------------------------------------------------
+MRD_BF16 = 5e-4
+
+
+def _nrms(want, got):
+    w = want.astype(np.float64); g = got.astype(np.float64)
+    return float(np.sqrt(np.mean((w - g) ** 2)) / max(1e-30, np.sqrt(np.mean(w ** 2))))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (100, 36, 50), (260, 130, 70), (512, 64, 2048), (33, 257, 19)])
+def test_bf16_sgemm(be, M, N, K):
+    outs, prc = _run(be, _sgemm_op(M, N, K), 5, tune=OpTune(hip_dtype="bf16"), include_ins=True)
+    assert prc.op.get_func_name() == "hip_sgemm_bf16"
+    want_b = bo.sgemm(bo.to_bf16(outs["a"]), bo.to_bf16(outs["b"]), f64acc=True)
+    sd = SsdsDiff.of(want_b, outs["c"])
+    assert not sd.has_nan() and sd.mrd < MRD_BF16, sd.basic_str()
+    assert _nrms(bo.sgemm(outs["a"], outs["b"], f64acc=True), outs["c"]) < 1e-2
+
+
+@pytest.mark.parametrize("shape", EDGE_CONVS + [(4, 96, 27, 27, 256, 5, 5, 1, 2), (3, 256, 13, 13, 384, 3, 3, 1, 1), (8, 256, 6, 6, 512, 6, 6, 1, 0)])
+def test_bf16_conv(be, shape):
+    op = _conv_op(*shape)
+    outs, prc = _run(be, op, 5, tune=OpTune(hip_dtype="bf16"), include_ins=True)
+    assert prc.op.get_func_name() == "hip_conv_bf16"
+    g = op.conv_geom()
+    want_b = bo.conv_fwd(bo.to_bf16(outs["in"]), bo.to_bf16(outs["filts"]), outs["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
+    sd = SsdsDiff.of(want_b, outs["out"])
+    assert not sd.has_nan() and sd.mrd < MRD_BF16, sd.basic_str()
+    want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
+    assert _nrms(want, outs["out"]) < 1e-2
