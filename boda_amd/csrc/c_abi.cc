@@ -130,6 +130,8 @@ int bodahip_compile_offline(const char *src_or_opts, const char *native_template
   if (code_size_out) *code_size_out = code.size();
   if (log_buf && log_n) { size_t const c = std::min(log_n - 1, log.size()); memcpy(log_buf, log.data(), c); log_buf[c] = 0; }
   ABI_CATCH }
+int bodahip_parse_op(const char *op_lexp, char *canon_buf, size_t canon_buf_sz) {
+  ABI_TRY put_str(canon_buf, canon_buf_sz, op_to_str(parse_op_lexp(S(op_lexp, "op"))), "canonical op"); ABI_CATCH }
 int bodahip_prebuild(const char *op_lexp, const char *arch, int num_cus, const char *tile, size_t *code_size_out) {
   ABI_TRY
   size_t const n = native_kernels_t::prebuild(parse_op_lexp(S(op_lexp, "op")), S(arch, "arch"), num_cus > 0 ? num_cus : 256, tile ? tile : "");

@@ -78,6 +78,7 @@ ABI = {  # symbol -> (restype, argtypes); every symbol include/bodahip.h declare
     "bodahip_last_launch": (C.c_int, [_ctxp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "bodahip_compile_offline": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
+    "bodahip_parse_op": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     "bodahip_prebuild": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_size_t)]),
 }
 for _n, (_r, _a) in ABI.items():
@@ -341,6 +342,13 @@ def compile_offline(src_or_opts: str, native_template: Optional[str] = None, arc
                                       1 if add_prelude else 0, 1 if use_cache else 0, C.byref(sz), log, 1 << 16)
     _chk(rc)
     return int(sz.value)
+
+
+def parse_op_native(line: str) -> str:
+    """The C++ op-line parser of the backend (csrc/lexp.cc), canonical form back.  Host-only."""
+    buf = C.create_string_buffer(1 << 16)
+    _chk(_lib.bodahip_parse_op(line.encode(), buf, 1 << 16))
+    return buf.value.decode()
 
 
 def prebuild(op: Op, arch: str = "gfx950", num_cus: int = 256, tile: str = "") -> int:

@@ -108,6 +108,9 @@ int bodahip_last_launch(bodahip_ctx *ctx, char *kernel_buf, size_t kernel_buf_sz
 int bodahip_compile_offline(const char *src_or_opts, const char *native_template_or_null, const char *arch, int add_prelude, int use_cache,
                             size_t *code_size_out, char *log_buf, size_t log_buf_sz);
 
+/* parse one op line (op_base_t lexp, current or legacy form -- what bodahip_compile does with bodahip_func_info.op) and
+ * write it back in canonical form (sorted str_vals / nda_vals, as NESI prints std::map).  Host-only; for tests/tools. */
+int bodahip_parse_op(const char *op_lexp, char *canon_buf, size_t canon_buf_sz);
 /* AOT: compile, into the on-disk code-object cache the runtime reads, the native-kernel specialisation run() would pick
  * for the op described by `op_lexp` (sgemm / Convolution line) on a device of `arch` with `num_cus` CUs.  No GPU needed. */
 int bodahip_prebuild(const char *op_lexp, const char *arch, int num_cus, const char *tile, size_t *code_size_out);

@@ -52,3 +52,23 @@ def test_cucl_prelude_compiles_generic_source_offline():
 ])
 def test_native_kernel_template_cross_compiles_for_gfx950(opts):
     assert R.compile_offline(opts + " -DKNAME=k_test", "gemm_conv_f32") > 4000
+
+
+def test_cpp_op_parser_agrees_with_python_on_every_fixture_line(golden_dir):
+    """csrc/lexp.cc (what bodahip_compile uses on rtc_func_info_t.op) == boda_amd/op.py on all fixture op lines, both text forms."""
+    import glob
+    from boda_amd.op import parse_op
+    n = 0
+    for fn in sorted(glob.glob(os.path.join(golden_dir, "ops", "*.txt"))):
+        for line in open(fn):
+            if line.strip():
+                assert R.parse_op_native(line) == parse_op(line).to_str(), (fn, line[:80])
+                n += 1
+    assert n > 400
+    with pytest.raises(RtErr):
+        R.parse_op_native("(str_vals=(type=sgemm),nda_vals=(a=(dims=(K=2,M=3))")
+    with pytest.raises(RtErr):
+        R.parse_op_native("(bogus=1)")
+    # annotated ops (func_name, uint32 scalars with values) round-trip too
+    s = "(str_vals=(func_name=hip_conv,type=Convolution),nda_vals=(conv_has_relu=(tn=uint32_t,v=1),stride=(tn=none,dims=(y=4,x=4))))"
+    assert R.parse_op_native(s) == s
