@@ -154,7 +154,10 @@ static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string
   (void)K;
   plan_t p; p.kname = bf16 ? "bodahip_sgemm_bf16" : "bodahip_sgemm_f32"; p.bf16 = bf16;
   p.cfg = choose_cfg((int)M, (int)N, (int)K, num_cus, false);
-  if (bf16 && tile.empty()) p.cfg.BK = 32;
+  if (bf16 && tile.empty()) { // staging-bound kernel: the largest tile that still gives every CU a workgroup (measured: 256x256 624 TF/s vs 128x128 457 at 8192^3)
+    p.cfg.BK = 32;
+    if (p.cfg.BI == 128 && p.cfg.BJ == 128 && (long)((M + 255) / 256) * ((N + 255) / 256) >= num_cus) { p.cfg.BI = 256; p.cfg.BJ = 256; p.cfg.WI = 4; p.cfg.WJ = 4; p.cfg.MINW = 1; }
+  }
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad sgemm_tile '" + tile + "'"); }
   if (bf16) {
     bf16_cfg(p.cfg, false);
@@ -175,7 +178,10 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   // output 1x1, no padding, kernel == whole input ("ipconv" case): the im2col row of image j is the contiguous image
   p.ipconv = (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W);
   p.cfg = choose_cfg(g.OC, (int)Nj, (int)Kt, num_cus, !p.ipconv);
-  if (bf16 && tile.empty()) p.cfg.BK = 32;
+  if (bf16 && tile.empty()) { // staging-bound: widen the pel tile (each filter value staged once per 256 pels) when the grid stays >= one workgroup per CU
+    p.cfg.BK = 32;
+    if (p.cfg.BI == 128 && p.cfg.BJ == 128 && (long)((g.OC + 127) / 128) * ((Nj + 255) / 256) >= num_cus) { p.cfg.BJ = 256; p.cfg.WI = 2; p.cfg.WJ = 4; p.cfg.MINW = 1; }
+  }
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad conv_tile '" + tile + "'"); }
   if (bf16) bf16_cfg(p.cfg, !p.ipconv); else check_cfg(p.cfg, !p.ipconv);
   p.defs = cfg_defs(p.cfg);
