@@ -35,7 +35,8 @@
 //
 // Compile-time parameters (-D):  KNAME BI BJ BK WI WJ MINW I_MODE J_MODE EPI [KH KW SY SX PY PX RELU SPLITK MT]
 //   I_MODE 0 k-major float4 | 1 k-major scalar | 2 i-major (k contiguous) float4 | 3 i-major scalar
-//   J_MODE 0 k-major float4 | 1 k-major scalar | 2 convolution gather from NCHW | 3 j-major (k contiguous) float4 | 4 j-major scalar
+//   J_MODE 0 k-major float4 | 1 k-major scalar | 2 convolution gather from NCHW, per element | 3 j-major (k contiguous) float4 | 4 j-major scalar
+//          6 convolution gather from NCHW, per (in_chan,ky) ROW of KW taps (-DJROWS rows per K step, BK = JROWS*KW): the default for KW >= 6 (wide kernels)
 //          5 1x1 convolution without padding, any stride (the reference's k1conv case, src/cnn_op.cc:51-60): k = in_chan, so
 //            J(k,j) = in[base_j + k*H*W] -- one add per gathered element, no table, no halo tests
 //          (3/4: convolutions whose output is 1x1 with no padding -- the reference's "ipconv" case, src/cnn_op.cc:49-50 --
@@ -114,10 +115,14 @@ constexpr int kLDJ = BJ + kPAD;
 constexpr int kITile = BK * kLDI;
 constexpr int kJTile = BK * kLDJ;
 static_assert(BI % (WI * MT) == 0 && BJ % (WJ * MT) == 0, "tile must be a multiple of the MFMA tile per wave");
-static_assert(BK % 4 == 0, "BK must be a multiple of 4");
-static_assert((BK * BI) % (4 * kNT) == 0 && (BK * BJ) % (4 * kNT) == 0, "tile must split evenly over the threads");
-constexpr int kNI = BK * BI / kNT; // staged floats per thread, operand I
-constexpr int kNJ = BK * BJ / kNT; // staged floats per thread, operand J
+static_assert(MT == 32 || BK % 4 == 0, "16x16x4 MFMA consumes four k per step");
+// staged floats per thread: whole passes of kNT threads, the last pass may be partial (lanes past the tile read nothing and
+// store nothing); vector modes stage 4 floats per lane per pass
+constexpr int staged(int elems, bool vec) { return vec ? 4 * ((elems / 4 + kNT - 1) / kNT) : (elems + kNT - 1) / kNT; }
+constexpr int kNI = staged(BK * BI, I_MODE == 0 || I_MODE == 2);
+constexpr int kNJ = (J_MODE == 2 || J_MODE == 5 || J_MODE == 6) ? (BK * BJ / kNT) : staged(BK * BJ, J_MODE == 0 || J_MODE == 3);
+static_assert((I_MODE != 0 && I_MODE != 2) || BK % 4 == 0, "float4 staging of I needs BK % 4 == 0");
+static_assert(BK % 2 == 0, "BK must be even (two k per MFMA)");
 
 // ---------------------------------------------------------------------------------------------------------------
 // global -> registers.  MODE 0/1: k-major rows of BX floats (x contiguous); MODE 2/3: x-major rows, k contiguous.
@@ -131,36 +136,42 @@ __device__ __forceinline__ float bload1(rsrc_t r, int byte_off) { return __built
 template <int MODE, int BX, int NR>
 __device__ __forceinline__ void load_tile(float (&r)[NR], rsrc_t P, int ld, int x0, int X, int k0, int K, int tid) {
   if constexpr (MODE == 0) {
-    constexpr int VPR = BX / 4;
+    constexpr int VPR = BX / 4, TOT = BK * VPR;
 #pragma unroll
     for (int p = 0; p < NR / 4; ++p) {
       int const v = tid + p * kNT, row = v / VPR, c4 = v % VPR;
       int const k = k0 + row, x = x0 + 4 * c4;
-      f32x4 const val = bload4(P, ((k < K) && (x < X)) ? ((k * ld + x) * 4) : kOOB);
+      bool const in_tile = ((p + 1) * kNT <= TOT) || (v < TOT);
+      f32x4 const val = bload4(P, (in_tile && (k < K) && (x < X)) ? ((k * ld + x) * 4) : kOOB);
       r[4 * p + 0] = val[0]; r[4 * p + 1] = val[1]; r[4 * p + 2] = val[2]; r[4 * p + 3] = val[3];
     }
   } else if constexpr (MODE == 1) {
+    constexpr int TOT = BK * BX;
 #pragma unroll
     for (int p = 0; p < NR; ++p) {
       int const e = tid + p * kNT, row = e / BX, c = e % BX;
       int const k = k0 + row, x = x0 + c;
-      r[p] = bload1(P, ((k < K) && (x < X)) ? ((k * ld + x) * 4) : kOOB);
+      bool const in_tile = ((p + 1) * kNT <= TOT) || (e < TOT);
+      r[p] = bload1(P, (in_tile && (k < K) && (x < X)) ? ((k * ld + x) * 4) : kOOB);
     }
   } else if constexpr (MODE == 2) {
-    constexpr int VPR = BK / 4;
+    constexpr int VPR = BK / 4, TOT = BX * VPR;
 #pragma unroll
     for (int p = 0; p < NR / 4; ++p) {
       int const v = tid + p * kNT, xr = v / VPR, k4 = v % VPR;
       int const x = x0 + xr, k = k0 + 4 * k4;
-      f32x4 const val = bload4(P, ((x < X) && (k < K)) ? ((x * ld + k) * 4) : kOOB);
+      bool const in_tile = ((p + 1) * kNT <= TOT) || (v < TOT);
+      f32x4 const val = bload4(P, (in_tile && (x < X) && (k < K)) ? ((x * ld + k) * 4) : kOOB);
       r[4 * p + 0] = val[0]; r[4 * p + 1] = val[1]; r[4 * p + 2] = val[2]; r[4 * p + 3] = val[3];
     }
   } else {
+    constexpr int TOT = BK * BX;
 #pragma unroll
     for (int p = 0; p < NR; ++p) {
       int const e = tid + p * kNT, xr = e / BK, kk = e % BK;
       int const x = x0 + xr, k = k0 + kk;
-      r[p] = bload1(P, ((x < X) && (k < K)) ? ((x * ld + k) * 4) : kOOB);
+      bool const in_tile = ((p + 1) * kNT <= TOT) || (e < TOT);
+      r[p] = bload1(P, (in_tile && (x < X) && (k < K)) ? ((x * ld + k) * 4) : kOOB);
     }
   }
 }
@@ -169,31 +180,89 @@ __device__ __forceinline__ void load_tile(float (&r)[NR], rsrc_t P, int ld, int 
 template <int MODE, int BX, int LD, int NR>
 __device__ __forceinline__ void store_tile(float const (&r)[NR], float *__restrict__ S, int tid) {
   if constexpr (MODE == 0) {
-    constexpr int VPR = BX / 4;
+    constexpr int VPR = BX / 4, TOT = BK * VPR;
 #pragma unroll
     for (int p = 0; p < NR / 4; ++p) {
       int const v = tid + p * kNT, row = v / VPR, c4 = v % VPR;
       f32x4 val = {r[4 * p + 0], r[4 * p + 1], r[4 * p + 2], r[4 * p + 3]};
-      *reinterpret_cast<f32x4 *>(S + row * LD + 4 * c4) = val;
+      if (((p + 1) * kNT <= TOT) || (v < TOT)) *reinterpret_cast<f32x4 *>(S + row * LD + 4 * c4) = val;
     }
   } else if constexpr (MODE == 1) {
+    constexpr int TOT = BK * BX;
 #pragma unroll
-    for (int p = 0; p < NR; ++p) { int const e = tid + p * kNT; S[(e / BX) * LD + (e % BX)] = r[p]; }
+    for (int p = 0; p < NR; ++p) { int const e = tid + p * kNT; if (((p + 1) * kNT <= TOT) || (e < TOT)) S[(e / BX) * LD + (e % BX)] = r[p]; }
   } else if constexpr (MODE == 2) {
-    constexpr int VPR = BK / 4;
+    constexpr int VPR = BK / 4, TOT = BX * VPR;
 #pragma unroll
     for (int p = 0; p < NR / 4; ++p) {
       int const v = tid + p * kNT, xr = v / VPR, k4 = v % VPR;
+      if (((p + 1) * kNT <= TOT) || (v < TOT)) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) S[(4 * k4 + e) * LD + xr] = r[4 * p + e];
+        for (int e = 0; e < 4; ++e) S[(4 * k4 + e) * LD + xr] = r[4 * p + e];
+      }
     }
   } else {
+    constexpr int TOT = BK * BX;
 #pragma unroll
-    for (int p = 0; p < NR; ++p) { int const e = tid + p * kNT; S[(e % BK) * LD + (e / BK)] = r[p]; }
+    for (int p = 0; p < NR; ++p) { int const e = tid + p * kNT; if (((p + 1) * kNT <= TOT) || (e < TOT)) S[(e % BK) * LD + (e / BK)] = r[p]; }
   }
 }
 
-#if J_MODE == 5
+#if J_MODE == 6
+// Row gather for KH x KW convolutions (KW >= 2; the host picks it for KW >= 6, where it measures faster).  The KW taps of one (in_chan, ky) row are contiguous in memory for a fixed
+// output position, whatever the stride: a K step is JROWS whole rows (BK = JROWS*KW), each thread owns one output position and
+// kRPT rows, and fetches a row with ONE address computation and ceil(KW/4) wide buffer loads.  Row validity (zero padding
+// above/below, K tail) makes the whole row's offset out of range; column validity (left/right padding) depends only on the
+// thread's ix0 and kx, is computed once per thread, and is applied as a select when the row is written to LDS (after the
+// MFMAs, so the loads stay in flight).  Per gathered element: ~1.3 VALU + 1/KW address + 1/min(KW,4) loads, vs ~6 + 1 + 1
+// of the per-element gather (J_MODE 2).  k order is unchanged (ascending (in_chan,ky,kx)): results stay bit-identical.
+#ifndef JROWS
+#error "J_MODE 6 needs -DJROWS"
+#endif
+constexpr int kRPP = kNT / BJ;      // row groups per K step (a wave belongs to exactly one)
+constexpr int kRPT = JROWS / kRPP;  // rows per thread per K step
+static_assert(BJ % 64 == 0 && kNT % BJ == 0 && JROWS % kRPP == 0 && BK == JROWS * KW && KW >= 2, "row gather geometry");
+struct gather_t { int base; int iy0; bool mx[KW]; bool first_tile; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+template <int N> __device__ __forceinline__ void bload_n(float *dst, rsrc_t r, int off) {
+  if constexpr (N >= 4) { f32x4 const v = bload4(r, off); dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; if constexpr (N > 4) bload_n<N - 4>(dst + 4, r, off + 16); }
+  // (whole-vector bit_casts: element-wise bit_casts of the b64/b96 results get mis-shrunk to a 1-dword load by this compiler)
+  else if constexpr (N == 3) { f32x3 const v = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, off, 0, 0)); dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; }
+  else if constexpr (N == 2) { f32x2 const v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0)); dst[0] = v[0]; dst[1] = v[1]; }
+  else { dst[0] = bload1(r, off); }
+}
+__device__ __forceinline__ void load_gather(float (&r)[kNJ], rsrc_t in, gather_t const &g, gemm_args_t const &p, int k0, int tid) {
+  int const row0 = __builtin_amdgcn_readfirstlane(tid / BJ);
+  int const rr = k0 / KW + row0 * kRPT; // first (in_chan,ky) row of this wave (scalar)
+  typedef int const __attribute__((address_space(4))) *ctab_t;
+  ctab_t const t_off = (ctab_t)(p.ktab + rr), t_ky = (ctab_t)(p.ktab + p.ktab_n + rr);
+#pragma unroll
+  for (int q = 0; q < kRPT; ++q) {
+    int const iy = g.iy0 + t_ky[q];
+    int off = (g.base + t_off[q]) * 4;
+    asm volatile("" : "+v"(off));
+    bool const row_ok = (unsigned)iy < (unsigned)p.H;
+    if (PX > 0 && g.first_tile) {
+      // the very first row of the tensor has nothing in front of it: with left padding its window would start at a negative
+      // (= out-of-range) offset and lose its valid taps.  Only the first pel tile can contain it: it gathers tap by tap.
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) r[q * KW + kx] = bload1(in, (row_ok && g.mx[kx]) ? (off + 4 * kx) : kOOB);
+    } else {
+      bload_n<KW>(&r[q * KW], in, row_ok ? off : kOOB);
+    }
+  }
+}
+__device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__restrict__ S, gather_t const &g, int tid) {
+  int const row0 = tid / BJ, jj = tid % BJ;
+#pragma unroll
+  for (int q = 0; q < kRPT; ++q)
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) S[((row0 * kRPT + q) * KW + kx) * kLDJ + jj] = g.mx[kx] ? r[q * KW + kx] : 0.f;
+}
+#define GATHER_ARG , g
+#define GATHER_PARM , gather_t const &g
+#elif J_MODE == 5
 // 1x1 / pad 0 convolution: thread = one output position, wave = kNJ consecutive input channels per K step.
 struct gather_t { int base4; }; // byte offset of (img, chan 0, oy*SY, ox*SX); columns past the end: 0x80000000 (out of range for every k)
 static_assert(BJ % 64 == 0 && kNT % BJ == 0, "gather: a wave must sit inside one k row (BJ multiple of 64, BJ <= threads)");
@@ -257,7 +326,7 @@ __device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__res
 #endif
 
 __device__ __forceinline__ void load_J(float (&rj)[kNJ], rsrc_t J, gemm_args_t const &p, int j0, int k0, int tid GATHER_PARM) {
-#if J_MODE == 2 || J_MODE == 5
+#if J_MODE == 2 || J_MODE == 5 || J_MODE == 6
   load_gather(rj, J, g, p, k0, tid);
 #elif J_MODE == 3 || J_MODE == 4
   load_tile<J_MODE - 1, BJ, kNJ>(rj, J, p.ldJ, j0, p.Nj, k0, p.K, tid);
@@ -265,8 +334,10 @@ __device__ __forceinline__ void load_J(float (&rj)[kNJ], rsrc_t J, gemm_args_t c
   load_tile<J_MODE, BJ, kNJ>(rj, J, p.ldJ, j0, p.Nj, k0, p.K, tid);
 #endif
 }
-__device__ __forceinline__ void store_J(float const (&rj)[kNJ], float *__restrict__ S, int tid) {
-#if J_MODE == 2 || J_MODE == 5
+__device__ __forceinline__ void store_J(float const (&rj)[kNJ], float *__restrict__ S, int tid GATHER_PARM) {
+#if J_MODE == 6
+  store_gather(rj, S, g, tid);
+#elif J_MODE == 2 || J_MODE == 5
   store_gather(rj, S, tid);
 #elif J_MODE == 3 || J_MODE == 4
   store_tile<J_MODE - 1, BJ, kLDJ, kNJ>(rj, S, tid);
@@ -303,7 +374,20 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   float *const Is0 = smem, *const Is1 = smem + kITile;
   float *const Js0 = smem + 2 * kITile, *const Js1 = smem + 2 * kITile + kJTile;
 
-#if J_MODE == 5
+#if J_MODE == 6
+  gather_t g;
+  {
+    int const OHW = p.OH * p.OW;
+    int const jg = j0 + (tid % BJ);
+    int const img = jg / OHW, pel = jg - img * OHW, oy = pel / p.OW, ox = pel - oy * p.OW;
+    int const ix0 = ox * SX - PX;
+    g.iy0 = (jg < p.Nj) ? (oy * SY - PY) : (1 << 29); // columns past the end fail the row test for every row
+    g.base = (img * p.C * p.H + (oy * SY - PY)) * p.W + ix0;
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) g.mx[kx] = (unsigned)(ix0 + kx) < (unsigned)p.W;
+    g.first_tile = (tile_j == 0); // workgroup-uniform
+  }
+#elif J_MODE == 5
   gather_t g;
   {
     int const OHW = p.OH * p.OW;
@@ -345,7 +429,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   load_tile<I_MODE, BI, kNI>(ri, rI, p.ldI, i0, p.Mi, kt_begin * BK, p.K, tid);
   load_J(rj, rJ, p, j0, kt_begin * BK, tid GATHER_ARG);
   store_tile<I_MODE, BI, kLDI, kNI>(ri, Is0, tid);
-  store_J(rj, Js0, tid);
+  store_J(rj, Js0, tid GATHER_ARG);
   __syncthreads();
 
   // MFMA operand fetch: lane l holds A[i = l % MT][k = l / MT] and B[k = l / MT][j = l % MT]
@@ -391,7 +475,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #if !(ABLATE & 4)
     if (more) {
       store_tile<I_MODE, BI, kLDI, kNI>(ri, (kt & 1) ? Is0 : Is1, tid);
-      store_J(rj, (kt & 1) ? Js0 : Js1, tid);
+      store_J(rj, (kt & 1) ? Js0 : Js1, tid GATHER_ARG);
     }
 #endif
     __syncthreads();

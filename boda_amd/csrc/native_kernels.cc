@@ -72,7 +72,8 @@ static bool parse_tile(string const &s, tile_cfg_t &c) {
 static void check_cfg(tile_cfg_t const &c, bool gather) {
   int const nt = c.threads();
   bool ok = c.BI > 0 && c.BJ > 0 && c.BK > 0 && c.WI > 0 && c.WJ > 0 && nt <= 1024 && (c.MT == 32 || c.MT == 16) && (c.BI % (c.WI * c.MT) == 0) && (c.BJ % (c.WJ * c.MT) == 0) &&
-            (c.BK % 4 == 0) && ((c.BK * c.BI) % (4 * nt) == 0) && ((c.BK * c.BJ) % (4 * nt) == 0);
+            (c.BK % 2 == 0) && (c.MT == 32 || c.BK % 4 == 0) && (c.BI % 4 == 0) && (c.BJ % 4 == 0);
+  if (gather) ok = ok && ((c.BK * c.BJ) % nt == 0); // the gathers give every thread whole elements / rows
   if (gather) ok = ok && (nt % c.BJ == 0) && (c.BJ % 64 == 0);
   ok = ok && c.SPLITK >= 1 && c.SPLITK <= 64 && c.MINW >= 1;
   int const accs = (c.BI / (c.WI * c.MT)) * (c.BJ / (c.WJ * c.MT));
@@ -107,7 +108,16 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather) {
     tile_cfg_t c2 = c; c2.BI = 64; c2.BJ = 64; c2.WI = 2; c2.WJ = 2; // four 32x32 wave tiles: ~0.87x the per-tile efficiency of 64x64 wave tiles
     long const tiles2 = ntiles(c2);
     bool const use_small = (tiles < num_cus) || (balance(tiles) < 0.87 * balance(tiles2));
-    if (!use_small) return c;
+    if (!use_small) {
+      // large k-major problems: 256x256 workgroups (16 waves, same 64x64 wave tiles) run at the same speed but halve the HBM
+      // re-reads of the k panels (measured 12288^3: 10.9 GB vs 24.2 GB per launch) -- taken only when they deal out as evenly
+      if (!gather && c.BI == 128 && c.BJ == 128) {
+        tile_cfg_t c4 = c; c4.BI = 256; c4.BJ = 256; c4.WI = 4; c4.WJ = 4; c4.MINW = 1;
+        long const tiles4 = ntiles(c4);
+        if (tiles4 >= num_cus && balance(tiles4) >= 0.98 * balance(tiles)) return c4;
+      }
+      return c;
+    }
     // Splitting K would fill the chip for tile-starved shapes, but it re-associates the fp32 sum: the reference's golden
     // digests (tolerance 2e-4 on max(1,|v|)) are only met robustly by the ascending-k chain, so SPLITK is an explicit tune
     // ("...xMINWxS"), never the default.
@@ -136,7 +146,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(hipModuleLaunchKernel(k.func, grid, 1, 1, (uint32_t)c.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false; int rows = 0; };
 
 // bf16 variant (kernels/gemm_conv_bf16.hip): BK = 32, 32x32x16 MFMA only, chunked staging
 static void bf16_cfg(tile_cfg_t &c, bool gather) {
@@ -183,12 +193,24 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
     if (p.cfg.BI == 128 && p.cfg.BJ == 128 && (long)((g.OC + 127) / 128) * ((Nj + 255) / 256) >= num_cus) { p.cfg.BJ = 256; p.cfg.WI = 2; p.cfg.WJ = 4; p.cfg.MINW = 1; }
   }
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad conv_tile '" + tile + "'"); }
+  // wide kernels: row gather (one address + wide loads per (in_chan,ky) row of KW taps): a K step is `rows` whole rows, BK = rows*KW.
+  // Measured (MI355X, B=256): 11x11/s4 +8%, 5x5 -3%, 3x3 -9% vs the per-element table gather (unaligned x3 loads cost more than the
+  // address arithmetic they save), so the default takes it for KW >= 6 only; BODAHIP_ROW_GATHER_MIN_KW overrides (>= 2).
+  p.rows = 0;
+  int rg_min_kw = 6; if (char const *e = getenv("BODAHIP_ROW_GATHER_MIN_KW")) rg_min_kw = std::max(2, atoi(e));
+  if (!bf16 && !p.ipconv && g.KW >= rg_min_kw && g.KW <= 16 && getenv("BODAHIP_NO_ROW_GATHER") == nullptr) {
+    int const rpp = std::max(1, p.cfg.threads() / p.cfg.BJ);               // row groups per K step
+    int rows = (g.KW <= 3) ? 8 : (g.KW <= 8 ? 4 : 2);                        // BK = 16..28 (22 for 11x11)
+    while (rows % rpp) rows += 2;
+    if ((rows * g.KW) % 2 == 0 && rows % rpp == 0 && p.cfg.threads() % p.cfg.BJ == 0 && p.cfg.BJ % 64 == 0 && p.cfg.MT == 32 && tile.empty()) { p.rows = rows; p.cfg.BK = rows * g.KW; }
+  }
   if (bf16) bf16_cfg(p.cfg, !p.ipconv); else check_cfg(p.cfg, !p.ipconv);
   p.defs = cfg_defs(p.cfg);
-  p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0) ? "2" : "3"));
+  p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0 && p.cfg.BK % 4 == 0) ? "2" : "3"));
   // 1x1 kernel, no padding (any stride): the reference's k1conv case -- one add per gathered element, no table
   p.k1 = !p.ipconv && g.KH == 1 && g.KW == 1 && g.PY == 0 && g.PX == 0;
-  p.defs.push_back(p.ipconv ? (string("-DJ_MODE=") + ((Kt % 4 == 0) ? "3" : "4")) : string(p.k1 ? "-DJ_MODE=5" : "-DJ_MODE=2"));
+  p.defs.push_back(p.ipconv ? (string("-DJ_MODE=") + ((Kt % 4 == 0) ? "3" : "4")) : string(p.k1 ? "-DJ_MODE=5" : (p.rows ? "-DJ_MODE=6" : "-DJ_MODE=2")));
+  if (p.rows) p.defs.push_back("-DJROWS=" + std::to_string(p.rows));
   p.defs.push_back("-DEPI=1");
   if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
   p.defs.push_back("-DKH=" + std::to_string(g.KH)); p.defs.push_back("-DKW=" + std::to_string(g.KW));
@@ -253,6 +275,26 @@ static ktab_t get_ktab(native_kernels_t::impl_t *impl, native_host_t *host, conv
   return ktab_t{d, (int)n};
 }
 
+// per-row tables of the row gather (two arrays of n ints): element offset of (in_chan,ky,kx=0) inside one image | ky.
+// Rows >= C*KH carry ky = 2^30 (fail the kernel's row-range test -> zero contribution).
+static ktab_t get_rtab(native_kernels_t::impl_t *impl, native_host_t *host, conv_geom_t const &g) {
+  string const key = "rows:" + std::to_string(g.C) + "," + std::to_string(g.H) + "," + std::to_string(g.W) + "," + std::to_string(g.KH);
+  long const R = (long)g.C * g.KH, n = ((R + 63) / 64 + 1) * 64;
+  auto it = impl->ktabs.find(key);
+  if (it != impl->ktabs.end()) return ktab_t{it->second, (int)n};
+  std::vector<int> h((size_t)n * 2);
+  for (long r = 0; r < n; ++r) {
+    if (r < R) { long const ic = r / g.KH, ky = r % g.KH; h[r] = (int)((ic * g.H + ky) * g.W); h[n + r] = (int)ky; }
+    else { h[r] = 0; h[n + r] = 1 << 30; }
+  }
+  void *d = nullptr;
+  hip_err_chk(hipMalloc(&d, h.size() * sizeof(int)), "hipMalloc(rtab)");
+  hip_err_chk(hipMemcpyAsync(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, host->nh_stream()), "hipMemcpyAsync(rtab)");
+  hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize");
+  impl->ktabs.emplace(key, d);
+  return ktab_t{d, (int)n};
+}
+
 static string tune_of(native_kernels_t::impl_t *impl, char const *key) { auto t = impl->tune.find(key); return (t == impl->tune.end()) ? string() : t->second; }
 
 void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16) {
@@ -289,7 +331,8 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.ldI = (int)Kt; ga.ldJ = p.ipconv ? (int)Kt : 0; ga.ldD = g.OH * g.OW;
   ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
   ga.I_bytes = (unsigned)f_bytes; ga.J_bytes = (unsigned)in_bytes;
-  if (!p.ipconv && !p.k1) { ktab_t const kt = get_ktab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
+  if (p.rows) { ktab_t const kt = get_rtab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
+  else if (!p.ipconv && !p.k1) { ktab_t const kt = get_ktab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
   ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
   setup_splitk(impl, host, ga, cfg, (size_t)Nj * g.OC);
   launch(host, k, ga, cfg);

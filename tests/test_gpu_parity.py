@@ -305,6 +305,21 @@ def test_conv_vs_oracle_bit_exact(be, shape):
     assert np.array_equal(want, outs["out"]), sd.basic_str()
 
 
+@pytest.mark.parametrize("shape", [s for s in EDGE_CONVS if s[6] >= 2] + [(3, 24, 15, 15, 100, 3, 3, 1, 1), (2, 3, 35, 35, 96, 11, 11, 4, 0)])
+def test_conv_row_gather_all_kernel_widths(be, shape, monkeypatch):
+    """The row gather (J_MODE 6) is the default for KW >= 6 only; force it for every KW >= 2 (padding, strides, first-row and
+    tensor-end windows, unaligned wide loads) and hold it to the same bit-exact bar."""
+    monkeypatch.setenv("BODAHIP_ROW_GATHER_MIN_KW", "2")
+    op = _conv_op(*shape)
+    outs, _ = _run(be, op, 5, include_ins=True)
+    g = op.conv_geom()
+    cfg = be.rtc.last_launch()["cfg"]
+    if not (g["OH"] == 1 and g["OW"] == 1 and g["PY"] == 0 and g["KH"] == shape[2]):  # ipconv shapes never gather
+        assert int(cfg.split("x")[2].split("_")[0]) % g["KW"] == 0, cfg  # BK = rows * KW: the row gather was taken
+    want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
+    assert np.array_equal(want, outs["out"]), SsdsDiff.of(want, outs["out"]).basic_str()
+
+
 def test_conv_without_relu_and_alias(be):
     op = _conv_op(2, 6, 10, 10, 12, 3, 3, 1, 1)
     anno = add_codegen_annotations(op, OpTune(use_culibs=1))
