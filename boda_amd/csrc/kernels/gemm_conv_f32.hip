@@ -34,9 +34,10 @@
 //     tiles, walked in groups of GROUP_I tiles along i so neighbouring workgroups share I / J panels in their L2.
 //
 // Compile-time parameters (-D):  KNAME BI BJ BK WI WJ MINW I_MODE J_MODE EPI [KH KW SY SX PY PX RELU SPLITK MT]
-//   I_MODE 0 k-major float4 | 1 k-major scalar | 2 i-major (k contiguous) float4 | 3 i-major scalar
+//   I_MODE 0 k-major float4 | 1 k-major scalar | 2 i-major (k contiguous) float4 | 3 i-major scalar | 4 i-major float2
 //   J_MODE 0 k-major float4 | 1 k-major scalar | 2 convolution gather from NCHW, per element | 3 j-major (k contiguous) float4 | 4 j-major scalar
 //          6 convolution gather from NCHW, per (in_chan,ky) ROW of KW taps (-DJROWS rows per K step, BK = JROWS*KW): the default for KW >= 6 (wide kernels)
+//          7 convolution from an LDS input patch (SX == 1, KH*KW >= 2; -DCH -DCW -DCOH -DCOW, BK = whole channels): see kCB below
 //          5 1x1 convolution without padding, any stride (the reference's k1conv case, src/cnn_op.cc:51-60): k = in_chan, so
 //            J(k,j) = in[base_j + k*H*W] -- one add per gathered element, no table, no halo tests
 //          (3/4: convolutions whose output is 1x1 with no padding -- the reference's "ipconv" case, src/cnn_op.cc:49-50 --
@@ -112,17 +113,61 @@ typedef f32x4 acc_t;
 constexpr int kPAD = 4;
 constexpr int kLDI = BI + kPAD;
 constexpr int kLDJ = BJ + kPAD;
-constexpr int kITile = BK * kLDI;
-constexpr int kJTile = BK * kLDJ;
+// I operands that are k-contiguous in memory (I_MODE 2/3/4: convolution filters) keep that layout in LDS: the tile is a straight
+// [BI][kLDK] copy (ds_write_b128 / b64 of what the loads returned, no transposing scalar writes), and the MFMA A operand is
+// fetched as one kRW-wide read per lane and kRW k -- row stride kLDK is chosen with kLDK/kRW odd, which makes both the
+// reads and the writes bank-conflict free -- of which lanes 0-31 use the even and lanes 32-63 the odd elements.
+#ifndef IROWS
+#define IROWS 0 // experiment hook: 0 k-major transposed image | 1 row image, wide writes + wide reads | 2 row image with odd stride, scalar writes / reads
+#endif
+#define I_ROWS (IROWS != 0 && MT == 32 && (I_MODE == 2 || I_MODE == 3 || I_MODE == 4))
+#if IROWS == 2
+constexpr int kRW = 1;
+constexpr int kLDK = BK + 1;
+#else
+constexpr int kRW = (BK % 4 == 0) ? 4 : 2;
+constexpr int kLDK = ((BK / kRW) % 2 == 1) ? BK : BK + kRW;
+#endif
+constexpr int kITile = I_ROWS ? BI * kLDK : BK * kLDI;
 static_assert(BI % (WI * MT) == 0 && BJ % (WJ * MT) == 0, "tile must be a multiple of the MFMA tile per wave");
 static_assert(MT == 32 || BK % 4 == 0, "16x16x4 MFMA consumes four k per step");
-// staged floats per thread: whole passes of kNT threads, the last pass may be partial (lanes past the tile read nothing and
-// store nothing); vector modes stage 4 floats per lane per pass
-constexpr int staged(int elems, bool vec) { return vec ? 4 * ((elems / 4 + kNT - 1) / kNT) : (elems + kNT - 1) / kNT; }
-constexpr int kNI = staged(BK * BI, I_MODE == 0 || I_MODE == 2);
-constexpr int kNJ = (J_MODE == 2 || J_MODE == 5 || J_MODE == 6) ? (BK * BJ / kNT) : staged(BK * BJ, J_MODE == 0 || J_MODE == 3);
-static_assert((I_MODE != 0 && I_MODE != 2) || BK % 4 == 0, "float4 staging of I needs BK % 4 == 0");
 static_assert(BK % 2 == 0, "BK must be even (two k per MFMA)");
+// staged floats per thread: whole passes of kNT threads, the last pass may be partial (lanes past the tile read nothing and
+// store nothing); vector modes stage 4 (2) floats per lane per pass
+constexpr int vec_w(int mode) { return (mode == 0 || mode == 2) ? 4 : (mode == 4 ? 2 : 1); }
+constexpr int staged(int elems, int w) { return w * ((elems / w + kNT - 1) / kNT); }
+constexpr int kNI = staged(BK * BI, vec_w(I_MODE));
+static_assert(vec_w(I_MODE) == 1 || BK % vec_w(I_MODE) == 0, "vector staging of I needs BK % width == 0");
+#if J_MODE == 7
+// Patch mode (stride-1-in-x KH x KW convolutions): the K step is kCB whole input channels; instead of an im2col image the LDS
+// holds, per channel, the zero-padded input rows the tile's output positions touch ("slots" of kWp floats).  Output rows of one
+// image share slots (row r+1 starts SY slots after row r); a tile that crosses into the next image starts a new slot group.
+//   element J(k=(c,ky,kx), j) = patch[c][ slot(j) + ky ][ ox(j)*SX + kx ]  =  lds[ bj(j) + koff(k) ]
+// -> the MFMA B operand is read straight from the patch (per-lane base + per-k constant); staging a channel costs
+//    kCS/kNT coalesced loads per thread instead of KH*KW*BJ/kNT gathered ones, and needs no per-element index arithmetic.
+#if !defined(CH) || !defined(CW) || !defined(COH) || !defined(COW)
+#error "J_MODE 7 needs -DCH -DCW -DCOH -DCOW (input / output plane sizes are compile-time)"
+#endif
+constexpr int kTaps = KH * KW, kCB = BK / kTaps, kWp = CW + 2 * PX;
+static_assert(BK % kTaps == 0 && KH >= SY && MT == 32, "patch mode geometry");
+constexpr int kRowsMax = (BJ - 2) / COW + 2;                     // output rows a BJ-pel tile can touch
+constexpr int kSegFull = (COH - 1) * SY + KH;                    // slots of a whole image
+constexpr int kSegMax0 = (COH - 1 + kRowsMax - 1) / COH + 1;     // images a tile can touch
+constexpr int kSegMax = kSegMax0 < kRowsMax ? kSegMax0 : kRowsMax;
+constexpr int kSlots = (kRowsMax - kSegMax) * SY + kSegMax * KH; // slots per channel (upper bound over tile positions)
+constexpr int kCS = kSlots * kWp;                                // floats per channel
+constexpr int kEPT = (kCS + kNT - 1) / kNT;                      // patch elements per thread per channel
+constexpr int kNJ = kCB * kEPT;
+constexpr int kJTile = kCB * kCS;
+constexpr int koff(int k) { return (k / kTaps) * kCS + ((k % kTaps) / KW) * kWp + (k % KW); }
+// k = 2kk+1 sits a fixed distance after k = 2kk: next tap of the row | first tap of the next row | first tap of the next channel.
+// Lanes 32-63 (odd k) fold that distance into their base address once; the even-k offset koff(2kk) is then an immediate.
+constexpr int kD0 = 1, kD1 = kWp - KW + 1, kD2 = kCS - (KH - 1) * kWp - (KW - 1);
+constexpr int kdelta_class(int kk) { return ((2 * kk) % KW != KW - 1) ? 0 : ((((2 * kk) % kTaps) != kTaps - 1) ? 1 : 2); }
+#else
+constexpr int kNJ = (J_MODE == 2 || J_MODE == 5 || J_MODE == 6) ? (BK * BJ / kNT) : staged(BK * BJ, (J_MODE == 0 || J_MODE == 3) ? 4 : 1);
+constexpr int kJTile = BK * kLDJ;
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // global -> registers.  MODE 0/1: k-major rows of BX floats (x contiguous); MODE 2/3: x-major rows, k contiguous.
@@ -131,6 +176,11 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int kOOB = (int)0x80000000; // byte offset beyond any num_records (tensors are <= 2^31 bytes): hardware returns 0
 __device__ __forceinline__ rsrc_t make_rsrc(float const *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)bytes, 0x00020000); }
 __device__ __forceinline__ f32x4 bload4(rsrc_t r, int byte_off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0)); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+// (whole-vector bit_casts: element-wise bit_casts of the b64/b96 results get mis-shrunk to a 1-dword load by this compiler)
+__device__ __forceinline__ f32x2 bload2(rsrc_t r, int byte_off) { return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0)); }
+__device__ __forceinline__ f32x3 bload3(rsrc_t r, int byte_off) { return __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, byte_off, 0, 0)); }
 __device__ __forceinline__ float bload1(rsrc_t r, int byte_off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0)); }
 
 template <int MODE, int BX, int NR>
@@ -164,6 +214,16 @@ __device__ __forceinline__ void load_tile(float (&r)[NR], rsrc_t P, int ld, int 
       f32x4 const val = bload4(P, (in_tile && (x < X) && (k < K)) ? ((x * ld + k) * 4) : kOOB);
       r[4 * p + 0] = val[0]; r[4 * p + 1] = val[1]; r[4 * p + 2] = val[2]; r[4 * p + 3] = val[3];
     }
+  } else if constexpr (MODE == 4) {
+    constexpr int VPR = BK / 2, TOT = BX * VPR;
+#pragma unroll
+    for (int p = 0; p < NR / 2; ++p) {
+      int const v = tid + p * kNT, xr = v / VPR, k2 = v % VPR;
+      int const x = x0 + xr, k = k0 + 2 * k2;
+      bool const in_tile = ((p + 1) * kNT <= TOT) || (v < TOT);
+      f32x2 const val = bload2(P, (in_tile && (x < X) && (k < K)) ? ((x * ld + k) * 4) : kOOB);
+      r[2 * p + 0] = val[0]; r[2 * p + 1] = val[1];
+    }
   } else {
     constexpr int TOT = BK * BX;
 #pragma unroll
@@ -177,9 +237,24 @@ __device__ __forceinline__ void load_tile(float (&r)[NR], rsrc_t P, int ld, int 
 }
 
 // registers -> LDS image [BK][LD] (k-major)
-template <int MODE, int BX, int LD, int NR>
+template <int MODE, int BX, int LD, int NR, bool ROWS = false>
 __device__ __forceinline__ void store_tile(float const (&r)[NR], float *__restrict__ S, int tid) {
-  if constexpr (MODE == 0) {
+  if constexpr (ROWS) { // x-major image [BX][LD]: the k-contiguous vectors are stored as loaded
+    constexpr int VW = vec_w(MODE), VPR = BK / VW, TOT = BX * VPR;
+#pragma unroll
+    for (int p = 0; p < NR / VW; ++p) {
+      int const v = tid + p * kNT, xr = v / VPR, kv = v % VPR;
+      if (((p + 1) * kNT <= TOT) || (v < TOT)) {
+        float *const d = S + xr * LD + VW * kv;
+        if constexpr (IROWS == 2) {
+#pragma unroll
+          for (int e = 0; e < VW; ++e) d[e] = r[VW * p + e];
+        } else if constexpr (VW == 4) { f32x4 const val = {r[4 * p + 0], r[4 * p + 1], r[4 * p + 2], r[4 * p + 3]}; *reinterpret_cast<f32x4 *>(d) = val; }
+        else if constexpr (VW == 2) { f32x2 const val = {r[2 * p + 0], r[2 * p + 1]}; *reinterpret_cast<f32x2 *>(d) = val; }
+        else { *d = r[p]; }
+      }
+    }
+  } else if constexpr (MODE == 0) {
     constexpr int VPR = BX / 4, TOT = BK * VPR;
 #pragma unroll
     for (int p = 0; p < NR / 4; ++p) {
@@ -200,6 +275,13 @@ __device__ __forceinline__ void store_tile(float const (&r)[NR], float *__restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) S[(4 * k4 + e) * LD + xr] = r[4 * p + e];
       }
+    }
+  } else if constexpr (MODE == 4) {
+    constexpr int VPR = BK / 2, TOT = BX * VPR;
+#pragma unroll
+    for (int p = 0; p < NR / 2; ++p) {
+      int const v = tid + p * kNT, xr = v / VPR, k2 = v % VPR;
+      if (((p + 1) * kNT <= TOT) || (v < TOT)) { S[(2 * k2) * LD + xr] = r[2 * p]; S[(2 * k2 + 1) * LD + xr] = r[2 * p + 1]; }
     }
   } else {
     constexpr int TOT = BK * BX;
@@ -223,13 +305,10 @@ constexpr int kRPP = kNT / BJ;      // row groups per K step (a wave belongs to 
 constexpr int kRPT = JROWS / kRPP;  // rows per thread per K step
 static_assert(BJ % 64 == 0 && kNT % BJ == 0 && JROWS % kRPP == 0 && BK == JROWS * KW && KW >= 2, "row gather geometry");
 struct gather_t { int base; int iy0; bool mx[KW]; bool first_tile; };
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x3 __attribute__((ext_vector_type(3)));
 template <int N> __device__ __forceinline__ void bload_n(float *dst, rsrc_t r, int off) {
   if constexpr (N >= 4) { f32x4 const v = bload4(r, off); dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; if constexpr (N > 4) bload_n<N - 4>(dst + 4, r, off + 16); }
-  // (whole-vector bit_casts: element-wise bit_casts of the b64/b96 results get mis-shrunk to a 1-dword load by this compiler)
-  else if constexpr (N == 3) { f32x3 const v = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, off, 0, 0)); dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; }
-  else if constexpr (N == 2) { f32x2 const v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0)); dst[0] = v[0]; dst[1] = v[1]; }
+  else if constexpr (N == 3) { f32x3 const v = bload3(r, off); dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; }
+  else if constexpr (N == 2) { f32x2 const v = bload2(r, off); dst[0] = v[0]; dst[1] = v[1]; }
   else { dst[0] = bload1(r, off); }
 }
 __device__ __forceinline__ void load_gather(float (&r)[kNJ], rsrc_t in, gather_t const &g, gemm_args_t const &p, int k0, int tid) {
@@ -259,6 +338,27 @@ __device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__res
   for (int q = 0; q < kRPT; ++q)
 #pragma unroll
     for (int kx = 0; kx < KW; ++kx) S[((row0 * kRPT + q) * KW + kx) * kLDJ + jj] = g.mx[kx] ? r[q * KW + kx] : 0.f;
+}
+#define GATHER_ARG , g
+#define GATHER_PARM , gather_t const &g
+#elif J_MODE == 7
+struct gather_t { int goff[kEPT]; }; // byte offset of (img, chan 0, iy, ix) of this thread's patch elements; kOOB: zero (padding / past the end)
+__device__ __forceinline__ void load_gather(float (&r)[kNJ], rsrc_t in, gather_t const &g, gemm_args_t const &p, int k0, int tid) {
+  int const c0 = k0 / kTaps; // scalar
+#pragma unroll
+  for (int cc = 0; cc < kCB; ++cc) {
+    // channels past the end (K tail) meet zero filter values: any finite data will do -> re-read the last channel of the image
+    int const coff = min(c0 + cc, p.C - 1) * (CH * CW * 4); // scalar; goff + coff < 2^32 and stays >= 2^31 for kOOB entries
+#pragma unroll
+    for (int e = 0; e < kEPT; ++e) r[cc * kEPT + e] = bload1(in, g.goff[e] + coff);
+  }
+}
+__device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__restrict__ S, int tid) {
+#pragma unroll
+  for (int cc = 0; cc < kCB; ++cc)
+#pragma unroll
+    for (int e = 0; e < kEPT; ++e)
+      if (((e + 1) * kNT <= kCS) || (tid + e * kNT < kCS)) S[cc * kCS + e * kNT + tid] = r[cc * kEPT + e];
 }
 #define GATHER_ARG , g
 #define GATHER_PARM , gather_t const &g
@@ -326,7 +426,7 @@ __device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__res
 #endif
 
 __device__ __forceinline__ void load_J(float (&rj)[kNJ], rsrc_t J, gemm_args_t const &p, int j0, int k0, int tid GATHER_PARM) {
-#if J_MODE == 2 || J_MODE == 5 || J_MODE == 6
+#if J_MODE == 2 || J_MODE == 5 || J_MODE == 6 || J_MODE == 7
   load_gather(rj, J, g, p, k0, tid);
 #elif J_MODE == 3 || J_MODE == 4
   load_tile<J_MODE - 1, BJ, kNJ>(rj, J, p.ldJ, j0, p.Nj, k0, p.K, tid);
@@ -337,7 +437,7 @@ __device__ __forceinline__ void load_J(float (&rj)[kNJ], rsrc_t J, gemm_args_t c
 __device__ __forceinline__ void store_J(float const (&rj)[kNJ], float *__restrict__ S, int tid GATHER_PARM) {
 #if J_MODE == 6
   store_gather(rj, S, g, tid);
-#elif J_MODE == 2 || J_MODE == 5
+#elif J_MODE == 2 || J_MODE == 5 || J_MODE == 7
   store_gather(rj, S, tid);
 #elif J_MODE == 3 || J_MODE == 4
   store_tile<J_MODE - 1, BJ, kLDJ, kNJ>(rj, S, tid);
@@ -387,6 +487,32 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     for (int kx = 0; kx < KW; ++kx) g.mx[kx] = (unsigned)(ix0 + kx) < (unsigned)p.W;
     g.first_tile = (tile_j == 0); // workgroup-uniform
   }
+#elif J_MODE == 7
+  gather_t g;
+  int bj[kTJ][3];
+  {
+    int const R0 = j0 / COW, img0 = R0 / COH, oy0 = R0 - img0 * COH;       // first output row of the tile (workgroup-uniform)
+    int const seg0 = (COH - 1 - oy0) * SY + KH;                            // slots of the first image's part
+    int const n_img = p.Nj / (COH * COW);
+#pragma unroll
+    for (int e = 0; e < kEPT; ++e) { // this thread's patch elements: slot s, padded column x
+      int const el = tid + e * kNT, s = el / kWp, ix = el - s * kWp - PX;
+      int const s2 = s - seg0, im2 = s2 / kSegFull;
+      int const img = (s < seg0) ? img0 : (img0 + 1 + im2);
+      int const iy = (s < seg0) ? (oy0 * SY - PY + s) : (s2 - im2 * kSegFull - PY);
+      bool const ok = (el < kCS) && (img < n_img) && ((unsigned)iy < (unsigned)CH) && ((unsigned)ix < (unsigned)CW);
+      g.goff[e] = ok ? (((img * p.C * CH + iy) * CW + ix) * 4) : kOOB;
+    }
+#pragma unroll
+    for (int t = 0; t < kTJ; ++t) { // MFMA B operand: this lane's output positions
+      int const jg = min(j0 + wj * (kTJ * MT) + t * MT + (lane % MT), p.Nj - 1);
+      int const R = jg / COW, ox = jg - R * COW, img = R / COH, oy = R - img * COH;
+      int const slot = (img == img0) ? ((oy - oy0) * SY) : (seg0 + (img - img0 - 1) * kSegFull + oy * SY);
+      int const b0 = slot * kWp + ox * SX;
+      bool const odd = (lane / MT) != 0;
+      bj[t][0] = b0 + (odd ? kD0 : 0); bj[t][1] = b0 + (odd ? kD1 : 0); bj[t][2] = b0 + (odd ? kD2 : 0);
+    }
+  }
 #elif J_MODE == 5
   gather_t g;
   {
@@ -428,18 +554,29 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   rsrc_t const rI = make_rsrc(p.I, p.I_bytes), rJ = make_rsrc(p.J, p.J_bytes); // built from kernel args only: provably wave-uniform
   load_tile<I_MODE, BI, kNI>(ri, rI, p.ldI, i0, p.Mi, kt_begin * BK, p.K, tid);
   load_J(rj, rJ, p, j0, kt_begin * BK, tid GATHER_ARG);
-  store_tile<I_MODE, BI, kLDI, kNI>(ri, Is0, tid);
+  store_tile<I_MODE, BI, I_ROWS ? kLDK : kLDI, kNI, I_ROWS>(ri, Is0, tid);
   store_J(rj, Js0, tid GATHER_ARG);
   __syncthreads();
 
   // MFMA operand fetch: lane l holds A[i = l % MT][k = l / MT] and B[k = l / MT][j = l % MT]
+#if I_ROWS
+  int const a_off = (wi * (kTI * MT) + (lane % MT)) * kLDK + ((IROWS == 2) ? (lane / MT) : 0);
+  bool const a_odd = (lane / MT) != 0;
+#else
   int const a_off = wi * (kTI * MT) + (lane % MT) + (lane / MT) * kLDI;
+#endif
+#if J_MODE != 7
   int const b_off = wj * (kTJ * MT) + (lane % MT) + (lane / MT) * kLDJ;
+#endif
 
   for (int kt = 0; kt < nkt; ++kt) {
     bool const more = (kt + 1) < nkt;
     float const *const Ic = ((kt & 1) ? Is1 : Is0) + a_off;
+#if J_MODE == 7
+    float const *const Jc = (kt & 1) ? Js1 : Js0;
+#else
     float const *const Jc = ((kt & 1) ? Js1 : Js0) + b_off;
+#endif
     if (more) { // prefetch K-tile kt+1 into registers; the loads fly under the MFMAs below
 #if !(ABLATE & 8)
       load_tile<I_MODE, BI, kNI>(ri, rI, p.ldI, i0, p.Mi, (kt_begin + kt + 1) * BK, p.K, tid);
@@ -451,13 +588,44 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #if SETPRIO
     __builtin_amdgcn_s_setprio(1); // co-resident waves of other workgroups are in their load phase: favour the MFMA issuer
 #endif
+#if I_ROWS && IROWS == 1
+    float aw[kTI][kRW / 2];
+#endif
 #pragma unroll
     for (int kk = 0; kk < BK / kKS; ++kk) {
       float a[kTI], b[kTJ];
+#if I_ROWS && IROWS == 2
+#pragma unroll
+      for (int t = 0; t < kTI; ++t) a[t] = Ic[t * MT * kLDK + 2 * kk];
+#elif I_ROWS
+      if (kk % (kRW / 2) == 0) { // one kRW-wide read per lane covers kRW/2 MFMA steps; lanes 32-63 keep the odd k, lanes 0-31 the even k
+#pragma unroll
+        for (int t = 0; t < kTI; ++t) {
+          if constexpr (kRW == 4) {
+            f32x4 const v = *reinterpret_cast<f32x4 const *>(Ic + t * MT * kLDK + 2 * kk);
+            float e0 = v[0], o0 = v[1], e1 = v[2], o1 = v[3];
+            asm volatile("" : "+v"(e0), "+v"(o0), "+v"(e1), "+v"(o1)); // opaque scalars: the selects below must stay v_cndmask (not an indexed private array)
+            aw[t][0] = a_odd ? o0 : e0; aw[t][1] = a_odd ? o1 : e1;
+          } else {
+            f32x2 const v = *reinterpret_cast<f32x2 const *>(Ic + t * MT * kLDK + 2 * kk);
+            float e0 = v[0], o0 = v[1];
+            asm volatile("" : "+v"(e0), "+v"(o0));
+            aw[t][0] = a_odd ? o0 : e0;
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < kTI; ++t) a[t] = aw[t][kk % (kRW / 2)];
+#else
 #pragma unroll
       for (int t = 0; t < kTI; ++t) a[t] = Ic[kk * kKS * kLDI + t * MT];
+#endif
 #pragma unroll
+#if J_MODE == 7
+      for (int t = 0; t < kTJ; ++t) b[t] = Jc[bj[t][kdelta_class(kk)] + koff(2 * kk)];
+#else
       for (int t = 0; t < kTJ; ++t) b[t] = Jc[kk * kKS * kLDJ + t * MT];
+#endif
 #pragma unroll
       for (int ta = 0; ta < kTI; ++ta)
 #pragma unroll
@@ -474,7 +642,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #endif
 #if !(ABLATE & 4)
     if (more) {
-      store_tile<I_MODE, BI, kLDI, kNI>(ri, (kt & 1) ? Is0 : Is1, tid);
+      store_tile<I_MODE, BI, I_ROWS ? kLDK : kLDI, kNI, I_ROWS>(ri, (kt & 1) ? Is0 : Is1, tid);
       store_J(rj, (kt & 1) ? Js0 : Js1, tid GATHER_ARG);
     }
 #endif

@@ -146,7 +146,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(hipModuleLaunchKernel(k.func, grid, 1, 1, (uint32_t)c.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false; int rows = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false; int rows = 0; };
 
 // bf16 variant (kernels/gemm_conv_bf16.hip): BK = 32, 32x32x16 MFMA only, chunked staging
 static void bf16_cfg(tile_cfg_t &c, bool gather) {
@@ -204,13 +204,50 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
     while (rows % rpp) rows += 2;
     if ((rows * g.KW) % 2 == 0 && rows % rpp == 0 && p.cfg.threads() % p.cfg.BJ == 0 && p.cfg.BJ % 64 == 0 && p.cfg.MT == 32 && tile.empty()) { p.rows = rows; p.cfg.BK = rows * g.KW; }
   }
-  if (bf16) bf16_cfg(p.cfg, !p.ipconv); else check_cfg(p.cfg, !p.ipconv);
-  p.defs = cfg_defs(p.cfg);
-  p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0 && p.cfg.BK % 4 == 0) ? "2" : "3"));
   // 1x1 kernel, no padding (any stride): the reference's k1conv case -- one add per gathered element, no table
   p.k1 = !p.ipconv && g.KH == 1 && g.KW == 1 && g.PY == 0 && g.PX == 0;
-  p.defs.push_back(p.ipconv ? (string("-DJ_MODE=") + ((Kt % 4 == 0) ? "3" : "4")) : string(p.k1 ? "-DJ_MODE=5" : (p.rows ? "-DJ_MODE=6" : "-DJ_MODE=2")));
+  // SX == 1, more than one tap: LDS input patch (J_MODE 7) -- a K step is CB whole input channels, staged as padded input rows
+  // (coalesced, ~KH*KW x fewer loads than an im2col image) and read by the MFMAs in place.  Needs compile-time plane sizes.
+  p.patch = false;
+  if (!bf16 && !p.ipconv && !p.k1 && !p.rows && g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && p.cfg.MT == 32 && p.cfg.SPLITK == 1 &&
+      getenv("BODAHIP_NO_PATCH") == nullptr) { // (an explicit tile keeps its BI/BJ/waves; its BK is replaced by whole channels)
+    int const taps = g.KH * g.KW;
+    int const bk_min = tile.empty() ? 32 : p.cfg.BK;                          // an explicit tile's BK is the lower bound for the K step
+    int cb = 1; while (cb * taps < bk_min || (cb * taps) % 2) ++cb;          // BK = cb*taps: even, >= 32 (3x3 -> 36, 5x5 -> 50, 2x2 -> 32)
+    int const bk = cb * taps, wp = g.W + 2 * g.PX;
+    auto fits = [&](tile_cfg_t const &c, long lds_max) {
+      int const rows_max = (c.BJ - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
+      long const cs = (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp;
+      long const lds = 2l * 4 * ((long)bk * (c.BI + 4) + cb * cs);
+      return bk <= 128 && lds <= lds_max && cs <= 16l * c.threads();
+    };
+    if (!tile.empty()) { if (fits(p.cfg, 160 * 1024)) { p.patch = true; p.cfg.BK = bk; } }
+    else {
+      // Staging the pel side is nearly free here, so the best tiles are narrow in out_chan and wide in pels (the filter tile is
+      // staged once per 256 pels) with few accumulators per wave (<= 128 VGPRs: four waves per SIMD).  Measured steady state on
+      // MI355X (B=256 AlexNet conv2-5, TF/s): 64x256 126-131 | 128x256 125-131 | 32x256 110-129 | 64x64 116-122 | 128x128 109-120;
+      // the score is that base rate x tile padding x how evenly the tiles deal out over the CUs.
+      struct cand_t { int bi, bj, wi, wj, minw; double base; };
+      static cand_t const cands[] = {{64, 256, 1, 4, 2, 1.00}, {128, 256, 2, 4, 1, 0.99}, {32, 256, 1, 4, 2, 0.90}, {64, 64, 2, 2, 2, 0.93}, {128, 128, 2, 2, 2, 0.92}, {32, 128, 1, 2, 2, 0.80}};
+      double best = -1;
+      for (cand_t const &cd : cands) {
+        tile_cfg_t c = p.cfg; c.BI = cd.bi; c.BJ = cd.bj; c.WI = cd.wi; c.WJ = cd.wj; c.MINW = cd.minw; c.BK = bk; c.MT = 32; c.SPLITK = 1;
+        if (!fits(c, 64 * 1024)) continue;
+        long const ti = (g.OC + c.BI - 1) / c.BI, tj = (Nj + c.BJ - 1) / c.BJ, tiles = ti * tj;
+        double const pad = ((double)g.OC / (double)(ti * c.BI)) * ((double)Nj / (double)(tj * c.BJ));
+        double const bal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
+        double const score = cd.base * pad * bal;
+        if (score > best) { best = score; p.cfg = c; p.patch = true; }
+      }
+    }
+  }
+  if (bf16) bf16_cfg(p.cfg, !p.ipconv); else check_cfg(p.cfg, !p.ipconv && !p.patch);
+  p.defs = cfg_defs(p.cfg);
+  p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0 && p.cfg.BK % 4 == 0) ? "2" : ((p.patch && Kt % 2 == 0) ? "4" : "3")));
+  p.defs.push_back(p.ipconv ? (string("-DJ_MODE=") + ((Kt % 4 == 0) ? "3" : "4")) : string(p.k1 ? "-DJ_MODE=5" : (p.patch ? "-DJ_MODE=7" : (p.rows ? "-DJ_MODE=6" : "-DJ_MODE=2"))));
   if (p.rows) p.defs.push_back("-DJROWS=" + std::to_string(p.rows));
+  if (p.patch) { p.defs.push_back("-DCH=" + std::to_string(g.H)); p.defs.push_back("-DCW=" + std::to_string(g.W));
+                 p.defs.push_back("-DCOH=" + std::to_string(g.OH)); p.defs.push_back("-DCOW=" + std::to_string(g.OW)); }
   p.defs.push_back("-DEPI=1");
   if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
   p.defs.push_back("-DKH=" + std::to_string(g.KH)); p.defs.push_back("-DKW=" + std::to_string(g.KW));
@@ -332,7 +369,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
   ga.I_bytes = (unsigned)f_bytes; ga.J_bytes = (unsigned)in_bytes;
   if (p.rows) { ktab_t const kt = get_rtab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
-  else if (!p.ipconv && !p.k1) { ktab_t const kt = get_ktab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
+  else if (!p.ipconv && !p.k1 && !p.patch) { ktab_t const kt = get_ktab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
   ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
   setup_splitk(impl, host, ga, cfg, (size_t)Nj * g.OC);
   launch(host, k, ga, cfg);

@@ -320,6 +320,19 @@ def test_conv_row_gather_all_kernel_widths(be, shape, monkeypatch):
     assert np.array_equal(want, outs["out"]), SsdsDiff.of(want, outs["out"]).basic_str()
 
 
+@pytest.mark.parametrize("shape", [s for s in EDGE_CONVS if s[5] * s[6] >= 2] + [(3, 24, 15, 15, 100, 3, 3, 1, 1), (4, 96, 27, 27, 256, 5, 5, 1, 2)])
+def test_conv_table_gather_when_patch_disabled(be, shape, monkeypatch):
+    """Stride-1 KxK convs default to the LDS-patch kernel (J_MODE 7); the per-element table gather (J_MODE 2) behind it (still
+    the default for strided 3x3/5x5 and padded 1x1) is held to the same bit-exact bar on the same shapes."""
+    monkeypatch.setenv("BODAHIP_NO_PATCH", "1")
+    monkeypatch.setenv("BODAHIP_NO_ROW_GATHER", "1")
+    op = _conv_op(*shape)
+    outs, _ = _run(be, op, 5, include_ins=True)
+    g = op.conv_geom()
+    want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
+    assert np.array_equal(want, outs["out"]), SsdsDiff.of(want, outs["out"]).basic_str()
+
+
 def test_conv_without_relu_and_alias(be):
     op = _conv_op(2, 6, 10, 10, 12, 3, 3, 1, 1)
     anno = add_codegen_annotations(op, OpTune(use_culibs=1))
