@@ -80,6 +80,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef ABLATE
 #define ABLATE 0 // experiment hook (tools/tile_sweep.py via BODAHIP_EXTRA_DEFS): 1 no epilogue stores | 2 no J loads | 4 no in-loop LDS stores | 8 no I loads
 #endif
+#ifndef PF
+#define PF 1 // K-tiles prefetched ahead in registers: 1 | 2 (two register sets; for workgroups that run alone on their CU)
+#endif
 #ifndef MT
 #define MT 32 // MFMA tile: 32 -> v_mfma_f32_32x32x2_f32 (default), 16 -> v_mfma_f32_16x16x4_f32 (4x more, smaller wave tiles for
 #endif        // shapes with too few 32x32 tiles to give every SIMD a wave; same fp32 rate, same ascending-k fma chain)
@@ -113,22 +116,7 @@ typedef f32x4 acc_t;
 constexpr int kPAD = 4;
 constexpr int kLDI = BI + kPAD;
 constexpr int kLDJ = BJ + kPAD;
-// I operands that are k-contiguous in memory (I_MODE 2/3/4: convolution filters) keep that layout in LDS: the tile is a straight
-// [BI][kLDK] copy (ds_write_b128 / b64 of what the loads returned, no transposing scalar writes), and the MFMA A operand is
-// fetched as one kRW-wide read per lane and kRW k -- row stride kLDK is chosen with kLDK/kRW odd, which makes both the
-// reads and the writes bank-conflict free -- of which lanes 0-31 use the even and lanes 32-63 the odd elements.
-#ifndef IROWS
-#define IROWS 0 // experiment hook: 0 k-major transposed image | 1 row image, wide writes + wide reads | 2 row image with odd stride, scalar writes / reads
-#endif
-#define I_ROWS (IROWS != 0 && MT == 32 && (I_MODE == 2 || I_MODE == 3 || I_MODE == 4))
-#if IROWS == 2
-constexpr int kRW = 1;
-constexpr int kLDK = BK + 1;
-#else
-constexpr int kRW = (BK % 4 == 0) ? 4 : 2;
-constexpr int kLDK = ((BK / kRW) % 2 == 1) ? BK : BK + kRW;
-#endif
-constexpr int kITile = I_ROWS ? BI * kLDK : BK * kLDI;
+constexpr int kITile = BK * kLDI;
 static_assert(BI % (WI * MT) == 0 && BJ % (WJ * MT) == 0, "tile must be a multiple of the MFMA tile per wave");
 static_assert(MT == 32 || BK % 4 == 0, "16x16x4 MFMA consumes four k per step");
 static_assert(BK % 2 == 0, "BK must be even (two k per MFMA)");
@@ -237,24 +225,9 @@ __device__ __forceinline__ void load_tile(float (&r)[NR], rsrc_t P, int ld, int 
 }
 
 // registers -> LDS image [BK][LD] (k-major)
-template <int MODE, int BX, int LD, int NR, bool ROWS = false>
+template <int MODE, int BX, int LD, int NR>
 __device__ __forceinline__ void store_tile(float const (&r)[NR], float *__restrict__ S, int tid) {
-  if constexpr (ROWS) { // x-major image [BX][LD]: the k-contiguous vectors are stored as loaded
-    constexpr int VW = vec_w(MODE), VPR = BK / VW, TOT = BX * VPR;
-#pragma unroll
-    for (int p = 0; p < NR / VW; ++p) {
-      int const v = tid + p * kNT, xr = v / VPR, kv = v % VPR;
-      if (((p + 1) * kNT <= TOT) || (v < TOT)) {
-        float *const d = S + xr * LD + VW * kv;
-        if constexpr (IROWS == 2) {
-#pragma unroll
-          for (int e = 0; e < VW; ++e) d[e] = r[VW * p + e];
-        } else if constexpr (VW == 4) { f32x4 const val = {r[4 * p + 0], r[4 * p + 1], r[4 * p + 2], r[4 * p + 3]}; *reinterpret_cast<f32x4 *>(d) = val; }
-        else if constexpr (VW == 2) { f32x2 const val = {r[2 * p + 0], r[2 * p + 1]}; *reinterpret_cast<f32x2 *>(d) = val; }
-        else { *d = r[p]; }
-      }
-    }
-  } else if constexpr (MODE == 0) {
+  if constexpr (MODE == 0) {
     constexpr int VPR = BX / 4, TOT = BK * VPR;
 #pragma unroll
     for (int p = 0; p < NR / 4; ++p) {
@@ -445,6 +418,41 @@ __device__ __forceinline__ void store_J(float const (&rj)[kNJ], float *__restric
   store_tile<J_MODE, BJ, kLDJ, kNJ>(rj, S, tid);
 #endif
 }
+// one K-tile of MFMAs out of LDS: Ic / Jc point at this lane's first A / B element of the tile
+__device__ __forceinline__ void mma_ktile(acc_t (&acc)[kTI][kTJ], float const *__restrict__ Ic, float const *__restrict__ Jc
+#if J_MODE == 7
+                                          , int const (&bj)[kTJ][3]
+#endif
+) {
+#if SETPRIO
+  __builtin_amdgcn_s_setprio(1); // co-resident waves of other workgroups are in their load phase: favour the MFMA issuer
+#endif
+#pragma unroll
+  for (int kk = 0; kk < BK / kKS; ++kk) {
+    float a[kTI], b[kTJ];
+#pragma unroll
+    for (int t = 0; t < kTI; ++t) a[t] = Ic[kk * kKS * kLDI + t * MT];
+#pragma unroll
+#if J_MODE == 7
+    for (int t = 0; t < kTJ; ++t) b[t] = Jc[bj[t][kdelta_class(kk)] + koff(2 * kk)];
+#else
+    for (int t = 0; t < kTJ; ++t) b[t] = Jc[kk * kKS * kLDJ + t * MT];
+#endif
+#pragma unroll
+    for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < kTJ; ++tb) {
+#if MT == 32
+        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+#else
+        acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+#endif
+      }
+  }
+#if SETPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
 } // namespace
 
 extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p) {
@@ -554,100 +562,65 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   rsrc_t const rI = make_rsrc(p.I, p.I_bytes), rJ = make_rsrc(p.J, p.J_bytes); // built from kernel args only: provably wave-uniform
   load_tile<I_MODE, BI, kNI>(ri, rI, p.ldI, i0, p.Mi, kt_begin * BK, p.K, tid);
   load_J(rj, rJ, p, j0, kt_begin * BK, tid GATHER_ARG);
-  store_tile<I_MODE, BI, I_ROWS ? kLDK : kLDI, kNI, I_ROWS>(ri, Is0, tid);
+  store_tile<I_MODE, BI, kLDI, kNI>(ri, Is0, tid);
   store_J(rj, Js0, tid GATHER_ARG);
   __syncthreads();
 
   // MFMA operand fetch: lane l holds A[i = l % MT][k = l / MT] and B[k = l / MT][j = l % MT]
-#if I_ROWS
-  int const a_off = (wi * (kTI * MT) + (lane % MT)) * kLDK + ((IROWS == 2) ? (lane / MT) : 0);
-  bool const a_odd = (lane / MT) != 0;
-#else
   int const a_off = wi * (kTI * MT) + (lane % MT) + (lane / MT) * kLDI;
-#endif
-#if J_MODE != 7
+#if J_MODE == 7
+  int const b_off = 0;
+#else
   int const b_off = wj * (kTJ * MT) + (lane % MT) + (lane / MT) * kLDJ;
 #endif
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    bool const more = (kt + 1) < nkt;
-    float const *const Ic = ((kt & 1) ? Is1 : Is0) + a_off;
 #if J_MODE == 7
-    float const *const Jc = (kt & 1) ? Js1 : Js0;
+#define MMA_KTILE(IS, JS) mma_ktile(acc, (IS) + a_off, (JS) + b_off, bj)
 #else
-    float const *const Jc = ((kt & 1) ? Js1 : Js0) + b_off;
+#define MMA_KTILE(IS, JS) mma_ktile(acc, (IS) + a_off, (JS) + b_off)
 #endif
-    if (more) { // prefetch K-tile kt+1 into registers; the loads fly under the MFMAs below
-#if !(ABLATE & 8)
-      load_tile<I_MODE, BI, kNI>(ri, rI, p.ldI, i0, p.Mi, (kt_begin + kt + 1) * BK, p.K, tid);
-#endif
-#if !(ABLATE & 2)
-      load_J(rj, rJ, p, j0, (kt_begin + kt + 1) * BK, tid GATHER_ARG);
-#endif
-    }
-#if SETPRIO
-    __builtin_amdgcn_s_setprio(1); // co-resident waves of other workgroups are in their load phase: favour the MFMA issuer
-#endif
-#if I_ROWS && IROWS == 1
-    float aw[kTI][kRW / 2];
-#endif
-#pragma unroll
-    for (int kk = 0; kk < BK / kKS; ++kk) {
-      float a[kTI], b[kTJ];
-#if I_ROWS && IROWS == 2
-#pragma unroll
-      for (int t = 0; t < kTI; ++t) a[t] = Ic[t * MT * kLDK + 2 * kk];
-#elif I_ROWS
-      if (kk % (kRW / 2) == 0) { // one kRW-wide read per lane covers kRW/2 MFMA steps; lanes 32-63 keep the odd k, lanes 0-31 the even k
-#pragma unroll
-        for (int t = 0; t < kTI; ++t) {
-          if constexpr (kRW == 4) {
-            f32x4 const v = *reinterpret_cast<f32x4 const *>(Ic + t * MT * kLDK + 2 * kk);
-            float e0 = v[0], o0 = v[1], e1 = v[2], o1 = v[3];
-            asm volatile("" : "+v"(e0), "+v"(o0), "+v"(e1), "+v"(o1)); // opaque scalars: the selects below must stay v_cndmask (not an indexed private array)
-            aw[t][0] = a_odd ? o0 : e0; aw[t][1] = a_odd ? o1 : e1;
-          } else {
-            f32x2 const v = *reinterpret_cast<f32x2 const *>(Ic + t * MT * kLDK + 2 * kk);
-            float e0 = v[0], o0 = v[1];
-            asm volatile("" : "+v"(e0), "+v"(o0));
-            aw[t][0] = a_odd ? o0 : e0;
-          }
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < kTI; ++t) a[t] = aw[t][kk % (kRW / 2)];
+#if ABLATE & 8
+#define LOAD_I(R, KT)
 #else
-#pragma unroll
-      for (int t = 0; t < kTI; ++t) a[t] = Ic[kk * kKS * kLDI + t * MT];
+#define LOAD_I(R, KT) load_tile<I_MODE, BI, kNI>(R, rI, p.ldI, i0, p.Mi, (kt_begin + (KT)) * BK, p.K, tid)
 #endif
-#pragma unroll
-#if J_MODE == 7
-      for (int t = 0; t < kTJ; ++t) b[t] = Jc[bj[t][kdelta_class(kk)] + koff(2 * kk)];
+#if ABLATE & 2
+#define LOAD_J(R, KT)
 #else
-      for (int t = 0; t < kTJ; ++t) b[t] = Jc[kk * kKS * kLDJ + t * MT];
+#define LOAD_J(R, KT) load_J(R, rJ, p, j0, (kt_begin + (KT)) * BK, tid GATHER_ARG)
 #endif
-#pragma unroll
-      for (int ta = 0; ta < kTI; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < kTJ; ++tb) {
-#if MT == 32
-          acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+#if ABLATE & 4
+#define STORE_IJ(RI, RJ, IS, JS)
 #else
-          acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+#define STORE_IJ(RI, RJ, IS, JS) do { store_tile<I_MODE, BI, kLDI, kNI>(RI, IS, tid); store_J(RJ, JS, tid GATHER_ARG); } while (0)
 #endif
-        }
-    }
-#if SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-#if !(ABLATE & 4)
-    if (more) {
-      store_tile<I_MODE, BI, I_ROWS ? kLDK : kLDI, kNI, I_ROWS>(ri, (kt & 1) ? Is0 : Is1, tid);
-      store_J(rj, (kt & 1) ? Js0 : Js1, tid GATHER_ARG);
-    }
-#endif
+
+#if PF == 2
+  // Two K-tiles in flight: while tile t is multiplied out of LDS, tile t+1 sits in one register set (its loads were issued a
+  // whole step earlier) and the loads of tile t+2 are issued into the other.  For workgroups that are alone on their CU
+  // (tile-starved shapes: one ~0.5 us MFMA phase per K step against ~1 us of HBM latency) this roughly doubles the bytes in flight.
+  float ri2[kNI], rj2[kNJ];
+  if (nkt > 1) { LOAD_I(ri, 1); LOAD_J(rj, 1); }
+  for (int kt = 0; kt < nkt; kt += 2) {
+    if (kt + 2 < nkt) { LOAD_I(ri2, kt + 2); LOAD_J(rj2, kt + 2); }
+    MMA_KTILE(Is0, Js0);
+    if (kt + 1 < nkt) STORE_IJ(ri, rj, Is1, Js1);
+    __syncthreads();
+    if (kt + 1 >= nkt) break;
+    if (kt + 3 < nkt) { LOAD_I(ri, kt + 3); LOAD_J(rj, kt + 3); }
+    MMA_KTILE(Is1, Js1);
+    if (kt + 2 < nkt) STORE_IJ(ri2, rj2, Is0, Js0);
     __syncthreads();
   }
+#else
+  for (int kt = 0; kt < nkt; ++kt) {
+    bool const more = (kt + 1) < nkt;
+    if (more) { LOAD_I(ri, kt + 1); LOAD_J(rj, kt + 1); } // prefetch K-tile kt+1 into registers; the loads fly under the MFMAs below
+    MMA_KTILE((kt & 1) ? Is1 : Is0, (kt & 1) ? Js1 : Js0);
+    if (more) STORE_IJ(ri, rj, (kt & 1) ? Is0 : Is1, (kt & 1) ? Js0 : Js1);
+    __syncthreads();
+  }
+#endif
 
   // ---- epilogue: MFMA C/D layout.  32x32: column j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16
   //                                16x16: column j = lane&15, row i = 4*(lane>>4) + r,               r < 4

@@ -57,15 +57,15 @@ void native_kernels_t::set_tune(string const &key, string const &val) {
   if (val.empty()) impl->tune.erase(key); else { impl->tune[key] = val; }
 }
 
-// "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"
+// "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF]]]]"
 static bool parse_tile(string const &s, tile_cfg_t &c) {
-  int v[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int n = 0; string cur;
+  int v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; int n = 0; string cur;
   for (size_t i = 0; i <= s.size(); ++i) {
-    if (i == s.size() || s[i] == 'x' || s[i] == ':') { if (cur.empty() || n >= 8) return false; v[n++] = atoi(cur.c_str()); cur.clear(); }
+    if (i == s.size() || s[i] == 'x' || s[i] == ':') { if (cur.empty() || n >= 9) return false; v[n++] = atoi(cur.c_str()); cur.clear(); }
     else if (s[i] >= '0' && s[i] <= '9') cur.push_back(s[i]); else return false;
   }
   if (n < 5) return false;
-  c.BI = v[0]; c.BJ = v[1]; c.BK = v[2]; c.WI = v[3]; c.WJ = v[4]; c.MINW = (n >= 6) ? v[5] : 1; c.SPLITK = (n >= 7) ? v[6] : 1; c.MT = (n >= 8) ? v[7] : 32;
+  c.BI = v[0]; c.BJ = v[1]; c.BK = v[2]; c.WI = v[3]; c.WJ = v[4]; c.MINW = (n >= 6) ? v[5] : 1; c.SPLITK = (n >= 7) ? v[6] : 1; c.MT = (n >= 8) ? v[7] : 32; c.PF = (n >= 9) ? v[8] : 1;
   return true;
 }
 // the static_asserts of the kernel, checked on the host so that a bad tune is an unsup_err, not a compile failure
@@ -75,7 +75,7 @@ static void check_cfg(tile_cfg_t const &c, bool gather) {
             (c.BK % 2 == 0) && (c.MT == 32 || c.BK % 4 == 0) && (c.BI % 4 == 0) && (c.BJ % 4 == 0);
   if (gather) ok = ok && ((c.BK * c.BJ) % nt == 0); // the gathers give every thread whole elements / rows
   if (gather) ok = ok && (nt % c.BJ == 0) && (c.BJ % 64 == 0);
-  ok = ok && c.SPLITK >= 1 && c.SPLITK <= 64 && c.MINW >= 1;
+  ok = ok && c.SPLITK >= 1 && c.SPLITK <= 64 && c.MINW >= 1 && (c.PF == 1 || c.PF == 2);
   int const accs = (c.BI / (c.WI * c.MT)) * (c.BJ / (c.WJ * c.MT));
   ok = ok && accs * (c.MT == 32 ? 16 : 4) <= 256;
   uint64_t const lds = 2ull * c.BK * (c.BI + 4 + c.BJ + 4) * 4;
@@ -96,7 +96,7 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather) {
   tile_cfg_t c;
   int const bi = pick_bi(Mi);
   if (bi == 128) { c.BI = 128; c.BJ = 128; c.WI = 2; c.WJ = 2; }
-  else if (bi == 96) { c.BI = 96; c.BJ = 128; c.WI = 1; c.WJ = 2; }
+  else if (bi == 96) { c.BI = 96; c.BJ = gather ? 256 : 128; c.WI = 1; c.WJ = gather ? 4 : 2; } // (conv1 11x11/s4, OC 96: 96x256 93 TF/s vs 96x128 90)
   else if (bi == 64) { c.BI = 64; c.BJ = 128; c.WI = 1; c.WJ = 2; }
   else { c.BI = 32; c.BJ = 128; c.WI = 1; c.WJ = 2; }
   c.BK = 16; c.MINW = 2; c.SPLITK = 1;
@@ -107,7 +107,7 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather) {
   if (Mi > 32) {
     tile_cfg_t c2 = c; c2.BI = 64; c2.BJ = 64; c2.WI = 2; c2.WJ = 2; // four 32x32 wave tiles: ~0.87x the per-tile efficiency of 64x64 wave tiles
     long const tiles2 = ntiles(c2);
-    bool const use_small = (tiles < num_cus) || (balance(tiles) < 0.87 * balance(tiles2));
+    bool const use_small = (tiles <= num_cus) || (balance(tiles) < 0.87 * balance(tiles2));
     if (!use_small) {
       // large k-major problems: 256x256 workgroups (16 waves, same 64x64 wave tiles) run at the same speed but halve the HBM
       // re-reads of the k panels (measured 12288^3: 10.9 GB vs 24.2 GB per launch) -- taken only when they deal out as evenly
@@ -128,15 +128,19 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather) {
   return c;
 }
 
+// 64x64 workgroups of four 32x32 wave tiles are what tile-starved shapes get (often a single workgroup per CU): their ~0.5 us
+// MFMA phase per K step cannot cover HBM latency with one K-tile in flight, two can (measured fc6 70 -> 81, fc7 67 -> 76,
+// sgemm 2048^3 95 -> 107 TF/s); larger tiles gain nothing and pay registers.
+static int pf_for(tile_cfg_t const &c) { return (c.BI == 64 && c.BJ == 64 && c.WI == 2 && c.WJ == 2 && c.MT == 32 && c.SPLITK == 1) ? 2 : 1; }
 static vect_string cfg_defs(tile_cfg_t const &c) {
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { // experiment hook: extra -D options for the native kernels
     vect_string r = {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI),
-                     "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW), "-DMT=" + std::to_string(c.MT)};
+                     "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW), "-DMT=" + std::to_string(c.MT), "-DPF=" + std::to_string(c.PF)};
     std::istringstream is(e); string tok; while (is >> tok) r.push_back(tok);
     return r;
   }
   return {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI),
-          "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW), "-DMT=" + std::to_string(c.MT)};
+          "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW), "-DMT=" + std::to_string(c.MT), "-DPF=" + std::to_string(c.PF)};
 }
 struct plan_t;
 static kernel_t &get_kernel(native_kernels_t::impl_t *impl, native_host_t *host, plan_t const &p);
@@ -174,6 +178,7 @@ static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string
     p.defs = cfg_defs(p.cfg); p.defs.push_back("-DI_MODE=0"); p.defs.push_back("-DJ_MODE=0"); p.defs.push_back("-DEPI=0");
     return p;
   }
+  if (!bf16 && tile.empty()) p.cfg.PF = pf_for(p.cfg);
   check_cfg(p.cfg, false);
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((M % 4 == 0) ? "0" : "1"));
@@ -188,6 +193,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   // output 1x1, no padding, kernel == whole input ("ipconv" case): the im2col row of image j is the contiguous image
   p.ipconv = (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W);
   p.cfg = choose_cfg(g.OC, (int)Nj, (int)Kt, num_cus, !p.ipconv);
+  if (bf16 && p.cfg.BI == 96) { p.cfg.BJ = 128; p.cfg.WJ = 2; } // (the bf16 kernel's chunked staging has no 96x256 form)
   if (bf16 && tile.empty()) { // staging-bound: widen the pel tile (each filter value staged once per 256 pels) when the grid stays >= one workgroup per CU
     p.cfg.BK = 32;
     if (p.cfg.BI == 128 && p.cfg.BJ == 128 && (long)((g.OC + 127) / 128) * ((Nj + 255) / 256) >= num_cus) { p.cfg.BJ = 256; p.cfg.WI = 2; p.cfg.WJ = 4; p.cfg.MINW = 1; }
@@ -202,7 +208,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
     int const rpp = std::max(1, p.cfg.threads() / p.cfg.BJ);               // row groups per K step
     int rows = (g.KW <= 3) ? 8 : (g.KW <= 8 ? 4 : 2);                        // BK = 16..28 (22 for 11x11)
     while (rows % rpp) rows += 2;
-    if ((rows * g.KW) % 2 == 0 && rows % rpp == 0 && p.cfg.threads() % p.cfg.BJ == 0 && p.cfg.BJ % 64 == 0 && p.cfg.MT == 32 && tile.empty()) { p.rows = rows; p.cfg.BK = rows * g.KW; }
+    if ((rows * g.KW) % 2 == 0 && rows % rpp == 0 && p.cfg.threads() % p.cfg.BJ == 0 && p.cfg.BJ % 64 == 0 && p.cfg.MT == 32) { p.rows = rows; p.cfg.BK = rows * g.KW; }
   }
   // 1x1 kernel, no padding (any stride): the reference's k1conv case -- one add per gathered element, no table
   p.k1 = !p.ipconv && g.KH == 1 && g.KW == 1 && g.PY == 0 && g.PX == 0;
@@ -241,6 +247,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
       }
     }
   }
+  if (!bf16 && tile.empty()) p.cfg.PF = pf_for(p.cfg);
   if (bf16) bf16_cfg(p.cfg, !p.ipconv); else check_cfg(p.cfg, !p.ipconv && !p.patch);
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0 && p.cfg.BK % 4 == 0) ? "2" : ((p.patch && Kt % 2 == 0) ? "4" : "3")));

@@ -202,7 +202,7 @@ def test_sgemm_vs_oracle_bit_exact(be, M, N, K):
 
 
 @pytest.mark.parametrize("tile", ["64x64x16x1x1", "128x64x16x2x1", "64x128x16x1x2", "32x128x16x1x2", "96x128x16x1x2", "128x128x32x2x2", "256x128x16x4x2",
-                                  "32x32x32x2x2x1x1x16", "64x64x64x4x4x1x1x16", "64x64x16x2x2x2x1x16"])
+                                  "32x32x32x2x2x1x1x16", "64x64x64x4x4x1x1x16", "64x64x16x2x2x2x1x16", "64x64x16x2x2x2x1x32x2", "128x128x16x2x2x1x1x32x2"])
 def test_sgemm_tiles_agree(be, tile):
     op = _sgemm_op(320, 448, 200)
     ref, _ = _run(be, op, 5)
@@ -344,7 +344,7 @@ def test_conv_without_relu_and_alias(be):
 
 
 @pytest.mark.parametrize("tile", ["64x64x16x1x1", "128x64x16x2x1", "32x128x16x1x2", "96x128x16x1x2", "128x128x32x2x2", "128x256x16x2x4",
-                                  "64x64x16x2x2x2x1x16", "32x64x32x2x2x1x1x16"])
+                                  "64x64x16x2x2x2x1x16", "32x64x32x2x2x1x1x16", "64x64x16x2x2x2x1x32x2", "128x128x32x2x2x1x1x32x2", "64x256x16x1x4x2"])
 def test_conv_tiles_agree(be, tile):
     op = _conv_op(3, 24, 15, 15, 100, 3, 3, 1, 1)
     ref, _ = _run(be, op, 5)
