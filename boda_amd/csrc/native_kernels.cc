@@ -83,49 +83,40 @@ static void check_cfg(tile_cfg_t const &c, bool gather) {
   if (!ok) unsup_err("native kernel: unsupported tile configuration " + c.str());
 }
 
-static int pick_bi(int Mi) { // minimise padded extent; ties -> larger tile
-  int best = 32; long best_pad = -1;
-  for (int bi : {32, 64, 96, 128}) { long const padded = ((Mi + bi - 1) / bi) * (long)bi; if (best_pad < 0 || padded <= best_pad) { best = bi; best_pad = padded; } }
-  return best;
-}
-
-// Tile / split-K heuristic.  Goal: >= ~1 four-wave workgroup per CU with the largest per-wave tile (64x64 feeds the
-// MFMA pipe with the fewest LDS reads); problems with too few output tiles get 32x32 per-wave tiles (64x64 workgroups)
-// (the K loop can additionally be split across workgroups, with a deterministic slab reduction, as an explicit tune).
-static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather) {
-  tile_cfg_t c;
-  int const bi = pick_bi(Mi);
-  if (bi == 128) { c.BI = 128; c.BJ = 128; c.WI = 2; c.WJ = 2; }
-  else if (bi == 96) { c.BI = 96; c.BJ = gather ? 256 : 128; c.WI = 1; c.WJ = gather ? 4 : 2; } // (conv1 11x11/s4, OC 96: 96x256 93 TF/s vs 96x128 90)
-  else if (bi == 64) { c.BI = 64; c.BJ = 128; c.WI = 1; c.WJ = 2; }
-  else { c.BI = 32; c.BJ = 128; c.WI = 1; c.WJ = 2; }
-  c.BK = 16; c.MINW = 2; c.SPLITK = 1;
-  auto ntiles = [&](tile_cfg_t const &t) { return (long)((Mi + t.BI - 1) / t.BI) * ((Nj + t.BJ - 1) / t.BJ); };
-  // fraction of the slowest CU's time that the average CU is busy when `tiles` equal workgroups are dealt to num_cus CUs
-  auto balance = [&](long tiles) { double const per = (double)tiles / num_cus; return per / (double)((tiles + num_cus - 1) / num_cus); };
-  long const tiles = ntiles(c);
-  if (Mi > 32) {
-    tile_cfg_t c2 = c; c2.BI = 64; c2.BJ = 64; c2.WI = 2; c2.WJ = 2; // four 32x32 wave tiles: ~0.87x the per-tile efficiency of 64x64 wave tiles
-    long const tiles2 = ntiles(c2);
-    bool const use_small = (tiles <= num_cus) || (balance(tiles) < 0.87 * balance(tiles2));
-    if (!use_small) {
-      // large k-major problems: 256x256 workgroups (16 waves, same 64x64 wave tiles) run at the same speed but halve the HBM
-      // re-reads of the k panels (measured 12288^3: 10.9 GB vs 24.2 GB per launch) -- taken only when they deal out as evenly
-      if (!gather && c.BI == 128 && c.BJ == 128) {
-        tile_cfg_t c4 = c; c4.BI = 256; c4.BJ = 256; c4.WI = 4; c4.WJ = 4; c4.MINW = 1;
-        long const tiles4 = ntiles(c4);
-        if (tiles4 >= num_cus && balance(tiles4) >= 0.98 * balance(tiles)) return c4;
-      }
-      return c;
-    }
-    // Splitting K would fill the chip for tile-starved shapes, but it re-associates the fp32 sum: the reference's golden
-    // digests (tolerance 2e-4 on max(1,|v|)) are only met robustly by the ascending-k chain, so SPLITK is an explicit tune
-    // ("...xMINWxS"), never the default.
-    // still fewer than half a workgroup per CU (e.g. AlexNet fc8, 1000x256 outputs): 16x16x4-MFMA wave tiles give 4x the waves
-    if (tiles2 < num_cus / 2 && !gather && 2.0 * Mi * (double)Nj * K >= 2.7e8) { c2.BI = 32; c2.BJ = 32; c2.BK = 32; c2.MT = 16; c2.MINW = 1; }
-    return c2;
+// Tile heuristic: score = measured base rate of the tile shape x fraction of the padded tile grid that is real work x how evenly
+// the workgroups deal out over the CUs (tiles / (num_cus * ceil(tiles / num_cus)); with fewer tiles than CUs this is the fraction
+// of CUs that get one).  Base rates are steady-state MI355X measurements relative to 128x128 (sgemm 4096^3..12288^3, AlexNet /
+// NiN / GoogLeNet layers, tools/tile_sweep.py):
+//   128x128 w2x2 1.00 | 256x256 w4x4 1.02 (k-major operands only: halves the HBM re-reads) | 96x256 w1x4 0.95 (gathers; OC = 96-multiples)
+//   64x64 w2x2 with two K-tiles in flight 0.93 (two-wave 64x128 / 32x128 workgroups measured 1.3-1.8x slower than this and are gone)
+//   32x64 as eight 16x16x4-MFMA waves 0.60 (thin out_chan / tile-starved: 2-2.7x faster than 32x128 there) | 32x32 m16 w2x2 0.45
+// Splitting K would fill the chip for tile-starved shapes too, but it re-associates the fp32 sum: the reference's golden digests
+// (tolerance 2e-4 on max(1,|v|)) are only met robustly by the ascending-k chain, so SPLITK is an explicit tune, never the default.
+static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather, bool bf16 = false) {
+  struct cand_t { int bi, bj, bk, wi, wj, minw, mt, pf; double base; bool gather_ok, plain_ok; };
+  // bf16 kernel (32x32x16 MFMA only, staging-bound: large tiles matter more; 8192^3: 256x256 624 TF/s vs 128x128 457)
+  static cand_t const cands_bf16[] = {
+    {128, 128, 32, 2, 2, 2, 32, 1, 1.00, true, true}, {256, 256, 32, 4, 4, 1, 32, 1, 1.35, false, true}, {128, 256, 32, 2, 4, 1, 32, 1, 1.15, true, false},
+    {96, 128, 32, 1, 2, 2, 32, 1, 0.85, true, true},  {64, 64, 32, 2, 2, 2, 32, 1, 0.70, true, true}};
+  static cand_t const cands_f32[] = {
+    {128, 128, 16, 2, 2, 2, 32, 1, 1.00, true, true},  {256, 256, 16, 4, 4, 1, 32, 1, 1.02, false, true}, {96, 256, 16, 1, 4, 2, 32, 1, 0.95, true, false},
+    {96, 128, 16, 1, 2, 2, 32, 1, 0.90, false, true},  {64, 64, 16, 2, 2, 2, 32, 2, 0.93, true, true},    {32, 64, 32, 2, 4, 1, 16, 2, 0.60, true, true},
+    {32, 32, 32, 2, 2, 1, 16, 1, 0.45, false, true}};
+  tile_cfg_t best_c; double best = -1;
+  cand_t const *cands = bf16 ? cands_bf16 : cands_f32;
+  int const n_cands = bf16 ? (int)(sizeof(cands_bf16) / sizeof(cand_t)) : (int)(sizeof(cands_f32) / sizeof(cand_t));
+  for (int ci = 0; ci < n_cands; ++ci) {
+    cand_t const &cd = cands[ci];
+    if (gather ? !cd.gather_ok : !cd.plain_ok) continue;
+    if (cd.mt == 16 && 2.0 * Mi * (double)Nj * K < 1e8) continue; // tiny problems: launch-bound either way, keep the common kernel
+    long const ti = (Mi + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
+    if (cd.bj == 256 && cd.bi >= 128 && tiles < num_cus) continue;
+    double const pad = ((double)Mi / (double)(ti * cd.bi)) * ((double)Nj / (double)(tj * cd.bj));
+    double const bal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
+    double const score = cd.base * pad * bal;
+    if (score > best) { best = score; best_c.BI = cd.bi; best_c.BJ = cd.bj; best_c.BK = cd.bk; best_c.WI = cd.wi; best_c.WJ = cd.wj; best_c.MINW = cd.minw; best_c.MT = cd.mt; best_c.PF = cd.pf; best_c.SPLITK = 1; }
   }
-  return c;
+  return best_c;
 }
 
 // 64x64 workgroups of four 32x32 wave tiles are what tile-starved shapes get (often a single workgroup per CU): their ~0.5 us
@@ -156,7 +147,7 @@ struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = fa
 static void bf16_cfg(tile_cfg_t &c, bool gather) {
   if (c.MT != 32) { c.MT = 32; c.BI = 64; c.BJ = 64; c.WI = 2; c.WJ = 2; }
   if (c.BK != 32 && c.BK != 64) c.BK = 32;
-  c.SPLITK = 1;
+  c.SPLITK = 1; c.PF = 1;
   int const nt = c.threads();
   bool ok = (c.BI % (c.WI * 32) == 0) && (c.BJ % (c.WJ * 32) == 0) && ((c.BI * c.BK / 8) % nt == 0) && ((c.BJ * c.BK / 8) % nt == 0) && nt <= 1024 &&
             (c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) * 16 <= 256 && 4ull * (c.BK + 8) * (c.BI + c.BJ) <= 160 * 1024;
@@ -167,18 +158,13 @@ static void bf16_cfg(tile_cfg_t &c, bool gather) {
 static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string const &tile, bool bf16 = false) {
   (void)K;
   plan_t p; p.kname = bf16 ? "bodahip_sgemm_bf16" : "bodahip_sgemm_f32"; p.bf16 = bf16;
-  p.cfg = choose_cfg((int)M, (int)N, (int)K, num_cus, false);
-  if (bf16 && tile.empty()) { // staging-bound kernel: the largest tile that still gives every CU a workgroup (measured: 256x256 624 TF/s vs 128x128 457 at 8192^3)
-    p.cfg.BK = 32;
-    if (p.cfg.BI == 128 && p.cfg.BJ == 128 && (long)((M + 255) / 256) * ((N + 255) / 256) >= num_cus) { p.cfg.BI = 256; p.cfg.BJ = 256; p.cfg.WI = 4; p.cfg.WJ = 4; p.cfg.MINW = 1; }
-  }
+  p.cfg = choose_cfg((int)M, (int)N, (int)K, num_cus, false, bf16);
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad sgemm_tile '" + tile + "'"); }
   if (bf16) {
     bf16_cfg(p.cfg, false);
     p.defs = cfg_defs(p.cfg); p.defs.push_back("-DI_MODE=0"); p.defs.push_back("-DJ_MODE=0"); p.defs.push_back("-DEPI=0");
     return p;
   }
-  if (!bf16 && tile.empty()) p.cfg.PF = pf_for(p.cfg);
   check_cfg(p.cfg, false);
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((M % 4 == 0) ? "0" : "1"));
@@ -192,12 +178,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   plan_t p; p.kname = bf16 ? "bodahip_conv_bf16" : "bodahip_conv_f32"; p.bf16 = bf16;
   // output 1x1, no padding, kernel == whole input ("ipconv" case): the im2col row of image j is the contiguous image
   p.ipconv = (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W);
-  p.cfg = choose_cfg(g.OC, (int)Nj, (int)Kt, num_cus, !p.ipconv);
-  if (bf16 && p.cfg.BI == 96) { p.cfg.BJ = 128; p.cfg.WJ = 2; } // (the bf16 kernel's chunked staging has no 96x256 form)
-  if (bf16 && tile.empty()) { // staging-bound: widen the pel tile (each filter value staged once per 256 pels) when the grid stays >= one workgroup per CU
-    p.cfg.BK = 32;
-    if (p.cfg.BI == 128 && p.cfg.BJ == 128 && (long)((g.OC + 127) / 128) * ((Nj + 255) / 256) >= num_cus) { p.cfg.BJ = 256; p.cfg.WI = 2; p.cfg.WJ = 4; p.cfg.MINW = 1; }
-  }
+  p.cfg = choose_cfg(g.OC, (int)Nj, (int)Kt, num_cus, !p.ipconv, bf16);
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad conv_tile '" + tile + "'"); }
   // wide kernels: row gather (one address + wide loads per (in_chan,ky) row of KW taps): a K step is `rows` whole rows, BK = rows*KW.
   // Measured (MI355X, B=256): 11x11/s4 +8%, 5x5 -3%, 3x3 -9% vs the per-element table gather (unaligned x3 loads cost more than the
@@ -215,7 +196,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   // SX == 1, more than one tap: LDS input patch (J_MODE 7) -- a K step is CB whole input channels, staged as padded input rows
   // (coalesced, ~KH*KW x fewer loads than an im2col image) and read by the MFMAs in place.  Needs compile-time plane sizes.
   p.patch = false;
-  if (!bf16 && !p.ipconv && !p.k1 && !p.rows && g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && p.cfg.MT == 32 && p.cfg.SPLITK == 1 &&
+  if (!bf16 && !p.ipconv && !p.k1 && !p.rows && g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && (tile.empty() || (p.cfg.MT == 32 && p.cfg.SPLITK == 1)) &&
       getenv("BODAHIP_NO_PATCH") == nullptr) { // (an explicit tile keeps its BI/BJ/waves; its BK is replaced by whole channels)
     int const taps = g.KH * g.KW;
     int const bk_min = tile.empty() ? 32 : p.cfg.BK;                          // an explicit tile's BK is the lower bound for the K step
@@ -247,7 +228,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
       }
     }
   }
-  if (!bf16 && tile.empty()) p.cfg.PF = pf_for(p.cfg);
+  if (p.patch && tile.empty()) p.cfg.PF = pf_for(p.cfg);
   if (bf16) bf16_cfg(p.cfg, !p.ipconv); else check_cfg(p.cfg, !p.ipconv && !p.patch);
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0 && p.cfg.BK % 4 == 0) ? "2" : ((p.patch && Kt % 2 == 0) ? "4" : "3")));
