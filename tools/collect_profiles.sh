@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh final'
+# then, back here:  python tools/make_profile_summaries.py gpurun_out/final r01
+# Kernel-trace stats and the PMC passes are separate runs (one --pmc set per run, never combined with other trace domains).
+D=${1:-final}
+R=$PWD
+O=$R/gpurun_out/$D
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+SQ="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/calib -o c -- python $R/tools/fetch_calib.py > $O/calib.log 2>&1
+for w in sgemm-ops-full alexnet nin; do
+  rocprofv3 --kernel-trace --stats -d $O/stats_$w -o p -- python $R/bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_$w.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_$w -o p -- python $R/bench.py --workload $w --steps 1 --warmup 0 --settle-ms 0 --no-cpu-baseline > $O/fetch_$w.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_$w -o p -- python $R/bench.py --workload $w --steps 1 --warmup 0 --settle-ms 0 --no-cpu-baseline > $O/write_$w.log 2>&1
+  rocprofv3 --kernel-trace --pmc $SQ -d $O/sq_$w -o p -- python $R/bench.py --workload $w --steps 1 --warmup 0 --settle-ms 0 --no-cpu-baseline > $O/sq_$w.log 2>&1
+done
+cd $R
+for w in sgemm-ops-full alexnet nin; do python bench.py --workload $w > $O/bench_$w.json 2>$O/bench_$w.err; done
+for w in nin-net alexnet-net googlenet resnet50; do python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
+for w in sgemm-ops-full alexnet nin googlenet resnet50; do python bench.py --workload $w --dtype bf16 --no-cpu-baseline > $O/bench_${w}_bf16.json 2>/dev/null; done
+find $O -name "*.db" -size +30M -delete   # keep the merge-back under the 64 MiB cap
+ls -la $O | head -50
