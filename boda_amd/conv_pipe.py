@@ -32,7 +32,7 @@ from .rtc import HipCompute, RtcArg, RtcCompileOpts, RtcFuncCall, RtcFuncInfo
 @dataclass
 class PipeOp:
     tag: str
-    type: str                      # Convolution | Pooling | ReLU | LRN | Dropout
+    type: str                      # Convolution | Pooling | ReLU | LRN | Dropout | Concat
     bot: str
     top: str
     out_chans: int = 0
@@ -41,6 +41,7 @@ class PipeOp:
     in_pad: Tuple[int, int] = (0, 0)
     avg_pool: int = 0
     lrn: Tuple[int, float, float, float] = (5, 1.0, 0.75, 1.0)  # local_size, alpha, beta, k (src/conv_util.cc:42-48)
+    bots: Tuple[str, ...] = ()     # Concat: all inputs in channel order (bot == bots[0])
 
     @property
     def in_place(self) -> bool:
@@ -62,6 +63,8 @@ class ConvPipe:
         d = self.nodes[op.bot]
         B, C, H, W = d.dsz("img"), d.dsz("chan"), d.dsz("y"), d.dsz("x")
         if op.type == "Convolution":
+            if tuple(op.kern_sz) == (0, 0):   # InnerProduct: a convolution whose kernel is the whole input (src/caffepb.cc:240-262)
+                op.kern_sz = (H, W)
             kh, kw = op.kern_sz
             oh = (H + 2 * op.in_pad[0] - kh) // op.stride[0] + 1; ow = (W + 2 * op.in_pad[1] - kw) // op.stride[1] + 1
             if oh < 1 or ow < 1:
@@ -78,6 +81,15 @@ class ConvPipe:
             out = Dims.make("float", img=B, chan=C, y=osz(H, op.kern_sz[0], op.stride[0], op.in_pad[0]), x=osz(W, op.kern_sz[1], op.stride[1], op.in_pad[1]))
         elif op.type in ("ReLU", "LRN", "Dropout"):
             out = d
+        elif op.type == "Concat":          # channel concatenation of same-sized maps (src/conv_util.cc:437-446)
+            ds = []
+            for b in op.bots:
+                if b not in self.nodes:
+                    raise RtErr(f"pipe: concat {op.tag} reads unknown node {b!r}")
+                ds.append(self.nodes[b])
+            if any((x.dsz("img"), x.dsz("y"), x.dsz("x")) != (B, H, W) for x in ds):
+                raise RtErr(f"pipe: concat {op.tag} of mismatched sizes")
+            out = Dims.make("float", img=B, chan=sum(x.dsz("chan") for x in ds), y=H, x=W)
         else:
             raise UnsupErr(f"pipe: op type {op.type!r} has no forward kernel in this backend")
         if op.top in self.nodes and not op.in_place:
@@ -141,6 +153,50 @@ def alexnet_ng_conv(batch: int, in_hw: int = 227) -> ConvPipe:
     return p
 
 
+def pipe_from_spec(name: str, lines: Sequence[str], batch: int) -> ConvPipe:
+    """ConvPipe from the one-line op records boda_amd.prototxt.pipe_spec writes (fixtures: tests/golden/nets/*.txt)."""
+    p: Optional[ConvPipe] = None
+    for ln in lines:
+        f = ln.split()
+        if not f or f[0].startswith("#"):
+            continue
+        if f[0] == "input":
+            p = ConvPipe(name, f[1], Dims.make("float", img=batch, chan=int(f[2]), y=int(f[3]), x=int(f[4])))
+            continue
+        if p is None:
+            raise RtErr("pipe spec: no input line before the first op")
+        k = f[0]
+        if k == "conv":
+            oc, kh, kw, sy, sx, py, px = (int(x) for x in f[4:11])
+            p.add(PipeOp(f[1], "Convolution", f[2], f[3], out_chans=oc, kern_sz=(kh, kw), stride=(sy, sx), in_pad=(py, px)))
+        elif k == "pool":
+            kh, kw, sy, sx, py, px, avg, glob = (int(x) for x in f[4:12])
+            p.add(PipeOp(f[1], "Pooling", f[2], f[3], kern_sz=None if glob else (kh, kw), stride=(sy, sx), in_pad=(py, px), avg_pool=avg))
+        elif k == "lrn":
+            p.add(PipeOp(f[1], "LRN", f[2], f[3], lrn=(int(f[4]), float(f[5]), float(f[6]), float(f[7]))))
+        elif k == "relu":
+            p.add(PipeOp(f[1], "ReLU", f[2], f[3]))
+        elif k == "drop":
+            p.add(PipeOp(f[1], "Dropout", f[2], f[3]))
+        elif k == "concat":
+            bots = tuple(f[3].split(","))
+            p.add(PipeOp(f[1], "Concat", bots[0], f[2], bots=bots))
+        else:
+            raise RtErr(f"pipe spec: unknown record {k!r}")
+    if p is None:
+        raise RtErr("pipe spec: empty")
+    return p
+
+
+def googlenet_conv(batch: int) -> ConvPipe:
+    """nets/googlenet_conv (TEST phase, incl. the two auxiliary heads): 64 convs, 9 inception Concats, 2 LRN, 16 pools; the op
+    records are a data fixture written by tests/golden/make_net_ops.py with this project's prototxt reader."""
+    import os
+    fn = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "nets", "googlenet_conv.txt")
+    with open(fn) as f:
+        return pipe_from_spec("googlenet_conv", f.read().splitlines(), batch)
+
+
 # ------------------------------------------------------------------------------------------------
 # non-conv forward kernels (CUCL dialect, dims as by-value args)
 # ------------------------------------------------------------------------------------------------
@@ -166,6 +222,13 @@ CUCL_GLOBAL_KERNEL void fwd_pool( GASQ float const * const in, GASQ float * cons
   }
   if( avg_pool ) { out_v /= avg_pool_sz; }
   out[GLOB_ID_1D] = out_v;
+}
+// Concat: copy one input into its channel range of the output (semantics of test/rtc/copy.cucl; src/rtc_fwd.cc:267-280)
+CUCL_GLOBAL_KERNEL void fwd_copy( GASQ float const * const in, GASQ float * const out, uint32_t const n_in, uint32_t const chw_in,
+                                  uint32_t const chw_out, uint32_t const off_out ) {
+  if( GLOB_ID_1D >= n_in ) { return; }
+  uint32_t const img = GLOB_ID_1D / chw_in;
+  out[img*chw_out + off_out + ( GLOB_ID_1D - img*chw_in )] = in[GLOB_ID_1D];
 }
 CUCL_GLOBAL_KERNEL void fwd_relu( GASQ float * const inout, uint32_t const n ) {
   if( GLOB_ID_1D >= n ) { return; }
@@ -194,6 +257,7 @@ CUCL_GLOBAL_KERNEL void fwd_lrn( GASQ float const * const in, GASQ float * const
 }
 """
 FWD_FUNCS = {"fwd_pool": ["in", "out", "avg_pool", "n_out", "H", "W", "OH", "OW", "KH", "KW", "SY", "SX", "PY", "PX"],
+             "fwd_copy": ["in", "out", "n_in", "chw_in", "chw_out", "off_out"],
              "fwd_relu": ["inout", "n"],
              "fwd_lrn": ["in", "out", "alpha", "beta", "k", "local_size", "n_pel", "C", "HW"]}
 _TPB = 256
@@ -276,6 +340,14 @@ class ConvPipeFwd:
                       "KH": _u32(op.kern_sz[0]), "KW": _u32(op.kern_sz[1]), "SY": _u32(op.stride[0]), "SX": _u32(op.stride[1]),
                       "PY": _u32(op.in_pad[0]), "PX": _u32(op.in_pad[1])}
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall("fwd_pool", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB), "fwd_pool"))
+            elif op.type == "Concat":
+                o = cp.nodes[op.top]; hw = o.dsz("y") * o.dsz("x"); chw_out = o.dsz("chan") * hw
+                c_done = 0
+                for bi, b in enumerate(op.bots):
+                    d = cp.nodes[b]; n = d.dims_prod(); chw_in = d.dsz("chan") * hw
+                    am = {"in": RtcArg.var(vn(b)), "out": RtcArg.var(op.top), "n_in": _u32(n), "chw_in": _u32(chw_in), "chw_out": _u32(chw_out), "off_out": _u32(c_done * hw)}
+                    self.fwd_calls.append(FwdCall(f"{op.tag}.{bi}", RtcFuncCall("fwd_copy", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB), "fwd_copy"))
+                    c_done += d.dsz("chan")
             elif op.type == "ReLU":
                 n = cp.nodes[op.top].dims_prod()
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall("fwd_relu", {"inout": RtcArg.var(vn(op.bot)), "n": _u32(n)}, tpb=_TPB, blks=(n + _TPB - 1) // _TPB), "fwd_relu"))
@@ -364,4 +436,6 @@ def oracle_forward(cp: ConvPipe, data: np.ndarray, params: Dict[str, np.ndarray]
             vals[op.top] = bo.lrn_fwd(x, *op.lrn)
         elif op.type == "Dropout":
             vals[op.top] = x
+        elif op.type == "Concat":
+            vals[op.top] = np.concatenate([vals[b] for b in op.bots], axis=1)
     return vals

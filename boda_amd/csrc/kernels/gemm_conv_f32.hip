@@ -277,7 +277,7 @@ __device__ __forceinline__ void store_tile(float const (&r)[NR], float *__restri
 constexpr int kRPP = kNT / BJ;      // row groups per K step (a wave belongs to exactly one)
 constexpr int kRPT = JROWS / kRPP;  // rows per thread per K step
 static_assert(BJ % 64 == 0 && kNT % BJ == 0 && JROWS % kRPP == 0 && BK == JROWS * KW && KW >= 2, "row gather geometry");
-struct gather_t { int base; int iy0; bool mx[KW]; bool first_tile; };
+struct gather_t { int base; int iy0; bool mx[KW]; bool edge_tile; };
 template <int N> __device__ __forceinline__ void bload_n(float *dst, rsrc_t r, int off) {
   if constexpr (N >= 4) { f32x4 const v = bload4(r, off); dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; if constexpr (N > 4) bload_n<N - 4>(dst + 4, r, off + 16); }
   else if constexpr (N == 3) { f32x3 const v = bload3(r, off); dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; }
@@ -295,9 +295,11 @@ __device__ __forceinline__ void load_gather(float (&r)[kNJ], rsrc_t in, gather_t
     int off = (g.base + t_off[q]) * 4;
     asm volatile("" : "+v"(off));
     bool const row_ok = (unsigned)iy < (unsigned)p.H;
-    if (PX > 0 && g.first_tile) {
-      // the very first row of the tensor has nothing in front of it: with left padding its window would start at a negative
-      // (= out-of-range) offset and lose its valid taps.  Only the first pel tile can contain it: it gathers tap by tap.
+    if (PX > 0 && g.edge_tile) {
+      // With left/right padding a row window can start before the tensor (very first input row: negative = out-of-range
+      // offset) or end past it (very last input row: the hardware range-checks a wide load as a whole, so the in-range taps
+      // of a window that crosses num_records would read 0 too).  Only tiles at the very start / end of the pel range can contain
+      // such a window: they gather tap by tap.
 #pragma unroll
       for (int kx = 0; kx < KW; ++kx) r[q * KW + kx] = bload1(in, (row_ok && g.mx[kx]) ? (off + 4 * kx) : kOOB);
     } else {
@@ -493,7 +495,9 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     g.base = (img * p.C * p.H + (oy * SY - PY)) * p.W + ix0;
 #pragma unroll
     for (int kx = 0; kx < KW; ++kx) g.mx[kx] = (unsigned)(ix0 + kx) < (unsigned)p.W;
-    g.first_tile = (tile_j == 0); // workgroup-uniform
+    // tiles holding output rows whose window touches the first input row of image 0 (oy <= PY/SY) or the last input row of the
+    // last image (at most KH/SY+1 output rows): workgroup-uniform
+    g.edge_tile = (j0 < (PY / SY + 1) * p.OW) || (j0 + BJ > p.Nj - (KH / SY + 1) * p.OW);
   }
 #elif J_MODE == 7
   gather_t g;

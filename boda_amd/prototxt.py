@@ -113,3 +113,54 @@ def conv_ops(text: str, batch: int, in_chw: Tuple[int, int, int] = (3, 224, 224)
         else:
             raise RtErr(f"prototxt: unhandled layer type {t!r} ({name!r})")
     return out
+
+
+def pipe_spec(text: str, in_chw: Tuple[int, int, int] = (3, 224, 224)) -> List[str]:
+    """-> the TEST-phase forward ops of a net definition as compact one-line records (boda_amd.conv_pipe.pipe_from_spec reads
+    them back): what the reference's reader keeps of each layer for conv_pipe_t (src/caffepb.cc:166-326).
+      input C H W | conv tag bot top oc kh kw sy sx py px | pool tag bot top kh kw sy sx py px avg global
+      lrn tag bot top local_size alpha beta k | relu tag bot top | drop tag bot top | concat tag top bot1,bot2,..."""
+    root = parse(text)
+    layers = root.get("layer", []) or root.get("layers", [])
+    out: List[str] = []
+    have_input = False
+    for L in layers:
+        if not _is_test_phase(L):
+            continue
+        t = str(_one(L, "type")).upper().replace("_", "")
+        bots, tops, name = L.get("bottom", []), L.get("top", []), _one(L, "name")
+        if t == "DATA":
+            cs = int(_one(_one(L, "transform_param", {}), "crop_size", in_chw[1]))
+            out.append(f"input {tops[0]} {in_chw[0]} {cs} {cs}"); have_input = True
+        elif t in ("ACCURACY", "SOFTMAX", "SOFTMAXWITHLOSS", "SOFTMAXLOSS"):
+            continue
+        elif t == "CONVOLUTION":
+            cp = _one(L, "convolution_param", {})
+            if int(_one(cp, "group", 1)) != 1:
+                raise RtErr(f"prototxt: grouped convolution {name!r} is not on this path")
+            k, s_, p_ = int(_one(cp, "kernel_size", 1)), int(_one(cp, "stride", 1)), int(_one(cp, "pad", 0))
+            out.append(f"conv {name} {bots[0]} {tops[0]} {int(_one(cp, 'num_output'))} {k} {k} {s_} {s_} {p_} {p_}")
+        elif t == "INNERPRODUCT":
+            out.append(f"conv {name} {bots[0]} {tops[0]} {int(_one(_one(L, 'inner_product_param', {}), 'num_output'))} 0 0 1 1 0 0")  # kernel = whole input
+        elif t == "POOLING":
+            pp = _one(L, "pooling_param", {})
+            glob = int(str(_one(pp, "global_pooling", "false")).lower() == "true")
+            k = 0 if glob else int(_one(pp, "kernel_size")); s_ = int(_one(pp, "stride", 1)); p_ = int(_one(pp, "pad", 0))
+            avg = int(str(_one(pp, "pool", "MAX")).upper() == "AVE")
+            out.append(f"pool {name} {bots[0]} {tops[0]} {k} {k} {s_} {s_} {p_} {p_} {avg} {glob}")
+        elif t == "LRN":
+            lp = _one(L, "lrn_param", {})
+            out.append(f"lrn {name} {bots[0]} {tops[0]} {int(_one(lp, 'local_size', 5))} {float(_one(lp, 'alpha', 1.0))} {float(_one(lp, 'beta', 0.75))} {float(_one(lp, 'k', 1.0))}")
+        elif t == "RELU":
+            out.append(f"relu {name} {bots[0]} {tops[0]}")
+        elif t == "DROPOUT":
+            out.append(f"drop {name} {bots[0]} {tops[0]}")
+        elif t == "CONCAT":
+            out.append(f"concat {name} {tops[0]} {','.join(bots)}")
+        else:
+            raise RtErr(f"prototxt: layer type {t!r} ({name!r}) has no forward op on this path")
+    if not have_input and "input" in root:
+        dims = [int(x) for x in root.get("input_dim", [])]
+        c, h, w = (dims[1], dims[2], dims[3]) if len(dims) == 4 else in_chw
+        out.insert(0, f"input {_one(root, 'input')} {c} {h} {w}")
+    return out

@@ -17,3 +17,20 @@ def test_alexnet_shapes_and_flops():
     assert cp.nodes["pool1"].sizes == (256, 96, 27, 27) and cp.nodes["pool5"].sizes == (256, 256, 6, 6)
     assert cp.nodes["fc6"].sizes == (256, 4096, 1, 1) and cp.nodes["fc8"].sizes == (256, 1000, 1, 1)
     assert cp.conv_flops() == sum(o.flops() for o in bench.alexnet_b256_ops(256))  # 581.3 GF
+
+
+def test_googlenet_from_spec_fixture():
+    """pipe_from_spec over the GoogLeNet op records: 64 convs whose op lines equal the per-layer conv-ops fixture (same reader,
+    two routes), inception Concat channel sums, ceil-mode pools, InnerProduct-free classifier heads."""
+    import os
+    from boda_amd.conv_pipe import googlenet_conv
+    from boda_amd.op import parse_op
+    cp = googlenet_conv(1)
+    convs = [o for o in cp.ops if o.type == "Convolution"]
+    assert len(convs) == 64 and sum(o.type == "Concat" for o in cp.ops) == 9 and sum(o.type == "LRN" for o in cp.ops) == 2
+    here = os.path.dirname(os.path.abspath(__file__))
+    want = [parse_op(l) for l in open(os.path.join(here, "golden", "ops", "googlenet_conv-conv-ops-b1.txt")).read().splitlines() if l.strip()]
+    assert [cp.conv_op(o).to_str() for o in convs] == [w.to_str() for w in want]
+    assert cp.nodes["pool1"].sizes == (1, 64, 56, 56) and cp.nodes["icp2_out"].sizes == (1, 480, 28, 28) and cp.nodes["icp9_out"].sizes == (1, 1024, 7, 7)
+    assert cp.nodes[cp.out_node()].sizes == (1, 1000, 1, 1)
+    assert abs(cp.conv_flops() / 1e9 - 3.182) < 1e-3

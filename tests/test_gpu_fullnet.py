@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from boda_amd.conv_pipe import ConvPipe, ConvPipeFwd, PipeOp, alexnet_ng_conv, nin_imagenet, oracle_forward
+from boda_amd.conv_pipe import ConvPipe, ConvPipeFwd, PipeOp, alexnet_ng_conv, googlenet_conv, nin_imagenet, oracle_forward
 from boda_amd.digest import SsdsDiff
 from boda_amd.op import Dims
 from boda_amd.rtc import make_rtc
@@ -36,9 +36,9 @@ def _params(cp):
     return ps
 
 
-@pytest.mark.parametrize("net,batch", [("nin", 3), ("alexnet", 2)])
+@pytest.mark.parametrize("net,batch", [("nin", 3), ("alexnet", 2), ("googlenet", 2)])
 def test_full_net_forward_matches_oracle(rtc, net, batch, tmp_path):
-    cp = nin_imagenet(batch) if net == "nin" else alexnet_ng_conv(batch)
+    cp = {"nin": nin_imagenet, "alexnet": alexnet_ng_conv, "googlenet": googlenet_conv}[net](batch)
     params = _params(cp)
     d = cp.nodes["data"]
     data = bo.gen_conv_in(*d.sizes)
@@ -51,18 +51,34 @@ def test_full_net_forward_matches_oracle(rtc, net, batch, tmp_path):
         nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
         io = {"data": data}
         fwd.run_fwd(["data"], io, nodes)
+        # (1) every op in isolation: the oracle applied to the inputs the device op actually consumed.  Convs (+ fused ReLU),
+        #     max-pools and Concat copies must be bit-exact; LRN (powf) and average pooling (fast-math division) to 1e-5.
+        relu_after = {o.bot for o in cp.ops if o.type == "ReLU" and o.in_place}
+        for op in cp.ops:
+            x = io.get(op.bot, data if op.bot == "data" else None)
+            if op.type == "Convolution":
+                w = bo.conv_fwd(x, params[op.tag + "_filts"], params[op.tag + "_biases"], op.stride, op.in_pad, relu=(op.top in relu_after))
+                assert np.array_equal(w, io[op.top]), (op.tag, SsdsDiff.of(w, io[op.top]).basic_str())
+            elif op.type == "Pooling":
+                w = bo.pool_fwd(x, op.kern_sz, op.stride, op.in_pad, bool(op.avg_pool))
+                if op.avg_pool:
+                    assert SsdsDiff.of(w, io[op.top]).mrd < 1e-5, op.tag
+                else:
+                    assert np.array_equal(w, io[op.top]), op.tag
+            elif op.type == "LRN":
+                assert SsdsDiff.of(bo.lrn_fwd(x, *op.lrn), io[op.top]).mrd < 1e-5, op.tag
+            elif op.type == "Concat":
+                assert np.array_equal(io[op.top], np.concatenate([io[b] for b in op.bots], axis=1)), op.tag
+        # (2) end to end against the oracle's own layer-by-layer forward, at the reference's full-net tolerance.  GoogLeNet is 22
+        #     conv layers deep and the hash-random weights let the ulp-level LRN / avg-pool differences grow (measured 5.5e-4 at
+        #     icp5 with every op exact in isolation), so its end-to-end bound only guards against gross errors.
         want = oracle_forward(cp, data, params, bo)
-        exact_ok = True
+        tol = 5e-3 if net == "googlenet" else FULLNET_MRD
         for op in cp.ops:
             if op.type in ("ReLU", "Dropout"):
                 continue
-            n = op.top
-            sd = SsdsDiff.of(want[n], io[n])
-            assert not sd.has_nan() and sd.mrd < FULLNET_MRD, (n, sd.basic_str())
-            if op.type == "LRN" or (op.type == "Pooling" and op.avg_pool):
-                exact_ok = False  # powf / fast-math division: ulp-level differences from here on
-            if exact_ok:
-                assert np.array_equal(want[n], io[n]), (n, sd.basic_str())
+            sd = SsdsDiff.of(want[op.top], io[op.top])
+            assert not sd.has_nan() and sd.mrd < tol, (op.top, sd.basic_str())
         assert io[cp.out_node()].shape[:2] == (batch, 1000)
         assert fwd.compute_dur_ms > 0
         prof = open(tmp_path / "per_call.py").read()
@@ -70,6 +86,23 @@ def test_full_net_forward_matches_oracle(rtc, net, batch, tmp_path):
         # second run (device-resident inputs) reproduces the same outputs
         ms = fwd.run_fwd_device_only()
         assert ms > 0 and np.array_equal(rtc.copy_var_to_nda(fwd.var_of(cp.out_node())), io[cp.out_node()])
+    finally:
+        fwd.release()
+
+
+def test_concat_copies_into_channel_ranges(rtc):
+    cp = ConvPipe("c", "data", Dims.make("float", img=3, chan=5, y=6, x=7))
+    cp.add(PipeOp("pa", "Pooling", "data", "pa", kern_sz=(3, 3), stride=(1, 1), in_pad=(1, 1)))
+    cp.add(PipeOp("pb", "Pooling", "data", "pb", kern_sz=(3, 3), stride=(1, 1), in_pad=(1, 1), avg_pool=1))
+    cp.add(PipeOp("cat", "Concat", "pa", "cat", bots=("pa", "data", "pb")))
+    data = bo.gen_conv_in(3, 5, 6, 7)
+    fwd = ConvPipeFwd(rtc); fwd.init(cp)
+    try:
+        io = {"data": data}
+        fwd.run_fwd(["data"], io, ["pa", "pb", "cat"])
+        assert [c.func for c in fwd.fwd_calls].count("fwd_copy") == 3 and io["cat"].shape == (3, 15, 6, 7)
+        assert np.array_equal(io["cat"], np.concatenate([io["pa"], data, io["pb"]], axis=1))
+        assert np.array_equal(io["pa"], oracle_forward(cp, data, {}, bo)["pa"])
     finally:
         fwd.release()
 

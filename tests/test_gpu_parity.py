@@ -291,6 +291,8 @@ EDGE_CONVS = [  # B, C, H, W, OC, KH, KW, S, P   (incl. 1x1 stride 1/2 -> k1 pat
     (1, 3, 12, 12, 16, 3, 3, 1, 1), (2, 5, 17, 13, 7, 5, 5, 2, 2), (3, 4, 9, 9, 33, 1, 1, 1, 0), (1, 8, 6, 6, 40, 6, 6, 1, 0),
     (2, 3, 35, 35, 96, 11, 11, 4, 0), (1, 16, 14, 14, 130, 7, 7, 2, 3), (5, 32, 7, 7, 64, 1, 1, 2, 0), (2, 6, 10, 10, 12, 3, 3, 1, 0),
     (1, 1, 5, 5, 1, 5, 5, 1, 2), (4, 20, 8, 8, 100, 3, 3, 1, 1),
+    # multi-tile with padding: the first / last row windows of the tensor sit in different workgroups than the bulk
+    (2, 3, 40, 40, 16, 7, 7, 2, 3), (3, 4, 33, 31, 20, 5, 5, 1, 2), (2, 3, 64, 64, 24, 11, 11, 4, 5), (1, 3, 150, 150, 64, 7, 7, 2, 3),
 ]
 
 
@@ -315,7 +317,7 @@ def test_conv_row_gather_all_kernel_widths(be, shape, monkeypatch):
     g = op.conv_geom()
     cfg = be.rtc.last_launch()["cfg"]
     if not (g["OH"] == 1 and g["OW"] == 1 and g["PY"] == 0 and g["KH"] == shape[2]):  # ipconv shapes never gather
-        assert int(cfg.split("x")[2].split("_")[0]) % g["KW"] == 0, cfg  # BK = rows * KW: the row gather was taken
+        assert "_m16" in cfg or int(cfg.split("x")[2].split("_")[0]) % g["KW"] == 0, cfg  # BK = rows * KW: the row gather was taken (32x32-MFMA tiles only)
     want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
     assert np.array_equal(want, outs["out"]), SsdsDiff.of(want, outs["out"]).basic_str()
 
@@ -460,3 +462,22 @@ def test_bf16_conv(be, shape):
     assert not sd.has_nan() and sd.mrd < MRD_BF16, sd.basic_str()
     want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
     assert _nrms(want, outs["out"]) < 1e-2
+
+
+@pytest.mark.parametrize("net", ["googlenet_conv", "resnet-50"])
+def test_every_conv_layer_of_config5_nets_bit_exact(be, net):
+    """BASELINE config 5's layer lists (64 GoogLeNet convs, 53 ResNet-50 convs + fc; shapes from the prototxts via our own reader):
+    every distinct layer at batch 2 through its default plan -- patch / row-gather / 1x1 / table modes, strided and padded,
+    first and last tiles of multi-tile grids -- must equal the oracle bit for bit."""
+    import bench
+    seen = set()
+    for op in bench.net_conv_ops(net, 2):
+        key = op.to_str()
+        if key in seen:
+            continue
+        seen.add(key)
+        outs, prc = _run(be, op, 5, include_ins=True)
+        g = op.conv_geom()
+        want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
+        assert np.array_equal(want, outs["out"]), (key, prc.launch["cfg"], SsdsDiff.of(want, outs["out"]).basic_str())
+    assert len(seen) >= 20
