@@ -407,12 +407,37 @@ class ConvPipeFwd:
         rtc.release_per_call_id_data()
         return ms
 
+    # -- hipGraph form of run_fwd_device_only: the call list captured once, replayed with one host call per forward pass
+    def capture_graph(self) -> int:
+        """Capture the forward call list into a hipGraph (after at least one ordinary run, so that every lazily built kernel and
+        table exists); -> number of captured calls."""
+        rtc = self.rtc
+        if getattr(self, "_graph", None) is not None:
+            rtc.graph_destroy(self._graph)
+        rtc.finish_and_sync()
+        rtc.graph_begin()
+        for c in self.fwd_calls:
+            rtc.run(c.rfc)
+        self._graph, n = rtc.graph_end()
+        return n
+
+    def run_graph(self) -> float:
+        """One forward pass as one graph launch; -> ms of the whole replay."""
+        rtc = self.rtc
+        cid = rtc.graph_launch(self._graph)
+        rtc.finish_and_sync()
+        ms = rtc.get_dur(cid, cid)
+        rtc.release_per_call_id_data()
+        return ms
+
     def get_info_log(self) -> str:
         return "\n".join(f"{c.tag}: {c.func}" for c in self.fwd_calls)
 
     def release(self) -> None:
         rtc = self.rtc
         rtc.finish_and_sync()
+        if getattr(self, "_graph", None) is not None:
+            rtc.graph_destroy(self._graph); self._graph = None
         for f in self._funcs:
             rtc.release_func(f)
         for v in self._vars:

@@ -8,6 +8,11 @@
 using namespace bodahip;
 namespace bodahip {
 void *hip_compute_stream(rtc_compute_t *rtc);
+void hip_compute_graph_begin(rtc_compute_t *rtc);
+uint32_t hip_compute_graph_end(rtc_compute_t *rtc);
+uint32_t hip_compute_graph_launch(rtc_compute_t *rtc, uint32_t id);
+uint32_t hip_compute_graph_num_calls(rtc_compute_t *rtc, uint32_t id);
+void hip_compute_graph_destroy(rtc_compute_t *rtc, uint32_t id);
 native_kernels_t *hip_compute_native(rtc_compute_t *rtc);
 extern char const *const k_src_gemm_conv_f32_ptr;
 }
@@ -101,6 +106,12 @@ int bodahip_copy_from_var(bodahip_ctx *ctx, void *host, const bodahip_dims *dims
   ABI_TRY if (!host) rt_err("null host pointer"); R(ctx).copy_var_to_nda(std::make_shared<nda_t>(to_dims(dims), host), S(vn, "vn")); ABI_CATCH }
 int bodahip_get_raw_ptr(bodahip_ctx *ctx, const char *vn, void **p) { ABI_TRY if (!p) rt_err("null out"); *p = R(ctx).get_var_raw_native_pointer(S(vn, "vn"))->rp_elems(); ABI_CATCH }
 
+int bodahip_graph_begin(bodahip_ctx *ctx) { ABI_TRY hip_compute_graph_begin(&R(ctx)); ABI_CATCH }
+int bodahip_graph_end(bodahip_ctx *ctx, uint32_t *graph_id, uint32_t *n_calls) {
+  ABI_TRY if (!graph_id) rt_err("null graph_id_out"); *graph_id = hip_compute_graph_end(&R(ctx)); if (n_calls) *n_calls = hip_compute_graph_num_calls(&R(ctx), *graph_id); ABI_CATCH }
+int bodahip_graph_launch(bodahip_ctx *ctx, uint32_t graph_id, uint32_t *call_id) {
+  ABI_TRY uint32_t const id = hip_compute_graph_launch(&R(ctx), graph_id); if (call_id) *call_id = id; ABI_CATCH }
+int bodahip_graph_destroy(bodahip_ctx *ctx, uint32_t graph_id) { ABI_TRY hip_compute_graph_destroy(&R(ctx), graph_id); ABI_CATCH }
 int bodahip_get_stream(bodahip_ctx *ctx, void **s) { ABI_TRY if (!s) rt_err("null out"); *s = hip_compute_stream(&R(ctx)); ABI_CATCH }
 int bodahip_get_device_info(bodahip_ctx *ctx, char *arch_buf, size_t n, int *num_cus, int *clock_khz) {
   ABI_TRY

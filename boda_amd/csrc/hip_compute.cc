@@ -264,7 +264,8 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
     call_evs.push_back(ce);
     return (uint32_t)call_evs.size() - 1;
   }
-  call_ev_t &get_call_ev(uint32_t id) { if (id >= call_evs.size()) rt_err("invalid call_id " + std::to_string(id)); return call_evs[id]; }
+  static constexpr uint32_t kCapturedCallId = 0xfffffffeu; // what run() returns while a graph is being captured: the call has no events of its own
+  call_ev_t &get_call_ev(uint32_t id) { if (id == kCapturedCallId) rt_err("this call was captured into a graph: time the graph launch instead"); if (id >= call_evs.size()) rt_err("invalid call_id " + std::to_string(id)); return call_evs[id]; }
   void release_per_call_id_data() override { for (auto &ce : call_evs) ev_pool.push_back(ce); call_evs.clear(); }
   float get_dur(uint32_t const &b, uint32_t const &e) override {
     use_dev();
@@ -279,6 +280,7 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
     if (fit == funcs.end()) rt_err("run: unknown function '" + rfc.rtc_func_name + "' (not compiled, or released)");
     hip_func_t &hf = fit->second;
     if (hf.native) {
+      if (capturing) { try { native->run(hf.info, rfc.arg_map); } catch (...) { graph_abort(); throw; } ++cap_calls; return kCapturedCallId; }
       uint32_t const call_id = alloc_call_id();
       hip_err_chk(hipEventRecord(get_call_ev(call_id).b, stream), "hipEventRecord");
       native->run(hf.info, rfc.arg_map);
@@ -300,6 +302,11 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
     }
     rtc_launch_check_blks_and_tpb(rfc.rtc_func_name, rfc.blks, rfc.tpb);
     if (rfc.tpb > (uint32_t)props.maxThreadsPerBlock) unsup_err("hip backend: tpb=" + std::to_string(rfc.tpb) + " exceeds device limit for '" + rfc.rtc_func_name + "'");
+    if (capturing) {
+      hipError_t const err = hipModuleLaunchKernel(hf.func, rfc.blks, 1, 1, rfc.tpb, 1, 1, 0, stream, kargs.empty() ? nullptr : kargs.data(), nullptr);
+      if (err != hipSuccess) { graph_abort(); hip_err_chk(err, ("hipModuleLaunchKernel(" + rfc.rtc_func_name + ") [capture]").c_str()); }
+      ++cap_calls; return kCapturedCallId;
+    }
     uint32_t const call_id = alloc_call_id();
     hip_err_chk(hipEventRecord(get_call_ev(call_id).b, stream), "hipEventRecord");
     hip_err_chk(hipModuleLaunchKernel(hf.func, rfc.blks, 1, 1, rfc.tpb, 1, 1, 0, stream, kargs.empty() ? nullptr : kargs.data(), nullptr),
@@ -307,12 +314,59 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
     hip_err_chk(hipEventRecord(get_call_ev(call_id).e, stream), "hipEventRecord");
     return call_id;
   }
-  void finish_and_sync() override { use_dev(); hip_err_chk(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+  void finish_and_sync() override { use_dev(); if (capturing) { graph_abort(); rt_err("finish_and_sync during graph capture"); } hip_err_chk(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
   void profile_start() override { (void)hipProfilerStart(); }
   void profile_stop() override { (void)hipProfilerStop(); }
 
   // ---- native_host_t: what the native kernels need from the backend
   hipStream_t nh_stream() override { return stream; }
+  bool nh_capturing() override { return capturing; }
+
+  // ---- hipGraph capture of a call list (launch-bound inner loops, e.g. the ~120 small kernels of a GoogLeNet forward at batch 64):
+  // graph_begin() ... run() x N ... graph_end() records the launches (arguments frozen as passed) instead of executing them;
+  // graph_launch() replays them with one host call and returns a call id whose duration is the whole replay.  Everything a call
+  // needs lazily (hiprtc specialisations, gather tables) must already exist: run the list once before capturing it.
+  bool capturing = false;
+  struct graph_t { hipGraph_t g = nullptr; hipGraphExec_t exec = nullptr; uint32_t n_calls = 0; };
+  std::vector<graph_t> graphs;
+  uint32_t cap_calls = 0;
+  void graph_begin() {
+    assert_st(init_done); use_dev();
+    if (capturing) rt_err("graph_begin: a capture is already in progress");
+    finish_and_sync();
+    hip_err_chk(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+    capturing = true; cap_calls = 0;
+  }
+  uint32_t graph_end() {
+    if (!capturing) rt_err("graph_end: no capture in progress");
+    capturing = false;
+    graph_t gr; gr.n_calls = cap_calls;
+    hip_err_chk(hipStreamEndCapture(stream, &gr.g), "hipStreamEndCapture");
+    if (!gr.g) rt_err("graph_end: capture produced no graph");
+    hip_err_chk(hipGraphInstantiate(&gr.exec, gr.g, nullptr, nullptr, 0), "hipGraphInstantiate");
+    graphs.push_back(gr);
+    return (uint32_t)graphs.size() - 1;
+  }
+  void graph_abort() { // error inside a capture: drop it so the stream is usable again
+    if (!capturing) return;
+    capturing = false; hipGraph_t g = nullptr; (void)hipStreamEndCapture(stream, &g); if (g) (void)hipGraphDestroy(g); (void)hipGetLastError();
+  }
+  graph_t &get_graph(uint32_t id) { if (id >= graphs.size() || !graphs[id].exec) rt_err("invalid graph id " + std::to_string(id)); return graphs[id]; }
+  uint32_t graph_launch(uint32_t id) {
+    use_dev();
+    if (capturing) rt_err("graph_launch during capture");
+    graph_t &gr = get_graph(id);
+    uint32_t const call_id = alloc_call_id();
+    hip_err_chk(hipEventRecord(get_call_ev(call_id).b, stream), "hipEventRecord");
+    hip_err_chk(hipGraphLaunch(gr.exec, stream), "hipGraphLaunch");
+    hip_err_chk(hipEventRecord(get_call_ev(call_id).e, stream), "hipEventRecord");
+    return call_id;
+  }
+  uint32_t graph_num_calls(uint32_t id) { return get_graph(id).n_calls; }
+  void graph_destroy(uint32_t id) {
+    graph_t &gr = get_graph(id); finish_and_sync();
+    (void)hipGraphExecDestroy(gr.exec); (void)hipGraphDestroy(gr.g); gr.exec = nullptr; gr.g = nullptr;
+  }
   string const &nh_arch() override { return arch; }
   int nh_num_cus() override { return props.multiProcessorCount; }
   void *nh_var_ptr(string const &vn) override { return must_find(vis, vn).buf->p; }
@@ -321,6 +375,12 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
 };
 
 p_rtc_compute_t make_hip_compute(int device_ordinal) { return std::make_shared<hip_compute_t>(device_ordinal); }
+static hip_compute_t &as_hip(rtc_compute_t *rtc) { hip_compute_t *h = dynamic_cast<hip_compute_t *>(rtc); if (!h) rt_err("not a hip_compute_t"); return *h; }
+void hip_compute_graph_begin(rtc_compute_t *rtc) { as_hip(rtc).graph_begin(); }
+uint32_t hip_compute_graph_end(rtc_compute_t *rtc) { return as_hip(rtc).graph_end(); }
+uint32_t hip_compute_graph_launch(rtc_compute_t *rtc, uint32_t id) { return as_hip(rtc).graph_launch(id); }
+uint32_t hip_compute_graph_num_calls(rtc_compute_t *rtc, uint32_t id) { return as_hip(rtc).graph_num_calls(id); }
+void hip_compute_graph_destroy(rtc_compute_t *rtc, uint32_t id) { as_hip(rtc).graph_destroy(id); }
 void *hip_compute_stream(rtc_compute_t *rtc) { hip_compute_t *h = dynamic_cast<hip_compute_t *>(rtc); if (!h) rt_err("not a hip_compute_t"); return (void *)h->stream; }
 native_kernels_t *hip_compute_native(rtc_compute_t *rtc) { hip_compute_t *h = dynamic_cast<hip_compute_t *>(rtc); if (!h || !h->native) rt_err("hip backend not initialised"); return h->native.get(); }
 

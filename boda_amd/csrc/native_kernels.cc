@@ -257,6 +257,7 @@ static void setup_splitk(native_kernels_t::impl_t *impl, native_host_t *host, ge
   size_t const slab = (out_elems + 3) & ~size_t(3);
   size_t const need = slab * (size_t)cfg.SPLITK * sizeof(float);
   if (impl->ws_bytes < need) {
+    if (host->nh_capturing()) rt_err("graph capture: split-K workspace not allocated yet -- run the call list once before capturing it");
     if (impl->ws) { hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize"); hip_err_chk(hipFree(impl->ws), "hipFree"); impl->ws = nullptr; impl->ws_bytes = 0; }
     hip_err_chk(hipMalloc(&impl->ws, need), "hipMalloc(split-k scratch)"); impl->ws_bytes = need;
   }
@@ -286,6 +287,7 @@ static ktab_t get_ktab(native_kernels_t::impl_t *impl, native_host_t *host, conv
   long const K = (long)g.C * g.KH * g.KW, n = ((K + 255) / 256 + 1) * 256;
   auto it = impl->ktabs.find(key);
   if (it != impl->ktabs.end()) return ktab_t{it->second, (int)n};
+  if (host->nh_capturing()) rt_err("graph capture: gather table not built yet -- run the call list once before capturing it");
   std::vector<int> h((size_t)n * 3);
   for (long k = 0; k < n; ++k) {
     if (k < K) { long const ic = k / (g.KH * g.KW), rem = k % (g.KH * g.KW), ky = rem / g.KW, kx = rem % g.KW;
@@ -307,6 +309,7 @@ static ktab_t get_rtab(native_kernels_t::impl_t *impl, native_host_t *host, conv
   long const R = (long)g.C * g.KH, n = ((R + 63) / 64 + 1) * 64;
   auto it = impl->ktabs.find(key);
   if (it != impl->ktabs.end()) return ktab_t{it->second, (int)n};
+  if (host->nh_capturing()) rt_err("graph capture: gather table not built yet -- run the call list once before capturing it");
   std::vector<int> h((size_t)n * 2);
   for (long r = 0; r < n; ++r) {
     if (r < R) { long const ic = r / g.KH, ky = r % g.KH; h[r] = (int)((ic * g.H + ky) * g.W); h[n + r] = (int)ky; }
@@ -400,6 +403,7 @@ static kernel_t &get_kernel(native_kernels_t::impl_t *impl, native_host_t *host,
   string key = p.kname; for (auto const &d : p.defs) key += " " + d;
   auto it = impl->kernels.find(key);
   if (it != impl->kernels.end()) return it->second;
+  if (host->nh_capturing()) rt_err("graph capture: native kernel '" + key + "' is not specialised yet -- run the call list once before capturing it");
   string log;
   std::vector<char> code = compile_plan(p, host->nh_arch(), &log);
   kernel_t k;

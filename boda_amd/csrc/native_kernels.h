@@ -22,6 +22,7 @@ string default_cache_dir();
 struct native_host_t {
   virtual ~native_host_t() {}
   virtual hipStream_t nh_stream() = 0;
+  virtual bool nh_capturing() = 0; // stream capture (hipGraph) in progress: nothing may be compiled / allocated / synchronised
   virtual string const &nh_arch() = 0;
   virtual int nh_num_cus() = 0;
   virtual void *nh_var_ptr(string const &vn) = 0;

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Union
+from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -72,6 +72,10 @@ ABI = {  # symbol -> (restype, argtypes); every symbol include/bodahip.h declare
     "bodahip_copy_to_var": (C.c_int, [_ctxp, C.c_char_p, C.POINTER(_CDims), C.c_void_p]),
     "bodahip_copy_from_var": (C.c_int, [_ctxp, C.c_void_p, C.POINTER(_CDims), C.c_char_p]),
     "bodahip_get_raw_ptr": (C.c_int, [_ctxp, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "bodahip_graph_begin": (C.c_int, [_ctxp]),
+    "bodahip_graph_end": (C.c_int, [_ctxp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "bodahip_graph_launch": (C.c_int, [_ctxp, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "bodahip_graph_destroy": (C.c_int, [_ctxp, C.c_uint32]),
     "bodahip_get_stream": (C.c_int, [_ctxp, C.POINTER(C.c_void_p)]),
     "bodahip_get_device_info": (C.c_int, [_ctxp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bodahip_set_tune": (C.c_int, [_ctxp, C.c_char_p, C.c_char_p]),
@@ -316,6 +320,24 @@ class HipCompute:
 
     def set_tune(self, key: str, value: str) -> None:
         _chk(_lib.bodahip_set_tune(self._ctx, key.encode(), (value or "").encode()))
+
+    # -- hipGraph capture of a call list (include/bodahip.h: bodahip_graph_*)
+    def graph_begin(self) -> None:
+        _chk(_lib.bodahip_graph_begin(self._ctx))
+
+    def graph_end(self) -> Tuple[int, int]:
+        """-> (graph id, number of captured calls)"""
+        gid = C.c_uint32(); n = C.c_uint32()
+        _chk(_lib.bodahip_graph_end(self._ctx, C.byref(gid), C.byref(n)))
+        return int(gid.value), int(n.value)
+
+    def graph_launch(self, graph_id: int) -> int:
+        cid = C.c_uint32()
+        _chk(_lib.bodahip_graph_launch(self._ctx, graph_id, C.byref(cid)))
+        return int(cid.value)
+
+    def graph_destroy(self, graph_id: int) -> None:
+        _chk(_lib.bodahip_graph_destroy(self._ctx, graph_id))
 
     def last_launch(self) -> dict:
         k = C.create_string_buffer(128); c = C.create_string_buffer(128); g = C.c_uint32(); b = C.c_uint32(); fl = C.c_double(); by = C.c_double()

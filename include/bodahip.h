@@ -96,6 +96,15 @@ int bodahip_copy_from_var(bodahip_ctx *ctx, void *host_data, const bodahip_dims 
 int bodahip_get_raw_ptr(bodahip_ctx *ctx, const char *vn, void **dev_ptr_out); /* ::get_var_raw_native_pointer() (:79) */
 
 /* ---- additions with no counterpart in the reference interface (plumbing / tooling) ---- */
+/* hipGraph capture of a call list (no counterpart in rtc_compute_t: the reference enqueues every call of a forward pass one by
+ * one, src/rtc_fwd.cc:545-549).  Between graph_begin and graph_end, bodahip_run() records the launch -- arguments frozen as
+ * passed, call_id_out = 0xfffffffe (no per-call events) -- instead of executing it; everything the calls need lazily (hiprtc
+ * specialisations, gather tables) must already exist, i.e. the list has been run once.  graph_launch replays the list with one
+ * host call; its call id times the whole replay through bodahip_get_dur. */
+int bodahip_graph_begin(bodahip_ctx *ctx);
+int bodahip_graph_end(bodahip_ctx *ctx, uint32_t *graph_id_out, uint32_t *n_calls_out);
+int bodahip_graph_launch(bodahip_ctx *ctx, uint32_t graph_id, uint32_t *call_id_out);
+int bodahip_graph_destroy(bodahip_ctx *ctx, uint32_t graph_id);
 int bodahip_get_stream(bodahip_ctx *ctx, void **hip_stream_out);   /* the backend's hipStream_t, for event timing / interop */
 int bodahip_get_device_info(bodahip_ctx *ctx, char *arch_buf, size_t arch_buf_sz, int *num_cus_out, int *clock_khz_out);
 /* tile override for the native kernels (the op_tune_t MNt/MNb/Kb analogue): key "sgemm_tile"|"conv_tile",

@@ -90,6 +90,39 @@ def test_full_net_forward_matches_oracle(rtc, net, batch, tmp_path):
         fwd.release()
 
 
+def test_graph_replay_equals_call_by_call(rtc):
+    """hipGraph capture of a whole forward call list (GoogLeNet: 118 launches): the replay writes the same bits as the
+    call-by-call run, can be relaunched, and captured calls have no per-call timing."""
+    from boda_amd.op import RtErr
+    cp = googlenet_conv(2)
+    data = bo.gen_conv_in(*cp.nodes["data"].sizes)
+    fwd = ConvPipeFwd(rtc); fwd.init(cp, op_params=_params(cp))
+    try:
+        io = {"data": data}
+        fwd.run_fwd(["data"], io, [cp.out_node(), "icp9_out"])
+        n = fwd.capture_graph()
+        assert n == len(fwd.fwd_calls) == 118
+        for node in (cp.out_node(), "icp9_out", "conv1"):
+            rtc.set_var_to_zero(fwd.var_of(node))
+        ms = fwd.run_graph()
+        assert ms > 0
+        assert np.array_equal(rtc.copy_var_to_nda(fwd.var_of(cp.out_node())), io[cp.out_node()])
+        assert np.array_equal(rtc.copy_var_to_nda(fwd.var_of("icp9_out")), io["icp9_out"])
+        rtc.copy_nda_to_var("data", data[::-1].copy())   # new input, same graph
+        fwd.run_graph()
+        got = rtc.copy_var_to_nda(fwd.var_of(cp.out_node()))
+        assert np.array_equal(got, io[cp.out_node()][::-1]) and not np.array_equal(got, io[cp.out_node()])
+        rtc.graph_begin()
+        cid = rtc.run(fwd.fwd_calls[0].rfc)
+        gid, n1 = rtc.graph_end()
+        assert n1 == 1
+        with pytest.raises(RtErr):
+            rtc.get_dur(cid, cid)
+        rtc.graph_destroy(gid)
+    finally:
+        fwd.release()
+
+
 def test_concat_copies_into_channel_ranges(rtc):
     cp = ConvPipe("c", "data", Dims.make("float", img=3, chan=5, y=6, x=7))
     cp.add(PipeOp("pa", "Pooling", "data", "pa", kern_sz=(3, 3), stride=(1, 1), in_pad=(1, 1)))
