@@ -481,3 +481,30 @@ def test_every_conv_layer_of_config5_nets_bit_exact(be, net):
         want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
         assert np.array_equal(want, outs["out"]), (key, prc.launch["cfg"], SsdsDiff.of(want, outs["out"]).basic_str())
     assert len(seen) >= 20
+
+
+def test_reference_shaped_cucl_sgemm_matches_oracle(be):
+    """boda_amd/ref_style.py: a register-tiled 8x8-per-thread sgemm in CUCL dialect (the structure of the reference's default
+    sgemm variant) through the generic hiprtc path -- same ascending-k fma chain, so the same bits as the oracle and the MFMA kernel."""
+    from boda_amd import ref_style
+    rtc = be.rtc
+    ref_style.compile_into(rtc)
+    M, N, K = 192, 256, 104
+    rng = np.random.default_rng(5)
+    a = rng.uniform(-5, 5, (K, M)).astype(np.float32); b = rng.uniform(-5, 5, (K, N)).astype(np.float32)
+    for vn, arr, d in (("rs_a", a, Dims.make("float", K=K, M=M)), ("rs_b", b, Dims.make("float", K=K, N=N)), ("rs_c", None, Dims.make("float", M=M, N=N))):
+        rtc.create_var_with_dims(vn, d)
+        if arr is not None:
+            rtc.copy_nda_to_var(vn, arr)
+    try:
+        rtc.run(ref_style.call("rs_a", "rs_b", "rs_c", M, N, K)); rtc.finish_and_sync()
+        got = rtc.copy_var_to_nda("rs_c")
+        want = bo.sgemm(a, b)
+        assert SsdsDiff.of(want, got).mrd < MRD
+        assert np.array_equal(want, got)
+        with pytest.raises(UnsupErr):
+            ref_style.call("rs_a", "rs_b", "rs_c", 100, 256, 104)
+    finally:
+        for vn in ("rs_a", "rs_b", "rs_c"):
+            rtc.release_var(vn)
+        rtc.release_per_call_id_data()
