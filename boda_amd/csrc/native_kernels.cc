@@ -103,6 +103,9 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather, bo
     {96, 128, 16, 1, 2, 2, 32, 1, 0.90, false, true},  {64, 64, 16, 2, 2, 2, 32, 2, 0.93, true, true},    {32, 64, 32, 2, 4, 1, 16, 2, 0.60, true, true},
     {32, 32, 32, 2, 2, 1, 16, 1, 0.45, false, true}};
   tile_cfg_t best_c; double best = -1;
+  // launches shorter than ~200 us at full rate also pay ramp-up / tail: about 0.6 tile-times per CU (measured NiN 1x1 layers at
+  // B=128: 507 128x128 tiles 83 TF/s, 2028 64x64 tiles 88-91), which favours finer tiles there
+  bool const short_kernel = !bf16 && 2.0 * Mi * (double)Nj * K < 2.4e10;
   cand_t const *cands = bf16 ? cands_bf16 : cands_f32;
   int const n_cands = bf16 ? (int)(sizeof(cands_bf16) / sizeof(cand_t)) : (int)(sizeof(cands_f32) / sizeof(cand_t));
   for (int ci = 0; ci < n_cands; ++ci) {
@@ -113,7 +116,8 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather, bo
     if (cd.bj == 256 && cd.bi >= 128 && tiles < num_cus) continue;
     double const pad = ((double)Mi / (double)(ti * cd.bi)) * ((double)Nj / (double)(tj * cd.bj));
     double const bal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
-    double const score = cd.base * pad * bal;
+    double score = cd.base * pad * bal;
+    if (short_kernel) { double const x = (double)tiles / num_cus; score *= x / (x + 0.6); }
     if (score > best) { best = score; best_c.BI = cd.bi; best_c.BJ = cd.bj; best_c.BK = cd.bk; best_c.WI = cd.wi; best_c.WJ = cd.wj; best_c.MINW = cd.minw; best_c.MT = cd.mt; best_c.PF = cd.pf; best_c.SPLITK = 1; }
   }
   return best_c;
@@ -223,7 +227,8 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
         long const ti = (g.OC + c.BI - 1) / c.BI, tj = (Nj + c.BJ - 1) / c.BJ, tiles = ti * tj;
         double const pad = ((double)g.OC / (double)(ti * c.BI)) * ((double)Nj / (double)(tj * c.BJ));
         double const bal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
-        double const score = cd.base * pad * bal;
+        double score = cd.base * pad * bal;
+        if (2.0 * g.OC * (double)Nj * Kt < 2.4e10) { double const x = (double)tiles / num_cus; score *= x / (x + 0.6); } // short launches: see choose_cfg
         if (score > best) { best = score; p.cfg = c; p.patch = true; }
       }
     }
