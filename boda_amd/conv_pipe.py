@@ -408,9 +408,11 @@ class ConvPipeFwd:
         return ms
 
     # -- hipGraph form of run_fwd_device_only: the call list captured once, replayed with one host call per forward pass
-    def capture_graph(self) -> int:
+    def capture_graph(self, parallel: bool = False) -> int:
         """Capture the forward call list into a hipGraph (after at least one ordinary run, so that every lazily built kernel and
-        table exists); -> number of captured calls."""
+        table exists); -> number of captured calls.  With parallel=True the graph gets the calls' true dependencies instead of
+        the launch order (read-after-write, write-after-write and write-after-read hazards between the vars they read and
+        write), so independent branches of the net -- inception modules -- may overlap on the GPU."""
         rtc = self.rtc
         if getattr(self, "_graph", None) is not None:
             rtc.graph_destroy(self._graph)
@@ -418,8 +420,42 @@ class ConvPipeFwd:
         rtc.graph_begin()
         for c in self.fwd_calls:
             rtc.run(c.rfc)
-        self._graph, n = rtc.graph_end()
+        if parallel:
+            self.call_deps = self._call_deps()
+            self._graph = rtc.graph_end_deps(self.call_deps); n = len(self.fwd_calls)
+        else:
+            self._graph, n = rtc.graph_end()
         return n
+
+    def _call_deps(self) -> List[List[int]]:
+        """deps[i] = the earlier calls that call i must run after.  A call reads its `in` / `inout` vars and writes its `out` /
+        `inout` vars (convs also read filts / biases, which nothing writes during a forward pass); Concat copies fill disjoint
+        channel ranges of one var and are not ordered among themselves."""
+        writers: Dict[str, List[int]] = {}   # var -> the call(s) that produced its current contents
+        readers: Dict[str, List[int]] = {}   # var -> calls that read it since
+        deps: List[List[int]] = []
+        for i, c in enumerate(self.fwd_calls):
+            am = c.rfc.arg_map
+            rd = [am[a].n for a in ("in", "inout") if a in am and am[a].is_var()]
+            wr = [am[a].n for a in ("out", "inout") if a in am and am[a].is_var()]
+            partial = c.func == "fwd_copy"
+            d = set()
+            for v in rd:
+                d.update(writers.get(v, []))
+            for v in wr:
+                if not (partial and not readers.get(v)):
+                    d.update(writers.get(v, []))
+                d.update(readers.get(v, []))
+            d.discard(i)
+            for v in rd:
+                readers.setdefault(v, []).append(i)
+            for v in wr:
+                if partial and not readers.get(v):
+                    writers.setdefault(v, []).append(i)
+                else:
+                    writers[v] = [i]; readers[v] = []
+            deps.append(sorted(d))
+        return deps
 
     def run_graph(self) -> float:
         """One forward pass as one graph launch; -> ms of the whole replay."""

@@ -13,6 +13,7 @@ uint32_t hip_compute_graph_end(rtc_compute_t *rtc);
 uint32_t hip_compute_graph_launch(rtc_compute_t *rtc, uint32_t id);
 uint32_t hip_compute_graph_num_calls(rtc_compute_t *rtc, uint32_t id);
 void hip_compute_graph_destroy(rtc_compute_t *rtc, uint32_t id);
+uint32_t hip_compute_graph_end_deps(rtc_compute_t *rtc, uint32_t n, uint32_t const *ptr, uint32_t const *idx);
 native_kernels_t *hip_compute_native(rtc_compute_t *rtc);
 extern char const *const k_src_gemm_conv_f32_ptr;
 }
@@ -111,6 +112,9 @@ int bodahip_graph_end(bodahip_ctx *ctx, uint32_t *graph_id, uint32_t *n_calls) {
   ABI_TRY if (!graph_id) rt_err("null graph_id_out"); *graph_id = hip_compute_graph_end(&R(ctx)); if (n_calls) *n_calls = hip_compute_graph_num_calls(&R(ctx), *graph_id); ABI_CATCH }
 int bodahip_graph_launch(bodahip_ctx *ctx, uint32_t graph_id, uint32_t *call_id) {
   ABI_TRY uint32_t const id = hip_compute_graph_launch(&R(ctx), graph_id); if (call_id) *call_id = id; ABI_CATCH }
+int bodahip_graph_end_deps(bodahip_ctx *ctx, uint32_t n_calls, const uint32_t *dep_ptr, const uint32_t *dep_idx, uint32_t *graph_id) {
+  ABI_TRY if (!graph_id || !dep_ptr) rt_err("null argument"); static uint32_t const none = 0;
+  *graph_id = hip_compute_graph_end_deps(&R(ctx), n_calls, dep_ptr, dep_idx ? dep_idx : &none); ABI_CATCH }
 int bodahip_graph_destroy(bodahip_ctx *ctx, uint32_t graph_id) { ABI_TRY hip_compute_graph_destroy(&R(ctx), graph_id); ABI_CATCH }
 int bodahip_get_stream(bodahip_ctx *ctx, void **s) { ABI_TRY if (!s) rt_err("null out"); *s = hip_compute_stream(&R(ctx)); ABI_CATCH }
 int bodahip_get_device_info(bodahip_ctx *ctx, char *arch_buf, size_t n, int *num_cus, int *clock_khz) {

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <map>
+#include <set>
 #include <cstdio>
 #include <cstdlib>
 #include <dlfcn.h>
@@ -152,6 +154,7 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
       native.reset(); funcs.clear(); vis.clear();
       for (auto &ce : call_evs) { (void)hipEventDestroy(ce.b); (void)hipEventDestroy(ce.e); }
       for (auto &ce : ev_pool) { (void)hipEventDestroy(ce.b); (void)hipEventDestroy(ce.e); }
+      for (auto &gr : graphs) { if (gr.exec) (void)hipGraphExecDestroy(gr.exec); if (gr.g) (void)hipGraphDestroy(gr.g); }
       (void)hipStreamDestroy(stream);
     }
   }
@@ -347,6 +350,47 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
     graphs.push_back(gr);
     return (uint32_t)graphs.size() - 1;
   }
+  // graph_end with the true dependencies of the captured calls: call i must run after calls dep_idx[dep_ptr[i] .. dep_ptr[i+1]) (all
+  // < i), and after nothing else.  A stream capture yields a chain (call i after call i-1); its edges are replaced by the given
+  // ones, so that independent branches of a net -- GoogLeNet's inception modules: four tile-starved conv chains that fit on
+  // the chip side by side -- become parallel branches of the graph and the runtime may overlap them.  The caller states the
+  // dependencies (hazards between the calls' vars); the backend does not infer them.  Requires one kernel per call.
+  uint32_t graph_end_deps(uint32_t n_calls, uint32_t const *dep_ptr, uint32_t const *dep_idx) {
+    if (!capturing) rt_err("graph_end: no capture in progress");
+    capturing = false;
+    graph_t gr; gr.n_calls = cap_calls;
+    hip_err_chk(hipStreamEndCapture(stream, &gr.g), "hipStreamEndCapture");
+    if (!gr.g) rt_err("graph_end: capture produced no graph");
+    try {
+      if (n_calls != cap_calls) rt_err("graph_end_deps: " + std::to_string(n_calls) + " dependency lists for " + std::to_string(cap_calls) + " captured calls");
+      size_t nn = 0, ne = 0;
+      hip_err_chk(hipGraphGetNodes(gr.g, nullptr, &nn), "hipGraphGetNodes");
+      if (nn != n_calls) rt_err("graph_end_deps: the capture holds " + std::to_string(nn) + " nodes for " + std::to_string(n_calls) + " calls (needs exactly one kernel per call)");
+      std::vector<hipGraphNode_t> nodes(nn);
+      hip_err_chk(hipGraphGetNodes(gr.g, nodes.data(), &nn), "hipGraphGetNodes");
+      hip_err_chk(hipGraphGetEdges(gr.g, nullptr, nullptr, &ne), "hipGraphGetEdges");
+      std::vector<hipGraphNode_t> ef(ne), et(ne);
+      if (ne) hip_err_chk(hipGraphGetEdges(gr.g, ef.data(), et.data(), &ne), "hipGraphGetEdges");
+      // capture order = the chain: root has no incoming edge, every node at most one successor
+      std::map<hipGraphNode_t, hipGraphNode_t> next; std::set<hipGraphNode_t> has_in;
+      for (size_t e = 0; e < ne; ++e) { if (!next.emplace(ef[e], et[e]).second) rt_err("graph_end_deps: captured graph is not a chain"); has_in.insert(et[e]); }
+      std::vector<hipGraphNode_t> order;
+      for (hipGraphNode_t n : nodes) if (!has_in.count(n)) order.push_back(n);
+      if (order.size() != 1 && nn > 0) rt_err("graph_end_deps: captured graph is not a chain");
+      while (order.size() < nn) { auto it = next.find(order.back()); if (it == next.end()) rt_err("graph_end_deps: captured graph is not a chain"); order.push_back(it->second); }
+      if (ne) hip_err_chk(hipGraphRemoveDependencies(gr.g, ef.data(), et.data(), ne), "hipGraphRemoveDependencies");
+      std::vector<hipGraphNode_t> nf, nt;
+      for (uint32_t i = 0; i < n_calls; ++i)
+        for (uint32_t k = dep_ptr[i]; k < dep_ptr[i + 1]; ++k) {
+          if (dep_idx[k] >= i) rt_err("graph_end_deps: call " + std::to_string(i) + " depends on call " + std::to_string(dep_idx[k]) + " (must be an earlier call)");
+          nf.push_back(order[dep_idx[k]]); nt.push_back(order[i]);
+        }
+      if (!nf.empty()) hip_err_chk(hipGraphAddDependencies(gr.g, nf.data(), nt.data(), nf.size()), "hipGraphAddDependencies");
+      hip_err_chk(hipGraphInstantiate(&gr.exec, gr.g, nullptr, nullptr, 0), "hipGraphInstantiate");
+    } catch (...) { (void)hipGraphDestroy(gr.g); throw; }
+    graphs.push_back(gr);
+    return (uint32_t)graphs.size() - 1;
+  }
   void graph_abort() { // error inside a capture: drop it so the stream is usable again
     if (!capturing) return;
     capturing = false; hipGraph_t g = nullptr; (void)hipStreamEndCapture(stream, &g); if (g) (void)hipGraphDestroy(g); (void)hipGetLastError();
@@ -381,6 +425,7 @@ uint32_t hip_compute_graph_end(rtc_compute_t *rtc) { return as_hip(rtc).graph_en
 uint32_t hip_compute_graph_launch(rtc_compute_t *rtc, uint32_t id) { return as_hip(rtc).graph_launch(id); }
 uint32_t hip_compute_graph_num_calls(rtc_compute_t *rtc, uint32_t id) { return as_hip(rtc).graph_num_calls(id); }
 void hip_compute_graph_destroy(rtc_compute_t *rtc, uint32_t id) { as_hip(rtc).graph_destroy(id); }
+uint32_t hip_compute_graph_end_deps(rtc_compute_t *rtc, uint32_t n, uint32_t const *ptr, uint32_t const *idx) { return as_hip(rtc).graph_end_deps(n, ptr, idx); }
 void *hip_compute_stream(rtc_compute_t *rtc) { hip_compute_t *h = dynamic_cast<hip_compute_t *>(rtc); if (!h) rt_err("not a hip_compute_t"); return (void *)h->stream; }
 native_kernels_t *hip_compute_native(rtc_compute_t *rtc) { hip_compute_t *h = dynamic_cast<hip_compute_t *>(rtc); if (!h || !h->native) rt_err("hip backend not initialised"); return h->native.get(); }
 

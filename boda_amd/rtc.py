@@ -75,6 +75,7 @@ ABI = {  # symbol -> (restype, argtypes); every symbol include/bodahip.h declare
     "bodahip_graph_begin": (C.c_int, [_ctxp]),
     "bodahip_graph_end": (C.c_int, [_ctxp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "bodahip_graph_launch": (C.c_int, [_ctxp, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "bodahip_graph_end_deps": (C.c_int, [_ctxp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "bodahip_graph_destroy": (C.c_int, [_ctxp, C.c_uint32]),
     "bodahip_get_stream": (C.c_int, [_ctxp, C.POINTER(C.c_void_p)]),
     "bodahip_get_device_info": (C.c_int, [_ctxp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -335,6 +336,16 @@ class HipCompute:
         cid = C.c_uint32()
         _chk(_lib.bodahip_graph_launch(self._ctx, graph_id, C.byref(cid)))
         return int(cid.value)
+
+    def graph_end_deps(self, deps: Sequence[Sequence[int]]) -> int:
+        """End the capture with the true dependencies of its calls (deps[i] = earlier calls that call i must run after)."""
+        ptr = [0]; idx: List[int] = []
+        for d in deps:
+            idx.extend(int(x) for x in d); ptr.append(len(idx))
+        P = (C.c_uint32 * len(ptr))(*ptr); I = (C.c_uint32 * max(1, len(idx)))(*idx)
+        gid = C.c_uint32()
+        _chk(_lib.bodahip_graph_end_deps(self._ctx, len(deps), P, I, C.byref(gid)))
+        return int(gid.value)
 
     def graph_destroy(self, graph_id: int) -> None:
         _chk(_lib.bodahip_graph_destroy(self._ctx, graph_id))

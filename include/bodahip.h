@@ -104,6 +104,10 @@ int bodahip_get_raw_ptr(bodahip_ctx *ctx, const char *vn, void **dev_ptr_out); /
 int bodahip_graph_begin(bodahip_ctx *ctx);
 int bodahip_graph_end(bodahip_ctx *ctx, uint32_t *graph_id_out, uint32_t *n_calls_out);
 int bodahip_graph_launch(bodahip_ctx *ctx, uint32_t graph_id, uint32_t *call_id_out);
+/* graph_end with the true dependencies of the n_calls captured calls (CSR: call i runs after calls dep_idx[dep_ptr[i] ..
+ * dep_ptr[i+1]), all earlier than i, and after nothing else): the chain a stream capture yields is re-wired so that independent
+ * branches of a net become parallel branches of the graph.  Requires exactly one kernel per captured call. */
+int bodahip_graph_end_deps(bodahip_ctx *ctx, uint32_t n_calls, const uint32_t *dep_ptr, const uint32_t *dep_idx, uint32_t *graph_id_out);
 int bodahip_graph_destroy(bodahip_ctx *ctx, uint32_t graph_id);
 int bodahip_get_stream(bodahip_ctx *ctx, void **hip_stream_out);   /* the backend's hipStream_t, for event timing / interop */
 int bodahip_get_device_info(bodahip_ctx *ctx, char *arch_buf, size_t arch_buf_sz, int *num_cus_out, int *clock_khz_out);

@@ -112,6 +112,15 @@ def test_graph_replay_equals_call_by_call(rtc):
         fwd.run_graph()
         got = rtc.copy_var_to_nda(fwd.var_of(cp.out_node()))
         assert np.array_equal(got, io[cp.out_node()][::-1]) and not np.array_equal(got, io[cp.out_node()])
+        # parallel branches: the graph re-wired to the calls' true dependencies (the four chains of an inception module are independent)
+        n = fwd.capture_graph(parallel=True)
+        deps = fwd.call_deps
+        assert n == 118 and deps[0] == [] and all(all(d < i for d in ds) for i, ds in enumerate(deps))
+        assert sum(1 for i, ds in enumerate(deps) if i and (i - 1) not in ds) > 30   # many calls do not depend on their predecessor
+        for _ in range(3):
+            rtc.set_var_to_zero(fwd.var_of(cp.out_node())); rtc.set_var_to_zero(fwd.var_of("icp5_out"))
+            fwd.run_graph()
+            assert np.array_equal(rtc.copy_var_to_nda(fwd.var_of(cp.out_node())), got)
         rtc.graph_begin()
         cid = rtc.run(fwd.fwd_calls[0].rfc)
         gid, n1 = rtc.graph_end()
