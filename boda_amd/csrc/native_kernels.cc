@@ -118,7 +118,8 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather, bo
     double const bal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
     double score = cd.base * pad * bal;
     if (short_kernel) { double const x = (double)tiles / num_cus; score *= x / (x + 0.6); }
-    if (score > best) { best = score; best_c.BI = cd.bi; best_c.BJ = cd.bj; best_c.BK = cd.bk; best_c.WI = cd.wi; best_c.WJ = cd.wj; best_c.MINW = cd.minw; best_c.MT = cd.mt; best_c.PF = cd.pf; best_c.SPLITK = 1; }
+    if (score > best) { best = score; best_c.BI = cd.bi; best_c.BJ = cd.bj; best_c.BK = (cd.bi == 64 && cd.bj == 64 && !gather && !bf16) ? 32 : cd.bk; // (k-contiguous / plain operands, usually cold from HBM: twice the bytes in flight; AlexNet fc6/fc7 in sequence 63 -> 78 TF/s)
+      best_c.WI = cd.wi; best_c.WJ = cd.wj; best_c.MINW = cd.minw; best_c.MT = cd.mt; best_c.PF = cd.pf; best_c.SPLITK = 1; }
   }
   return best_c;
 }
