@@ -58,6 +58,7 @@ struct gemm_args_t { // identical to gemm_conv_f32.hip (one host-side struct)
   int splitk, kt_per;
   float *ws; long ws_slab;
   unsigned I_bytes, J_bytes;
+  unsigned D_bytes;             // (used by the f32 kernel's epilogue; kept for a common argument block)
   int const *ktab; int ktab_n;
 };
 

@@ -96,6 +96,7 @@ struct gemm_args_t {
   int splitk, kt_per;     // SPLITK: number of K slices, K-tiles per slice
   float *ws; long ws_slab; // SPLITK: partial-sum slabs, ws_slab elements apart
   unsigned I_bytes, J_bytes; // sizes of the I / J tensors (buffer-descriptor num_records; host guarantees <= 2^31)
+  unsigned D_bytes;             // size of the output tensor (host guarantees < 2^32: 32-bit store offsets)
   int const *ktab; int ktab_n; // J_MODE 2: per-k gather tables, three arrays of ktab_n ints: element offset of (in_chan,ky,kx)
                                // inside one image | ky | kx ; rows k >= K carry ky = 2^30 (fail the row-range test)
 };
@@ -628,11 +629,65 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 
   // ---- epilogue: MFMA C/D layout.  32x32: column j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16
   //                                16x16: column j = lane&15, row i = 4*(lane>>4) + r,               r < 4
-#if SPLITK
-  float *const Dp = p.ws + (long)slice * p.ws_slab;
+#if !SPLITK
+  // The biases of this lane's kTI*kNA rows are fetched up front (one batch of loads in flight instead of a load -> wait -> add ->
+  // store chain per output; rows past the end read 0), and the stores are buffer stores with 32-bit offsets (per-lane column part
+  // + a wave-uniform per-row part in the scalar offset operand).  For layers with a short K loop (1x1 convolutions, K = 96..1024) the old per-output chain cost about as much as the K loop itself.
+  {
+    rsrc_t const rD = make_rsrc(p.D, p.D_bytes);
+#if EPI == 1
+    rsrc_t const rB = make_rsrc(p.bias, (unsigned)p.Mi * 4u);
+    unsigned const S4 = (unsigned)(p.OH * p.OW) * 4u;
 #else
-  float *const Dp = p.D;
+    unsigned const S4 = (unsigned)p.ldD * 4u;
 #endif
+    int const ib = i0 + wi * (kTI * MT) + 4 * (lane / MT);
+    auto rowc = [](int ta, int r) { return ta * MT + ((MT == 32) ? ((r & 3) + 8 * (r >> 2)) : r); }; // wave-uniform part of the row index
+    unsigned const ipart = (unsigned)ib * S4;   // this lane's first row; the (ta, r) part of the row offset is wave-uniform -> scalar offset operand
+#if EPI == 1
+    float bv[kTI][kNA];
+#pragma unroll
+    for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+      for (int r = 0; r < kNA; ++r) bv[ta][r] = bload1(rB, (ib + rowc(ta, r)) * 4);
+#endif
+    // the store loop twice: branch-free for tiles inside the row range (all of them when out_chan / M is a multiple of BI), with a
+    // per-row range test for the last tile row
+    auto store_all = [&](bool const edge) {
+#pragma unroll
+      for (int tb = 0; tb < kTJ; ++tb) {
+        int const jg = j0 + wj * (kTJ * MT) + tb * MT + (lane % MT);
+        if (jg >= p.Nj) continue;
+#if EPI == 1
+        int const OHW = p.OH * p.OW;
+        int const img = jg / OHW, pel = jg - img * OHW;
+        unsigned const jpart = ((unsigned)img * (unsigned)p.Mi * (unsigned)OHW + (unsigned)pel) * 4u;
+#else
+        unsigned const jpart = (unsigned)jg * 4u;
+#endif
+#pragma unroll
+        for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+          for (int r = 0; r < kNA; ++r) {
+            if (edge && (ib + rowc(ta, r) >= p.Mi)) continue;
+            float v = acc[ta][tb][r];
+#if EPI == 1
+            v = v + bv[ta][r];
+#if RELU
+            v = (v > 0.f) ? v : 0.f;
+#endif
+#endif
+#if ABLATE & 1
+            if (v == 123.456f)
+#endif
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rD, (int)(jpart + ipart), (int)((unsigned)rowc(ta, r) * S4), 0);
+          }
+      }
+    };
+    if (i0 + BI <= p.Mi) store_all(false); else store_all(true); // workgroup-uniform
+  }
+#else  // SPLITK: raw partial tiles into this slice's slab (64-bit addressing; bias / ReLU happen in the reduce kernel)
+  float *const Dp = p.ws + (long)slice * p.ws_slab;
 #pragma unroll
   for (int tb = 0; tb < kTJ; ++tb) {
     int const jg = j0 + wj * (kTJ * MT) + tb * MT + (lane % MT);
@@ -671,6 +726,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
       }
     }
   }
+#endif
 }
 #endif // !REDUCE_ONLY
 

@@ -19,6 +19,7 @@ struct gemm_args_t { // must match kernels/gemm_conv_f32.hip
   int splitk, kt_per;
   float *ws; long ws_slab;
   unsigned I_bytes, J_bytes;
+  unsigned D_bytes;
   void const *ktab; int ktab_n;
 };
 
@@ -343,6 +344,8 @@ void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t 
   ga.Mi = (int)M; ga.Nj = (int)N; ga.K = (int)K; ga.ldI = (int)M; ga.ldJ = (int)N; ga.ldD = (int)N;
   if ((uint64_t)K * M * 4 > 0x80000000ull || (uint64_t)K * N * 4 > 0x80000000ull) unsup_err("hip_sgemm: operands larger than 2 GiB are not supported (32-bit buffer offsets)");
   ga.I_bytes = (unsigned)((uint64_t)K * M * 4); ga.J_bytes = (unsigned)((uint64_t)K * N * 4);
+  if ((uint64_t)M * N * 4 >= 0xfffffff0ull) unsup_err("hip_sgemm: c of 4 GiB or more is not supported (32-bit store offsets)");
+  ga.D_bytes = (unsigned)((uint64_t)M * N * 4);
   ga.tiles_i = (int)((M + cfg.BI - 1) / cfg.BI); ga.tiles_j = (int)((N + cfg.BJ - 1) / cfg.BJ);
   setup_splitk(impl, host, ga, cfg, (size_t)M * N);
   launch(host, k, ga, cfg);
@@ -365,6 +368,9 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.ldI = (int)Kt; ga.ldJ = p.ipconv ? (int)Kt : 0; ga.ldD = g.OH * g.OW;
   ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
   ga.I_bytes = (unsigned)f_bytes; ga.J_bytes = (unsigned)in_bytes;
+  uint64_t const out_bytes = (uint64_t)Nj * g.OC * 4;
+  if (out_bytes >= 0xfffffff0ull) unsup_err("hip_conv: out of 4 GiB or more is not supported (32-bit store offsets)");
+  ga.D_bytes = (unsigned)out_bytes;
   if (p.rows) { ktab_t const kt = get_rtab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
   else if (!p.ipconv && !p.k1 && !p.patch) { ktab_t const kt = get_ktab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
   ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
