@@ -251,36 +251,55 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     __syncthreads();
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA family: column j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int tb = 0; tb < kTJ; ++tb) {
-    int const jg = j0 + wj * (kTJ * 32) + tb * 32 + (lane & 31);
-    if (jg >= p.Nj) continue;
+  // epilogue (as in gemm_conv_f32.hip): C/D layout of the 32x32 MFMA family: column j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // Biases of this lane's kTI*16 rows fetched up front, buffer stores with 32-bit offsets (per-lane column part + wave-uniform
+  // per-row part in the scalar offset operand); branch-free for tiles inside the row range.
+  {
+    rsrc_t const rD = make_rsrc(p.D, p.D_bytes);
 #if EPI == 1
-    int const OHW = p.OH * p.OW;
-    int const img = jg / OHW, pel = jg - img * OHW;
-    long const joff = (long)img * p.Mi * OHW + pel;
-    long const istride = OHW;
+    rsrc_t const rB = make_rsrc(p.bias, (unsigned)p.Mi * 4u);
+    unsigned const S4 = (unsigned)(p.OH * p.OW) * 4u;
 #else
-    long const joff = jg;
-    long const istride = p.ldD;
+    unsigned const S4 = (unsigned)p.ldD * 4u;
 #endif
-#pragma unroll
-    for (int ta = 0; ta < kTI; ++ta) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int const ig = i0 + wi * (kTI * 32) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (ig < p.Mi) {
-          float v = acc[ta][tb][r];
+    int const ib = i0 + wi * (kTI * 32) + 4 * (lane >> 5);
+    auto rowc = [](int ta, int r) { return ta * 32 + (r & 3) + 8 * (r >> 2); };
+    unsigned const ipart = (unsigned)ib * S4;
 #if EPI == 1
-          v = v + p.bias[ig];
+    float bv[kTI][16];
+#pragma unroll
+    for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bv[ta][r] = bload1(rB, (ib + rowc(ta, r)) * 4);
+#endif
+    auto store_all = [&](bool const edge) {
+#pragma unroll
+      for (int tb = 0; tb < kTJ; ++tb) {
+        int const jg = j0 + wj * (kTJ * 32) + tb * 32 + (lane & 31);
+        if (jg >= p.Nj) continue;
+#if EPI == 1
+        int const OHW = p.OH * p.OW;
+        int const img = jg / OHW, pel = jg - img * OHW;
+        unsigned const jpart = ((unsigned)img * (unsigned)p.Mi * (unsigned)OHW + (unsigned)pel) * 4u;
+#else
+        unsigned const jpart = (unsigned)jg * 4u;
+#endif
+#pragma unroll
+        for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (edge && (ib + rowc(ta, r) >= p.Mi)) continue;
+            float v = acc[ta][tb][r];
+#if EPI == 1
+            v = v + bv[ta][r];
 #if RELU
-          v = (v > 0.f) ? v : 0.f;
+            v = (v > 0.f) ? v : 0.f;
 #endif
 #endif
-          p.D[joff + (long)ig * istride] = v;
-        }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rD, (int)(jpart + ipart), (int)((unsigned)rowc(ta, r) * S4), 0);
+          }
       }
-    }
+    };
+    if (i0 + BI <= p.Mi) store_all(false); else store_all(true); // workgroup-uniform
   }
 }
