@@ -1,0 +1,263 @@
+"""CUCL template instantiation -- the part of Boda's code generator that every *generic* (non-convolution-variant) kernel goes
+through, restated from `src/rtc_func_gen.cc` so that a Boda checkout's `test/rtc/*.cucl` templates can be turned into the
+source text + arg list + launch geometry that `be=hip` compiles (first part).
+
+A template is C-like source with
+  * `%(name)` template variables,
+  * one magic comment per kernel argument:  `<decl> // CUCL IN|OUT|INOUT|REF[_DYN] dim:dim:... [alt spec ...]`  (`:` alone = scalar),
+  * index declarations:                     `// CUCL IX <ix_var> <arg> [use_dims=a:b:c]`,
+  * `// CUCL INCLUDE file.h`.
+Instantiating it for an op (`op_base_t`: `func_name` + named ndas) defines (`rtc_call_gen_t::init`, `src/rtc_func_gen.cc:346-421`)
+  rtc_func_name | <arg>_tn | <arg>_<dim>_dim | <arg>_<dim>_stride | <arg>_dims_prod   (`insert_nda_dims_sz`, `:214-225`)
+  <scalar by-value arg> -> its C constant when the op carries a value, else the argument's own name
+  <ix>_<dim> = ((ix/stride)%dim) | <ix>_<dim>_nomod | <ix>_dims_prod                     (`insert_nda_ix_exprs`, `:227-246`)
+  tpb | blks | warp_sz
+and the launch geometry from the special index names (`:7-23`): GLOB_ID_1D -> tpb 256, blks = ceil(prod/tpb); GRP_ID_1D -> blks;
+LOC_ID_1D -> tpb.  Supported here: everything static.  `_DYN` arguments (run-time dims through `cai__*` args), `_multi`
+arguments and the convolution variants' custom code generation (`src/cnn_codegen.cc`) raise UnsupErr -- `be=hip` serves those
+ops through its native kernels instead.
+"""
+from __future__ import annotations
+import os
+import re
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+from .op import Dims, Nda, Op, RtErr, UnsupErr
+
+DEFAULT_TPB = 256  # rtc_call_geom_t::get_default_tpb (src/rtc_func_gen.H)
+
+
+@dataclass
+class ArgDecl:
+    vn: str
+    tn: str            # C type name; "" = any (declared as %(vn_tn)); "none" for void
+    loi: int           # levels of indirection: 0 = by value, 1 = pointer
+    io_type: str       # IN | OUT | INOUT | REF
+    ok_dims: List[Tuple[str, ...]]   # acceptable dim-name lists
+
+
+@dataclass
+class IxDecl:
+    ix_vn: str
+    arg_vn: str
+    use_dims: List[str] = field(default_factory=list)
+
+
+@dataclass
+class Template:
+    name: str
+    text: str
+    arg_decls: List[ArgDecl]
+    ix_decls: List[IxDecl]
+
+
+@dataclass
+class Instance:
+    """What rtc_codegen_t hands to rtc_compute_t::compile / ::run for one generated function."""
+    func_name: str
+    src: str
+    arg_names: List[str]
+    tpb: int
+    blks: int
+
+
+def _parse_arg_decl(line: str) -> Tuple[str, str, int]:
+    """`GASQ float const * const in, // ...` -> (vn, tn, loi)   (arg_decl_t::arg_parse, src/rtc_func_gen.cc:30-38)"""
+    decl = line.split("//")[0].strip().rstrip(" ,);{")
+    toks = decl.split()
+    if not toks:
+        raise RtErr("invalid CUCL io var decl; no var name found:" + line)
+    vn, loi, tn = toks[-1], 0, ""
+    for t in reversed(toks[:-1]):
+        if t == "*":
+            loi += 1; continue
+        if t == "const":
+            continue
+        tn = t; break
+    return vn, tn, loi
+
+
+def parse_template(name: str, text: str, include_dir: Optional[str] = None) -> Template:
+    out_lines: List[str] = []
+    arg_decls: List[ArgDecl] = []
+    ix_decls: List[IxDecl] = []
+    for ln_no, line in enumerate(text.split("\n"), 1):
+        out_lines.append(line)
+        if "//" not in line:
+            continue
+        parts = line.split("//", 1)[1].split()
+        if not parts or parts[0] != "CUCL":
+            continue
+        try:
+            if len(parts) < 2:
+                raise RtErr("invalid CUCL magic comment. missing directive after CUCL.")
+            cd = parts[1]
+            dyn = cd.endswith("_DYN")
+            if dyn:
+                cd = cd[:-4]
+            if cd == "IX":
+                if dyn:
+                    raise RtErr("invalid use of _DYN suffix on CUCL IX decl")
+                if len(parts) < 4:
+                    raise RtErr("invalid CUCL IX decl; missing ix_name and/or arg_name.")
+                ix = IxDecl(parts[2], parts[3])
+                for opt in parts[4:]:
+                    kv = opt.split("=")
+                    if len(kv) != 2 or kv[0] != "use_dims":
+                        raise RtErr(f"invalid CUCL IX decl option '{opt}'. known opts: use_dims")
+                    ix.use_dims = kv[1].split(":")
+                ix_decls.append(ix)
+            elif cd in ("IN", "INOUT", "OUT", "REF"):
+                if len(parts) < 3:
+                    raise RtErr("invalid CUCL IN/INOUT/OUT annotation; missing dims spec.")
+                if dyn:
+                    raise UnsupErr(f"CUCL template {name}: _DYN argument (run-time dims) is not supported by this restatement")
+                vn, tn, loi = _parse_arg_decl(line)
+                if tn.endswith("_multi"):
+                    raise UnsupErr(f"CUCL template {name}: _multi argument '{vn}' is not supported by this restatement")
+                if not tn:
+                    raise RtErr("invalid CUCL io var decl; no var type found.")
+                if loi > 1:
+                    raise RtErr("invalid CUCL io var decl; should be exactly zero or one level-of-indirection/*.")
+                if loi == 0 and cd == "REF":
+                    raise RtErr("invalid CUCL io var decl; REF args must not be by-value (since no value(s) will be passed)")
+                if tn == f"%({vn}_tn)":
+                    tn = ""
+                if tn == "void":
+                    tn = "none"
+                specs = [tuple() if sp == ":" else tuple(sp.split(":")) for sp in parts[2:]]
+                for sp in specs:
+                    if any(not d for d in sp):
+                        raise RtErr("invalid (currently forbidden/unused) empty dim name in nda_spec")
+                arg_decls.append(ArgDecl(vn, tn, loi, cd, specs))
+            elif cd == "INCLUDE":
+                if len(parts) != 3:
+                    raise RtErr("invalid CUCL INCLUDE decl; must be exactly CUCL INCLUDE filename.h.")
+                if include_dir is None:
+                    raise RtErr(f"CUCL INCLUDE {parts[2]}: no include directory given")
+                with open(os.path.join(include_dir, parts[2])) as f:
+                    out_lines.append(f.read())
+            else:
+                raise RtErr(f"invalid CUCL directive '{cd}'.")
+        except RtErr as e:
+            raise type(e)(f"Error parsing CUCL template {name} on line {ln_no}:\n--> {line}\n{e}") from None
+    return Template(name, "\n".join(out_lines), arg_decls, ix_decls)
+
+
+_C_SUFFIX = {"float": "f", "double": "", "uint32_t": "U", "int32_t": "", "uint16_t": "U", "uint8_t": "U", "half": "f"}
+
+
+def _scalar_const(nda: Nda) -> str:
+    v = nda.v[0] if nda.v is not None else None
+    if nda.tn in ("float", "double", "half"):
+        s = repr(float(v))
+        return s + ("f" if nda.tn != "double" else "")
+    return str(int(v)) + _C_SUFFIX.get(nda.tn, "")
+
+
+def _strides(sizes: Tuple[int, ...]) -> List[int]:
+    st, acc = [], 1
+    for s in reversed(sizes):
+        st.append(acc); acc *= s
+    return list(reversed(st))
+
+
+def instantiate(t: Template, op: Op, gen_fn: str) -> Instance:
+    """rtc_call_gen_t::init + instantiate_template for a fully static op."""
+    tsvs: Dict[str, str] = {"rtc_func_name": gen_fn}
+    tpb = int(op.nda_vals["tpb"].v[0]) if "tpb" in op.nda_vals and op.nda_vals["tpb"].v is not None else 0
+    blks = 0
+    errs: List[str] = []
+
+    def arg_dims(vn: str, tag: str) -> Dims:
+        if vn not in op.nda_vals:
+            raise RtErr(f"referenced {tag} arg '{vn}' not present in dims_vals")
+        return op.get_dims(vn)
+
+    def put(k: str, v: str) -> None:
+        if k in tsvs:
+            raise RtErr(f"template variable '{k}' defined twice")
+        tsvs[k] = v
+
+    for ix in t.ix_decls:
+        d = arg_dims(ix.arg_vn, "IX")
+        names, sizes = list(d.names), list(d.sizes)
+        if ix.use_dims:
+            sel = []
+            for u in ix.use_dims:
+                if u not in names:
+                    raise RtErr(f"specified use_dim '{u}' not found in target arg's dims")
+                sel.append(names.index(u))
+            names, sizes = [names[i] for i in sel], [sizes[i] for i in sel]
+        if not names or any(s == 0 for s in sizes):
+            raise UnsupErr(f"CUCL template {t.name}: IX {ix.ix_vn} over dynamically sized arg")
+        st = _strides(tuple(sizes)); prod = 1
+        for s in sizes:
+            prod *= s
+        for i, (n, s, sd) in enumerate(zip(names, sizes, st)):
+            v = f"({ix.ix_vn}/{sd})" if sd > 1 else ix.ix_vn
+            put(f"{ix.ix_vn}_{n}_nomod", v)
+            if i:
+                v = f"({v}%{s})" if s > 1 else "0"   # the outermost dim is left to overflow (src/rtc_func_gen.cc:233-241)
+            put(f"{ix.ix_vn}_{n}", v)
+        put(f"{ix.ix_vn}_dims_prod", str(prod))
+        if ix.ix_vn == "GLOB_ID_1D":
+            tpb = tpb or DEFAULT_TPB
+            if blks:
+                raise RtErr("CUCL error: GLOB_ID_1D IX encoutered after setting blks (some other way)")
+            blks = -(-prod // tpb)
+        elif ix.ix_vn == "GRP_ID_1D":
+            if blks:
+                raise RtErr("CUCL error: GRP_ID_1D IX encoutered after setting blks (some other way)")
+            blks = prod
+        elif ix.ix_vn == "LOC_ID_1D":
+            if tpb:
+                raise RtErr("CUCL error: LOC_ID_1D IX encoutered after setting tpb (some other way)")
+            tpb = prod
+
+    arg_names: List[str] = []
+    for ad in t.arg_decls:
+        arg_names.append(ad.vn)
+        if ad.vn not in op.nda_vals:
+            errs.append(f"referenced {ad.io_type} arg '{ad.vn}' not present in dims_vals; "); continue
+        nda = op.nda_vals[ad.vn]; d = nda.dims if nda.dims is not None else Dims((), (), nda.tn)
+        if not any(tuple(d.names) == sp for sp in ad.ok_dims):
+            errs.append(f"call arg '{ad.vn}' incompatible with decl arg (dim count mismatch or dim name mismatch: {tuple(d.names)} vs {ad.ok_dims}); ")
+            continue
+        if ad.tn and ad.tn != "none" and nda.tn not in (ad.tn, "none") and d.names:
+            errs.append(f"call arg '{ad.vn}' has type {nda.tn}, template wants {ad.tn}; ")
+        if ad.loi == 0 and d.dims_prod() != 1:
+            errs.append(f"call arg '{ad.vn}' incompatible with decl arg (by-value arguments must be scalar); "); continue
+        put(f"{ad.vn}_tn", nda.tn)
+        dims_only = ad.io_type == "REF" and nda.tn == "none"
+        st = _strides(tuple(d.sizes))
+        for n, s, sd in zip(d.names, d.sizes, st):
+            put(f"{ad.vn}_{n}_dim", str(s))
+            if not dims_only:
+                put(f"{ad.vn}_{n}_stride", str(sd))
+        if not dims_only:
+            put(f"{ad.vn}_dims_prod", str(d.dims_prod()))
+        if ad.loi == 0:
+            put(ad.vn, _scalar_const(nda) if nda.v is not None else ad.vn)
+    if errs:
+        raise RtErr(f"RTC template function instantiation argument error: {t.name}: " + "".join(errs))
+    if "tpb" not in tsvs:
+        tsvs["tpb"] = str(tpb)
+    tsvs["blks"] = str(blks); tsvs["warp_sz"] = "UNKNOWN"
+
+    def sub(m: "re.Match") -> str:
+        k = m.group(1)
+        if k not in tsvs:
+            raise RtErr(f"CUCL template {t.name}: unknown template variable %({k})")
+        return tsvs[k]
+    src = re.sub(r"%\(([A-Za-z0-9_]+)\)", sub, t.text).replace("%%", "%")
+    if not tpb:
+        raise RtErr(f"CUCL template {t.name}: launch geometry not determined (no GLOB_ID_1D / LOC_ID_1D index)")
+    return Instance(gen_fn, src, arg_names, tpb, blks)
+
+
+def load_template(rtc_dir: str, name: str) -> Template:
+    """A Boda checkout's test/rtc/<name>.cucl (rtc_template_t::init, src/rtc_func_gen.cc:47-63)."""
+    with open(os.path.join(rtc_dir, name + ".cucl")) as f:
+        return parse_template(name, f.read(), include_dir=rtc_dir)

@@ -508,3 +508,27 @@ def test_reference_shaped_cucl_sgemm_matches_oracle(be):
         for vn in ("rs_a", "rs_b", "rs_c"):
             rtc.release_var(vn)
         rtc.release_per_call_id_data()
+
+
+def test_cucl_template_instance_runs_through_generic_path(be):
+    """A CUCL *template* (magic-comment arg decls, %(...) variables, CUCL IX index expressions) instantiated by
+    boda_amd/cucl_template.py -- the reference's rtc_func_gen layer -- compiled and launched by the backend with the generated
+    arg list and geometry."""
+    from boda_amd.cucl_template import instantiate, parse_template
+    from boda_amd.op import Nda
+    from test_cucl_template_cpu import OWN
+    rtc = be.rtc
+    t = parse_template("own", OWN)
+    din, dout = Dims.make("float", img=2, chan=3, y=9, x=7), Dims.make("float", img=2, chan=3, y=5, x=4)
+    op = Op({"type": "own", "func_name": "own"}, {"in": Nda(din), "out": Nda(dout), "stride": Nda(Dims(("y", "x"), (2, 2), "none"), "none"),
+                                                  "shift": Nda(None, "uint32_t", (7,))})
+    inst = instantiate(t, op, "own__gpu0")
+    rtc.compile([RtcFuncInfo(inst.func_name, inst.src, inst.arg_names, op)])
+    x = np.arange(din.dims_prod(), dtype=np.float32).reshape(din.sizes)
+    rtc.create_var_with_dims("tpl_in", din); rtc.create_var_with_dims("tpl_out", dout); rtc.copy_nda_to_var("tpl_in", x)
+    try:
+        am = {"in": RtcArg.var("tpl_in"), "out": RtcArg.var("tpl_out"), "stride": RtcArg.ref(op.get_dims("stride")), "shift": RtcArg.scalar(7, "uint32_t")}
+        rtc.run(RtcFuncCall(inst.func_name, am, tpb=inst.tpb, blks=inst.blks)); rtc.finish_and_sync()
+        assert np.array_equal(rtc.copy_var_to_nda("tpl_out"), x[:, :, ::2, ::2][:, :, :5, :4] + 7)
+    finally:
+        rtc.release_var("tpl_in"); rtc.release_var("tpl_out"); rtc.release_func(inst.func_name); rtc.release_per_call_id_data()
