@@ -102,7 +102,7 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather, bo
   static cand_t const cands_f32[] = {
     {128, 128, 16, 2, 2, 2, 32, 1, 1.00, true, true},  {256, 256, 16, 4, 4, 1, 32, 1, 1.02, false, true}, {96, 256, 16, 1, 4, 2, 32, 1, 0.95, true, false},
     {96, 128, 16, 1, 2, 2, 32, 1, 0.90, false, true},  {64, 64, 16, 2, 2, 2, 32, 2, 0.93, true, true},    {32, 64, 32, 2, 4, 1, 16, 2, 0.60, true, true},
-    {32, 32, 32, 2, 2, 1, 16, 1, 0.45, false, true}};
+    {32, 32, 64, 2, 2, 1, 16, 2, 0.45, false, true}}; // (BK 64 + two K-tiles in flight: AlexNet fc8 24 -> 32 TF/s in sequence)
   tile_cfg_t best_c; double best = -1;
   // launches shorter than ~200 us at full rate also pay ramp-up / tail: about 0.6 tile-times per CU (measured NiN 1x1 layers at
   // B=128: 507 128x128 tiles 83 TF/s, 2028 64x64 tiles 88-91), which favours finer tiles there
