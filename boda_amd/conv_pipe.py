@@ -22,6 +22,7 @@ import numpy as np
 
 from . import gen_data as gd
 from .cnn_op import NATIVE_ARGS, OpTune, add_codegen_annotations
+from .cucl_template import instantiate, parse_template
 from .op import Dims, Nda, Op, RtErr, UnsupErr
 from .rtc import HipCompute, RtcArg, RtcCompileOpts, RtcFuncCall, RtcFuncInfo
 
@@ -256,6 +257,76 @@ CUCL_GLOBAL_KERNEL void fwd_lrn( GASQ float const * const in, GASQ float * const
   }
 }
 """
+# Pooling as a CUCL *template* (boda_amd/cucl_template.py): one generated function per distinct pooling geometry, window size /
+# stride / padding / plane sizes as constants, so the window loops unroll and the index arithmetic folds -- how the reference
+# specialises its own pool kernel (test/rtc/pool.cucl + src/rtc_func_gen.cc); the generic fwd_pool above stays as the fallback.
+POOL_TEMPLATE = """
+// only in-bounds (non-padding) pixels take part, for max and for average pooling
+CUCL_GLOBAL_KERNEL void %(rtc_func_name)( GASQ float const * const in, // CUCL IN img:chan:y:x
+                                          uint32_t const avg_pool, // CUCL IN :
+                                          GASQ void const * const kern_sz, // CUCL REF y:x
+                                          GASQ void const * const stride, // CUCL REF y:x
+                                          GASQ void const * const in_pad, // CUCL REF y:x
+                                          GASQ float * const out ) // CUCL OUT img:chan:y:x
+{
+  // CUCL IX GLOB_ID_1D out
+  if( GLOB_ID_1D >= %(GLOB_ID_1D_dims_prod) ) { return; }
+  GASQ float const * const ip = in + %(GLOB_ID_1D_img_nomod)*%(in_img_stride) + %(GLOB_ID_1D_chan)*%(in_chan_stride);
+  int32_t const y0 = (int32_t)%(GLOB_ID_1D_y)*%(stride_y_dim) - %(in_pad_y_dim);
+  int32_t const x0 = (int32_t)%(GLOB_ID_1D_x)*%(stride_x_dim) - %(in_pad_x_dim);
+  float out_v = %(avg_pool) ? 0.0f : -FLT_MAX;
+  float n_in = 0.0f;
+  for( int32_t ky = 0; ky != %(kern_sz_y_dim); ++ky ) {
+    int32_t const in_y = y0 + ky;
+    if( in_y < 0 || in_y >= %(in_y_dim) ) { continue; }
+    for( int32_t kx = 0; kx != %(kern_sz_x_dim); ++kx ) {
+      int32_t const in_x = x0 + kx;
+      if( in_x < 0 || in_x >= %(in_x_dim) ) { continue; }
+      float const v = ip[in_y*%(in_y_stride) + in_x];
+      if( %(avg_pool) ) { out_v += v; n_in += 1.0f; } else { out_v = ( v > out_v ) ? v : out_v; }
+    }
+  }
+  if( %(avg_pool) ) { out_v /= n_in; }
+  out[GLOB_ID_1D] = out_v;
+}
+"""
+# across-channel LRN, running-sum form, as a template: local_size, channel count and strides are constants (ring buffer in
+# registers, loops unrolled by the compiler); one thread per (img, y, x)
+LRN_TEMPLATE = """
+CUCL_GLOBAL_KERNEL void %(rtc_func_name)( float const alpha, // CUCL IN :
+                                          float const beta, // CUCL IN :
+                                          float const k, // CUCL IN :
+                                          uint32_t const local_size, // CUCL IN :
+                                          GASQ float const * const in, // CUCL IN img:chan:y:x
+                                          GASQ void const * const work, // CUCL REF img:cblk:cblk_sz:y:x
+                                          GASQ float * const out ) // CUCL OUT img:chan:y:x
+{
+  // one thread per (img, block of cblk_sz channels, y, x): the window sum runs over its block plus a halo of local_size/2 channels
+  // on either side (a few loads recomputed per block buys cblk x the threads of the one-thread-per-pixel form)
+  // CUCL IX GLOB_ID_1D work use_dims=img:cblk:y:x
+  if( GLOB_ID_1D >= %(GLOB_ID_1D_dims_prod) ) { return; }
+  float ls_buf[%(local_size)];
+  for( int32_t i = 0; i != %(local_size); ++i ) { ls_buf[i] = 0.0f; }
+  int32_t const hls = %(local_size) >> 1;
+  int32_t const c0 = (int32_t)%(GLOB_ID_1D_cblk)*%(work_cblk_sz_dim);
+  int32_t const base = %(GLOB_ID_1D_img_nomod)*%(in_img_stride) + %(GLOB_ID_1D_y)*%(in_y_stride) + %(GLOB_ID_1D_x);
+  float ls_sum = 0.0f;
+  float const alpha_over_ls = %(alpha) / (float)%(local_size);
+  for( int32_t j = 0; j < %(work_cblk_sz_dim) + 2*hls; ++j ) {
+    int32_t const ic = c0 - hls + j;      // channel entering the window; the window is then centred on channel ic - hls
+    int32_t const lsb_ix = j %% %(local_size);
+    float const ls_old = ls_buf[lsb_ix];
+    ls_buf[lsb_ix] = (ic >= 0 && ic < %(in_chan_dim)) ? in[base + ic*%(in_chan_stride)] : 0.0f;
+    ls_sum += ls_buf[lsb_ix]*ls_buf[lsb_ix]; ls_sum -= ls_old*ls_old;
+    if( j >= 2*hls && ic - hls < %(in_chan_dim) ) {
+      float const scale_base = %(k) + ls_sum*alpha_over_ls;
+      out[base + (ic - hls)*%(in_chan_stride)] = ls_buf[(lsb_ix + %(local_size) - hls) %% %(local_size)] * powf( scale_base, -%(beta) );
+    }
+  }
+}
+"""
+_POOL_T = parse_template("pool", POOL_TEMPLATE)
+_LRN_T = parse_template("lrn", LRN_TEMPLATE)
 FWD_FUNCS = {"fwd_pool": ["in", "out", "avg_pool", "n_out", "H", "W", "OH", "OW", "KH", "KW", "SY", "SX", "PY", "PX"],
              "fwd_copy": ["in", "out", "n_in", "chw_in", "chw_out", "off_out"],
              "fwd_relu": ["inout", "n"],
@@ -287,6 +358,7 @@ class ConvPipeFwd:
         self.compute_dur_ms = float("nan")
         self._vars: List[str] = []
         self._funcs: List[str] = []
+        self.templated_pool = True   # pooling / LRN kernels generated per geometry from POOL_TEMPLATE / LRN_TEMPLATE (False: the generic fwd_pool / fwd_lrn)
 
     # -- init: annotate, fuse, create vars, generate calls, upload params
     def init(self, cp: ConvPipe, op_params: Optional[Dict[str, np.ndarray]] = None, gen_mode: int = 5) -> None:
@@ -332,6 +404,21 @@ class ConvPipeFwd:
                 am = {"filts": RtcArg.var(op.tag + "_filts"), "biases": RtcArg.var(op.tag + "_biases"), "in": RtcArg.var(vn(op.bot)),
                       "stride": RtcArg.ref(anno.get_dims("stride")), "in_pad": RtcArg.ref(anno.get_dims("in_pad")), "out": RtcArg.var(op.top)}
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(gen_fn, am), fn, cop.flops()))
+            elif op.type == "Pooling" and self.templated_pool:
+                i, o = cp.nodes[op.bot], cp.nodes[op.top]
+                none = lambda yx: Nda(Dims(("y", "x"), tuple(yx), "none"), "none")
+                pop = Op({"type": "Pooling", "func_name": "pool"}, {"in": Nda(i), "out": Nda(o), "kern_sz": none(op.kern_sz), "stride": none(op.stride),
+                                                                    "in_pad": none(op.in_pad), "avg_pool": Nda(None, "uint32_t", (int(op.avg_pool),))})
+                sig = pop.to_str()
+                cache = rtc.__dict__.setdefault("_pool_funcs", {})      # one generated function per distinct signature (rtc_func_sigs_map_t)
+                if sig not in cache:
+                    inst = instantiate(_POOL_T, pop, f"fwd_pool__{len(cache)}")
+                    rtc.compile([RtcFuncInfo(inst.func_name, inst.src, inst.arg_names, pop)])
+                    cache[sig] = inst
+                inst = cache[sig]
+                am = {"in": RtcArg.var(vn(op.bot)), "out": RtcArg.var(op.top), "avg_pool": _u32(op.avg_pool), "kern_sz": RtcArg.ref(pop.get_dims("kern_sz")),
+                      "stride": RtcArg.ref(pop.get_dims("stride")), "in_pad": RtcArg.ref(pop.get_dims("in_pad"))}
+                self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(inst.func_name, am, tpb=inst.tpb, blks=inst.blks), "fwd_pool"))
             elif op.type == "Pooling":
                 i, o = cp.nodes[op.bot], cp.nodes[op.top]
                 n = o.dims_prod()
@@ -351,6 +438,24 @@ class ConvPipeFwd:
             elif op.type == "ReLU":
                 n = cp.nodes[op.top].dims_prod()
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall("fwd_relu", {"inout": RtcArg.var(vn(op.bot)), "n": _u32(n)}, tpb=_TPB, blks=(n + _TPB - 1) // _TPB), "fwd_relu"))
+            elif op.type == "LRN" and self.templated_pool:
+                d = cp.nodes[op.bot]
+                ls, alpha, beta, k = op.lrn
+                f32 = lambda v: Nda(None, "float", (float(v),))
+                cblk_sz = 32
+                work = Dims(("img", "cblk", "cblk_sz", "y", "x"), (d.dsz("img"), -(-d.dsz("chan") // cblk_sz), cblk_sz, d.dsz("y"), d.dsz("x")), "none")
+                lop = Op({"type": "LRN", "func_name": "lrn"}, {"in": Nda(d), "out": Nda(d), "alpha": f32(alpha), "beta": f32(beta), "k": f32(k),
+                                                               "local_size": Nda(None, "uint32_t", (int(ls),)), "work": Nda(work, "none")})
+                sig = lop.to_str()
+                cache = rtc.__dict__.setdefault("_pool_funcs", {})
+                if sig not in cache:
+                    inst = instantiate(_LRN_T, lop, f"fwd_lrn__{len(cache)}")
+                    rtc.compile([RtcFuncInfo(inst.func_name, inst.src, inst.arg_names, lop)])
+                    cache[sig] = inst
+                inst = cache[sig]
+                am = {"in": RtcArg.var(vn(op.bot)), "out": RtcArg.var(op.top), "alpha": _f32(alpha), "beta": _f32(beta), "k": _f32(k), "local_size": _u32(ls),
+                      "work": RtcArg.ref(work)}
+                self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(inst.func_name, am, tpb=inst.tpb, blks=inst.blks), "fwd_lrn"))
             elif op.type == "LRN":
                 d = cp.nodes[op.bot]; hw = d.dsz("y") * d.dsz("x"); n = d.dsz("img") * hw
                 ls, alpha, beta, k = op.lrn
