@@ -358,6 +358,7 @@ class ConvPipeFwd:
         self.compute_dur_ms = float("nan")
         self._vars: List[str] = []
         self._funcs: List[str] = []
+        self.concat_elim = True      # convs write straight into their channel range of a Concat output where legal
         self.templated_pool = True   # pooling / LRN kernels generated per geometry from POOL_TEMPLATE / LRN_TEMPLATE (False: the generic fwd_pool / fwd_lrn)
 
     # -- init: annotate, fuse, create vars, generate calls, upload params
@@ -379,6 +380,26 @@ class ConvPipeFwd:
                 has_relu[op.tag] = hr
                 if hr:
                     fused.add(nxt.tag)
+        # Concat elimination: a Concat input that is produced by a convolution and read by nothing but the Concat is never
+        # materialised -- the conv writes its channel range of the Concat output directly (hip_conv's out_chan_off), which removes
+        # the channel-offset copy the reference makes per input (src/rtc_fwd.cc:267-280) and one tensor round trip through HBM
+        self.slices: Dict[str, Tuple[str, int, int]] = {}      # node -> (concat output node, first channel, channels)
+        if self.concat_elim:
+            readers: Dict[str, int] = {}
+            for o in cp.ops:
+                if not o.in_place:
+                    for b in (o.bots or (o.bot,)):
+                        readers[b] = readers.get(b, 0) + 1
+            conv_tops = {o.top for o in cp.ops if o.type == "Convolution"}
+            for o in cp.ops:
+                if o.type != "Concat":
+                    continue
+                c_done = 0
+                for b in o.bots:
+                    ch = cp.nodes[b].dsz("chan")
+                    if b in conv_tops and readers.get(b, 0) == 1 and o.bots.count(b) == 1:
+                        self.slices[b] = (o.top, c_done, ch)
+                    c_done += ch
         # vars: the source node, then one per op output (in-place ops and Dropout reuse their input var)
         alias: Dict[str, str] = {}
         def vn(node: str) -> str:
@@ -386,6 +407,9 @@ class ConvPipeFwd:
         rtc.create_var_with_dims(cp.in_node, cp.nodes[cp.in_node]); self._vars.append(cp.in_node)
         for pn, pd in cp.params.items():
             rtc.create_var_with_dims(pn, pd); self._vars.append(pn); self.op_param_names.append(pn)
+        made = set()
+        for cat in sorted({t for (t, _, _) in self.slices.values()}):   # Concat outputs that convs write into exist before those convs
+            rtc.create_var_with_dims(cat, cp.nodes[cat]); self._vars.append(cat); made.add(cat)
         for op in cp.ops:
             if op.tag in fused:
                 continue
@@ -393,7 +417,7 @@ class ConvPipeFwd:
                 if not op.in_place:
                     alias[op.top] = vn(op.bot)
                 continue
-            if not op.in_place:
+            if not op.in_place and op.top not in made and op.top not in self.slices:
                 rtc.create_var_with_dims(op.top, cp.nodes[op.top]); self._vars.append(op.top)
             if op.type == "Convolution":
                 cop = cp.conv_op(op)
@@ -403,6 +427,9 @@ class ConvPipeFwd:
                 rtc.compile([RtcFuncInfo(gen_fn, "", [a for a, _ in NATIVE_ARGS[fn]], anno)]); self._funcs.append(gen_fn)
                 am = {"filts": RtcArg.var(op.tag + "_filts"), "biases": RtcArg.var(op.tag + "_biases"), "in": RtcArg.var(vn(op.bot)),
                       "stride": RtcArg.ref(anno.get_dims("stride")), "in_pad": RtcArg.ref(anno.get_dims("in_pad")), "out": RtcArg.var(op.top)}
+                if op.top in self.slices:
+                    cat, c_off, _ = self.slices[op.top]
+                    am["out"] = RtcArg.var(cat); am["out_chan_off"] = _u32(c_off)
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(gen_fn, am), fn, cop.flops()))
             elif op.type == "Pooling" and self.templated_pool:
                 i, o = cp.nodes[op.bot], cp.nodes[op.top]
@@ -432,6 +459,8 @@ class ConvPipeFwd:
                 c_done = 0
                 for bi, b in enumerate(op.bots):
                     d = cp.nodes[b]; n = d.dims_prod(); chw_in = d.dsz("chan") * hw
+                    if b in self.slices:        # already written in place by its conv
+                        c_done += d.dsz("chan"); continue
                     am = {"in": RtcArg.var(vn(b)), "out": RtcArg.var(op.top), "n_in": _u32(n), "chw_in": _u32(chw_in), "chw_out": _u32(chw_out), "off_out": _u32(c_done * hw)}
                     self.fwd_calls.append(FwdCall(f"{op.tag}.{bi}", RtcFuncCall("fwd_copy", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB), "fwd_copy"))
                     c_done += d.dsz("chan")
@@ -492,7 +521,11 @@ class ConvPipeFwd:
             c.call_id = rtc.run(c.rfc)
         rtc.finish_and_sync()
         for v in to_get_vns:
-            fwd[v] = rtc.copy_var_to_nda(self.var_of(v))
+            if v in self.slices:     # a conv output that only exists as a channel range of its Concat output
+                cat, c_off, ch = self.slices[v]
+                fwd[v] = np.ascontiguousarray(rtc.copy_var_to_nda(cat)[:, c_off:c_off + ch])
+            else:
+                fwd[v] = rtc.copy_var_to_nda(self.var_of(v))
         self.compute_dur_ms = rtc.get_dur(self.fwd_calls[0].call_id, self.fwd_calls[-1].call_id) if self.fwd_calls else 0.0
         self.per_call_ms = [(c.tag, c.func, rtc.get_dur(c.call_id, c.call_id), c.flops) for c in self.fwd_calls]
         if self.per_call_fn:
@@ -543,7 +576,7 @@ class ConvPipeFwd:
             am = c.rfc.arg_map
             rd = [am[a].n for a in ("in", "inout") if a in am and am[a].is_var()]
             wr = [am[a].n for a in ("out", "inout") if a in am and am[a].is_var()]
-            partial = c.func == "fwd_copy"
+            partial = c.func == "fwd_copy" or "out_chan_off" in am   # writers of disjoint channel ranges of one var: unordered among themselves
             d = set()
             for v in rd:
                 d.update(writers.get(v, []))

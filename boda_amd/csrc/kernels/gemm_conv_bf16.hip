@@ -59,6 +59,8 @@ struct gemm_args_t { // identical to gemm_conv_f32.hip (one host-side struct)
   float *ws; long ws_slab;
   unsigned I_bytes, J_bytes;
   unsigned D_bytes;             // (used by the f32 kernel's epilogue; kept for a common argument block)
+  int out_ctot, out_coff;      // EPI 1: channels of the output tensor and first channel written (== Mi, 0 unless the conv writes a slice
+                               // of a wider tensor: Concat elimination)
   int const *ktab; int ktab_n;
 };
 
@@ -280,7 +282,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #if EPI == 1
         int const OHW = p.OH * p.OW;
         int const img = jg / OHW, pel = jg - img * OHW;
-        unsigned const jpart = ((unsigned)img * (unsigned)p.Mi * (unsigned)OHW + (unsigned)pel) * 4u;
+        unsigned const jpart = (((unsigned)img * (unsigned)p.out_ctot + (unsigned)p.out_coff) * (unsigned)OHW + (unsigned)pel) * 4u;
 #else
         unsigned const jpart = (unsigned)jg * 4u;
 #endif

@@ -97,6 +97,8 @@ struct gemm_args_t {
   float *ws; long ws_slab; // SPLITK: partial-sum slabs, ws_slab elements apart
   unsigned I_bytes, J_bytes; // sizes of the I / J tensors (buffer-descriptor num_records; host guarantees <= 2^31)
   unsigned D_bytes;             // size of the output tensor (host guarantees < 2^32: 32-bit store offsets)
+  int out_ctot, out_coff;      // EPI 1: channels of the output tensor and first channel written (== Mi, 0 unless the conv writes a slice
+                               // of a wider tensor: Concat elimination)
   int const *ktab; int ktab_n; // J_MODE 2: per-k gather tables, three arrays of ktab_n ints: element offset of (in_chan,ky,kx)
                                // inside one image | ky | kx ; rows k >= K carry ky = 2^30 (fail the row-range test)
 };
@@ -661,7 +663,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #if EPI == 1
         int const OHW = p.OH * p.OW;
         int const img = jg / OHW, pel = jg - img * OHW;
-        unsigned const jpart = ((unsigned)img * (unsigned)p.Mi * (unsigned)OHW + (unsigned)pel) * 4u;
+        unsigned const jpart = (((unsigned)img * (unsigned)p.out_ctot + (unsigned)p.out_coff) * (unsigned)OHW + (unsigned)pel) * 4u;
 #else
         unsigned const jpart = (unsigned)jg * 4u;
 #endif

@@ -20,6 +20,7 @@ struct gemm_args_t { // must match kernels/gemm_conv_f32.hip
   float *ws; long ws_slab;
   unsigned I_bytes, J_bytes;
   unsigned D_bytes;
+  int out_ctot, out_coff;
   void const *ktab; int ktab_n;
 };
 
@@ -354,7 +355,8 @@ void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t 
   last_launch.flops = 2.0 * M * N * K; last_launch.algo_bytes = 4.0 * ((double)K * M + (double)K * N + (double)M * N);
 }
 
-void native_kernels_t::conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16) {
+void native_kernels_t::conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16, int out_ctot, int out_coff) {
+  if (out_ctot <= 0) { out_ctot = g.OC; out_coff = 0; }
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   if (!Nj || !g.OC) return;
   if (Nj > 0x7fffffffl || Kt > 0x7fffffffl) unsup_err("hip_conv: dims exceed int32");
@@ -368,7 +370,9 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.ldI = (int)Kt; ga.ldJ = p.ipconv ? (int)Kt : 0; ga.ldD = g.OH * g.OW;
   ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
   ga.I_bytes = (unsigned)f_bytes; ga.J_bytes = (unsigned)in_bytes;
-  uint64_t const out_bytes = (uint64_t)Nj * g.OC * 4;
+  uint64_t const out_bytes = (uint64_t)Nj * out_ctot * 4;
+  if (cfg.SPLITK > 1 && out_ctot != g.OC) unsup_err("hip_conv: split-K tiles cannot write a channel slice of a wider output");
+  ga.out_ctot = out_ctot; ga.out_coff = out_coff;
   if (out_bytes >= 0xfffffff0ull) unsup_err("hip_conv: out of 4 GiB or more is not supported (32-bit store offsets)");
   ga.D_bytes = (unsigned)out_bytes;
   if (p.rows) { ktab_t const kt = get_rtab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
@@ -460,11 +464,20 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     assert_st(f.sz() == 4 && in.sz() == 4 && out.sz() == 4 && bi.sz() == 1);
     conv_geom_t g = geom_from_dims(f, in, out, stride, in_pad, fi.op.get_u32("conv_has_relu") != 0);
     if (f.dsz("in_chan") != (uint32_t)g.C) rt_err("hip_conv: filts.in_chan != in.chan");
-    if (bi.dsz("out_chan") != (uint32_t)g.OC || out.dsz("chan") != (uint32_t)g.OC || out.dsz("img") != (uint32_t)g.B) rt_err("hip_conv: inconsistent biases/out dims");
+    // optional by-value arg out_chan_off: `out` is then a wider tensor (an inception module's Concat output) and this conv writes
+    // channels [out_chan_off, out_chan_off + out_chan) of it -- the channel-offset copy of src/rtc_fwd.cc:267-280 folded into the store
+    int out_ctot = 0, out_coff = 0;
+    auto oi = am.find("out_chan_off");
+    if (oi != am.end()) {
+      if (oi->second.is_var() || !oi->second.v || !oi->second.v->rp_elems()) rt_err("hip_conv: out_chan_off must be a by-value uint32");
+      out_coff = (int)*(uint32_t const *)oi->second.v->rp_elems(); out_ctot = (int)out.dsz("chan");
+      if (out_coff < 0 || out_coff + g.OC > out_ctot) rt_err("hip_conv: out_chan_off + out_chan exceeds the channels of out");
+    }
+    if (bi.dsz("out_chan") != (uint32_t)g.OC || (!out_ctot && out.dsz("chan") != (uint32_t)g.OC) || out.dsz("img") != (uint32_t)g.B) rt_err("hip_conv: inconsistent biases/out dims");
     if (!g.SY || !g.SX) rt_err("hip_conv: zero stride");
     // out = (in + 2*pad - k)/stride + 1, floor (src/conv_util.cc:167-173)
     if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW) rt_err("hip_conv: out dims do not match in/filts/stride/in_pad");
-    conv((float const *)host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), (float const *)host->nh_var_ptr(inm), (float *)host->nh_var_ptr(onm), g, bf16);
+    conv((float const *)host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), (float const *)host->nh_var_ptr(inm), (float *)host->nh_var_ptr(onm), g, bf16, out_ctot, out_coff);
     return;
   }
   rt_err("unknown/unhandled native hip function: " + fn);

@@ -53,7 +53,7 @@ struct native_kernels_t {
 
   // direct entry points on raw device pointers (used by run() and by the C ABI's fast paths)
   void sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16 = false);
-  void conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16 = false);
+  void conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16 = false, int out_ctot = 0, int out_coff = 0);
 
   // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"
   void set_tune(string const &key, string const &val);

@@ -91,7 +91,7 @@ def test_full_net_forward_matches_oracle(rtc, net, batch, tmp_path):
 
 
 def test_graph_replay_equals_call_by_call(rtc):
-    """hipGraph capture of a whole forward call list (GoogLeNet: 118 launches): the replay writes the same bits as the
+    """hipGraph capture of a whole forward call list (GoogLeNet: 82 launches): the replay writes the same bits as the
     call-by-call run, can be relaunched, and captured calls have no per-call timing."""
     from boda_amd.op import RtErr
     cp = googlenet_conv(2)
@@ -101,7 +101,7 @@ def test_graph_replay_equals_call_by_call(rtc):
         io = {"data": data}
         fwd.run_fwd(["data"], io, [cp.out_node(), "icp9_out"])
         n = fwd.capture_graph()
-        assert n == len(fwd.fwd_calls) == 118
+        assert n == len(fwd.fwd_calls) == 82 and len(fwd.slices) == 36   # 118 calls minus the 36 Concat copies the convs make unnecessary
         for node in (cp.out_node(), "icp9_out", "conv1"):
             rtc.set_var_to_zero(fwd.var_of(node))
         ms = fwd.run_graph()
@@ -115,7 +115,7 @@ def test_graph_replay_equals_call_by_call(rtc):
         # parallel branches: the graph re-wired to the calls' true dependencies (the four chains of an inception module are independent)
         n = fwd.capture_graph(parallel=True)
         deps = fwd.call_deps
-        assert n == 118 and deps[0] == [] and all(all(d < i for d in ds) for i, ds in enumerate(deps))
+        assert n == 82 and deps[0] == [] and all(all(d < i for d in ds) for i, ds in enumerate(deps))
         assert sum(1 for i, ds in enumerate(deps) if i and (i - 1) not in ds) > 30   # many calls do not depend on their predecessor
         for _ in range(3):
             rtc.set_var_to_zero(fwd.var_of(cp.out_node())); rtc.set_var_to_zero(fwd.var_of("icp5_out"))
