@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from boda_amd import gen_data as gd
-from boda_amd.cnn_op import OpTune, add_codegen_annotations
+from boda_amd.cnn_op import NATIVE_ARGS, OpTune, add_codegen_annotations
 from boda_amd.digest import Digest, read_wisdoms, SsdsDiff
 from boda_amd.op import Dims, Op, RtErr, UnsupErr, parse_op, read_ops
 from boda_amd.ops_prof import OpsBackend, ops_prof, profile_rcg_call
@@ -532,3 +532,35 @@ def test_cucl_template_instance_runs_through_generic_path(be):
         assert np.array_equal(rtc.copy_var_to_nda("tpl_out"), x[:, :, ::2, ::2][:, :, :5, :4] + 7)
     finally:
         rtc.release_var("tpl_in"); rtc.release_var("tpl_out"); rtc.release_func(inst.func_name); rtc.release_per_call_id_data()
+
+
+def test_conv_writes_channel_slice_of_wider_output(be):
+    """hip_conv's optional out_chan_off: `out` is a wider tensor, the conv writes exactly its channel range of it (Concat
+    elimination in the full-net driver) -- bit-exact values, every other channel untouched, bad offsets refused."""
+    rtc = be.rtc
+    op = _conv_op(3, 6, 10, 10, 12, 3, 3, 1, 1)
+    anno = add_codegen_annotations(op, OpTune())
+    fn = anno.get_func_name()
+    rtc.compile([RtcFuncInfo("slice_conv", "", [a for a, _ in NATIVE_ARGS[fn]], anno)])
+    g = op.conv_geom()
+    x = bo.gen_conv_in(3, 6, 10, 10); f = bo.gen_conv_filts(12, 6, 3, 3); b = bo.gen_conv_biases(12)
+    wide = Dims.make("float", img=3, chan=30, y=10, x=10)
+    names = {"in": ("sl_in", anno.get_dims("in"), x), "filts": ("sl_f", anno.get_dims("filts"), f), "biases": ("sl_b", anno.get_dims("biases"), b),
+             "out": ("sl_out", wide, np.full(wide.sizes, 7.0, np.float32))}
+    for vn, d, arr in names.values():
+        rtc.create_var_with_dims(vn, d); rtc.copy_nda_to_var(vn, arr)
+    try:
+        am = {an: RtcArg.var(names[an][0]) for an in names}
+        am["stride"] = RtcArg.ref(anno.get_dims("stride")); am["in_pad"] = RtcArg.ref(anno.get_dims("in_pad"))
+        am["out_chan_off"] = RtcArg.scalar(11, "uint32_t")
+        rtc.run(RtcFuncCall("slice_conv", am)); rtc.finish_and_sync()
+        got = rtc.copy_var_to_nda("sl_out")
+        want = bo.conv_fwd(x, f, b, (1, 1), (1, 1), True)
+        assert np.array_equal(got[:, 11:23], want) and (got[:, :11] == 7).all() and (got[:, 23:] == 7).all()
+        am["out_chan_off"] = RtcArg.scalar(19, "uint32_t")     # 19 + 12 > 30
+        with pytest.raises(RtErr):
+            rtc.run(RtcFuncCall("slice_conv", am))
+    finally:
+        for vn, _, _ in names.values():
+            rtc.release_var(vn)
+        rtc.release_func("slice_conv"); rtc.release_per_call_id_data()
