@@ -580,3 +580,17 @@ def test_conv_random_shapes_bit_exact(be, tile):
         g = op.conv_geom()
         want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
         assert np.array_equal(want, outs["out"]), (sh, prc.launch["cfg"])
+
+
+@pytest.mark.parametrize("tile", ["", "128x128x16x2x2x2", "256x256x16x4x4x1", "32x32x64x2x2x1x1x16x2"])
+def test_sgemm_random_shapes_bit_exact(be, tile):
+    """Seeded random (M, N, K) incl. sizes that are not multiples of 4 / of the tile: default plan and three forced tiles == oracle."""
+    rng = np.random.default_rng(3 + len(tile))
+    for _ in range(12):
+        M, N, K = (int(rng.integers(1, 700)) for _ in range(3))
+        if rng.random() < 0.4:
+            M, N = 4 * (M // 4 + 1), 4 * (N // 4 + 1)      # the float4 loader modes
+        op = _sgemm_op(M, N, K)
+        outs, prc = _run(be, op, 5, tune=OpTune(hip_tile=tile), include_ins=True)
+        want = bo.sgemm(outs["a"], outs["b"])
+        assert np.array_equal(want, outs["c"]), ((M, N, K), prc.launch["cfg"])
