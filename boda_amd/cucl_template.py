@@ -13,9 +13,12 @@ Instantiating it for an op (`op_base_t`: `func_name` + named ndas) defines (`rtc
   <ix>_<dim> = ((ix/stride)%dim) | <ix>_<dim>_nomod | <ix>_dims_prod                     (`insert_nda_ix_exprs`, `:227-246`)
   tpb | blks | warp_sz
 and the launch geometry from the special index names (`:7-23`): GLOB_ID_1D -> tpb 256, blks = ceil(prod/tpb); GRP_ID_1D -> blks;
-LOC_ID_1D -> tpb.  Supported here: everything static.  `_DYN` arguments (run-time dims through `cai__*` args), `_multi`
-arguments and the convolution variants' custom code generation (`src/cnn_codegen.cc`) raise UnsupErr -- `be=hip` serves those
-ops through its native kernels instead.
+LOC_ID_1D -> tpb.  `_DYN` arguments keep their dims out of the generated source: `<arg>_<dim>_dim` etc. become references to extra
+trailing `int32_t cai__<arg>_<dim>_{dim,stride}` / `cai__<arg>_dims_prod` by-value arguments (declared through the template's
+`%(cucl_arg_info_decls)`), an index over such an argument likewise, and values and launch geometry are supplied per call
+(`Instance.call_args`; `add_dyn_nda_dims_sz`, `src/rtc_func_gen.cc:429-469`, `rcg_func_call_t::run`, `:496-584`).  `_multi`
+arguments and the convolution variants' custom code generation (`src/cnn_codegen.cc`) raise UnsupErr -- `be=hip` serves those ops
+through its native kernels instead.
 """
 from __future__ import annotations
 import os
@@ -35,6 +38,7 @@ class ArgDecl:
     loi: int           # levels of indirection: 0 = by value, 1 = pointer
     io_type: str       # IN | OUT | INOUT | REF
     ok_dims: List[Tuple[str, ...]]   # acceptable dim-name lists
+    dyn: bool = False  # _DYN: dims arrive per call through cai__* arguments
 
 
 @dataclass
@@ -57,9 +61,33 @@ class Instance:
     """What rtc_codegen_t hands to rtc_compute_t::compile / ::run for one generated function."""
     func_name: str
     src: str
-    arg_names: List[str]
+    arg_names: List[str]   # regular args in declaration order, then the cai__* args of dynamic dims
     tpb: int
-    blks: int
+    blks: int              # 0 when the geometry depends on dynamic dims (see call_args)
+    dyn_vars: List[Tuple[str, str, Tuple[str, ...]]] = field(default_factory=list)   # (cai prefix, source arg, use_dims)
+
+    def call_args(self, dims_of: Dict[str, Dims]) -> Tuple[Dict[str, int], int, int]:
+        """Per-call part of a function with dynamic dims: the cai__* argument values from the actual dims of the source args,
+        and the launch geometry (a dynamic GLOB_ID_1D index sets blks = ceil(prod / tpb)).  -> (cai values, tpb, blks)"""
+        vals: Dict[str, int] = {}
+        tpb, blks = self.tpb, self.blks
+        for pre, src, use in self.dyn_vars:
+            d = dims_of[src]
+            names, sizes = list(d.names), list(d.sizes)
+            if use:
+                sel = [names.index(u) for u in use]
+                names, sizes = [names[i] for i in sel], [sizes[i] for i in sel]
+            st = _strides(tuple(sizes)); prod = 1
+            for n_, s_, sd in zip(names, sizes, st):
+                vals[f"cai__{pre}_{n_}_dim"] = s_; vals[f"cai__{pre}_{n_}_stride"] = sd; prod *= s_
+            vals[f"cai__{pre}_dims_prod"] = prod
+            if pre == "GLOB_ID_1D":
+                tpb = tpb or DEFAULT_TPB; blks = -(-prod // tpb)
+            elif pre == "GRP_ID_1D":
+                blks = prod
+            elif pre == "LOC_ID_1D":
+                tpb = prod
+        return vals, tpb, blks
 
 
 def _parse_arg_decl(line: str) -> Tuple[str, str, int]:
@@ -111,9 +139,9 @@ def parse_template(name: str, text: str, include_dir: Optional[str] = None) -> T
             elif cd in ("IN", "INOUT", "OUT", "REF"):
                 if len(parts) < 3:
                     raise RtErr("invalid CUCL IN/INOUT/OUT annotation; missing dims spec.")
-                if dyn:
-                    raise UnsupErr(f"CUCL template {name}: _DYN argument (run-time dims) is not supported by this restatement")
                 vn, tn, loi = _parse_arg_decl(line)
+                if dyn and loi == 0:
+                    raise RtErr("invalid CUCL io var decl; by-value arguments must not be DYN")
                 if tn.endswith("_multi"):
                     raise UnsupErr(f"CUCL template {name}: _multi argument '{vn}' is not supported by this restatement")
                 if not tn:
@@ -130,7 +158,7 @@ def parse_template(name: str, text: str, include_dir: Optional[str] = None) -> T
                 for sp in specs:
                     if any(not d for d in sp):
                         raise RtErr("invalid (currently forbidden/unused) empty dim name in nda_spec")
-                arg_decls.append(ArgDecl(vn, tn, loi, cd, specs))
+                arg_decls.append(ArgDecl(vn, tn, loi, cd, specs, dyn))
             elif cd == "INCLUDE":
                 if len(parts) != 3:
                     raise RtErr("invalid CUCL INCLUDE decl; must be exactly CUCL INCLUDE filename.h.")
@@ -180,7 +208,44 @@ def instantiate(t: Template, op: Op, gen_fn: str) -> Instance:
             raise RtErr(f"template variable '{k}' defined twice")
         tsvs[k] = v
 
+    dyn_args = {ad.vn for ad in t.arg_decls if ad.dyn}
+    dyn_vars: List[Tuple[str, str, Tuple[str, ...]]] = []
+    cai_names: List[str] = []
+    cai_decls: List[str] = []
+
+    def add_dyn(pre: str, names, add_refs: bool) -> None:
+        for n in names:
+            for kind in ("dim", "stride"):
+                cn = f"cai__{pre}_{n}_{kind}"
+                cai_names.append(cn); cai_decls.append(f"   ,int32_t {cn}")
+                if add_refs:
+                    put(f"{pre}_{n}_{kind}", cn)
+        cn = f"cai__{pre}_dims_prod"
+        cai_names.append(cn); cai_decls.append(f"   ,int32_t {cn}")
+        if add_refs:
+            put(f"{pre}_dims_prod", cn)
+
     for ix in t.ix_decls:
+        if ix.arg_vn in dyn_args:      # index over an argument whose dims are only known per call (insert_nda_dyn_ix_exprs)
+            d = arg_dims(ix.arg_vn, "IX")
+            names = list(ix.use_dims) if ix.use_dims else list(d.names)
+            for u in names:
+                if u not in d.names:
+                    raise RtErr(f"specified use_dim '{u}' not found in target arg's dims")
+            if ix.ix_vn == ix.arg_vn:
+                raise RtErr("CUCL IX over a dynamic arg must not share its name")
+            dyn_vars.append((ix.ix_vn, ix.arg_vn, tuple(ix.use_dims)))
+            add_dyn(ix.ix_vn, names, False)
+            for i, n in enumerate(names):
+                v = f"({ix.ix_vn}/cai__{ix.ix_vn}_{n}_stride)"
+                put(f"{ix.ix_vn}_{n}_nomod", v)
+                if i:
+                    v = f"({v}%cai__{ix.ix_vn}_{n}_dim)"
+                put(f"{ix.ix_vn}_{n}", v)
+            put(f"{ix.ix_vn}_dims_prod", f"cai__{ix.ix_vn}_dims_prod")
+            if ix.ix_vn == "GLOB_ID_1D":
+                tpb = tpb or DEFAULT_TPB
+            continue
         d = arg_dims(ix.arg_vn, "IX")
         names, sizes = list(d.names), list(d.sizes)
         if ix.use_dims:
@@ -230,6 +295,10 @@ def instantiate(t: Template, op: Op, gen_fn: str) -> Instance:
         if ad.loi == 0 and d.dims_prod() != 1:
             errs.append(f"call arg '{ad.vn}' incompatible with decl arg (by-value arguments must be scalar); "); continue
         put(f"{ad.vn}_tn", nda.tn)
+        if ad.dyn:
+            dyn_vars.append((ad.vn, ad.vn, ()))
+            add_dyn(ad.vn, d.names, True)
+            continue
         dims_only = ad.io_type == "REF" and nda.tn == "none"
         st = _strides(tuple(d.sizes))
         for n, s, sd in zip(d.names, d.sizes, st):
@@ -245,6 +314,10 @@ def instantiate(t: Template, op: Op, gen_fn: str) -> Instance:
     if "tpb" not in tsvs:
         tsvs["tpb"] = str(tpb)
     tsvs["blks"] = str(blks); tsvs["warp_sz"] = "UNKNOWN"
+    if cai_decls:
+        tsvs["cucl_arg_info_decls"] = "// begin cucl_arg_info_decls\n" + "\n".join(cai_decls) + "\n"
+    elif "cucl_arg_info_decls" not in tsvs:
+        tsvs["cucl_arg_info_decls"] = ""
 
     def sub(m: "re.Match") -> str:
         k = m.group(1)
@@ -254,7 +327,7 @@ def instantiate(t: Template, op: Op, gen_fn: str) -> Instance:
     src = re.sub(r"%\(([A-Za-z0-9_]+)\)", sub, t.text).replace("%%", "%")
     if not tpb:
         raise RtErr(f"CUCL template {t.name}: launch geometry not determined (no GLOB_ID_1D / LOC_ID_1D index)")
-    return Instance(gen_fn, src, arg_names, tpb, blks)
+    return Instance(gen_fn, src, arg_names + cai_names, tpb, blks, dyn_vars)
 
 
 def load_template(rtc_dir: str, name: str) -> Template:

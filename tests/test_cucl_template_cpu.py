@@ -53,8 +53,35 @@ def test_own_template_vars_geometry_and_offline_compile():
         instantiate(t, Op({"type": "own", "func_name": "own"}, {k: v for k, v in op.nda_vals.items() if k != "stride"}), "x")
     with pytest.raises(RtErr):
         instantiate(t, Op({"type": "own", "func_name": "own"}, dict(op.nda_vals, out=Nda(Dims.make("float", img=2, y=5, x=4)))), "x")
+    with pytest.raises(RtErr):
+        parse_template("dyn", "void f( float const a ) // CUCL IN_DYN :\n{}")      # by-value arguments must not be DYN
     with pytest.raises(UnsupErr):
-        parse_template("dyn", "void f( GASQ float * const a ) // CUCL OUT_DYN x\n{}")
+        parse_template("multi", "void f( GASQ float_multi const * const ins ) // CUCL IN img:chan:y:x\n{}")
+
+
+DYN = """
+CUCL_GLOBAL_KERNEL void %(rtc_func_name)( GASQ float * const a, // CUCL OUT_DYN K:M
+                                          float const vi // CUCL IN :
+                                          %(cucl_arg_info_decls) )
+{
+  // CUCL IX GLOB_ID_1D a
+  if( GLOB_ID_1D >= %(a_dims_prod) ) { return; }
+  a[GLOB_ID_1D] = %(vi) + %(GLOB_ID_1D_K)*1000 + %(GLOB_ID_1D_M) + %(a_M_dim);
+}
+"""
+
+
+def test_dyn_argument_dims_become_trailing_cai_args():
+    t = parse_template("dyn", DYN)
+    op = Op({"type": "dyn", "func_name": "dyn"}, {"a": Nda(Dims.make("float", K=0, M=0)), "vi": Nda(None, "float", None)})
+    inst = instantiate(t, op, "dyn__0")
+    assert inst.arg_names == ["a", "vi", "cai__GLOB_ID_1D_K_dim", "cai__GLOB_ID_1D_K_stride", "cai__GLOB_ID_1D_M_dim", "cai__GLOB_ID_1D_M_stride",
+                              "cai__GLOB_ID_1D_dims_prod", "cai__a_K_dim", "cai__a_K_stride", "cai__a_M_dim", "cai__a_M_stride", "cai__a_dims_prod"]
+    assert inst.blks == 0 and inst.tpb == 256          # geometry is per call
+    assert "GLOB_ID_1D >= cai__a_dims_prod" in inst.src and ",int32_t cai__a_M_stride" in inst.src and "%(" not in inst.src
+    vals, tpb, blks = inst.call_args({"a": Dims.make("float", K=37, M=20)})
+    assert vals["cai__a_K_stride"] == 20 and vals["cai__GLOB_ID_1D_dims_prod"] == 740 and (tpb, blks) == (256, 3)
+    assert rtc.compile_offline(inst.src) > 0
 
 
 REF_RTC = "/root/reference/test/rtc"
@@ -79,10 +106,23 @@ REF_OPS = {
 }
 
 
+_dynf = lambda **d: Nda(Dims.make("float", **d))
+REF_OPS.update({
+    "gen_data_sgemm_a": {"a": _dynf(K=0, M=0), "mode": Nda(None, "uint32_t", None), "vi": Nda(None, "float", None)},
+    "gen_data_sgemm_b": {"b": _dynf(K=0, N=0), "mode": Nda(None, "uint32_t", None), "vi": Nda(None, "float", None)},
+    "gen_data_Convolution_in": {"in": _dynf(img=0, chan=0, y=0, x=0), "mode": Nda(None, "uint32_t", None), "vi": Nda(None, "float", None)},
+    "gen_data_Convolution_filts": {"filts": _dynf(out_chan=0, in_chan=0, y=0, x=0), "mode": Nda(None, "uint32_t", None), "vi": Nda(None, "float", None)},
+    "gen_data_Convolution_biases": {"biases": _dynf(out_chan=0), "mode": Nda(None, "uint32_t", None), "vi": Nda(None, "float", None)},
+    "quantize": {"out": _dynf(img=0, chan=0, y=0, x=0), "max_val": u32(255), "drop_mask": u32(3)},
+})
+
+
 @pytest.mark.skipif(not os.path.isdir(REF_RTC), reason="no Boda checkout here (the GPU box has none)")
 @pytest.mark.parametrize("name", sorted(REF_OPS))
 def test_reference_generic_templates_instantiate_and_compile_for_gfx950(name):
     t = load_template(REF_RTC, name)
     inst = instantiate(t, Op({"type": name, "func_name": name}, REF_OPS[name]), f"{name}__gen0")
-    assert inst.arg_names == [a.vn for a in t.arg_decls] and inst.blks >= 1 and "%(" not in inst.src
+    n_reg = len(t.arg_decls)
+    assert inst.arg_names[:n_reg] == [a.vn for a in t.arg_decls] and all(a.startswith("cai__") for a in inst.arg_names[n_reg:])
+    assert (inst.blks >= 1 or inst.dyn_vars) and "%(" not in inst.src
     assert rtc.compile_offline(inst.src) > 0

@@ -594,3 +594,28 @@ def test_sgemm_random_shapes_bit_exact(be, tile):
         outs, prc = _run(be, op, 5, tune=OpTune(hip_tile=tile), include_ins=True)
         want = bo.sgemm(outs["a"], outs["b"])
         assert np.array_equal(want, outs["c"]), ((M, N, K), prc.launch["cfg"])
+
+
+def test_cucl_template_dyn_dims_per_call(be):
+    """A template with an OUT_DYN argument: one generated function serves any dims; the cai__* arguments and the launch geometry
+    come from Instance.call_args per call (the reference's rcg_func_call_t::run flow)."""
+    from boda_amd.cucl_template import instantiate, parse_template
+    from boda_amd.op import Nda
+    from test_cucl_template_cpu import DYN
+    rtc = be.rtc
+    op = Op({"type": "dyn", "func_name": "dyn"}, {"a": Nda(Dims.make("float", K=0, M=0)), "vi": Nda(None, "float", None)})
+    inst = instantiate(parse_template("dyn", DYN), op, "dyn__gpu0")
+    rtc.compile([RtcFuncInfo(inst.func_name, inst.src, inst.arg_names, op)])
+    try:
+        for K, M in ((37, 20), (5, 301)):
+            d = Dims.make("float", K=K, M=M)
+            vn = f"dyn_a_{K}"; rtc.create_var_with_dims(vn, d)
+            vals, tpb, blks = inst.call_args({"a": d})
+            am = {"a": RtcArg.var(vn), "vi": RtcArg.scalar(0.5, "float")}
+            am.update({k: RtcArg.scalar(v, "int32_t") for k, v in vals.items()})
+            rtc.run(RtcFuncCall(inst.func_name, am, tpb=tpb, blks=blks)); rtc.finish_and_sync()
+            kk, mm = np.meshgrid(np.arange(K), np.arange(M), indexing="ij")
+            assert np.array_equal(rtc.copy_var_to_nda(vn), (0.5 + kk * 1000 + mm + M).astype(np.float32))
+            rtc.release_var(vn)
+    finally:
+        rtc.release_func(inst.func_name); rtc.release_per_call_id_data()
