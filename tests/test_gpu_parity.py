@@ -619,3 +619,27 @@ def test_cucl_template_dyn_dims_per_call(be):
             rtc.release_var(vn)
     finally:
         rtc.release_func(inst.func_name); rtc.release_per_call_id_data()
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 10, 10, 12, 3, 3, 1, 1), (3, 5, 17, 13, 70, 5, 5, 2, 2), (2, 19, 11, 11, 40, 1, 1, 1, 0), (2, 3, 35, 35, 96, 11, 11, 4, 0)])
+def test_reference_shaped_cucl_conv_matches_oracle(be, shape):
+    """boda_amd/ref_style.py: the register-tiled generic-conv structure of the reference as CUCL source through the generic path --
+    a second GPU implementation of Convolution+bias+ReLU; same ascending-k fma chain, so the same bits as the oracle."""
+    from boda_amd import ref_style
+    rtc = be.rtc
+    ref_style.compile_into(rtc)
+    op = _conv_op(*shape); g = op.conv_geom()
+    x = bo.gen_conv_in(*shape[:4]); f = bo.gen_conv_filts(shape[4], shape[1], shape[5], shape[6]); b = bo.gen_conv_biases(shape[4])
+    names = {"in": ("rsc_in", x), "filts": ("rsc_f", f), "biases": ("rsc_b", b), "out": ("rsc_out", None)}
+    for an, (vn, arr) in names.items():
+        rtc.create_var_with_dims(vn, op.get_dims(an))
+        if arr is not None:
+            rtc.copy_nda_to_var(vn, arr)
+    try:
+        rtc.run(ref_style.conv_call("rsc_f", "rsc_b", "rsc_in", "rsc_out", g)); rtc.finish_and_sync()
+        want = bo.conv_fwd(x, f, b, (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
+        assert np.array_equal(want, rtc.copy_var_to_nda("rsc_out"))
+    finally:
+        for vn, _ in names.values():
+            rtc.release_var(vn)
+        rtc.release_per_call_id_data()
