@@ -1,4 +1,4 @@
-"""A reference-SHAPED sgemm for the same silicon: what Boda's own code generator structure gives on MI355X.
+"""Reference-SHAPED sgemm and conv for the same silicon: what Boda's own code generator structure gives on MI355X.
 
 The reference cannot be built here, so its generated kernels cannot be timed on this GPU.  This module
 restates the *structure* of its default `sgemm` variant -- `op_tune` MNt=8:8, MNb=8:16, Kb=8 (`src/cnn_op.H:18-20`,
