@@ -202,28 +202,6 @@ def googlenet_conv(batch: int) -> ConvPipe:
 # non-conv forward kernels (CUCL dialect, dims as by-value args)
 # ------------------------------------------------------------------------------------------------
 FWD_SRC = """
-// pooling: only in-bounds (non-padding) pixels take part, for max and for average (semantics of test/rtc/pool.cucl)
-CUCL_GLOBAL_KERNEL void fwd_pool( GASQ float const * const in, GASQ float * const out, uint32_t const avg_pool, uint32_t const n_out,
-                                  uint32_t const H, uint32_t const W, uint32_t const OH, uint32_t const OW, uint32_t const KH, uint32_t const KW,
-                                  uint32_t const SY, uint32_t const SX, uint32_t const PY, uint32_t const PX ) {
-  if( GLOB_ID_1D >= n_out ) { return; }
-  uint32_t const ox = GLOB_ID_1D % OW; uint32_t const oy = ( GLOB_ID_1D / OW ) % OH; uint32_t const plane = GLOB_ID_1D / ( OW * OH );
-  GASQ float const * const ip = in + plane * H * W;
-  float out_v = avg_pool ? 0.0f : -FLT_MAX;
-  float avg_pool_sz = 0;
-  for( int32_t kx = 0; kx != (int32_t)KW; ++kx ) {
-    for( int32_t ky = 0; ky != (int32_t)KH; ++ky ) {
-      int const in_y = oy*SY + ky - PY;
-      int const in_x = ox*SX + kx - PX;
-      if( in_y >= 0 && in_x >= 0 && in_x < (int)W && in_y < (int)H ) {
-        float const v = ip[in_y*W + in_x];
-        if( avg_pool ) { out_v += v; avg_pool_sz += 1; } else if( v > out_v ) { out_v = v; }
-      }
-    }
-  }
-  if( avg_pool ) { out_v /= avg_pool_sz; }
-  out[GLOB_ID_1D] = out_v;
-}
 // Concat: copy one input into its channel range of the output (semantics of test/rtc/copy.cucl; src/rtc_fwd.cc:267-280)
 CUCL_GLOBAL_KERNEL void fwd_copy( GASQ float const * const in, GASQ float * const out, uint32_t const n_in, uint32_t const chw_in,
                                   uint32_t const chw_out, uint32_t const off_out ) {
@@ -231,37 +209,21 @@ CUCL_GLOBAL_KERNEL void fwd_copy( GASQ float const * const in, GASQ float * cons
   uint32_t const img = GLOB_ID_1D / chw_in;
   out[img*chw_out + off_out + ( GLOB_ID_1D - img*chw_in )] = in[GLOB_ID_1D];
 }
+// stand-alone ReLU (one that could not be fused into its conv): non-positive values, -0.0 included, become +0.0; NaN passes through
 CUCL_GLOBAL_KERNEL void fwd_relu( GASQ float * const inout, uint32_t const n ) {
-  if( GLOB_ID_1D >= n ) { return; }
-  inout[GLOB_ID_1D] = (inout[GLOB_ID_1D] <= 0) ? 0.0f : inout[GLOB_ID_1D];
-}
-// across-channel LRN, running-sum ("match caffe") form (semantics of test/rtc/lrn.cucl); one thread per (img,y,x)
-CUCL_GLOBAL_KERNEL void fwd_lrn( GASQ float const * const in, GASQ float * const out, float const alpha, float const beta, float const k,
-                                 uint32_t const local_size, uint32_t const n_pel, uint32_t const C, uint32_t const HW ) {
-  if( GLOB_ID_1D >= n_pel ) { return; }
-  float ls_buf[16];
-  for( uint32_t i = 0; i != 16; ++i ) { ls_buf[i] = 0.0f; }
-  int32_t const hls = local_size >> 1;
-  uint32_t const base = ( GLOB_ID_1D / HW ) * C * HW + ( GLOB_ID_1D % HW );
-  float ls_sum = 0.0f;
-  float const alpha_over_ls = alpha / (float)local_size;
-  for( int32_t ic = 0; ic < (int32_t)C + hls; ++ic ) {
-    int32_t const lsb_ix = ic % (int32_t)local_size;
-    float const ls_old = ls_buf[lsb_ix];
-    ls_buf[lsb_ix] = (ic < (int32_t)C) ? in[base + ic*HW] : 0.0f;
-    ls_sum += ls_buf[lsb_ix]*ls_buf[lsb_ix]; ls_sum -= ls_old*ls_old;
-    if( ic >= hls ) {
-      float const scale_base = k + ls_sum*alpha_over_ls;
-      out[base + (ic - hls)*HW] = ls_buf[(lsb_ix + local_size - hls) % local_size] * powf( scale_base, -beta );
-    }
+  uint32_t const i = GLOB_ID_1D;
+  if( i < n ) {
+    float const v = inout[i];
+    if( v <= 0.0f ) { inout[i] = 0.0f; }
   }
 }
 """
 # Pooling as a CUCL *template* (boda_amd/cucl_template.py): one generated function per distinct pooling geometry, window size /
 # stride / padding / plane sizes as constants, so the window loops unroll and the index arithmetic folds -- how the reference
-# specialises its own pool kernel (test/rtc/pool.cucl + src/rtc_func_gen.cc); the generic fwd_pool above stays as the fallback.
+# specialises its own pool kernel (test/rtc/pool.cucl + src/rtc_func_gen.cc).  The window is clipped to the plane once per output
+# (padding pixels never take part, for max or for average); taps are visited column by column, the order the reference sums an
+# average in, so averages come out bit-identical to it; the divisor is the clipped window's area.
 POOL_TEMPLATE = """
-// only in-bounds (non-padding) pixels take part, for max and for average pooling
 CUCL_GLOBAL_KERNEL void %(rtc_func_name)( GASQ float const * const in, // CUCL IN img:chan:y:x
                                           uint32_t const avg_pool, // CUCL IN :
                                           GASQ void const * const kern_sz, // CUCL REF y:x
@@ -271,27 +233,32 @@ CUCL_GLOBAL_KERNEL void %(rtc_func_name)( GASQ float const * const in, // CUCL I
 {
   // CUCL IX GLOB_ID_1D out
   if( GLOB_ID_1D >= %(GLOB_ID_1D_dims_prod) ) { return; }
-  GASQ float const * const ip = in + %(GLOB_ID_1D_img_nomod)*%(in_img_stride) + %(GLOB_ID_1D_chan)*%(in_chan_stride);
-  int32_t const y0 = (int32_t)%(GLOB_ID_1D_y)*%(stride_y_dim) - %(in_pad_y_dim);
+  int32_t const y0 = (int32_t)%(GLOB_ID_1D_y)*%(stride_y_dim) - %(in_pad_y_dim);   // window origin in the plane (may lie in the padding)
   int32_t const x0 = (int32_t)%(GLOB_ID_1D_x)*%(stride_x_dim) - %(in_pad_x_dim);
-  float out_v = %(avg_pool) ? 0.0f : -FLT_MAX;
-  float n_in = 0.0f;
-  for( int32_t ky = 0; ky != %(kern_sz_y_dim); ++ky ) {
-    int32_t const in_y = y0 + ky;
-    if( in_y < 0 || in_y >= %(in_y_dim) ) { continue; }
-    for( int32_t kx = 0; kx != %(kern_sz_x_dim); ++kx ) {
-      int32_t const in_x = x0 + kx;
-      if( in_x < 0 || in_x >= %(in_x_dim) ) { continue; }
-      float const v = ip[in_y*%(in_y_stride) + in_x];
-      if( %(avg_pool) ) { out_v += v; n_in += 1.0f; } else { out_v = ( v > out_v ) ? v : out_v; }
+  int32_t const ty_lo = ( y0 < 0 ) ? -y0 : 0;                                       // taps [t_lo, t_hi) fall inside the plane
+  int32_t const tx_lo = ( x0 < 0 ) ? -x0 : 0;
+  int32_t const ty_hi = ( %(in_y_dim) - y0 < %(kern_sz_y_dim) ) ? %(in_y_dim) - y0 : %(kern_sz_y_dim);
+  int32_t const tx_hi = ( %(in_x_dim) - x0 < %(kern_sz_x_dim) ) ? %(in_x_dim) - x0 : %(kern_sz_x_dim);
+  int32_t const w0 = %(GLOB_ID_1D_img_nomod)*%(in_img_stride) + %(GLOB_ID_1D_chan)*%(in_chan_stride) + y0*%(in_y_stride) + x0;
+  float acc = %(avg_pool) ? 0.0f : -FLT_MAX;
+  for( int32_t tx = 0; tx != %(kern_sz_x_dim); ++tx ) {
+    if( tx < tx_lo || tx >= tx_hi ) { continue; }
+    for( int32_t ty = 0; ty != %(kern_sz_y_dim); ++ty ) {
+      if( ty < ty_lo || ty >= ty_hi ) { continue; }
+      float const v = in[w0 + ty*%(in_y_stride) + tx];
+      acc = %(avg_pool) ? ( acc + v ) : ( ( v > acc ) ? v : acc );
     }
   }
-  if( %(avg_pool) ) { out_v /= n_in; }
-  out[GLOB_ID_1D] = out_v;
+  int32_t const n_y = ( ty_hi > ty_lo ) ? ty_hi - ty_lo : 0;
+  int32_t const n_x = ( tx_hi > tx_lo ) ? tx_hi - tx_lo : 0;
+  if( %(avg_pool) ) { acc /= (float)( n_y*n_x ); }
+  out[GLOB_ID_1D] = acc;
 }
 """
-# across-channel LRN, running-sum form, as a template: local_size, channel count and strides are constants (ring buffer in
-# registers, loops unrolled by the compiler); one thread per (img, y, x)
+# Across-channel LRN as a template: local_size, channel count and strides are constants.  The window of the last local_size inputs
+# lives in a register shift line (newest last); the sum of its squares is carried from channel to channel -- add the entering
+# square, then take away the leaving one, the update order of the reference's caffe-matching path (test/rtc/lrn.cucl:35-50), which
+# the oracle restates -- and   out[c] = in[c] * ( k + sumsq * alpha / local_size ) ^ -beta   once the window is centred on c.
 LRN_TEMPLATE = """
 CUCL_GLOBAL_KERNEL void %(rtc_func_name)( float const alpha, // CUCL IN :
                                           float const beta, // CUCL IN :
@@ -301,36 +268,40 @@ CUCL_GLOBAL_KERNEL void %(rtc_func_name)( float const alpha, // CUCL IN :
                                           GASQ void const * const work, // CUCL REF img:cblk:cblk_sz:y:x
                                           GASQ float * const out ) // CUCL OUT img:chan:y:x
 {
-  // one thread per (img, block of cblk_sz channels, y, x): the window sum runs over its block plus a halo of local_size/2 channels
-  // on either side (a few loads recomputed per block buys cblk x the threads of the one-thread-per-pixel form)
+  // one thread per (img, block of cblk_sz channels, y, x): it slides the window over its block plus a halo of local_size/2 channels
+  // on either side (a few loads repeated per block buys cblk x the threads of a one-thread-per-pixel form)
   // CUCL IX GLOB_ID_1D work use_dims=img:cblk:y:x
   if( GLOB_ID_1D >= %(GLOB_ID_1D_dims_prod) ) { return; }
-  float ls_buf[%(local_size)];
-  for( int32_t i = 0; i != %(local_size); ++i ) { ls_buf[i] = 0.0f; }
-  int32_t const hls = %(local_size) >> 1;
-  int32_t const c0 = (int32_t)%(GLOB_ID_1D_cblk)*%(work_cblk_sz_dim);
-  int32_t const base = %(GLOB_ID_1D_img_nomod)*%(in_img_stride) + %(GLOB_ID_1D_y)*%(in_y_stride) + %(GLOB_ID_1D_x);
-  float ls_sum = 0.0f;
-  float const alpha_over_ls = %(alpha) / (float)%(local_size);
-  for( int32_t j = 0; j < %(work_cblk_sz_dim) + 2*hls; ++j ) {
-    int32_t const ic = c0 - hls + j;      // channel entering the window; the window is then centred on channel ic - hls
-    int32_t const lsb_ix = j %% %(local_size);
-    float const ls_old = ls_buf[lsb_ix];
-    ls_buf[lsb_ix] = (ic >= 0 && ic < %(in_chan_dim)) ? in[base + ic*%(in_chan_stride)] : 0.0f;
-    ls_sum += ls_buf[lsb_ix]*ls_buf[lsb_ix]; ls_sum -= ls_old*ls_old;
-    if( j >= 2*hls && ic - hls < %(in_chan_dim) ) {
-      float const scale_base = %(k) + ls_sum*alpha_over_ls;
-      out[base + (ic - hls)*%(in_chan_stride)] = ls_buf[(lsb_ix + %(local_size) - hls) %% %(local_size)] * powf( scale_base, -%(beta) );
+  int32_t const kHalf = %(local_size) / 2;
+  int32_t const kLast = %(local_size) - 1;
+  int32_t const pel = %(GLOB_ID_1D_img_nomod)*%(in_img_stride) + %(GLOB_ID_1D_y)*%(in_y_stride) + %(GLOB_ID_1D_x);
+  int32_t const c_first = (int32_t)%(GLOB_ID_1D_cblk)*%(work_cblk_sz_dim);      // first channel this thread writes
+  float const per_elem = %(alpha) / (float)%(local_size);
+  float line[%(local_size)];
+  for( int32_t i = 0; i <= kLast; ++i ) { line[i] = 0.0f; }
+  float sumsq = 0.0f;
+  for( int32_t step = 0; step != %(work_cblk_sz_dim) + 2*kHalf; ++step ) {
+    int32_t const c_in = c_first - kHalf + step;          // channel entering the window (zero outside the tensor)
+    int32_t const c_out = c_in - kHalf;                   // channel the window is centred on after this step
+    float const entering = ( c_in >= 0 && c_in < %(in_chan_dim) ) ? in[pel + c_in*%(in_chan_stride)] : 0.0f;
+    float const leaving = line[0];
+    for( int32_t i = 0; i != kLast; ++i ) { line[i] = line[i+1]; }
+    line[kLast] = entering;
+    {
+      // the carried sum loses digits if the compiler regroups it (CUCL sources build with fast-math): keep the written order
+      #pragma clang fp reassociate(off) contract(off)
+      sumsq = ( sumsq + entering*entering ) - leaving*leaving;
+    }
+    if( c_out >= c_first && c_out < %(in_chan_dim) ) {
+      out[pel + c_out*%(in_chan_stride)] = line[kLast - kHalf] * powf( %(k) + sumsq*per_elem, -%(beta) );
     }
   }
 }
 """
 _POOL_T = parse_template("pool", POOL_TEMPLATE)
 _LRN_T = parse_template("lrn", LRN_TEMPLATE)
-FWD_FUNCS = {"fwd_pool": ["in", "out", "avg_pool", "n_out", "H", "W", "OH", "OW", "KH", "KW", "SY", "SX", "PY", "PX"],
-             "fwd_copy": ["in", "out", "n_in", "chw_in", "chw_out", "off_out"],
-             "fwd_relu": ["inout", "n"],
-             "fwd_lrn": ["in", "out", "alpha", "beta", "k", "local_size", "n_pel", "C", "HW"]}
+FWD_FUNCS = {"fwd_copy": ["in", "out", "n_in", "chw_in", "chw_out", "off_out"],
+             "fwd_relu": ["inout", "n"]}
 _TPB = 256
 _u32 = lambda v: RtcArg.scalar(int(v), "uint32_t")
 _f32 = lambda v: RtcArg.scalar(float(v), "float")
@@ -359,7 +330,6 @@ class ConvPipeFwd:
         self._vars: List[str] = []
         self._funcs: List[str] = []
         self.concat_elim = True      # convs write straight into their channel range of a Concat output where legal
-        self.templated_pool = True   # pooling / LRN kernels generated per geometry from POOL_TEMPLATE / LRN_TEMPLATE (False: the generic fwd_pool / fwd_lrn)
 
     # -- init: annotate, fuse, create vars, generate calls, upload params
     def init(self, cp: ConvPipe, op_params: Optional[Dict[str, np.ndarray]] = None, gen_mode: int = 5) -> None:
@@ -431,7 +401,7 @@ class ConvPipeFwd:
                     cat, c_off, _ = self.slices[op.top]
                     am["out"] = RtcArg.var(cat); am["out_chan_off"] = _u32(c_off)
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(gen_fn, am), fn, cop.flops()))
-            elif op.type == "Pooling" and self.templated_pool:
+            elif op.type == "Pooling":
                 i, o = cp.nodes[op.bot], cp.nodes[op.top]
                 none = lambda yx: Nda(Dims(("y", "x"), tuple(yx), "none"), "none")
                 pop = Op({"type": "Pooling", "func_name": "pool"}, {"in": Nda(i), "out": Nda(o), "kern_sz": none(op.kern_sz), "stride": none(op.stride),
@@ -446,14 +416,6 @@ class ConvPipeFwd:
                 am = {"in": RtcArg.var(vn(op.bot)), "out": RtcArg.var(op.top), "avg_pool": _u32(op.avg_pool), "kern_sz": RtcArg.ref(pop.get_dims("kern_sz")),
                       "stride": RtcArg.ref(pop.get_dims("stride")), "in_pad": RtcArg.ref(pop.get_dims("in_pad"))}
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(inst.func_name, am, tpb=inst.tpb, blks=inst.blks), "fwd_pool"))
-            elif op.type == "Pooling":
-                i, o = cp.nodes[op.bot], cp.nodes[op.top]
-                n = o.dims_prod()
-                am = {"in": RtcArg.var(vn(op.bot)), "out": RtcArg.var(op.top), "avg_pool": _u32(op.avg_pool), "n_out": _u32(n),
-                      "H": _u32(i.dsz("y")), "W": _u32(i.dsz("x")), "OH": _u32(o.dsz("y")), "OW": _u32(o.dsz("x")),
-                      "KH": _u32(op.kern_sz[0]), "KW": _u32(op.kern_sz[1]), "SY": _u32(op.stride[0]), "SX": _u32(op.stride[1]),
-                      "PY": _u32(op.in_pad[0]), "PX": _u32(op.in_pad[1])}
-                self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall("fwd_pool", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB), "fwd_pool"))
             elif op.type == "Concat":
                 o = cp.nodes[op.top]; hw = o.dsz("y") * o.dsz("x"); chw_out = o.dsz("chan") * hw
                 c_done = 0
@@ -467,7 +429,7 @@ class ConvPipeFwd:
             elif op.type == "ReLU":
                 n = cp.nodes[op.top].dims_prod()
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall("fwd_relu", {"inout": RtcArg.var(vn(op.bot)), "n": _u32(n)}, tpb=_TPB, blks=(n + _TPB - 1) // _TPB), "fwd_relu"))
-            elif op.type == "LRN" and self.templated_pool:
+            elif op.type == "LRN":
                 d = cp.nodes[op.bot]
                 ls, alpha, beta, k = op.lrn
                 f32 = lambda v: Nda(None, "float", (float(v),))
@@ -485,14 +447,6 @@ class ConvPipeFwd:
                 am = {"in": RtcArg.var(vn(op.bot)), "out": RtcArg.var(op.top), "alpha": _f32(alpha), "beta": _f32(beta), "k": _f32(k), "local_size": _u32(ls),
                       "work": RtcArg.ref(work)}
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(inst.func_name, am, tpb=inst.tpb, blks=inst.blks), "fwd_lrn"))
-            elif op.type == "LRN":
-                d = cp.nodes[op.bot]; hw = d.dsz("y") * d.dsz("x"); n = d.dsz("img") * hw
-                ls, alpha, beta, k = op.lrn
-                if ls > 16:
-                    raise UnsupErr("fwd_lrn: local_size > 16")
-                am = {"in": RtcArg.var(vn(op.bot)), "out": RtcArg.var(op.top), "alpha": _f32(alpha), "beta": _f32(beta), "k": _f32(k),
-                      "local_size": _u32(ls), "n_pel": _u32(n), "C": _u32(d.dsz("chan")), "HW": _u32(hw)}
-                self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall("fwd_lrn", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB), "fwd_lrn"))
         self._alias = alias
         # params: given arrays (copy_ndas_to_vars, src/rtc_fwd.cc:524) or the deterministic on-device pattern
         for pn in self.op_param_names:

@@ -324,52 +324,51 @@ int bo_num_threads(void) {
  * Non-conv forward ops of a full-net rtc_fwd (NiN / AlexNet): pooling, ReLU, LRN.
  * ------------------------------------------------------------------------------------------- */
 
-/* Pooling: test/rtc/pool.cucl:12-40.  Only in-bounds (non-padding) pixels take part, for max AND average; loop order
- * kx outer / ky inner; max starts at -FLT_MAX; average divides by the number of in-bounds pixels.
+/* Pooling, semantics of test/rtc/pool.cucl:12-40: padding pixels never take part, for max or for average; the reference visits
+ * the window column by column (x outer, y inner), which fixes the summation order of an average; a max starts from -FLT_MAX; an
+ * average divides by the number of in-plane taps (a window wholly in the padding gives -FLT_MAX / NaN, as there).  Restated here with the window clipped to the plane up front.
  * Output size uses the Caffe ceil convention (src/conv_util.cc:198-204) -- computed by the caller. */
 void bo_pool_fwd(float const *in, float *out, uint32_t B, uint32_t C, uint32_t H, uint32_t W, uint32_t KH, uint32_t KW,
                  uint32_t SY, uint32_t SX, uint32_t PY, uint32_t PX, uint32_t OH, uint32_t OW, uint32_t avg_pool) {
   int64_t const planes = (int64_t)B * C;
   #pragma omp parallel for schedule(static)
   for (int64_t p = 0; p < planes; ++p) {
-    float const *ip = in + (size_t)p * H * W; float *op = out + (size_t)p * OH * OW;
-    for (uint32_t oy = 0; oy < OH; ++oy) for (uint32_t ox = 0; ox < OW; ++ox) {
-      float out_v = avg_pool ? 0.0f : -3.402823466e+38f; float n = 0.0f;
-      for (uint32_t kx = 0; kx < KW; ++kx) for (uint32_t ky = 0; ky < KH; ++ky) {
-        int32_t const iy = (int32_t)(oy * SY + ky) - (int32_t)PY, ix = (int32_t)(ox * SX + kx) - (int32_t)PX;
-        if (iy >= 0 && ix >= 0 && ix < (int32_t)W && iy < (int32_t)H) {
-          float const v = ip[(size_t)iy * W + ix];
-          if (avg_pool) { out_v += v; n += 1.0f; } else if (v > out_v) { out_v = v; }
+    float const *plane = in + (size_t)p * H * W; float *dst = out + (size_t)p * OH * OW;
+    for (int64_t oy = 0; oy < OH; ++oy) {
+      int64_t const y0 = oy * SY - (int64_t)PY, ya = y0 < 0 ? 0 : y0, yb = (y0 + KH > H) ? (ya > H ? ya : (int64_t)H) : y0 + KH; /* rows [ya, yb) */
+      for (int64_t ox = 0; ox < OW; ++ox) {
+        int64_t const x0 = ox * SX - (int64_t)PX, xa = x0 < 0 ? 0 : x0, xb = (x0 + KW > W) ? (xa > W ? xa : (int64_t)W) : x0 + KW; /* cols */
+        float acc = avg_pool ? 0.0f : -3.402823466e+38f;
+        for (int64_t x = xa; x < xb; ++x) for (int64_t y = ya; y < yb; ++y) {
+          float const v = plane[y * W + x];
+          if (avg_pool) acc += v; else if (v > acc) acc = v;
         }
+        if (avg_pool) acc /= (float)((yb - ya) * (xb - xa));
+        dst[oy * OW + ox] = acc;
       }
-      if (avg_pool) out_v /= n;
-      op[(size_t)oy * OW + ox] = out_v;
     }
   }
 }
-/* ReLU in place: test/rtc/relu.cucl:1-5  ( x <= 0 -> 0 ) */
-void bo_relu(float *inout, uint64_t n) { for (uint64_t i = 0; i < n; ++i) inout[i] = (inout[i] <= 0.0f) ? 0.0f : inout[i]; }
-/* LRN across channels, the LRN_MATCH_CAFFE running-sum form: test/rtc/lrn.cucl:35-50.
- *   scale_base = k + ls_sum * (alpha/local_size);  out = in * powf(scale_base, -beta) */
+/* ReLU in place, semantics of test/rtc/relu.cucl:1-5: every value that is <= 0 (so -0.0 too) becomes +0.0, NaN is kept */
+void bo_relu(float *inout, uint64_t n) { for (float *v = inout; v != inout + n; ++v) if (*v <= 0.0f) *v = 0.0f; }
+/* LRN across channels, semantics of the reference's caffe-matching running-sum path (test/rtc/lrn.cucl:35-50): a window of
+ * local_size channels slides along the channel axis of one pixel; the sum of squares is carried along -- the entering square is
+ * added first, then the leaving one subtracted, an order that matters in float -- and once the window is centred on channel c
+ *   out[c] = in[c] * powf(k + sumsq * (alpha / local_size), -beta).   Channels outside the tensor count as zero. */
 void bo_lrn_fwd(float const *in, float *out, uint32_t B, uint32_t C, uint32_t H, uint32_t W, uint32_t local_size, float alpha, float beta, float k) {
-  int32_t const hls = (int32_t)(local_size >> 1);
-  float const alpha_over_ls = alpha / (float)local_size;
-  size_t const cs = (size_t)H * W;
+  int64_t const half = local_size / 2, plane = (int64_t)H * W, nchan = C;
+  float const per_elem = alpha / (float)local_size;
   #pragma omp parallel for schedule(static)
-  for (int64_t bp = 0; bp < (int64_t)B * (int64_t)cs; ++bp) {
-    size_t const img = (size_t)bp / cs, pel = (size_t)bp % cs;
-    float const *ib = in + img * C * cs + pel; float *ob = out + img * C * cs + pel;
-    float ls_buf[64]; for (uint32_t i = 0; i < local_size; ++i) ls_buf[i] = 0.0f;
-    float ls_sum = 0.0f;
-    for (int32_t ic = 0; ic < (int32_t)C + hls; ++ic) {
-      int32_t const lsb = ic % (int32_t)local_size;
-      float const ls_old = ls_buf[lsb];
-      ls_buf[lsb] = (ic < (int32_t)C) ? ib[(size_t)ic * cs] : 0.0f;
-      ls_sum += ls_buf[lsb] * ls_buf[lsb]; ls_sum -= ls_old * ls_old;
-      if (ic >= hls) {
-        float const scale_base = k + ls_sum * alpha_over_ls;
-        ob[(size_t)(ic - hls) * cs] = ls_buf[(lsb + (int32_t)local_size - hls) % (int32_t)local_size] * powf(scale_base, -beta);
-      }
+  for (int64_t pix = 0; pix < (int64_t)B * plane; ++pix) {
+    int64_t const first = (pix / plane) * nchan * plane + pix % plane;     /* channel 0 of this pixel; channels are `plane` apart */
+    float sumsq = 0.0f;
+    for (int64_t c_in = 0; c_in < nchan + half; ++c_in) {                  /* c_in: channel entering the window */
+      int64_t const c_gone = c_in - (int64_t)local_size, c_mid = c_in - half;
+      float const entering = c_in < nchan ? in[first + c_in * plane] : 0.0f;
+      float const leaving = c_gone >= 0 ? in[first + c_gone * plane] : 0.0f;
+      sumsq += entering * entering;
+      sumsq -= leaving * leaving;
+      if (c_mid >= 0) out[first + c_mid * plane] = in[first + c_mid * plane] * powf(k + sumsq * per_elem, -beta);
     }
   }
 }

@@ -125,3 +125,33 @@ def test_conv_oracle_vs_torch_independent():
         assert out.shape == ref.shape and bo.mrd(ref, out) < 1e-5
         out_nr = bo.conv_fwd(i, f, b, (S, S), (P, P), False)
         assert out_nr.min() < 0
+
+
+def test_pool_lrn_relu_oracle_vs_independent_definitions():
+    """The non-conv oracle ops against their textbook definitions: torch's pooling (Caffe-style: ceil sizes, padding pixels
+    excluded from max and from the average's divisor) and a direct float64 window sum for LRN."""
+    torch = pytest.importorskip("torch")
+    F = torch.nn.functional
+    rng = np.random.default_rng(3)
+    for (B, C, H, W, K, S, P) in [(2, 5, 13, 13, 3, 2, 0), (1, 4, 14, 14, 3, 2, 1), (2, 3, 7, 9, 3, 1, 1), (1, 2, 6, 6, 6, 1, 0), (2, 3, 12, 12, 2, 2, 0)]:
+        x = rng.standard_normal((B, C, H, W), dtype=np.float32)
+        t = torch.from_numpy(x)
+        mx = bo.pool_fwd(x, (K, K), (S, S), (P, P), False)
+        ref = F.max_pool2d(t, K, S, P, ceil_mode=True).numpy()
+        assert mx.shape == ref.shape and np.array_equal(mx, ref)
+        av = bo.pool_fwd(x, (K, K), (S, S), (P, P), True)
+        ones = torch.ones_like(t).double()
+        ssum = F.avg_pool2d(t.double(), K, S, P, ceil_mode=True, count_include_pad=True, divisor_override=1)
+        cnt = F.avg_pool2d(ones, K, S, P, ceil_mode=True, count_include_pad=True, divisor_override=1)
+        assert av.shape == ssum.shape and bo.mrd((ssum / cnt).float().numpy(), av) < 1e-5
+    for (B, C, H, W, ls, alpha, beta, k) in [(2, 11, 3, 4, 5, 1e-2, 0.75, 2.0), (1, 3, 2, 2, 5, 1e-4, 0.75, 1.0), (1, 9, 2, 3, 3, 5e-2, 0.5, 1.5)]:
+        x = rng.standard_normal((B, C, H, W), dtype=np.float32) * 3
+        got = bo.lrn_fwd(x, ls, alpha, beta, k)
+        xd = x.astype(np.float64); want = np.empty_like(xd)
+        for c in range(C):
+            lo, hi = max(0, c - ls // 2), min(C, c + ls // 2 + 1)
+            want[:, c] = xd[:, c] * (k + (xd[:, lo:hi] ** 2).sum(1) * alpha / ls) ** -beta
+        assert bo.mrd(want.astype(np.float32), got) < 1e-5
+    x = np.array([-1.5, -0.0, 0.0, 2.0, np.nan, -np.inf, np.inf], np.float32)
+    y = bo.relu(x)
+    assert np.array_equal(y[[0, 1, 2, 3, 5, 6]], np.array([0, 0, 0, 2, 0, np.inf], np.float32)) and np.isnan(y[4]) and not np.signbit(y[1])
