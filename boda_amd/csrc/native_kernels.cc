@@ -36,6 +36,7 @@ struct native_kernels_t::impl_t {
 native_kernels_t::native_kernels_t(native_host_t *host_) : impl(new impl_t), host(host_) {
   if (char const *e = getenv("BODAHIP_SGEMM_TILE")) impl->tune["sgemm_tile"] = e;
   if (char const *e = getenv("BODAHIP_CONV_TILE")) impl->tune["conv_tile"] = e;
+  if (char const *e = getenv("BODAHIP_K1_STREAM")) impl->tune["k1_stream"] = e;
 }
 native_kernels_t::~native_kernels_t() {
   for (auto &kv : impl->kernels) { if (kv.second.mod) (void)hipModuleUnload(kv.second.mod); }
@@ -55,7 +56,7 @@ void native_kernels_t::check_compile_time(rtc_func_info_t const &fi) {
   rt_err("unknown/unhandled native hip function: " + fn);
 }
 void native_kernels_t::set_tune(string const &key, string const &val) {
-  if (key != "sgemm_tile" && key != "conv_tile") rt_err("set_tune: unknown key '" + key + "'");
+  if (key != "sgemm_tile" && key != "conv_tile" && key != "k1_stream") rt_err("set_tune: unknown key '" + key + "'");
   if (val.empty()) impl->tune.erase(key); else { impl->tune[key] = val; }
 }
 
@@ -148,7 +149,46 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(hipModuleLaunchKernel(k.func, grid, 1, 1, (uint32_t)c.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false; int rows = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false; int rows = 0; };
+
+// Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
+//   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
+// In the returned plan cfg.BI = out_chans per workgroup, cfg.BJ = pels per super-block, cfg.BK = in_chans.
+static bool plan_k1_stream(conv_geom_t const &g, int num_cus, string const &spec, plan_t &p) {
+  (void)num_cus;
+  if (spec == "off" || getenv("BODAHIP_NO_K1_STREAM")) return false;
+  if (!(g.KH == 1 && g.KW == 1 && g.SY == 1 && g.SX == 1 && g.PY == 0 && g.PX == 0)) return false; // (a spec only applies to the shapes the kernel covers)
+  long const Nj = (long)g.B * g.OH * g.OW;
+  int WI = 0, WJ = 0, OCB = 0, CB = 0, MINW = 0;
+  auto regs = [&](int ocb, int cb) { return (g.C + 1) / 2 * cb + 2 * 16 * ocb * cb + 30; }; // operand ring + two accumulator sets
+  auto lds = [&](int wi, int ocb) { long const oct = wi * ocb * 32; return 4 * ((long)((g.C + 1) / 2 * 2) * (oct | 1) + oct); };
+  if (!spec.empty()) {
+    int v[5] = {0, 0, 0, 0, 0}, n = 0; size_t i = 0;
+    while (i < spec.size() && n < 5) { size_t j = spec.find('x', i); if (j == string::npos) j = spec.size(); v[n++] = atoi(spec.substr(i, j - i).c_str()); i = j + 1; }
+    if (n < 4) rt_err("bad k1_stream spec '" + spec + "' (WIxWJxOCBxCB[xMINW])");
+    WI = v[0]; WJ = v[1]; OCB = v[2]; CB = v[3]; MINW = v[4];
+    if (WI < 1 || WJ < 1 || WI * WJ > 16 || OCB < 1 || OCB > 4 || CB < 1 || CB > 2 || regs(OCB, CB) > 256 || lds(WI, OCB) > 160 * 1024)
+      unsup_err("k1_stream: unsupported configuration '" + spec + "' for this shape");
+  } else {
+    // automatic: only where it measured ahead of the tiled kernel (MI355X, steady clocks): few K steps, a long pel axis, one out_chan
+    // tile (the input is streamed once).  NiN cccp1/2 (96->96 @55x55) B=128/256: 86/172 us vs 96/190 tiled; ResNet-50 res2 64->256
+    // @56x56 B=64: 74 vs 81; at small batch or with 64 out_chans the tiled kernel's finer tiles win, and the layout's R+W ceiling
+    // (tools/mem_pattern_probe.py: 2.8-4.2 TB/s on planes that are not a multiple of 128 bytes) bounds both.
+    if (g.C <= 128 && g.OC > 64 && g.OC <= 128 && Nj >= 300000) { WI = 1; WJ = 8; OCB = (g.OC + 31) / 32; CB = 1; }
+    else if (g.C <= 64 && g.OC > 128 && g.OC <= 512 && g.OC % 256 == 0 && Nj >= 150000) { WI = 8; WJ = 1; OCB = g.OC / 256; CB = 2; }
+    else return false;
+    if (regs(OCB, CB) > 250 || lds(WI, OCB) > 80 * 1024) return false;
+  }
+  if (!MINW) { int const r = regs(OCB, CB); MINW = std::max(1, std::min(8, 512 / r)); int const wpw = (WI * WJ + 3) / 4; // waves per SIMD of one workgroup
+               long const by_lds = std::max(1l, (160l * 1024) / lds(WI, OCB)); MINW = (int)std::max(1l, std::min((long)MINW, by_lds * wpw)); }
+  p.stream = true; p.kname = "bodahip_k1_stream_f32";
+  p.cfg.BI = WI * OCB * 32; p.cfg.BJ = WJ * CB * 32; p.cfg.BK = g.C; p.cfg.WI = WI; p.cfg.WJ = WJ; p.cfg.MINW = MINW; p.cfg.SPLITK = 1; p.cfg.MT = 32; p.cfg.PF = 1;
+  p.defs = {"-DKC=" + std::to_string(g.C), "-DHW=" + std::to_string(g.OH * g.OW), "-DWI=" + std::to_string(WI), "-DWJ=" + std::to_string(WJ),
+            "-DOCB=" + std::to_string(OCB), "-DCB=" + std::to_string(CB), "-DMINW=" + std::to_string(MINW), string("-DRELU=") + (g.relu ? "1" : "0"),
+            string("-DEDGE_OC=") + ((g.OC % (WI * OCB * 32)) ? "1" : "0")};
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return true;
+}
 
 // bf16 variant (kernels/gemm_conv_bf16.hip): BK = 32, 32x32x16 MFMA only, chunked staging
 static void bf16_cfg(tile_cfg_t &c, bool gather) {
@@ -180,9 +220,10 @@ static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string
   if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
   return p;
 }
-static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false) {
+static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false, string const &k1s = string()) {
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
-  plan_t p; p.kname = bf16 ? "bodahip_conv_bf16" : "bodahip_conv_f32"; p.bf16 = bf16;
+  plan_t p;
+  if (!bf16 && tile.empty() && plan_k1_stream(g, num_cus, k1s, p)) return p; p.kname = bf16 ? "bodahip_conv_bf16" : "bodahip_conv_f32"; p.bf16 = bf16;
   // output 1x1, no padding, kernel == whole input ("ipconv" case): the im2col row of image j is the contiguous image
   p.ipconv = (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W);
   p.cfg = choose_cfg(g.OC, (int)Nj, (int)Kt, num_cus, !p.ipconv, bf16);
@@ -254,7 +295,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
 }
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
-  return hiprtc_compile(p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32, p.kname, arch, opts, log, true);
+  return hiprtc_compile(p.stream ? k_src_k1_stream_f32 : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32), p.kname, arch, opts, log, true);
 }
 
 static void setup_splitk(native_kernels_t::impl_t *impl, native_host_t *host, gemm_args_t &ga, tile_cfg_t const &cfg, size_t out_elems) {
@@ -360,7 +401,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   if (!Nj || !g.OC) return;
   if (Nj > 0x7fffffffl || Kt > 0x7fffffffl) unsup_err("hip_conv: dims exceed int32");
-  plan_t const p = plan_conv(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), bf16);
+  plan_t const p = plan_conv(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), bf16, tune_of(impl, "k1_stream"));
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
   gemm_args_t ga; memset(&ga, 0, sizeof(ga));
@@ -376,8 +417,21 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   if (out_bytes >= 0xfffffff0ull) unsup_err("hip_conv: out of 4 GiB or more is not supported (32-bit store offsets)");
   ga.D_bytes = (unsigned)out_bytes;
   if (p.rows) { ktab_t const kt = get_rtab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
-  else if (!p.ipconv && !p.k1 && !p.patch) { ktab_t const kt = get_ktab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
+  else if (!p.ipconv && !p.k1 && !p.patch && !p.stream) { ktab_t const kt = get_ktab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
   ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
+  if (p.stream) {
+    // persistent workgroups: as many as fit the chip at the kernel's occupancy, trimmed to the smallest count with the same number of
+    // super-blocks per workgroup (an even deal); workgroup w of an out_chan tile takes super-blocks w, w + kt_per, ...
+    long const slots = std::max(1l, (long)host->nh_num_cus() * std::max(1, cfg.MINW * 4 / (cfg.WI * cfg.WJ)) / ga.tiles_i);
+    long const per = (ga.tiles_j + slots - 1) / slots;
+    ga.kt_per = (int)((ga.tiles_j + per - 1) / per); ga.splitk = 1;
+    void *params[] = {&ga};
+    hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(ga.kt_per * ga.tiles_i), 1, 1, (uint32_t)cfg.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(k1_stream)");
+    last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(ga.kt_per * ga.tiles_i); last_launch.block = cfg.threads();
+    last_launch.flops = 2.0 * Nj * g.OC * Kt;
+    last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
+    return;
+  }
   setup_splitk(impl, host, ga, cfg, (size_t)Nj * g.OC);
   launch(host, k, ga, cfg);
   if (cfg.SPLITK > 1) reduce_splitk(impl, host, ga, Nj * g.OC, true, g.relu, g.OH * g.OW, g.OC);

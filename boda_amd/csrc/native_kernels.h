@@ -6,7 +6,8 @@
 //     hip_sgemm  (alias cublas_sgemm)   args a:K:M  b:K:N  c:M:N                      test/rtc/cublas_sgemm.cucl:1-4
 //     hip_conv   (alias cudnn_conv)     args filts biases in stride(REF) in_pad(REF) out   test/rtc/cudnn_conv.cucl:1-7
 //     hip_sgemm_bf16 / hip_conv_bf16    same contracts; bf16 operands (converted while staging), fp32 accumulate (config 5)
-// and lands them on kernels/gemm_conv_f32.hip, specialised with hiprtc per shape class at first use.
+// and lands them on kernels/gemm_conv_f32.hip (and, for short-K 1x1 convs with a long pel axis, kernels/k1_stream_f32.hip),
+// specialised with hiprtc per shape class at first use.
 #pragma once
 #include "rtc_types.h"
 #include <hip/hip_runtime.h>
@@ -55,7 +56,7 @@ struct native_kernels_t {
   void sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16 = false);
   void conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16 = false, int out_ctot = 0, int out_coff = 0);
 
-  // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"
+  // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"; key "k1_stream" -> "off" | "WIxWJxOCBxCB[xMINW]"
   void set_tune(string const &key, string const &val);
   static size_t prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile);
   launch_info_t last_launch;

@@ -643,3 +643,81 @@ def test_reference_shaped_cucl_conv_matches_oracle(be, shape):
         for vn, _ in names.values():
             rtc.release_var(vn)
         rtc.release_per_call_id_data()
+
+
+K1S_CASES = [  # (B, C, H, W, OC, spec): odd / tiny in_chan counts, out_chans that are not a multiple of the wave's rows, ragged pel tails,
+    (3, 96, 11, 9, 96, "1x4x3x1"),          # blocks straddling images, several out_chan tiles
+    (2, 7, 5, 5, 40, "1x2x2x1"),
+    (5, 33, 13, 13, 70, "2x2x2x2"),
+    (1, 2, 1, 1, 3, "1x1x1x1"),
+    (4, 64, 14, 14, 256, "8x1x1x2"),
+    (2, 128, 8, 8, 130, "4x2x1x1"),
+    (2, 1, 9, 7, 33, "1x4x2x2"),
+    (6, 24, 20, 20, 64, "1x8x2x1"),
+]
+
+
+@pytest.mark.parametrize("case", K1S_CASES, ids=lambda c: "x".join(str(v) for v in c[:5]) + "_" + c[5])
+@pytest.mark.parametrize("relu", [True, False])
+def test_k1_stream_kernel_bit_exact(be, case, relu):
+    """The streaming 1x1 kernel (kernels/k1_stream_f32.hip, tune key k1_stream) forced onto small shapes: same bits as the oracle,
+    and a guard band around the output stays untouched (its stores rely on the buffer range check for the pel tail)."""
+    rtc = be.rtc
+    B, C, H, W, OC, spec = case
+    op = _conv_op(B, C, H, W, OC, 1, 1, 1, 0)
+    anno = add_codegen_annotations(op, OpTune())
+    anno.nda_vals["conv_has_relu"].v = (int(relu),)
+    fn = anno.get_func_name()
+    rtc.compile([RtcFuncInfo("k1s_conv", "", [a for a, _ in NATIVE_ARGS[fn]], anno)])
+    x = bo.gen_conv_in(B, C, H, W); f = bo.gen_conv_filts(OC, C, 1, 1); b = bo.gen_conv_biases(OC)
+    wide = Dims.make("float", img=B, chan=OC + 5, y=H, x=W)
+    names = {"in": ("k1_in", anno.get_dims("in"), x), "filts": ("k1_f", anno.get_dims("filts"), f), "biases": ("k1_b", anno.get_dims("biases"), b),
+             "out": ("k1_out", wide, np.full(wide.sizes, 7.0, np.float32))}
+    for vn, d, arr in names.values():
+        rtc.create_var_with_dims(vn, d); rtc.copy_nda_to_var(vn, arr)
+    try:
+        am = {an: RtcArg.var(names[an][0]) for an in names}
+        am["stride"] = RtcArg.ref(anno.get_dims("stride")); am["in_pad"] = RtcArg.ref(anno.get_dims("in_pad"))
+        am["out_chan_off"] = RtcArg.scalar(2, "uint32_t")
+        rtc.set_tune("k1_stream", spec)
+        rtc.run(RtcFuncCall("k1s_conv", am)); rtc.finish_and_sync()
+        assert rtc.last_launch()["kernel"] == "bodahip_k1_stream_f32"
+        got = rtc.copy_var_to_nda("k1_out")
+        want = bo.conv_fwd(x, f, b, (1, 1), (0, 0), relu)
+        assert np.array_equal(got[:, 2:2 + OC], want), SsdsDiff.of(want, got[:, 2:2 + OC]).basic_str()
+        assert (got[:, :2] == 7).all() and (got[:, 2 + OC:] == 7).all()
+        rtc.set_tune("k1_stream", "off")
+        rtc.run(RtcFuncCall("k1s_conv", am)); rtc.finish_and_sync()
+        assert rtc.last_launch()["kernel"] == "bodahip_conv_f32" and np.array_equal(rtc.copy_var_to_nda("k1_out"), got)
+    finally:
+        rtc.set_tune("k1_stream", "")
+        for vn, _, _ in names.values():
+            rtc.release_var(vn)
+        rtc.release_func("k1s_conv"); rtc.release_per_call_id_data()
+
+
+def test_k1_stream_auto_choice_matches_tiled_kernel(be):
+    """At the sizes where the planner picks the streaming kernel by itself (NiN cccp1 at B=128: 96 -> 96 chans on 55x55) its output is
+    bit-identical to the tiled kernel's (which the oracle pins at small sizes), and a spec never captures shapes it does not cover."""
+    rtc = be.rtc
+    op = _conv_op(128, 96, 55, 55, 96, 1, 1, 1, 0)
+    anno = add_codegen_annotations(op, OpTune()); fn = anno.get_func_name()
+    rtc.compile([RtcFuncInfo("k1s_auto", "", [a for a, _ in NATIVE_ARGS[fn]], anno)])
+    am = {}
+    for an, io in NATIVE_ARGS[fn]:
+        if io == "REF": am[an] = RtcArg.ref(anno.get_dims(an)); continue
+        rtc.create_var_with_dims("k1a_" + an, anno.get_dims(an)); am[an] = RtcArg.var("k1a_" + an)
+        if io == "IN": rtc.run(gd.gen_call("Convolution", an, "k1a_" + an, anno.get_dims(an), 5, 0.0))
+    try:
+        rtc.run(RtcFuncCall("k1s_auto", am)); rtc.finish_and_sync()
+        assert rtc.last_launch()["kernel"] == "bodahip_k1_stream_f32"
+        a = rtc.copy_var_to_nda("k1a_out")
+        rtc.set_tune("k1_stream", "off"); rtc.set_var_to_zero("k1a_out")
+        rtc.run(RtcFuncCall("k1s_auto", am)); rtc.finish_and_sync()
+        assert rtc.last_launch()["kernel"] == "bodahip_conv_f32"
+        assert np.array_equal(a, rtc.copy_var_to_nda("k1a_out")) and float(np.abs(a).max()) > 0
+    finally:
+        rtc.set_tune("k1_stream", "")
+        for an, io in NATIVE_ARGS[fn]:
+            if io != "REF": rtc.release_var("k1a_" + an)
+        rtc.release_func("k1s_auto"); rtc.release_per_call_id_data()
