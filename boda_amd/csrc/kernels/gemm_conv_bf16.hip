@@ -62,6 +62,7 @@ struct gemm_args_t { // identical to gemm_conv_f32.hip (one host-side struct)
   int out_ctot, out_coff;      // EPI 1: channels of the output tensor and first channel written (== Mi, 0 unless the conv writes a slice
                                // of a wider tensor: Concat elimination)
   int const *ktab; int ktab_n;
+  long bsI, bsJ, bsD; // (batched sgemm launches of gemm_conv_f32.hip only)
 };
 
 namespace {

@@ -101,6 +101,7 @@ struct gemm_args_t {
                                // of a wider tensor: Concat elimination)
   int const *ktab; int ktab_n; // J_MODE 2: per-k gather tables, three arrays of ktab_n ints: element offset of (in_chan,ky,kx)
                                // inside one image | ky | kx ; rows k >= K carry ky = 2^30 (fail the row-range test)
+  long bsI, bsJ, bsD;          // batched launches (gridDim.y problems of one shape, e.g. the 16 Winograd-domain sgemms): element strides of I / J / D per blockIdx.y
 };
 
 #ifndef REDUCE_ONLY
@@ -566,7 +567,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   int const nkt = nkt_all;
 #endif
 
-  rsrc_t const rI = make_rsrc(p.I, p.I_bytes), rJ = make_rsrc(p.J, p.J_bytes); // built from kernel args only: provably wave-uniform
+  rsrc_t const rI = make_rsrc(p.I + (long)blockIdx.y * p.bsI, p.I_bytes), rJ = make_rsrc(p.J + (long)blockIdx.y * p.bsJ, p.J_bytes); // kernel args and block ids only: provably wave-uniform
   load_tile<I_MODE, BI, kNI>(ri, rI, p.ldI, i0, p.Mi, kt_begin * BK, p.K, tid);
   load_J(rj, rJ, p, j0, kt_begin * BK, tid GATHER_ARG);
   store_tile<I_MODE, BI, kLDI, kNI>(ri, Is0, tid);
@@ -636,7 +637,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   // store chain per output; rows past the end read 0), and the stores are buffer stores with 32-bit offsets (per-lane column part
   // + a wave-uniform per-row part in the scalar offset operand).  For layers with a short K loop (1x1 convolutions, K = 96..1024) the old per-output chain cost about as much as the K loop itself.
   {
-    rsrc_t const rD = make_rsrc(p.D, p.D_bytes);
+    rsrc_t const rD = make_rsrc(p.D + (long)blockIdx.y * p.bsD, p.D_bytes);
 #if EPI == 1
     rsrc_t const rB = make_rsrc(p.bias, (unsigned)p.Mi * 4u);
     unsigned const S4 = (unsigned)(p.OH * p.OW) * 4u;

@@ -44,6 +44,7 @@ struct gemm_args_t { // same layout as gemm_conv_f32.hip (one host-side struct s
   unsigned D_bytes;
   int out_ctot, out_coff;
   int const *ktab; int ktab_n;
+  long bsI, bsJ, bsD; // (batched sgemm launches of gemm_conv_f32.hip only)
 };
 
 namespace {

@@ -22,6 +22,7 @@ struct gemm_args_t { // must match kernels/gemm_conv_f32.hip
   unsigned D_bytes;
   int out_ctot, out_coff;
   void const *ktab; int ktab_n;
+  long bsI, bsJ, bsD;
 };
 
 struct kernel_t { hipModule_t mod = nullptr; hipFunction_t func = nullptr; };
@@ -31,15 +32,18 @@ struct native_kernels_t::impl_t {
   std::map<string, string> tune;
   void *ws = nullptr; size_t ws_bytes = 0; // split-K partial-sum slabs (grow-only scratch, like the reference's cudnn scratch var)
   std::map<string, void *> ktabs;           // im2col gather tables, one per (C,H,W,KH,KW) (device memory)
+  hipModule_t wino_mod = nullptr; hipFunction_t wino_filt = nullptr, wino_in = nullptr, wino_out = nullptr; // kernels/winograd_f32.hip
 };
 
 native_kernels_t::native_kernels_t(native_host_t *host_) : impl(new impl_t), host(host_) {
   if (char const *e = getenv("BODAHIP_SGEMM_TILE")) impl->tune["sgemm_tile"] = e;
   if (char const *e = getenv("BODAHIP_CONV_TILE")) impl->tune["conv_tile"] = e;
   if (char const *e = getenv("BODAHIP_K1_STREAM")) impl->tune["k1_stream"] = e;
+  if (char const *e = getenv("BODAHIP_CONV_ALGO")) impl->tune["conv_algo"] = e;
 }
 native_kernels_t::~native_kernels_t() {
   for (auto &kv : impl->kernels) { if (kv.second.mod) (void)hipModuleUnload(kv.second.mod); }
+  if (impl->wino_mod) (void)hipModuleUnload(impl->wino_mod);
   if (impl->ws) (void)hipFree(impl->ws);
   for (auto &kv : impl->ktabs) (void)hipFree(kv.second);
   delete impl;
@@ -56,7 +60,8 @@ void native_kernels_t::check_compile_time(rtc_func_info_t const &fi) {
   rt_err("unknown/unhandled native hip function: " + fn);
 }
 void native_kernels_t::set_tune(string const &key, string const &val) {
-  if (key != "sgemm_tile" && key != "conv_tile" && key != "k1_stream") rt_err("set_tune: unknown key '" + key + "'");
+  if (key != "sgemm_tile" && key != "conv_tile" && key != "k1_stream" && key != "conv_algo") rt_err("set_tune: unknown key '" + key + "'");
+  if (key == "conv_algo" && !val.empty() && val != "direct" && val != "winograd" && val != "winograd_all") rt_err("set_tune: conv_algo must be direct | winograd | winograd_all");
   if (val.empty()) impl->tune.erase(key); else { impl->tune[key] = val; }
 }
 
@@ -202,10 +207,10 @@ static void bf16_cfg(tile_cfg_t &c, bool gather) {
   if (!ok) unsup_err("native bf16 kernel: unsupported tile configuration " + c.str());
 }
 
-static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string const &tile, bool bf16 = false) {
+static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string const &tile, bool bf16 = false, int batch = 1) {
   (void)K;
   plan_t p; p.kname = bf16 ? "bodahip_sgemm_bf16" : "bodahip_sgemm_f32"; p.bf16 = bf16;
-  p.cfg = choose_cfg((int)M, (int)N, (int)K, num_cus, false, bf16);
+  p.cfg = choose_cfg((int)M, (int)std::min<uint64_t>((uint64_t)N * batch, 0x7fffffffull), (int)K, num_cus, false, bf16); // (a batch deals batch x the tiles)
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad sgemm_tile '" + tile + "'"); }
   if (bf16) {
     bf16_cfg(p.cfg, false);
@@ -298,6 +303,13 @@ static std::vector<char> compile_plan(plan_t const &p, string const &arch, strin
   return hiprtc_compile(p.stream ? k_src_k1_stream_f32 : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32), p.kname, arch, opts, log, true);
 }
 
+// grow-only scratch shared by the split-K slabs and the Winograd-domain tensors (like the reference's cudnn scratch var)
+static void ensure_ws(native_kernels_t::impl_t *impl, native_host_t *host, size_t need) {
+  if (impl->ws_bytes >= need) return;
+  if (host->nh_capturing()) rt_err("graph capture: kernel workspace not allocated yet -- run the call list once before capturing it");
+  if (impl->ws) { hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize"); hip_err_chk(hipFree(impl->ws), "hipFree"); impl->ws = nullptr; impl->ws_bytes = 0; }
+  hip_err_chk(hipMalloc(&impl->ws, need), "hipMalloc(kernel scratch)"); impl->ws_bytes = need;
+}
 static void setup_splitk(native_kernels_t::impl_t *impl, native_host_t *host, gemm_args_t &ga, tile_cfg_t const &cfg, size_t out_elems) {
   ga.splitk = cfg.SPLITK; ga.kt_per = 0; ga.ws = nullptr; ga.ws_slab = 0;
   if (cfg.SPLITK <= 1) { ga.splitk = 1; return; }
@@ -305,11 +317,7 @@ static void setup_splitk(native_kernels_t::impl_t *impl, native_host_t *host, ge
   ga.kt_per = (nkt + cfg.SPLITK - 1) / cfg.SPLITK;
   size_t const slab = (out_elems + 3) & ~size_t(3);
   size_t const need = slab * (size_t)cfg.SPLITK * sizeof(float);
-  if (impl->ws_bytes < need) {
-    if (host->nh_capturing()) rt_err("graph capture: split-K workspace not allocated yet -- run the call list once before capturing it");
-    if (impl->ws) { hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize"); hip_err_chk(hipFree(impl->ws), "hipFree"); impl->ws = nullptr; impl->ws_bytes = 0; }
-    hip_err_chk(hipMalloc(&impl->ws, need), "hipMalloc(split-k scratch)"); impl->ws_bytes = need;
-  }
+  ensure_ws(impl, host, need);
   ga.ws = (float *)impl->ws; ga.ws_slab = (long)slab;
 }
 
@@ -396,11 +404,90 @@ void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t 
   last_launch.flops = 2.0 * M * N * K; last_launch.algo_bytes = 4.0 * ((double)K * M + (double)K * N + (double)M * N);
 }
 
+// ---- F(2x2,3x3) Winograd path (kernels/winograd_f32.hip): opt-in, tune key conv_algo = "winograd" -----------------------------------
+struct wino_args_t { // must match kernels/winograd_f32.hip
+  float const *in; float const *filts; float const *bias; float *out;
+  float *U; float *V; float *M;
+  int B0, Bc;
+  int C, H, W, OC, OH, OW;
+  int TH, TW, Tc;
+  int PY, PX, relu;
+  int out_ctot, out_coff;
+};
+// conv_algo = "winograd_all": every 3x3 / stride-1 convolution; "winograd": only where it measured ahead of the direct kernel -- with
+// fewer than 96 input channels the transform-domain sgemms are too short (K = in_chan) and the streaming transforms dominate
+// (ResNet res2 64->64 @56x56: 228 vs 179 us direct; res3 128->128 @28x28: 145 vs 172; res4 256->256 @14x14: 108 vs 185)
+static bool winograd_applies(conv_geom_t const &g, string const &algo) {
+  if (!(g.KH == 3 && g.KW == 3 && g.SY == 1 && g.SX == 1)) return false;
+  return algo == "winograd_all" || (algo == "winograd" && g.C >= 96 && g.OC >= 64);
+}
+void native_kernels_t::conv_winograd(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, int out_ctot, int out_coff) {
+  if (!impl->wino_mod) {
+    if (host->nh_capturing()) rt_err("graph capture: Winograd transform kernels are not compiled yet -- run the call list once before capturing it");
+    string log;
+    std::vector<char> code = hiprtc_compile(k_src_winograd_f32, "bodahip_winograd", host->nh_arch(), {}, &log, true);
+    hip_err_chk(hipModuleLoadData(&impl->wino_mod, code.data()), "hipModuleLoadData(winograd)");
+    hip_err_chk(hipModuleGetFunction(&impl->wino_filt, impl->wino_mod, "bodahip_wino_filt"), "hipModuleGetFunction(wino_filt)");
+    hip_err_chk(hipModuleGetFunction(&impl->wino_in, impl->wino_mod, "bodahip_wino_in"), "hipModuleGetFunction(wino_in)");
+    hip_err_chk(hipModuleGetFunction(&impl->wino_out, impl->wino_mod, "bodahip_wino_out"), "hipModuleGetFunction(wino_out)");
+  }
+  int const TH = (g.OH + 1) / 2, TW = (g.OW + 1) / 2, tpi = TH * TW;
+  // images per chunk: bounds the scratch (V + M <= 1 GiB; BODAHIP_WINO_CHUNK_MB overrides); a multiple of 4 keeps the sgemm's N on its
+  // vector-load path.  Measured: chunks small enough to keep V and M inside the 256 MB Infinity Cache (96 / 192 MB) LOSE 5 % to
+  // one big batched sgemm (AlexNet conv4 B=256: 713 / 715 vs 674 us) -- the shorter sgemms cost more than the HBM round trip saves.
+  size_t const per_img = (size_t)16 * (g.C + g.OC) * tpi * 4;
+  size_t chunk_mb = 1024; if (char const *e = getenv("BODAHIP_WINO_CHUNK_MB")) chunk_mb = (size_t)std::max(1, atoi(e));
+  long Bc = std::max<long>(1, std::min<long>(g.B, (long)((chunk_mb << 20) / per_img)));
+  if (Bc >= 4) Bc &= ~3l;
+  long const Tc_max = Bc * tpi;
+  if ((uint64_t)g.C * Tc_max * 4 >= 0x7ffffff0ull || (uint64_t)g.OC * Tc_max * 4 >= 0x7ffffff0ull) unsup_err("hip_conv (winograd): transformed planes of 2 GiB or more");
+  size_t const nU = (size_t)16 * g.C * g.OC, nV = (size_t)16 * g.C * Tc_max, nM = (size_t)16 * g.OC * Tc_max;
+  ensure_ws(impl, host, (nU + nV + nM) * sizeof(float));
+  wino_args_t wa; memset(&wa, 0, sizeof(wa));
+  wa.in = in; wa.filts = filts; wa.bias = biases; wa.out = out;
+  wa.U = (float *)impl->ws; wa.V = wa.U + nU; wa.M = wa.V + nV;
+  wa.C = g.C; wa.H = g.H; wa.W = g.W; wa.OC = g.OC; wa.OH = g.OH; wa.OW = g.OW; wa.TH = TH; wa.TW = TW; wa.PY = g.PY; wa.PX = g.PX; wa.relu = g.relu ? 1 : 0;
+  wa.out_ctot = out_ctot; wa.out_coff = out_coff;
+  void *wparams[] = {&wa};
+  auto launch1 = [&](hipFunction_t f, long n, char const *what) {
+    hip_err_chk(hipModuleLaunchKernel(f, (uint32_t)((n + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), wparams, nullptr), what);
+  };
+  launch1(impl->wino_filt, (long)g.C * g.OC, "hipModuleLaunchKernel(wino_filt)");
+  string const tile = tune_of(impl, "sgemm_tile");
+  tile_cfg_t last_cfg; uint32_t last_grid = 0;
+  for (long b0 = 0; b0 < g.B; b0 += Bc) {
+    long const bc = std::min<long>(Bc, g.B - b0), Tc = bc * tpi;
+    wa.B0 = (int)b0; wa.Bc = (int)bc; wa.Tc = (int)Tc;
+    launch1(impl->wino_in, (long)g.C * Tc, "hipModuleLaunchKernel(wino_in)");
+    plan_t const p = plan_sgemm((uint32_t)g.OC, (uint32_t)Tc, (uint32_t)g.C, host->nh_num_cus(), tile, false, 16);
+    if (p.cfg.SPLITK > 1) unsup_err("hip_conv (winograd): split-K sgemm tiles are not supported for the batched transform-domain sgemm");
+    kernel_t &k = get_kernel(impl, host, p);
+    gemm_args_t ga; memset(&ga, 0, sizeof(ga));
+    ga.I = wa.U; ga.J = wa.V; ga.D = wa.M;
+    ga.Mi = g.OC; ga.Nj = (int)Tc; ga.K = g.C; ga.ldI = g.OC; ga.ldJ = (int)Tc; ga.ldD = (int)Tc;
+    ga.I_bytes = (unsigned)((uint64_t)g.C * g.OC * 4); ga.J_bytes = (unsigned)((uint64_t)g.C * Tc * 4); ga.D_bytes = (unsigned)((uint64_t)g.OC * Tc * 4);
+    ga.bsI = (long)g.C * g.OC; ga.bsJ = (long)g.C * Tc; ga.bsD = (long)g.OC * Tc;
+    ga.tiles_i = (g.OC + p.cfg.BI - 1) / p.cfg.BI; ga.tiles_j = (int)((Tc + p.cfg.BJ - 1) / p.cfg.BJ); ga.splitk = 1;
+    void *gparams[] = {&ga};
+    hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j), 16, 1, (uint32_t)p.cfg.threads(), 1, 1, 0, host->nh_stream(), gparams, nullptr),
+                "hipModuleLaunchKernel(winograd sgemm)");
+    launch1(impl->wino_out, (long)g.OC * Tc, "hipModuleLaunchKernel(wino_out)");
+    last_cfg = p.cfg; last_grid = (uint32_t)(ga.tiles_i * ga.tiles_j * 16);
+  }
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * 9;
+  last_launch.kernel = "bodahip_conv_winograd_f32"; last_launch.cfg = last_cfg; last_launch.grid = last_grid; last_launch.block = last_cfg.threads();
+  last_launch.flops = 2.0 * Nj * g.OC * Kt; // effective flops, as the reference credits any fast algorithm (src/latex-util.H:116-133)
+  last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
+}
+
 void native_kernels_t::conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16, int out_ctot, int out_coff) {
   if (out_ctot <= 0) { out_ctot = g.OC; out_coff = 0; }
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   if (!Nj || !g.OC) return;
   if (Nj > 0x7fffffffl || Kt > 0x7fffffffl) unsup_err("hip_conv: dims exceed int32");
+  if (!bf16 && winograd_applies(g, tune_of(impl, "conv_algo")) && tune_of(impl, "conv_tile").empty()) {
+    conv_winograd(filts, biases, in, out, g, out_ctot, out_coff); return;
+  }
   plan_t const p = plan_conv(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), bf16, tune_of(impl, "k1_stream"));
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);

@@ -56,7 +56,10 @@ struct native_kernels_t {
   void sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16 = false);
   void conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16 = false, int out_ctot = 0, int out_coff = 0);
 
-  // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"; key "k1_stream" -> "off" | "WIxWJxOCBxCB[xMINW]"
+  void conv_winograd(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, int out_ctot, int out_coff);
+
+  // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"; key "k1_stream" -> "off" | "WIxWJxOCBxCB[xMINW]";
+  // key "conv_algo" -> "winograd": 3x3 / stride-1 convs go through the F(2x2,3x3) path (kernels/winograd_f32.hip; not bit-exact)
   void set_tune(string const &key, string const &val);
   static size_t prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile);
   launch_info_t last_launch;
