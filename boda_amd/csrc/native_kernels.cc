@@ -433,8 +433,10 @@ void native_kernels_t::conv_winograd(float const *filts, float const *biases, fl
   }
   int const TH = (g.OH + 1) / 2, TW = (g.OW + 1) / 2, tpi = TH * TW;
   // images per chunk: bounds the scratch (V + M <= 1 GiB; BODAHIP_WINO_CHUNK_MB overrides); a multiple of 4 keeps the sgemm's N on its
-  // vector-load path.  Measured: chunks small enough to keep V and M inside the 256 MB Infinity Cache (96 / 192 MB) LOSE 5 % to
-  // one big batched sgemm (AlexNet conv4 B=256: 713 / 715 vs 674 us) -- the shorter sgemms cost more than the HBM round trip saves.
+  // vector-load path.  Measured: (a) chunks small enough to keep V and M inside the 256 MB Infinity Cache (96 / 192 MB) LOSE 5 % to
+  // one big batched sgemm (AlexNet conv4 B=256: 713 / 715 vs 674 us) -- the shorter sgemms cost more than the HBM round trip saves;
+  // (b) a three-stream pipeline over chunks (input transform k+1 | sgemm k | output transform k-1, event-linked) is slower still
+  // (2 / 4 / 8 chunks: 722 / 741 / 808 us): each cross-stream event wait costs more than the ~40 us of transform it would hide.
   size_t const per_img = (size_t)16 * (g.C + g.OC) * tpi * 4;
   size_t chunk_mb = 1024; if (char const *e = getenv("BODAHIP_WINO_CHUNK_MB")) chunk_mb = (size_t)std::max(1, atoi(e));
   long Bc = std::max<long>(1, std::min<long>(g.B, (long)((chunk_mb << 20) / per_img)));
