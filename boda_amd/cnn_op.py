@@ -31,6 +31,7 @@ class OpTune:
     tconv_max_ksz: tuple = (11, 11)
     ipconv: int = 0
     hip_dtype: str = ""  # extension: "" / "f32" = exact fp32 MFMA path; "bf16" = bf16 operands, fp32 accumulate (BASELINE config 5)
+    hip_algo: str = ""  # extension: "" = the bit-exact direct kernels; "winograd": func hip_conv_winograd (3x3 / stride-1 layers through F(2x2,3x3), mrd <= ~2e-3)
     hip_tile: str = ""  # extension: workgroup tile of the native kernels "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF]]]]" ("" = heuristic)
 
     _ALWAYS = ("MNt", "MNb", "tconv_max_ksz")  # u32_pt_t fields print as "8 8" != default text "8:8": always dumped
@@ -50,7 +51,7 @@ class OpTune:
                 if len(parts) != 2:
                     raise RtErr(f"op_tune: {k} needs two values")
                 setattr(t, k, (int(parts[0]), int(parts[1])))
-            elif k in ("use_be", "hip_tile", "hip_dtype"):
+            elif k in ("use_be", "hip_tile", "hip_dtype", "hip_algo"):
                 setattr(t, k, str(v))
             else:
                 setattr(t, k, int(v))
@@ -103,7 +104,7 @@ def add_codegen_annotations(op: Op, tune: OpTune) -> Op:
         if tune.use_culibs:
             a.set_func_name("cudnn_conv")
         elif native and not (tune.k1conv or tune.tconv or tune.ipconv):
-            a.set_func_name("hip_conv_bf16" if tune.hip_dtype == "bf16" else "hip_conv")
+            a.set_func_name("hip_conv_bf16" if tune.hip_dtype == "bf16" else ("hip_conv_winograd" if tune.hip_algo == "winograd" else "hip_conv"))
         else:
             raise UnsupErr(f"variant '{ref_conv_variant(op, tune)}' is generated by the reference's CUCL code generator; "
                            f"be=hip provides hip_conv / cudnn_conv (op_tune={tune.to_str()})")
@@ -128,4 +129,5 @@ NATIVE_ARGS: Dict[str, tuple] = {
     "hip_conv_bf16": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
     "hip_conv": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
     "cudnn_conv": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
+    "hip_conv_winograd": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
 }

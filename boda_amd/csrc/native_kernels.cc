@@ -56,7 +56,7 @@ bool native_kernels_t::is_native_func_name(string const &fn) {
 void native_kernels_t::check_compile_time(rtc_func_info_t const &fi) {
   string const &fn = fi.op.get_func_name();
   if (fn == "hip_sgemm" || fn == "cublas_sgemm" || fn == "hip_sgemm_bf16") return;
-  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
+  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
   rt_err("unknown/unhandled native hip function: " + fn);
 }
 void native_kernels_t::set_tune(string const &key, string const &val) {
@@ -482,12 +482,12 @@ void native_kernels_t::conv_winograd(float const *filts, float const *biases, fl
   last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
 }
 
-void native_kernels_t::conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16, int out_ctot, int out_coff) {
+void native_kernels_t::conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16, int out_ctot, int out_coff, char const *algo) {
   if (out_ctot <= 0) { out_ctot = g.OC; out_coff = 0; }
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   if (!Nj || !g.OC) return;
   if (Nj > 0x7fffffffl || Kt > 0x7fffffffl) unsup_err("hip_conv: dims exceed int32");
-  if (!bf16 && winograd_applies(g, tune_of(impl, "conv_algo")) && tune_of(impl, "conv_tile").empty()) {
+  if (!bf16 && winograd_applies(g, algo ? string(algo) : tune_of(impl, "conv_algo")) && tune_of(impl, "conv_tile").empty()) {
     conv_winograd(filts, biases, in, out, g, out_ctot, out_coff); return;
   }
   plan_t const p = plan_conv(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), bf16, tune_of(impl, "k1_stream"));
@@ -596,7 +596,7 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     sgemm((float const *)host->nh_var_ptr(an), (float const *)host->nh_var_ptr(bn), (float *)host->nh_var_ptr(cn), M, N, K, bf16);
     return;
   }
-  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16") {
+  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd") {
     string const fnm = var_of(am, "filts"), bnm = var_of(am, "biases"), inm = var_of(am, "in"), onm = var_of(am, "out");
     dims_t const f = host->nh_var_dims(fnm), bi = host->nh_var_dims(bnm), in = host->nh_var_dims(inm), out = host->nh_var_dims(onm);
     need_float(f, "filts"); need_float(bi, "biases"); need_float(in, "in"); need_float(out, "out");
@@ -620,7 +620,8 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     if (!g.SY || !g.SX) rt_err("hip_conv: zero stride");
     // out = (in + 2*pad - k)/stride + 1, floor (src/conv_util.cc:167-173)
     if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW) rt_err("hip_conv: out dims do not match in/filts/stride/in_pad");
-    conv((float const *)host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), (float const *)host->nh_var_ptr(inm), (float *)host->nh_var_ptr(onm), g, bf16, out_ctot, out_coff);
+    conv((float const *)host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), (float const *)host->nh_var_ptr(inm), (float *)host->nh_var_ptr(onm), g, bf16, out_ctot, out_coff,
+         (fn == "hip_conv_winograd") ? "winograd_all" : nullptr); // hip_conv_winograd: the F(2x2,3x3) path for this function (3x3 / stride 1; others: direct)
     return;
   }
   rt_err("unknown/unhandled native hip function: " + fn);

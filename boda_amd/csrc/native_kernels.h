@@ -6,6 +6,7 @@
 //     hip_sgemm  (alias cublas_sgemm)   args a:K:M  b:K:N  c:M:N                      test/rtc/cublas_sgemm.cucl:1-4
 //     hip_conv   (alias cudnn_conv)     args filts biases in stride(REF) in_pad(REF) out   test/rtc/cudnn_conv.cucl:1-7
 //     hip_sgemm_bf16 / hip_conv_bf16    same contracts; bf16 operands (converted while staging), fp32 accumulate (config 5)
+//     hip_conv_winograd                 same contract as hip_conv; 3x3 / stride-1 layers through F(2x2,3x3) Winograd (mrd <= ~2e-3)
 // and lands them on kernels/gemm_conv_f32.hip (and, for short-K 1x1 convs with a long pel axis, kernels/k1_stream_f32.hip),
 // specialised with hiprtc per shape class at first use.
 #pragma once
@@ -54,7 +55,8 @@ struct native_kernels_t {
 
   // direct entry points on raw device pointers (used by run() and by the C ABI's fast paths)
   void sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16 = false);
-  void conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16 = false, int out_ctot = 0, int out_coff = 0);
+  void conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16 = false, int out_ctot = 0, int out_coff = 0,
+            char const *algo = nullptr);
 
   void conv_winograd(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, int out_ctot, int out_coff);
 

@@ -766,3 +766,21 @@ def test_winograd_conv_within_reference_tolerance(be, case, relu):
         for vn, _, _ in names.values():
             rtc.release_var(vn)
         rtc.release_func("wino_conv"); rtc.release_per_call_id_data()
+
+
+def test_winograd_by_func_name_through_op_tune(be):
+    """op_tune hip_algo=winograd -> func hip_conv_winograd: the Winograd path for that function only (3x3 / stride 1), the exact direct
+    kernel for shapes it does not cover, nothing sticky on the backend."""
+    rtc = be.rtc
+    wino = OpTune.parse("(hip_algo=winograd)")
+    assert add_codegen_annotations(_conv_op(2, 6, 12, 12, 10, 3, 3, 1, 1), wino).get_func_name() == "hip_conv_winograd"
+    outs, _ = _run(be, _conv_op(2, 6, 12, 12, 10, 3, 3, 1, 1), tune=wino)
+    assert rtc.last_launch()["kernel"] == "bodahip_conv_winograd_f32"
+    want = bo.conv_fwd(bo.gen_conv_in(2, 6, 12, 12), bo.gen_conv_filts(10, 6, 3, 3), bo.gen_conv_biases(10), (1, 1), (1, 1), True)
+    sd = SsdsDiff.of(want, outs["out"])
+    assert not sd.has_nan() and 0 < sd.mrd < 5e-4, sd.basic_str()
+    outs, _ = _run(be, _conv_op(2, 6, 12, 12, 10, 5, 5, 2, 1), tune=wino)
+    assert rtc.last_launch()["kernel"] == "bodahip_conv_f32"
+    assert np.array_equal(outs["out"], bo.conv_fwd(bo.gen_conv_in(2, 6, 12, 12), bo.gen_conv_filts(10, 6, 5, 5), bo.gen_conv_biases(10), (2, 2), (1, 1), True))
+    outs, _ = _run(be, _conv_op(2, 6, 12, 12, 10, 3, 3, 1, 1))
+    assert rtc.last_launch()["kernel"] == "bodahip_conv_f32" and np.array_equal(outs["out"], want)
