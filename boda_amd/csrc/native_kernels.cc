@@ -154,7 +154,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(hipModuleLaunchKernel(k.func, grid, 1, 1, (uint32_t)c.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false; int rows = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, patch16 = false; int rows = 0, cg = 0; };
 
 // Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
 //   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
@@ -225,10 +225,48 @@ static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string
   if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
   return p;
 }
+// bf16 convolution from a channel-innermost LDS patch (kernels/conv_patch_bf16.hip): KH x KW kernels, stride 1 in x, in_chan % 8 == 0
+static bool plan_patch_bf16(conv_geom_t const &g, int num_cus, plan_t &p) {
+  if (getenv("BODAHIP_NO_PATCH16")) return false;
+  int const taps = g.KH * g.KW;
+  if (!(g.SX == 1 && taps >= 2 && g.KH >= g.SY && g.C % 8 == 0 && g.C >= 16)) return false;
+  if (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W) return false; // ("ipconv" shapes stay on the j-major path)
+  int cg = 1; while ((cg * taps) % 2 || cg * taps < 16) ++cg;                 // k-slots per K step: even, >= 16
+  if (cg > 4) return false;
+  long const Nj = (long)g.B * g.OH * g.OW;
+  int const wp = g.W + 2 * g.PX;
+  auto lds = [&](int bi, int bj) {
+    int const rows_max = (bj - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
+    long const cs = (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp;
+    return 16l * ((long)cg * taps * bi + cg * cs);
+  };
+  struct cand_t { int bi, bj, wi, wj; };
+  static cand_t const cands[] = {{128, 128, 2, 2}, {64, 128, 1, 4}, {64, 64, 2, 2}};
+  int pick = -1;
+  for (int ci = 0; ci < 3; ++ci) {
+    cand_t const &c = cands[ci];
+    if (lds(c.bi, c.bj) > 64 * 1024) continue;
+    long const tiles = (long)((g.OC + c.bi - 1) / c.bi) * ((Nj + c.bj - 1) / c.bj);
+    if (pick < 0) pick = ci;
+    if (tiles >= (long)num_cus * 3 / 2) { pick = ci; break; }                 // the largest tile that still gives every CU work
+    pick = ci;
+  }
+  if (pick < 0) return false;
+  cand_t const &c = cands[pick];
+  p.patch16 = true; p.bf16 = true; p.cg = cg; p.kname = "bodahip_conv_patch_bf16";
+  p.cfg.BI = c.bi; p.cfg.BJ = c.bj; p.cfg.BK = cg * 8 * taps; p.cfg.WI = c.wi; p.cfg.WJ = c.wj; p.cfg.MINW = 2; p.cfg.SPLITK = 1; p.cfg.MT = 32; p.cfg.PF = 1;
+  p.defs = {"-DBI=" + std::to_string(c.bi), "-DBJ=" + std::to_string(c.bj), "-DWI=" + std::to_string(c.wi), "-DWJ=" + std::to_string(c.wj), "-DMINW=2",
+            "-DCG=" + std::to_string(cg), "-DKH=" + std::to_string(g.KH), "-DKW=" + std::to_string(g.KW), "-DSY=" + std::to_string(g.SY),
+            "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX), "-DCH=" + std::to_string(g.H), "-DCW=" + std::to_string(g.W),
+            "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW), string("-DRELU=") + (g.relu ? "1" : "0")};
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return true;
+}
 static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false, string const &k1s = string()) {
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   plan_t p;
-  if (!bf16 && tile.empty() && plan_k1_stream(g, num_cus, k1s, p)) return p; p.kname = bf16 ? "bodahip_conv_bf16" : "bodahip_conv_f32"; p.bf16 = bf16;
+  if (!bf16 && tile.empty() && plan_k1_stream(g, num_cus, k1s, p)) return p;
+  if (bf16 && tile.empty() && plan_patch_bf16(g, num_cus, p)) return p; p.kname = bf16 ? "bodahip_conv_bf16" : "bodahip_conv_f32"; p.bf16 = bf16;
   // output 1x1, no padding, kernel == whole input ("ipconv" case): the im2col row of image j is the contiguous image
   p.ipconv = (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W);
   p.cfg = choose_cfg(g.OC, (int)Nj, (int)Kt, num_cus, !p.ipconv, bf16);
@@ -300,7 +338,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
 }
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
-  return hiprtc_compile(p.stream ? k_src_k1_stream_f32 : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32), p.kname, arch, opts, log, true);
+  return hiprtc_compile(p.patch16 ? k_src_conv_patch_bf16 : (p.stream ? k_src_k1_stream_f32 : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
 }
 
 // grow-only scratch shared by the split-K slabs and the Winograd-domain tensors (like the reference's cudnn scratch var)
@@ -506,8 +544,29 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   if (out_bytes >= 0xfffffff0ull) unsup_err("hip_conv: out of 4 GiB or more is not supported (32-bit store offsets)");
   ga.D_bytes = (unsigned)out_bytes;
   if (p.rows) { ktab_t const kt = get_rtab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
-  else if (!p.ipconv && !p.k1 && !p.patch && !p.stream) { ktab_t const kt = get_ktab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
+  else if (!p.ipconv && !p.k1 && !p.patch && !p.stream && !p.patch16) { ktab_t const kt = get_ktab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
   ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
+  if (p.patch16) {
+    // filters re-laid-out once per call into F'[group][tap][out_chan][8] bf16 (scratch), then the patch kernel
+    int const taps = g.KH * g.KW, ncg = (g.C + 7) / 8;
+    size_t const fbytes = (size_t)ncg * taps * g.OC * 16;
+    if (fbytes >= 0x7ffffff0ull) unsup_err("hip_conv_bf16: re-laid-out filters of 2 GiB or more");
+    ensure_ws(impl, host, fbytes);
+    plan_t fp; fp.patch16 = true; fp.bf16 = true; fp.kname = "bodahip_filt_bf16"; fp.defs = {"-DFILT_ONLY=1"};
+    kernel_t &fk = get_kernel(impl, host, fp);
+    gemm_args_t fa; memset(&fa, 0, sizeof(fa));
+    fa.I = filts; fa.D = (float *)impl->ws; fa.Mi = g.OC; fa.C = g.C; fa.K = taps;
+    void *fparams[] = {&fa};
+    long const nchunks = (long)ncg * taps * g.OC;
+    hip_err_chk(hipModuleLaunchKernel(fk.func, (uint32_t)((nchunks + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), fparams, nullptr), "hipModuleLaunchKernel(filt_bf16)");
+    ga.I = (float const *)impl->ws; ga.I_bytes = (unsigned)fbytes;
+    void *params[] = {&ga};
+    hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j), 1, 1, (uint32_t)cfg.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(conv_patch_bf16)");
+    last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(ga.tiles_i * ga.tiles_j); last_launch.block = cfg.threads();
+    last_launch.flops = 2.0 * Nj * g.OC * Kt;
+    last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
+    return;
+  }
   if (p.stream) {
     // persistent workgroups: as many as fit the chip at the kernel's occupancy, trimmed to the smallest count with the same number of
     // super-blocks per workgroup (an even deal); workgroup w of an out_chan tile takes super-blocks w, w + kt_per, ...
@@ -549,6 +608,7 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
     p = plan_conv(geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims("out"), op.get_dims("stride"), op.get_dims("in_pad"), relu), num_cus, tile, bf16);
   } else rt_err("prebuild: op type '" + t + "' has no native kernel");
   size_t const n = compile_plan(p, arch, &log).size();
+  if (p.patch16) { plan_t fp; fp.patch16 = true; fp.bf16 = true; fp.kname = "bodahip_filt_bf16"; fp.defs = {"-DFILT_ONLY=1"}; compile_plan(fp, arch, &log); }
   if (p.cfg.SPLITK > 1) { // the matching second-pass kernel
     plan_t r; r.kname = "bodahip_splitk_reduce"; bool const epi = (t == "Convolution");
     bool const relu = epi && (op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true);

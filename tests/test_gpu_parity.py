@@ -429,11 +429,12 @@ def test_ops_prof_harness_end_to_end(be, golden_dir, tmp_path):
 # ---------------------------------------------------------------------------------------------------------------
 # bf16-operand kernels (BASELINE config 5).  The reference has no bf16 path: parity is UNPINNED for them by construction.
 # Stated bounds: (1) vs the oracle fed the same bf16-rounded operands (only the fp32 summation order differs: the 16-deep
-# MFMA is not a sequential chain): max-rel-diff < 5e-4 (measured worst 2.3e-4 at K=2048);  (2) vs the exact fp32 oracle:
+# MFMA is not a sequential chain, and the patch kernel orders k channel-innermost): max-rel-diff < 1e-3 (measured worst 5.2e-4 at
+# K = 2400, AlexNet conv2's 5x5 x 96 channels, through conv_patch_bf16.hip; 2.3e-4 at K=2048 through the gather kernel);  (2) vs the exact fp32 oracle:
 # normalised RMS error < 1e-2
 # (bf16 has 8 mantissa bits: ~2^-9 relative rounding per operand).
 # ---------------------------------------------------------------------------------------------------------------
-MRD_BF16 = 5e-4
+MRD_BF16 = 1e-3
 
 
 def _nrms(want, got):

@@ -9,8 +9,11 @@ def conv_op(B,C,H,W,OC,K=1,S=1,P=0):
         "biases":d(("out_chan",),(OC,)),"out":d(("img","chan","y","x"),(B,OC,OH,OW)),"stride":none((S,S)),"in_pad":none((P,P)),"kern_sz":none((K,K)),
         "conv_has_relu":Nda(None,"uint32_t",(1,))})
 t0=time.time()
-B,C,H,OC=[int(x) for x in sys.argv[1:5]]
-n=rtc.prebuild(conv_op(B,C,H,H,OC))
+a=[int(x) for x in sys.argv[1:8]]+[1,1,0][len(sys.argv)-5:] if len(sys.argv)<8 else [int(x) for x in sys.argv[1:8]]
+B,C,H,OC,K,S,P=a
+op=conv_op(B,C,H,H,OC,K,S,P)
+if os.environ.get("BF16"): op.str_vals["func_name"]="hip_conv_bf16"
+n=rtc.prebuild(op)
 print("code bytes",n)
 f=max(glob.glob("boda_amd/_kcache/*.hsaco"),key=os.path.getmtime)
 print(f)
