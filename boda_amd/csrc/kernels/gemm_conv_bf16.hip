@@ -48,6 +48,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef RELU
 #define RELU 0
 #endif
+#ifndef SPLITK
+#define SPLITK 0 // 1: the grid is tiles x p.splitk; slice s accumulates K-tiles [s*kt_per, (s+1)*kt_per) and stores its raw partial tile to slab s
+#endif           // of p.ws; bodahip_splitk_reduce (gemm_conv_f32.hip) sums the slabs and applies the epilogue.  Chosen by the host for
+                 // tile-starved shapes with a long K (fully-connected layers): this path is not order-exact anyway.
 
 struct gemm_args_t { // identical to gemm_conv_f32.hip (one host-side struct)
   float const *I; float const *J; float *D; float const *bias;
@@ -180,7 +184,12 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 
   int tile_i, tile_j; // XCD-aware workgroup -> tile map, as in gemm_conv_f32.hip
   {
-    int const bid = blockIdx.x, nb = p.tiles_i * p.tiles_j;
+#if SPLITK
+    int const bid = blockIdx.x / p.splitk;
+#else
+    int const bid = blockIdx.x;
+#endif
+    int const nb = p.tiles_i * p.tiles_j;
     int const q = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
     int const nid = ((xcd < rr) ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
     int const group_sz = GROUP_I * p.tiles_j, gid = nid / group_sz, first_i = gid * GROUP_I;
@@ -215,10 +224,17 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   float ri[kCI * 8], rj[kCJ * 8];
-  int const nkt = (p.K + BK - 1) / BK;
+  int const nkt_all = (p.K + BK - 1) / BK;
+#if SPLITK
+  int const slice = blockIdx.x % p.splitk;
+  int const kt_begin = slice * p.kt_per;
+  int const nkt = max(0, min(nkt_all, kt_begin + p.kt_per) - kt_begin);
+#else
+  int const kt_begin = 0, nkt = nkt_all;
+#endif
   rsrc_t const rI = make_rsrc(p.I, p.I_bytes), rJ = make_rsrc(p.J, p.J_bytes);
-  load_I(ri, rI, p, i0, 0, tid);
-  load_J(rj, rJ, p, j0, 0, tid GATHER_ARG);
+  load_I(ri, rI, p, i0, kt_begin * BK, tid);
+  load_J(rj, rJ, p, j0, kt_begin * BK, tid GATHER_ARG);
   store_chunks<BI, kCI>(ri, Is0, tid);
   store_chunks<BJ, kCJ>(rj, Js0, tid);
   __syncthreads();
@@ -232,8 +248,8 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     __bf16 const *const Ic = ((kt & 1) ? Is1 : Is0) + a_off;
     __bf16 const *const Jc = ((kt & 1) ? Js1 : Js0) + b_off;
     if (more) {
-      load_I(ri, rI, p, i0, (kt + 1) * BK, tid);
-      load_J(rj, rJ, p, j0, (kt + 1) * BK, tid GATHER_ARG);
+      load_I(ri, rI, p, i0, (kt_begin + kt + 1) * BK, tid);
+      load_J(rj, rJ, p, j0, (kt_begin + kt + 1) * BK, tid GATHER_ARG);
     }
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
@@ -254,6 +270,30 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     __syncthreads();
   }
 
+#if SPLITK
+  { // raw partial tiles into this slice's slab, indexed like D (bias / ReLU happen in the reduce kernel)
+    float *const Dp = p.ws + (long)slice * p.ws_slab;
+#pragma unroll
+    for (int tb = 0; tb < kTJ; ++tb) {
+      int const jg = j0 + wj * (kTJ * 32) + tb * 32 + (lane & 31);
+      if (jg >= p.Nj) continue;
+#if EPI == 1
+      int const OHW = p.OH * p.OW;
+      int const img = jg / OHW, pel = jg - img * OHW;
+      long const joff = (long)img * p.Mi * OHW + pel, istride = OHW;
+#else
+      long const joff = jg, istride = p.ldD;
+#endif
+#pragma unroll
+      for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int const ig = i0 + wi * (kTI * 32) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (ig < p.Mi) Dp[joff + (long)ig * istride] = acc[ta][tb][r];
+        }
+    }
+  }
+#else
   // epilogue (as in gemm_conv_f32.hip): C/D layout of the 32x32 MFMA family: column j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5).
   // Biases of this lane's kTI*16 rows fetched up front, buffer stores with 32-bit offsets (per-lane column part + wave-uniform
   // per-row part in the scalar offset operand); branch-free for tiles inside the row range.
@@ -305,4 +345,5 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     };
     if (i0 + BI <= p.Mi) store_all(false); else store_all(true); // workgroup-uniform
   }
+#endif // SPLITK
 }

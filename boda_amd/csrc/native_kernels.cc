@@ -196,10 +196,21 @@ static bool plan_k1_stream(conv_geom_t const &g, int num_cus, string const &spec
 }
 
 // bf16 variant (kernels/gemm_conv_bf16.hip): BK = 32, 32x32x16 MFMA only, chunked staging
-static void bf16_cfg(tile_cfg_t &c, bool gather) {
+static void bf16_cfg(tile_cfg_t &c, bool gather, long tiles_hint = 0, long K = 0, int num_cus = 0, bool explicit_tile = false) {
   if (c.MT != 32) { c.MT = 32; c.BI = 64; c.BJ = 64; c.WI = 2; c.WJ = 2; }
   if (c.BK != 32 && c.BK != 64) c.BK = 32;
-  c.SPLITK = 1; c.PF = 1;
+  c.PF = 1;
+  // split-K by default for tile-starved shapes with a long K loop (fully-connected layers: AlexNet fc6 = 256 tiles x 288 K steps):
+  // aim at ~4 workgroups per CU, keep >= 8 K steps per slice.  (The bf16 path has no order-exactness to lose.)
+  if (!explicit_tile) {
+    c.SPLITK = 1;
+    if (tiles_hint > 0 && num_cus > 0 && getenv("BODAHIP_NO_BF16_SPLITK") == nullptr) {
+      long const nkt = (K + c.BK - 1) / c.BK;
+      long s = std::min<long>(16, (4l * num_cus + tiles_hint - 1) / tiles_hint);
+      s = std::min<long>(s, nkt / 8);
+      if (s >= 2 && nkt >= 32) c.SPLITK = (int)s;
+    }
+  }
   int const nt = c.threads();
   bool ok = (c.BI % (c.WI * 32) == 0) && (c.BJ % (c.WJ * 32) == 0) && ((c.BI * c.BK / 8) % nt == 0) && ((c.BJ * c.BK / 8) % nt == 0) && nt <= 1024 &&
             (c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) * 16 <= 256 && 4ull * (c.BK + 8) * (c.BI + c.BJ) <= 160 * 1024;
@@ -213,8 +224,10 @@ static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string
   p.cfg = choose_cfg((int)M, (int)std::min<uint64_t>((uint64_t)N * batch, 0x7fffffffull), (int)K, num_cus, false, bf16); // (a batch deals batch x the tiles)
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad sgemm_tile '" + tile + "'"); }
   if (bf16) {
-    bf16_cfg(p.cfg, false);
+    long const tiles = (long)((M + p.cfg.BI - 1) / p.cfg.BI) * ((N + p.cfg.BJ - 1) / p.cfg.BJ);
+    bf16_cfg(p.cfg, false, tiles, K, num_cus, !tile.empty());
     p.defs = cfg_defs(p.cfg); p.defs.push_back("-DI_MODE=0"); p.defs.push_back("-DJ_MODE=0"); p.defs.push_back("-DEPI=0");
+    if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
     return p;
   }
   check_cfg(p.cfg, false);
@@ -262,7 +275,7 @@ static bool plan_patch_bf16(conv_geom_t const &g, int num_cus, plan_t &p) {
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
   return true;
 }
-static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false, string const &k1s = string()) {
+static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false, string const &k1s = string(), bool allow_splitk = true) {
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   plan_t p;
   if (!bf16 && tile.empty() && plan_k1_stream(g, num_cus, k1s, p)) return p;
@@ -321,7 +334,8 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
     }
   }
   if (p.patch && tile.empty()) p.cfg.PF = pf_for(p.cfg);
-  if (bf16) bf16_cfg(p.cfg, !p.ipconv); else check_cfg(p.cfg, !p.ipconv && !p.patch);
+  if (bf16) bf16_cfg(p.cfg, !p.ipconv, (long)((g.OC + p.cfg.BI - 1) / p.cfg.BI) * ((Nj + p.cfg.BJ - 1) / p.cfg.BJ), Kt, allow_splitk ? num_cus : 0, !tile.empty());
+  else check_cfg(p.cfg, !p.ipconv && !p.patch);
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0 && p.cfg.BK % 4 == 0) ? "2" : ((p.patch && Kt % 2 == 0) ? "4" : "3")));
   p.defs.push_back(p.ipconv ? (string("-DJ_MODE=") + ((Kt % 4 == 0) ? "3" : "4")) : string(p.k1 ? "-DJ_MODE=5" : (p.patch ? "-DJ_MODE=7" : (p.rows ? "-DJ_MODE=6" : "-DJ_MODE=2"))));
@@ -528,7 +542,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   if (!bf16 && winograd_applies(g, algo ? string(algo) : tune_of(impl, "conv_algo")) && tune_of(impl, "conv_tile").empty()) {
     conv_winograd(filts, biases, in, out, g, out_ctot, out_coff); return;
   }
-  plan_t const p = plan_conv(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), bf16, tune_of(impl, "k1_stream"));
+  plan_t const p = plan_conv(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), bf16, tune_of(impl, "k1_stream"), out_ctot == g.OC);
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
   gemm_args_t ga; memset(&ga, 0, sizeof(ga));
