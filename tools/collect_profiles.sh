@@ -16,10 +16,13 @@ for w in sgemm-ops-full alexnet nin; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_$w -o p -- python $R/bench.py --workload $w --steps 1 --warmup 0 --settle-ms 0 --no-cpu-baseline > $O/write_$w.log 2>&1
   rocprofv3 --kernel-trace --pmc $SQ -d $O/sq_$w -o p -- python $R/bench.py --workload $w --steps 1 --warmup 0 --settle-ms 0 --no-cpu-baseline > $O/sq_$w.log 2>&1
 done
+rocprofv3 --kernel-trace --stats -d $O/stats_alexnet_winograd -o p -- python $R/bench.py --workload alexnet --conv-algo winograd --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_alexnet_winograd.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats_alexnet_bf16 -o p -- python $R/bench.py --workload alexnet --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_alexnet_bf16.log 2>&1
 cd $R
 for w in sgemm-ops-full alexnet nin; do python bench.py --workload $w > $O/bench_$w.json 2>$O/bench_$w.err; done
 for w in nin-net alexnet-net googlenet-net googlenet resnet50; do python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
 for w in sgemm-ops-full alexnet nin googlenet resnet50; do python bench.py --workload $w --dtype bf16 --no-cpu-baseline > $O/bench_${w}_bf16.json 2>/dev/null; done
+for w in alexnet nin googlenet resnet50 alexnet-net; do python bench.py --workload $w --conv-algo winograd --no-cpu-baseline > $O/bench_${w}_winograd.json 2>/dev/null; done
 find $O -name "*.db" -size +30M -delete   # keep the merge-back under the 64 MiB cap
 ls -la $O | head -50
 for w in googlenet resnet50; do python bench.py --workload $w --batch 256 --no-cpu-baseline > $O/bench_${w}_b256.json 2>/dev/null; python bench.py --workload $w --batch 256 --dtype bf16 --no-cpu-baseline > $O/bench_${w}_b256_bf16.json 2>/dev/null; done

@@ -52,5 +52,11 @@ for w in ("sgemm-ops-full", "alexnet", "nin"):
             f.write(line + "\n")
         f.write(f"# total per step: fetch {tot_f/1e9:.3f} GB (corrected), write {tot_w/1e9:.3f} GB\n")
     res[w] = {"hbm_bytes_per_step": int(tot_f + tot_w), "fetch_bytes_corrected": int(tot_f), "write_bytes": int(tot_w)}
+for w, cmd in (("alexnet_winograd", "--workload alexnet --conv-algo winograd"), ("alexnet_bf16", "--workload alexnet --dtype bf16")):   # kernel stats only
+    sdb = os.path.join(src, f"stats_{w}", "p_results.db")
+    if os.path.exists(sdb):
+        with open(os.path.join(out, f"{tag}_{w}_kernel_stats.txt"), "w") as f:
+            f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py {cmd} --steps 5 --warmup 2 --no-cpu-baseline\n")
+            f.write(subprocess.check_output([sys.executable, summ, sdb, "--by-grid"], text=True))
 json.dump(res, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -14,7 +14,7 @@ ops = bench.alexnet_b256_ops(256)
 calls = []
 TILES = dict((int(kv.split(":")[0]), kv.split(":")[1]) for kv in os.environ.get("TILES", "").split(",") if kv)   # op index -> hip_tile
 for i, op in enumerate(ops):
-    anno = add_codegen_annotations(op, OpTune(hip_tile=TILES.get(i, ""))); fn = anno.get_func_name(); g = f"{fn}__{i}"
+    anno = add_codegen_annotations(op, OpTune(hip_tile=TILES.get(i, ""), hip_dtype=os.environ.get("DTYPE", ""))); fn = anno.get_func_name(); g = f"{fn}__{i}"
     rtc.compile([RtcFuncInfo(g, "", [x for x, _ in NATIVE_ARGS[fn]], anno)])
     am = {}
     for an, io in NATIVE_ARGS[fn]:
