@@ -152,4 +152,10 @@ int bodahip_prebuild(const char *op_lexp, const char *arch, int num_cus, const c
   size_t const n = native_kernels_t::prebuild(parse_op_lexp(S(op_lexp, "op")), S(arch, "arch"), num_cus > 0 ? num_cus : 256, tile ? tile : "");
   if (code_size_out) *code_size_out = n;
   ABI_CATCH }
+int bodahip_explain_plan(const char *op_lexp, int num_cus, const char *tile, char *plan_buf, size_t plan_buf_sz) {
+  ABI_TRY
+  string plan;
+  native_kernels_t::prebuild(parse_op_lexp(S(op_lexp, "op")), "", num_cus > 0 ? num_cus : 256, tile ? tile : "", &plan);
+  put_str(plan_buf, plan_buf_sz, plan, "plan");
+  ABI_CATCH }
 } // extern "C"

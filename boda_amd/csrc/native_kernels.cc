@@ -208,7 +208,7 @@ static void bf16_cfg(tile_cfg_t &c, bool gather, long tiles_hint = 0, long K = 0
       long const nkt = (K + c.BK - 1) / c.BK;
       long s = std::min<long>(16, (4l * num_cus + tiles_hint - 1) / tiles_hint);
       s = std::min<long>(s, nkt / 8);
-      if (s >= 2 && nkt >= 32) c.SPLITK = (int)s;
+      if (s >= 2 && nkt >= 64 && tiles_hint <= num_cus) c.SPLITK = (int)s;   // (ResNet res4 1x1 1024->256, 196 tiles x 32 K steps: 47 us split vs 42 not)
     }
   }
   int const nt = c.threads();
@@ -612,7 +612,8 @@ static conv_geom_t geom_from_dims(dims_t const &f, dims_t const &in, dims_t cons
 }
 
 // AOT: compile (into the on-disk code-object cache) the specialisation that run() would pick for `op`.  No device needed.
-size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile) {
+// With arch == "" nothing is compiled and *plan_out receives "<kernel> <tile> <-D options>": the planner's decision (host-logic tests).
+size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile, string *plan_out) {
   string const &t = op.get_type();
   plan_t p; string log;
   bool const bf16 = op.has_func_name() && (op.get_func_name() == "hip_sgemm_bf16" || op.get_func_name() == "hip_conv_bf16");
@@ -621,6 +622,8 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
     p = plan_conv(geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims("out"), op.get_dims("stride"), op.get_dims("in_pad"), relu), num_cus, tile, bf16);
   } else rt_err("prebuild: op type '" + t + "' has no native kernel");
+  if (plan_out) { *plan_out = p.kname + " " + p.cfg.str(); for (auto const &d : p.defs) *plan_out += " " + d; }
+  if (arch.empty()) return 0;
   size_t const n = compile_plan(p, arch, &log).size();
   if (p.patch16) { plan_t fp; fp.patch16 = true; fp.bf16 = true; fp.kname = "bodahip_filt_bf16"; fp.defs = {"-DFILT_ONLY=1"}; compile_plan(fp, arch, &log); }
   if (p.cfg.SPLITK > 1) { // the matching second-pass kernel

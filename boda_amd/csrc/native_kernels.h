@@ -63,7 +63,7 @@ struct native_kernels_t {
   // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"; key "k1_stream" -> "off" | "WIxWJxOCBxCB[xMINW]";
   // key "conv_algo" -> "winograd": 3x3 / stride-1 convs go through the F(2x2,3x3) path (kernels/winograd_f32.hip; not bit-exact)
   void set_tune(string const &key, string const &val);
-  static size_t prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile);
+  static size_t prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile, string *plan_out = nullptr);
   launch_info_t last_launch;
   uint32_t num_specialisations() const;
   struct impl_t;

@@ -85,6 +85,7 @@ ABI = {  # symbol -> (restype, argtypes); every symbol include/bodahip.h declare
     "bodahip_compile_offline": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
     "bodahip_parse_op": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     "bodahip_prebuild": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_size_t)]),
+    "bodahip_explain_plan": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]),
 }
 for _n, (_r, _a) in ABI.items():
     _f = getattr(_lib, _n)  # AttributeError here == library does not export what the header declares
@@ -375,6 +376,13 @@ def compile_offline(src_or_opts: str, native_template: Optional[str] = None, arc
                                       1 if add_prelude else 0, 1 if use_cache else 0, C.byref(sz), log, 1 << 16)
     _chk(rc)
     return int(sz.value)
+
+
+def explain_plan(op: Op, num_cus: int = 256, tile: str = "") -> str:
+    """The native planner's choice for an annotated op: '<kernel> <tile> <-D options>'.  Host-only, nothing is compiled."""
+    buf = C.create_string_buffer(1 << 14)
+    _chk(_lib.bodahip_explain_plan(op.to_str().encode(), num_cus, tile.encode(), buf, 1 << 14))
+    return buf.value.decode()
 
 
 def parse_op_native(line: str) -> str:

@@ -129,6 +129,9 @@ int bodahip_parse_op(const char *op_lexp, char *canon_buf, size_t canon_buf_sz);
 /* AOT: compile, into the on-disk code-object cache the runtime reads, the native-kernel specialisation run() would pick
  * for the op described by `op_lexp` (sgemm / Convolution line) on a device of `arch` with `num_cus` CUs.  No GPU needed. */
 int bodahip_prebuild(const char *op_lexp, const char *arch, int num_cus, const char *tile, size_t *code_size_out);
+/* the planner's decision for an annotated op, without compiling or touching a device: "<kernel> <tile> <-D options ...>"
+ * (variant / blocking selection is host logic: the counterpart of add_codegen_annotations' choice, src/cnn_op.cc:16-378) */
+int bodahip_explain_plan(const char *op_lexp, int num_cus, const char *tile, char *plan_buf, size_t plan_buf_sz);
 
 #ifdef __cplusplus
 }

@@ -72,3 +72,56 @@ def test_cpp_op_parser_agrees_with_python_on_every_fixture_line(golden_dir):
     # annotated ops (func_name, uint32 scalars with values) round-trip too
     s = "(str_vals=(func_name=hip_conv,type=Convolution),nda_vals=(conv_has_relu=(tn=uint32_t,v=1),stride=(tn=none,dims=(y=4,x=4))))"
     assert R.parse_op_native(s) == s
+
+
+def _conv(B, C, H, OC, K, S=1, P=0, func="hip_conv"):
+    from boda_amd.op import parse_op
+    OH = (H + 2 * P - K) // S + 1
+    return parse_op(f"(str_vals=(type=Convolution,func_name={func}),nda_vals=(biases=(dims=(out_chan={OC})),filts=(dims=(out_chan={OC},in_chan={C},y={K},x={K})),"
+                    f"in=(dims=(img={B},chan={C},y={H},x={H})),in_pad=(tn=none,dims=(y={P},x={P})),kern_sz=(tn=none,dims=(y={K},x={K})),"
+                    f"out=(dims=(img={B},chan={OC},y={OH},x={OH})),out_chans=(tn=uint32_t,v={OC}),stride=(tn=none,dims=(y={S},x={S})),conv_has_relu=(tn=uint32_t,v=1)))")
+
+
+def test_planner_picks_the_documented_kernel_and_operand_mode_per_shape():
+    """Variant / blocking selection is host logic (the counterpart of add_codegen_annotations' choice, src/cnn_op.cc:16-378): checked
+    without a device through bodahip_explain_plan.  One shape per operand mode of DESIGN.md section 3."""
+    ex = R.explain_plan
+    def mode(plan, key): return re.search(rf"-D{key}=(\d+)", plan).group(1)
+    p = ex(_conv(256, 96, 27, 256, 5, 1, 2))                      # AlexNet conv2: LDS input patch
+    assert p.startswith("bodahip_conv_f32 ") and mode(p, "J_MODE") == "7" and "-DCH=27" in p and "-DRELU=1" in p
+    p = ex(_conv(256, 3, 227, 96, 11, 4, 0))                      # AlexNet conv1: row gather (KW >= 6)
+    assert mode(p, "J_MODE") == "6" and "-DJROWS=" in p
+    p = ex(_conv(256, 256, 27, 256, 1))                           # NiN cccp3: 1x1, tiled kernel (K = 256 is not "short")
+    assert p.startswith("bodahip_conv_f32 ") and mode(p, "J_MODE") == "5"
+    p = ex(_conv(256, 256, 6, 4096, 6))                           # AlexNet fc6: output 1x1 = contiguous images
+    assert mode(p, "J_MODE") in ("3", "4")
+    p = ex(_conv(256, 96, 27, 256, 3, 2, 1))                      # stride 2 in x: per-element table gather
+    assert mode(p, "J_MODE") == "2"
+    p = ex(_conv(256, 96, 55, 96, 1))                             # NiN cccp1 at B=256: the streaming 1x1 kernel, one out_chan tile
+    assert p.startswith("bodahip_k1_stream_f32 96x256x96_w1x8") and "-DKC=96" in p and "-DHW=3025" in p and "-DOCB=3" in p and "-DEDGE_OC=0" in p
+    assert ex(_conv(8, 96, 55, 96, 1)).startswith("bodahip_conv_f32 ")             # ... but not at small batch
+    assert ex(_conv(64, 64, 56, 256, 1)).startswith("bodahip_k1_stream_f32 256x64x64_w8x1")   # ResNet-50 res2 64 -> 256
+    assert ex(_conv(256, 96, 55, 96, 1), tile="64x64x16x2x2x2").startswith("bodahip_conv_f32 64x64x16_w2x2")  # an explicit tile wins
+    # bf16: channel-innermost LDS patch for stride-1-in-x kernels on >= 16 channels (a multiple of 8), the gather kernel otherwise;
+    # split-K only for tile-starved long-K shapes (fc6), never for the big layers
+    p = ex(_conv(256, 256, 13, 384, 3, 1, 1, func="hip_conv_bf16"))
+    assert p.startswith("bodahip_conv_patch_bf16 128x128x144_w2x2") and "-DCG=2" in p
+    assert ex(_conv(256, 3, 227, 96, 11, 4, 0, func="hip_conv_bf16")).startswith("bodahip_conv_bf16 ")
+    p = ex(_conv(256, 256, 6, 4096, 6, func="hip_conv_bf16"))
+    assert p.startswith("bodahip_conv_bf16 ") and "_s" in p.split()[1] and "-DSPLITK=1" in p
+    assert "-DSPLITK" not in ex(_conv(64, 1024, 14, 256, 1, func="hip_conv_bf16"))
+
+
+def test_planner_sgemm_tiles_follow_problem_size():
+    from boda_amd.op import parse_op
+    def sg(M, N, K, fn="hip_sgemm"):
+        return parse_op(f"(str_vals=(type=sgemm,func_name={fn}),nda_vals=(a=(dims=(K={K},M={M})),b=(dims=(K={K},N={N})),c=(dims=(M={M},N={N}))))")
+    big, small = R.explain_plan(sg(8192, 8192, 8192)), R.explain_plan(sg(256, 256, 256))
+    assert big.startswith("bodahip_sgemm_f32 256x256") and "-DI_MODE=0" in big and "-DSPLITK" not in big
+    assert small.startswith("bodahip_sgemm_f32 ") and small.split()[1] != big.split()[1]
+    assert "-DI_MODE=1" in R.explain_plan(sg(130, 64, 50)) and "-DJ_MODE=1" in R.explain_plan(sg(128, 66, 50))     # scalar staging for ragged M / N
+    assert R.explain_plan(sg(8192, 8192, 8192), tile="128x128x16x2x2x2x4").count("-DSPLITK=1") == 1           # split-K only as an explicit tune
+    assert R.explain_plan(sg(4096, 4096, 4096, "hip_sgemm_bf16")).startswith("bodahip_sgemm_bf16 256x256")
+    # the tile heuristic balances tiles over the CUs it is told about: a 512^3 problem on 256 CUs takes the thin 16x16-MFMA tiles, on 16 CUs 64x64
+    assert R.explain_plan(sg(512, 512, 512), num_cus=256).split()[1] == "32x32x64_w2x2_m16_p2"
+    assert R.explain_plan(sg(512, 512, 512), num_cus=16).split()[1] == "64x64x32_w2x2_p2"

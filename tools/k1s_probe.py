@@ -20,7 +20,7 @@ shapes = [tuple(int(x) for x in s.split(":")) for s in os.environ.get("SHAPES", 
 specs = os.environ.get("SPECS", "off,auto").split(",")
 for si, (B, C, H, OC) in enumerate(shapes):
     op = conv_op(B, C, H, OC)
-    anno = add_codegen_annotations(op, OpTune()); fn = anno.get_func_name(); g = f"{fn}__{si}"
+    anno = add_codegen_annotations(op, OpTune(hip_dtype=os.environ.get("DTYPE", ""))); fn = anno.get_func_name(); g = f"{fn}__{si}"
     rtc.compile([RtcFuncInfo(g, "", [x for x, _ in NATIVE_ARGS[fn]], anno)])
     am = {}
     for an, io in NATIVE_ARGS[fn]:
@@ -30,9 +30,11 @@ for si, (B, C, H, OC) in enumerate(shapes):
     call = RtcFuncCall(g, am)
     fl = 2.0 * B * H * H * OC * C; by = 4.0 * (B * H * H * (C + OC) + OC * C + OC)
     ref = None
-    for spec in specs:
+    tiles = os.environ.get("TILES", "").split(",") if os.environ.get("TILES") else None
+    for spec in (tiles or specs):
         try:
-            rtc.set_tune("k1_stream", "" if spec == "auto" else spec)
+            if tiles: rtc.set_tune("conv_tile", "" if spec == "auto" else spec)
+            else: rtc.set_tune("k1_stream", "" if spec == "auto" else spec)
             rtc.set_var_to_zero(f"out_{si}")
             for _ in range(int(os.environ.get('SETTLE', '400'))): rtc.run(call)
             rtc.finish_and_sync(); rtc.release_per_call_id_data()
@@ -40,7 +42,7 @@ for si, (B, C, H, OC) in enumerate(shapes):
             ms = np.array([rtc.get_dur(c, c) for c in ids]); rtc.release_per_call_id_data()
             out = rtc.copy_var_to_nda(f"out_{si}") if hasattr(rtc, "copy_var_to_nda") else None
             ll = rtc.last_launch(); li = f"{ll.get('kernel')} {ll.get('tile', ll.get('cfg'))} grid {ll.get('grid')}"
-            same = "ref" if ref is None else ("SAME" if np.array_equal(ref, out) else f"DIFF({int((ref != out).sum())})")
+            same = "ref" if ref is None else ("SAME" if np.array_equal(ref, out) else f"DIFF({int((ref != out).sum())}, max {float(np.abs(ref - out).max()):.3g})")
             if ref is None: ref = out
             print(f"B{B} C{C} {H}x{H} OC{OC} spec={spec:12s} mean {ms.mean()*1e3:7.1f} us min {ms.min()*1e3:7.1f} us  {fl/ms.mean()/1e9:6.1f} TF/s {by/ms.mean()/1e6:6.0f} GB/s  {same}  {li}", flush=True)
         except Exception as e:
