@@ -166,3 +166,32 @@ def test_pool_lrn_relu_kernels_vs_oracle(rtc):
         assert SsdsDiff.of(want["n"], io["n"]).mrd < 1e-5 and SsdsDiff.of(want["g"], io["g"]).mrd < 1e-5
     finally:
         fwd.release()
+
+
+@pytest.mark.parametrize("net,batch", [("nin", 2), ("googlenet", 2)])
+def test_full_net_forward_bf16_operands(rtc, net, batch):
+    """op_tune hip_dtype=bf16 through the full-net driver (config 5's arithmetic on whole nets): every conv goes to a bf16 kernel
+    (channel-innermost LDS patch / gather / 1x1, incl. writes into Concat channel slices); parity is unpinned for bf16 (the reference
+    has none) -- stated bound: normalised RMS error of every node < 3e-2 against the exact fp32 oracle forward, no NaNs."""
+    from boda_amd.cnn_op import OpTune
+    cp = {"nin": nin_imagenet, "googlenet": googlenet_conv}[net](batch)
+    params = _params(cp)
+    data = bo.gen_conv_in(*cp.nodes["data"].sizes)
+    fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16"))
+    fwd.init(cp, op_params=params)
+    try:
+        funcs = [c.func for c in fwd.fwd_calls]
+        assert funcs.count("hip_conv_bf16") == sum(o.type == "Convolution" for o in cp.ops) and "hip_conv" not in funcs
+        nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
+        io = {"data": data}
+        fwd.run_fwd(["data"], io, nodes)
+        want = oracle_forward(cp, data, params, bo)
+        for op in cp.ops:
+            if op.type in ("ReLU", "Dropout"):
+                continue
+            w = want[op.top].astype(np.float64); g = io[op.top].astype(np.float64)
+            assert np.isfinite(g).all(), op.top
+            nrms = float(np.sqrt(np.mean((w - g) ** 2)) / max(1e-30, np.sqrt(np.mean(w ** 2))))
+            assert nrms < 3e-2, (op.top, nrms)
+    finally:
+        fwd.release()

@@ -23,6 +23,7 @@ for w in sgemm-ops-full alexnet nin; do python bench.py --workload $w > $O/bench
 for w in nin-net alexnet-net googlenet-net googlenet resnet50; do python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
 for w in sgemm-ops-full alexnet nin googlenet resnet50; do python bench.py --workload $w --dtype bf16 --no-cpu-baseline > $O/bench_${w}_bf16.json 2>/dev/null; done
 for w in alexnet nin googlenet resnet50 alexnet-net; do python bench.py --workload $w --conv-algo winograd --no-cpu-baseline > $O/bench_${w}_winograd.json 2>/dev/null; done
+for w in nin-net alexnet-net googlenet-net; do python bench.py --workload $w --dtype bf16 --no-cpu-baseline > $O/bench_${w}_bf16.json 2>/dev/null; done
 find $O -name "*.db" -size +30M -delete   # keep the merge-back under the 64 MiB cap
 ls -la $O | head -50
 for w in googlenet resnet50; do python bench.py --workload $w --batch 256 --no-cpu-baseline > $O/bench_${w}_b256.json 2>/dev/null; python bench.py --workload $w --batch 256 --dtype bf16 --no-cpu-baseline > $O/bench_${w}_b256_bf16.json 2>/dev/null; done
