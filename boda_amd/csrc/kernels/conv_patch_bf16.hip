@@ -48,7 +48,49 @@ struct gemm_args_t { // identical to gemm_conv_f32.hip (one host-side struct); I
   long bsI, bsJ, bsD;
 };
 
-#ifdef FILT_ONLY
+#ifdef S2D_ONLY
+// Space-to-depth front end for strided convolutions on few input channels (the conv1 layers: 11x11/4 or 7x7/2 on 3 channels), which
+// the patch kernel cannot take directly (stride 1 in x, channels in groups of 8): an s x s block of input pixels becomes s*s channels,
+//   in2[b][c*s*s + dy*s + dx][Y][X] = in[b][c][s*Y + dy - Pry][s*X + dx - Prx]       (zero outside; Pr = pad rounded up to a multiple of s)
+//   f2 [oc][c*s*s + dy*s + dx][a][b] = filts[oc][c][s*a + dy - (Pry - PY)][s*b + dx - (Prx - PX)]   (zero outside)
+// and the layer is the stride-1, unpadded ceil((K + Pr - P)/s)-square convolution of in2 with f2 -- same outputs, term for term.
+struct s2d_args_t {
+  float const *src; float *dst;
+  int B, C, H, W, OC, KH, KW;       // source tensor geometry (filters: OC, C, KH, KW)
+  int S, C2, H2, W2;                // block size; channels (padded to a multiple of 8), rows, cols of the result (filters: rows = KHb, cols = KWb)
+  int oy, ox;                       // input: Pr (rounded-up pad) per axis; filters: Pr - P per axis
+  int filt;                         // 0: input tensor, 1: filters
+  int mode, c2_lo;                  // mode 0: one thread per result element with channel >= c2_lo (filters; the zero pad channels of the input)
+};                                  // mode 1: one thread per (b, c, Y, dy, X): S consecutive source pixels -> S channel planes (reads and writes coalesced)
+extern "C" __global__ __launch_bounds__(256) void KNAME(s2d_args_t const p) {
+  long const idx = (long)blockIdx.x * 256 + threadIdx.x;
+  int const SH = p.filt ? p.KH : p.H, SW = p.filt ? p.KW : p.W, ss = p.S * p.S;
+  if (p.mode == 1) {
+    long const n = (long)p.B * p.C * p.H2 * p.S * p.W2;
+    if (idx >= n) return;
+    int const X = (int)(idx % p.W2); long r = idx / p.W2;
+    int const dy = (int)(r % p.S); r /= p.S;
+    int const Y = (int)(r % p.H2); r /= p.H2;
+    int const c = (int)(r % p.C), b = (int)(r / p.C);
+    int const y = p.S * Y + dy - p.oy, x0 = p.S * X - p.ox;
+    bool const yok = (unsigned)y < (unsigned)SH;
+    float const *row = p.src + (((long)b * p.C + c) * SH + (yok ? y : 0)) * SW;
+    float *d = p.dst + ((((long)b * p.C2 + (long)c * ss + dy * p.S) * p.H2 + Y) * p.W2 + X);
+    long const plane = (long)p.H2 * p.W2;
+    for (int dx = 0; dx < p.S; ++dx) { int const x = x0 + dx; d[dx * plane] = (yok && (unsigned)x < (unsigned)SW) ? row[x] : 0.f; }
+    return;
+  }
+  int const nc = p.C2 - p.c2_lo;
+  long const n = (long)(p.filt ? p.OC : p.B) * nc * p.H2 * p.W2;
+  if (idx >= n) return;
+  int const X = (int)(idx % p.W2), Y = (int)((idx / p.W2) % p.H2), c2 = p.c2_lo + (int)((idx / ((long)p.W2 * p.H2)) % nc), b = (int)(idx / ((long)p.W2 * p.H2 * nc));
+  int const c = c2 / ss, dy = (c2 / p.S) % p.S, dx = c2 % p.S;
+  int const y = p.S * Y + dy - p.oy, x = p.S * X + dx - p.ox;
+  float v = 0.f;
+  if (c < p.C && (unsigned)y < (unsigned)SH && (unsigned)x < (unsigned)SW) v = p.src[(((long)b * p.C + c) * SH + y) * SW + x];
+  p.dst[(((long)b * p.C2 + c2) * p.H2 + Y) * p.W2 + X] = v;
+}
+#elif defined(FILT_ONLY)
 // F'[(cg*taps + tap)*OC + oc] (16-byte chunks) = bf16( filts[oc][8*cg + e][tap] ), e = 0..7; channels past C are zero.
 // args: I = filts (fp32 OIHW), D = F' (as float*), Mi = OC, C = in_chans, K = taps
 extern "C" __global__ __launch_bounds__(256) void KNAME(gemm_args_t const p) {

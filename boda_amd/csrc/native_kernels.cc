@@ -254,9 +254,11 @@ static bool plan_patch_bf16(conv_geom_t const &g, int num_cus, plan_t &p) {
     return 16l * ((long)cg * taps * bi + cg * cs);
   };
   struct cand_t { int bi, bj, wi, wj; };
-  static cand_t const cands[] = {{128, 128, 2, 2}, {64, 128, 1, 4}, {64, 64, 2, 2}};
+  static cand_t const cands[] = {{128, 128, 2, 2}, {96, 128, 1, 4}, {64, 128, 1, 4}, {64, 64, 2, 2}};
   int pick = -1;
-  for (int ci = 0; ci < 3; ++ci) {
+  for (int ci = 0; ci < 4; ++ci) {
+    if (cands[ci].bi == 96 && !(g.OC % 128 > 64 && g.OC % 128 <= 96)) continue;   // 96-row tiles only where they remove padding (out_chan = 96, 224, ...)
+    if (cands[ci].bi == 128 && g.OC % 128 > 64 && g.OC % 128 <= 96 && g.OC < 256) continue;
     cand_t const &c = cands[ci];
     if (lds(c.bi, c.bj) > 64 * 1024) continue;
     long const tiles = (long)((g.OC + c.bi - 1) / c.bi) * ((Nj + c.bj - 1) / c.bj);
@@ -456,6 +458,39 @@ void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t 
   last_launch.flops = 2.0 * M * N * K; last_launch.algo_bytes = 4.0 * ((double)K * M + (double)K * N + (double)M * N);
 }
 
+// patch16 launch: filters re-laid-out once per call into F'[group][tap][out_chan][8] bf16 (scratch at ws_off), then the patch kernel
+static void launch_patch16(native_kernels_t::impl_t *impl, native_host_t *host, plan_t const &p, kernel_t &k, gemm_args_t &ga, float const *filts,
+                           conv_geom_t const &g, size_t ws_off) {
+  int const taps = g.KH * g.KW, ncg = (g.C + 7) / 8;
+  size_t const fbytes = (size_t)ncg * taps * g.OC * 16;
+  if (fbytes >= 0x7ffffff0ull) unsup_err("hip_conv_bf16: re-laid-out filters of 2 GiB or more");
+  if (impl->ws_bytes < ws_off + fbytes) ensure_ws(impl, host, ws_off + fbytes);
+  plan_t fp; fp.patch16 = true; fp.bf16 = true; fp.kname = "bodahip_filt_bf16"; fp.defs = {"-DFILT_ONLY=1"};
+  kernel_t &fk = get_kernel(impl, host, fp);
+  gemm_args_t fa; memset(&fa, 0, sizeof(fa));
+  fa.I = filts; fa.D = (float *)((char *)impl->ws + ws_off); fa.Mi = g.OC; fa.C = g.C; fa.K = taps;
+  void *fparams[] = {&fa};
+  long const nchunks = (long)ncg * taps * g.OC;
+  hip_err_chk(hipModuleLaunchKernel(fk.func, (uint32_t)((nchunks + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), fparams, nullptr), "hipModuleLaunchKernel(filt_bf16)");
+  ga.I = (float const *)((char *)impl->ws + ws_off); ga.I_bytes = (unsigned)fbytes;
+  void *params[] = {&ga};
+  hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j), 1, 1, (uint32_t)p.cfg.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(conv_patch_bf16)");
+}
+
+// bf16 conv1-type layers (stride s in both axes, few input channels): space-to-depth front end + the patch kernel (kernels/conv_patch_bf16.hip)
+struct s2d_args_t { float const *src; float *dst; int B, C, H, W, OC, KH, KW; int S, C2, H2, W2; int oy, ox; int filt; int mode, c2_lo; };
+static bool s2d_geom(conv_geom_t const &g, conv_geom_t &g2, int &pry, int &prx) {
+  if (getenv("BODAHIP_NO_S2D")) return false;
+  int const s = g.SY;
+  if (!(s >= 2 && s <= 4 && g.SX == s && g.KH > s && g.KW > s && g.C * s * s <= 64 && g.C <= 8)) return false;
+  pry = (g.PY + s - 1) / s * s; prx = (g.PX + s - 1) / s * s;
+  int const khb = (g.KH + (pry - g.PY) + s - 1) / s, kwb = (g.KW + (prx - g.PX) + s - 1) / s;
+  if (khb * kwb > 16) return false;
+  g2 = g; g2.C = (g.C * s * s + 7) / 8 * 8; if (g2.C < 16) g2.C = 16;
+  g2.KH = khb; g2.KW = kwb; g2.SY = 1; g2.SX = 1; g2.PY = 0; g2.PX = 0; g2.H = g.OH + khb - 1; g2.W = g.OW + kwb - 1;
+  return true;
+}
+
 // ---- F(2x2,3x3) Winograd path (kernels/winograd_f32.hip): opt-in, tune key conv_algo = "winograd" -----------------------------------
 struct wino_args_t { // must match kernels/winograd_f32.hip
   float const *in; float const *filts; float const *bias; float *out;
@@ -542,6 +577,47 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   if (!bf16 && winograd_applies(g, algo ? string(algo) : tune_of(impl, "conv_algo")) && tune_of(impl, "conv_tile").empty()) {
     conv_winograd(filts, biases, in, out, g, out_ctot, out_coff); return;
   }
+  if (bf16 && tune_of(impl, "conv_tile").empty()) {
+    conv_geom_t g2; int pry = 0, prx = 0; plan_t p2;
+    if (s2d_geom(g, g2, pry, prx) && plan_patch_bf16(g2, host->nh_num_cus(), p2)) {
+      size_t const in2 = (size_t)g.B * g2.C * g2.H * g2.W, f2 = (size_t)g.OC * g2.C * g2.KH * g2.KW;
+      if (in2 * 4 >= 0x7ffffff0ull) unsup_err("hip_conv_bf16: space-to-depth input of 2 GiB or more");
+      size_t const off_in2 = 0, off_f2 = (in2 * 4 + 255) & ~size_t(255), off_fp = (off_f2 + f2 * 4 + 255) & ~size_t(255);
+      size_t const fpb = (size_t)(g2.C / 8) * g2.KH * g2.KW * g.OC * 16;
+      ensure_ws(impl, host, off_fp + fpb);
+      plan_t sp; sp.patch16 = true; sp.bf16 = true; sp.kname = "bodahip_s2d"; sp.defs = {"-DS2D_ONLY=1"};
+      kernel_t &sk = get_kernel(impl, host, sp);
+      s2d_args_t sa; memset(&sa, 0, sizeof(sa));
+      sa.B = g.B; sa.C = g.C; sa.H = g.H; sa.W = g.W; sa.OC = g.OC; sa.KH = g.KH; sa.KW = g.KW; sa.S = g.SY; sa.C2 = g2.C;
+      void *sparams[] = {&sa};
+      sa.src = in; sa.dst = (float *)((char *)impl->ws + off_in2); sa.H2 = g2.H; sa.W2 = g2.W; sa.oy = pry; sa.ox = prx; sa.filt = 0;
+      sa.mode = 1; sa.c2_lo = 0;
+      long const n1 = (long)g.B * g.C * g2.H * g.SY * g2.W;
+      hip_err_chk(hipModuleLaunchKernel(sk.func, (uint32_t)((n1 + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), sparams, nullptr), "hipModuleLaunchKernel(s2d in)");
+      sa.mode = 0; sa.c2_lo = g.C * g.SY * g.SY;
+      if (sa.c2_lo < g2.C) { // zero pad channels up to a multiple of 8
+        long const n0 = (long)g.B * (g2.C - sa.c2_lo) * g2.H * g2.W;
+        hip_err_chk(hipModuleLaunchKernel(sk.func, (uint32_t)((n0 + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), sparams, nullptr), "hipModuleLaunchKernel(s2d pad)");
+      }
+      sa.c2_lo = 0;
+      sa.src = filts; sa.dst = (float *)((char *)impl->ws + off_f2); sa.H2 = g2.KH; sa.W2 = g2.KW; sa.oy = pry - g.PY; sa.ox = prx - g.PX; sa.filt = 1;
+      hip_err_chk(hipModuleLaunchKernel(sk.func, (uint32_t)((f2 + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), sparams, nullptr), "hipModuleLaunchKernel(s2d filts)");
+      kernel_t &k2 = get_kernel(impl, host, p2);
+      gemm_args_t ga; memset(&ga, 0, sizeof(ga));
+      ga.J = (float const *)((char *)impl->ws + off_in2); ga.D = out; ga.bias = biases;
+      ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = g2.C * g2.KH * g2.KW; ga.C = g2.C; ga.H = g2.H; ga.W = g2.W; ga.OH = g.OH; ga.OW = g.OW;
+      ga.J_bytes = (unsigned)(in2 * 4);
+      uint64_t const out_bytes = (uint64_t)Nj * out_ctot * 4;
+      if (out_bytes >= 0xfffffff0ull) unsup_err("hip_conv: out of 4 GiB or more is not supported (32-bit store offsets)");
+      ga.D_bytes = (unsigned)out_bytes; ga.out_ctot = out_ctot; ga.out_coff = out_coff;
+      ga.tiles_i = (g.OC + p2.cfg.BI - 1) / p2.cfg.BI; ga.tiles_j = (int)((Nj + p2.cfg.BJ - 1) / p2.cfg.BJ); ga.splitk = 1;
+      launch_patch16(impl, host, p2, k2, ga, (float const *)((char *)impl->ws + off_f2), g2, off_fp);
+      last_launch.kernel = "bodahip_conv_patch_bf16(s2d)"; last_launch.cfg = p2.cfg; last_launch.grid = (uint32_t)(ga.tiles_i * ga.tiles_j); last_launch.block = p2.cfg.threads();
+      last_launch.flops = 2.0 * Nj * g.OC * Kt;
+      last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
+      return;
+    }
+  }
   plan_t const p = plan_conv(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), bf16, tune_of(impl, "k1_stream"), out_ctot == g.OC);
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
@@ -560,22 +636,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   if (p.rows) { ktab_t const kt = get_rtab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
   else if (!p.ipconv && !p.k1 && !p.patch && !p.stream && !p.patch16) { ktab_t const kt = get_ktab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
   ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
-  if (p.patch16) {
-    // filters re-laid-out once per call into F'[group][tap][out_chan][8] bf16 (scratch), then the patch kernel
-    int const taps = g.KH * g.KW, ncg = (g.C + 7) / 8;
-    size_t const fbytes = (size_t)ncg * taps * g.OC * 16;
-    if (fbytes >= 0x7ffffff0ull) unsup_err("hip_conv_bf16: re-laid-out filters of 2 GiB or more");
-    ensure_ws(impl, host, fbytes);
-    plan_t fp; fp.patch16 = true; fp.bf16 = true; fp.kname = "bodahip_filt_bf16"; fp.defs = {"-DFILT_ONLY=1"};
-    kernel_t &fk = get_kernel(impl, host, fp);
-    gemm_args_t fa; memset(&fa, 0, sizeof(fa));
-    fa.I = filts; fa.D = (float *)impl->ws; fa.Mi = g.OC; fa.C = g.C; fa.K = taps;
-    void *fparams[] = {&fa};
-    long const nchunks = (long)ncg * taps * g.OC;
-    hip_err_chk(hipModuleLaunchKernel(fk.func, (uint32_t)((nchunks + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), fparams, nullptr), "hipModuleLaunchKernel(filt_bf16)");
-    ga.I = (float const *)impl->ws; ga.I_bytes = (unsigned)fbytes;
-    void *params[] = {&ga};
-    hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j), 1, 1, (uint32_t)cfg.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(conv_patch_bf16)");
+  if (p.patch16) { launch_patch16(impl, host, p, k, ga, filts, g, 0); 
     last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(ga.tiles_i * ga.tiles_j); last_launch.block = cfg.threads();
     last_launch.flops = 2.0 * Nj * g.OC * Kt;
     last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);

