@@ -259,6 +259,7 @@ static bool plan_patch_bf16(conv_geom_t const &g, int num_cus, plan_t &p) {
   for (int ci = 0; ci < 4; ++ci) {
     if (cands[ci].bi == 96 && !(g.OC % 128 > 64 && g.OC % 128 <= 96)) continue;   // 96-row tiles only where they remove padding (out_chan = 96, 224, ...)
     if (cands[ci].bi == 128 && g.OC % 128 > 64 && g.OC % 128 <= 96 && g.OC < 256) continue;
+    if (cands[ci].bi > 64 && g.OC <= 64) continue;                                       // (no rows of padding for thin layers)
     cand_t const &c = cands[ci];
     if (lds(c.bi, c.bj) > 64 * 1024) continue;
     long const tiles = (long)((g.OC + c.bi - 1) / c.bi) * ((Nj + c.bj - 1) / c.bj);
@@ -676,14 +677,19 @@ static conv_geom_t geom_from_dims(dims_t const &f, dims_t const &in, dims_t cons
 // With arch == "" nothing is compiled and *plan_out receives "<kernel> <tile> <-D options>": the planner's decision (host-logic tests).
 size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile, string *plan_out) {
   string const &t = op.get_type();
-  plan_t p; string log;
+  plan_t p; string log, s2d;
   bool const bf16 = op.has_func_name() && (op.get_func_name() == "hip_sgemm_bf16" || op.get_func_name() == "hip_conv_bf16");
   if (t == "sgemm") { dims_t const &a = op.get_dims("a"), &b = op.get_dims("b"); p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, tile, bf16); }
   else if (t == "Convolution") {
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
-    p = plan_conv(geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims("out"), op.get_dims("stride"), op.get_dims("in_pad"), relu), num_cus, tile, bf16);
+    conv_geom_t const g = geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims("out"), op.get_dims("stride"), op.get_dims("in_pad"), relu);
+    conv_geom_t g2; int pry = 0, prx = 0;
+    if (bf16 && tile.empty() && s2d_geom(g, g2, pry, prx) && plan_patch_bf16(g2, num_cus, p)) { // conv1-type layers: space-to-depth front end (see conv())
+      s2d = "s2d(" + std::to_string(g2.C) + "x" + std::to_string(g2.H) + "x" + std::to_string(g2.W) + ",k" + std::to_string(g2.KH) + "x" + std::to_string(g2.KW) + ")+";
+      if (!arch.empty()) { plan_t sp; sp.patch16 = true; sp.bf16 = true; sp.kname = "bodahip_s2d"; sp.defs = {"-DS2D_ONLY=1"}; compile_plan(sp, arch, &log); }
+    } else p = plan_conv(g, num_cus, tile, bf16);
   } else rt_err("prebuild: op type '" + t + "' has no native kernel");
-  if (plan_out) { *plan_out = p.kname + " " + p.cfg.str(); for (auto const &d : p.defs) *plan_out += " " + d; }
+  if (plan_out) { *plan_out = s2d + p.kname + " " + p.cfg.str(); for (auto const &d : p.defs) *plan_out += " " + d; }
   if (arch.empty()) return 0;
   size_t const n = compile_plan(p, arch, &log).size();
   if (p.patch16) { plan_t fp; fp.patch16 = true; fp.bf16 = true; fp.kname = "bodahip_filt_bf16"; fp.defs = {"-DFILT_ONLY=1"}; compile_plan(fp, arch, &log); }

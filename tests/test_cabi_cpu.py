@@ -106,7 +106,9 @@ def test_planner_picks_the_documented_kernel_and_operand_mode_per_shape():
     # split-K only for tile-starved long-K shapes (fc6), never for the big layers
     p = ex(_conv(256, 256, 13, 384, 3, 1, 1, func="hip_conv_bf16"))
     assert p.startswith("bodahip_conv_patch_bf16 128x128x144_w2x2") and "-DCG=2" in p
-    assert ex(_conv(256, 3, 227, 96, 11, 4, 0, func="hip_conv_bf16")).startswith("bodahip_conv_bf16 ")
+    assert ex(_conv(256, 3, 227, 96, 11, 4, 0, func="hip_conv_bf16")).startswith("s2d(48x57x57,k3x3)+bodahip_conv_patch_bf16 96x128x144_w1x4")   # conv1: space-to-depth front end
+    assert ex(_conv(64, 3, 224, 64, 7, 2, 3, func="hip_conv_bf16")).startswith("s2d(16x115x115,k4x4)+bodahip_conv_patch_bf16 64x")               # 7x7/2 pad 3 -> 4x4 on 16 channels
+    assert ex(_conv(64, 96, 27, 256, 3, 2, 1, func="hip_conv_bf16")).startswith("bodahip_conv_bf16 ")                                            # strided on many channels: gather kernel
     p = ex(_conv(256, 256, 6, 4096, 6, func="hip_conv_bf16"))
     assert p.startswith("bodahip_conv_bf16 ") and "_s" in p.split()[1] and "-DSPLITK=1" in p
     assert "-DSPLITK" not in ex(_conv(64, 1024, 14, 256, 1, func="hip_conv_bf16"))
