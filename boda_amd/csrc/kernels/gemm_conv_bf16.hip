@@ -48,6 +48,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef RELU
 #define RELU 0
 #endif
+#ifndef SWAPST
+#define SWAPST ((BJ / (WJ * 32)) % 2 == 0)
+#endif
 #ifndef SPLITK
 #define SPLITK 0 // 1: the grid is tiles x p.splitk; slice s accumulates K-tiles [s*kt_per, (s+1)*kt_per) and stores its raw partial tile to slab s
 #endif           // of p.ws; bodahip_splitk_reduce (gemm_conv_f32.hip) sums the slabs and applies the epilogue.  Chosen by the host for
@@ -315,6 +318,40 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #pragma unroll
       for (int r = 0; r < 16; ++r) bv[ta][r] = bload1(rB, (ib + rowc(ta, r)) * 4);
 #endif
+#if SWAPST
+    // paired 256-byte row stores (see gemm_conv_f32.hip): bias / ReLU in the MFMA layout, then v_permlane32_swap so that one register
+    // holds 64 consecutive pels of row i and the other of row i+4
+    auto store_all = [&](bool const edge) {
+      int const ibl = i0 + wi * (kTI * 32);
+#pragma unroll
+      for (int tp = 0; tp < kTJ / 2; ++tp) {
+        int const jg = j0 + wj * (kTJ * 32) + tp * 64 + lane;
+#if EPI == 1
+        int const OHW = p.OH * p.OW;
+        int const img = jg / OHW, pel = jg - img * OHW;
+        unsigned const jpart = (jg < p.Nj) ? ((((unsigned)img * (unsigned)p.out_ctot + (unsigned)p.out_coff) * (unsigned)OHW + (unsigned)pel) * 4u + (unsigned)ibl * S4) : 0x80000000u;
+#else
+        unsigned const jpart = (jg < p.Nj) ? ((unsigned)jg * 4u + (unsigned)ibl * S4) : 0x80000000u;
+#endif
+#pragma unroll
+        for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float va = acc[ta][2 * tp][r], vb = acc[ta][2 * tp + 1][r];
+#if EPI == 1
+            va = va + bv[ta][r]; vb = vb + bv[ta][r];
+#if RELU
+            va = (va > 0.f) ? va : 0.f; vb = (vb > 0.f) ? vb : 0.f;
+#endif
+#endif
+            auto const sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, va), __builtin_bit_cast(unsigned, vb), false, false);
+            int const rc = rowc(ta, r);
+            if (!(edge && (ibl + rc >= p.Mi))) __builtin_amdgcn_raw_buffer_store_b32((int)sw[0], rD, (int)jpart, (int)((unsigned)rc * S4), 0);
+            if (!(edge && (ibl + rc + 4 >= p.Mi))) __builtin_amdgcn_raw_buffer_store_b32((int)sw[1], rD, (int)jpart, (int)((unsigned)(rc + 4) * S4), 0);
+          }
+      }
+    };
+#else
     auto store_all = [&](bool const edge) {
 #pragma unroll
       for (int tb = 0; tb < kTJ; ++tb) {
@@ -343,6 +380,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
           }
       }
     };
+#endif
     if (i0 + BI <= p.Mi) store_all(false); else store_all(true); // workgroup-uniform
   }
 #endif // SPLITK

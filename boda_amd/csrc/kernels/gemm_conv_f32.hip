@@ -80,6 +80,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef ABLATE
 #define ABLATE 0 // experiment hook (tools/tile_sweep.py via BODAHIP_EXTRA_DEFS): 1 no epilogue stores | 2 no J loads | 4 no in-loop LDS stores | 8 no I loads
 #endif
+#ifndef SWAPST
+#define SWAPST ((BJ / (WJ * 32)) % 2 == 0) // paired 256-byte row stores in the epilogue (see there); 0 forces the plain per-block stores
+#endif
 #ifndef PF
 #define PF 1 // K-tiles prefetched ahead in registers: 1 | 2 (two register sets; for workgroups that run alone on their CU)
 #endif
@@ -654,6 +657,46 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #pragma unroll
       for (int r = 0; r < kNA; ++r) bv[ta][r] = bload1(rB, (ib + rowc(ta, r)) * 4);
 #endif
+#if MT == 32 && SWAPST
+    // Paired stores (even number of 32-pel blocks per wave): the MFMA layout gives a lane row i (+4 for lanes 32-63) of ONE 32-pel block,
+    // so a plain store instruction writes two 128-byte segments in two different rows.  After bias / ReLU (done in that layout: each
+    // lane has its own row's bias) v_permlane32_swap exchanges the upper half of block 2t's register with the lower half of block
+    // 2t+1's: one register then holds 64 CONSECUTIVE pels of row i, the other of row i+4, and each store writes 256 contiguous bytes.
+    // On planes that are not a multiple of 128 bytes (55x55, 27x27, 13x13 ...) that is one whole cache line + two partial ones per
+    // instruction instead of four partial ones (partial-line writes are what caps the NCHW R+W stream, tools/mem_pattern_probe.py).
+    auto store_all = [&](bool const edge) {
+      int const ibl = i0 + wi * (kTI * MT);                                  // first row of this wave (no per-lane part any more)
+#pragma unroll
+      for (int tp = 0; tp < kTJ / 2; ++tp) {
+        int const jg = j0 + wj * (kTJ * MT) + tp * 64 + lane;              // 64 consecutive pels: lanes 0-31 block 2tp, lanes 32-63 block 2tp+1
+#if EPI == 1
+        int const OHW = p.OH * p.OW;
+        int const img = jg / OHW, pel = jg - img * OHW;
+        unsigned const jpart = (jg < p.Nj) ? ((((unsigned)img * (unsigned)p.out_ctot + (unsigned)p.out_coff) * (unsigned)OHW + (unsigned)pel) * 4u + (unsigned)ibl * S4) : 0x80000000u;
+#else
+        unsigned const jpart = (jg < p.Nj) ? ((unsigned)jg * 4u + (unsigned)ibl * S4) : 0x80000000u;   // (past the last column: dropped by the range check)
+#endif
+#pragma unroll
+        for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+          for (int r = 0; r < kNA; ++r) {
+            float va = acc[ta][2 * tp][r], vb = acc[ta][2 * tp + 1][r];
+#if EPI == 1
+            va = va + bv[ta][r]; vb = vb + bv[ta][r];
+#if RELU
+            va = (va > 0.f) ? va : 0.f; vb = (vb > 0.f) ? vb : 0.f;
+#endif
+#endif
+            auto const sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, va), __builtin_bit_cast(unsigned, vb), false, false);
+            int const rc = rowc(ta, r);
+            if (!(edge && (ibl + rc >= p.Mi)))
+              __builtin_amdgcn_raw_buffer_store_b32((int)sw[0], rD, (int)jpart, (int)((unsigned)rc * S4), 0);
+            if (!(edge && (ibl + rc + 4 >= p.Mi)))
+              __builtin_amdgcn_raw_buffer_store_b32((int)sw[1], rD, (int)jpart, (int)((unsigned)(rc + 4) * S4), 0);
+          }
+      }
+    };
+#else
     // the store loop twice: branch-free for tiles inside the row range (all of them when out_chan / M is a multiple of BI), with a
     // per-row range test for the last tile row
     auto store_all = [&](bool const edge) {
@@ -687,6 +730,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
           }
       }
     };
+#endif
     if (i0 + BI <= p.Mi) store_all(false); else store_all(true); // workgroup-uniform
   }
 #else  // SPLITK: raw partial tiles into this slice's slab (64-bit addressing; bias / ReLU happen in the reduce kernel)
