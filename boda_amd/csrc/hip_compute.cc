@@ -283,7 +283,7 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
     if (fit == funcs.end()) rt_err("run: unknown function '" + rfc.rtc_func_name + "' (not compiled, or released)");
     hip_func_t &hf = fit->second;
     if (hf.native) {
-      if (capturing) { try { native->run(hf.info, rfc.arg_map); } catch (...) { graph_abort(); throw; } ++cap_calls; return kCapturedCallId; }
+      if (capturing) { try { native->run(hf.info, rfc.arg_map); } catch (...) { graph_abort(); throw; } note_captured_call(); return kCapturedCallId; }
       uint32_t const call_id = alloc_call_id();
       hip_err_chk(hipEventRecord(get_call_ev(call_id).b, stream), "hipEventRecord");
       native->run(hf.info, rfc.arg_map);
@@ -308,7 +308,7 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
     if (capturing) {
       hipError_t const err = hipModuleLaunchKernel(hf.func, rfc.blks, 1, 1, rfc.tpb, 1, 1, 0, stream, kargs.empty() ? nullptr : kargs.data(), nullptr);
       if (err != hipSuccess) { graph_abort(); hip_err_chk(err, ("hipModuleLaunchKernel(" + rfc.rtc_func_name + ") [capture]").c_str()); }
-      ++cap_calls; return kCapturedCallId;
+      note_captured_call(); return kCapturedCallId;
     }
     uint32_t const call_id = alloc_call_id();
     hip_err_chk(hipEventRecord(get_call_ev(call_id).b, stream), "hipEventRecord");
@@ -330,6 +330,13 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
   // graph_launch() replays them with one host call and returns a call id whose duration is the whole replay.  Everything a call
   // needs lazily (hiprtc specialisations, gather tables) must already exist: run the list once before capturing it.
   bool capturing = false;
+  std::vector<hipGraphNode_t> cap_last;   // per captured call: the last graph node it produced (a call may launch several kernels)
+  void note_captured_call() {
+    ++cap_calls;
+    hipStreamCaptureStatus st; unsigned long long id = 0; hipGraph_t g = nullptr; hipGraphNode_t const *deps = nullptr; size_t nd = 0;
+    hipError_t const e = hipStreamGetCaptureInfo_v2(stream, &st, &id, &g, &deps, &nd);
+    cap_last.push_back((e == hipSuccess && nd == 1) ? deps[0] : nullptr);
+  }
   struct graph_t { hipGraph_t g = nullptr; hipGraphExec_t exec = nullptr; uint32_t n_calls = 0; };
   std::vector<graph_t> graphs;
   uint32_t cap_calls = 0;
@@ -338,7 +345,7 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
     if (capturing) rt_err("graph_begin: a capture is already in progress");
     finish_and_sync();
     hip_err_chk(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
-    capturing = true; cap_calls = 0;
+    capturing = true; cap_calls = 0; cap_last.clear();
   }
   uint32_t graph_end() {
     if (!capturing) rt_err("graph_end: no capture in progress");
@@ -365,7 +372,7 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
       if (n_calls != cap_calls) rt_err("graph_end_deps: " + std::to_string(n_calls) + " dependency lists for " + std::to_string(cap_calls) + " captured calls");
       size_t nn = 0, ne = 0;
       hip_err_chk(hipGraphGetNodes(gr.g, nullptr, &nn), "hipGraphGetNodes");
-      if (nn != n_calls) rt_err("graph_end_deps: the capture holds " + std::to_string(nn) + " nodes for " + std::to_string(n_calls) + " calls (needs exactly one kernel per call)");
+      if (nn < n_calls) rt_err("graph_end_deps: the capture holds " + std::to_string(nn) + " nodes for " + std::to_string(n_calls) + " calls");
       std::vector<hipGraphNode_t> nodes(nn);
       hip_err_chk(hipGraphGetNodes(gr.g, nodes.data(), &nn), "hipGraphGetNodes");
       hip_err_chk(hipGraphGetEdges(gr.g, nullptr, nullptr, &ne), "hipGraphGetEdges");
@@ -378,13 +385,38 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
       for (hipGraphNode_t n : nodes) if (!has_in.count(n)) order.push_back(n);
       if (order.size() != 1 && nn > 0) rt_err("graph_end_deps: captured graph is not a chain");
       while (order.size() < nn) { auto it = next.find(order.back()); if (it == next.end()) rt_err("graph_end_deps: captured graph is not a chain"); order.push_back(it->second); }
+      // call i = the chain segment [first[i], last[i]]: a call may have launched several kernels (Winograd, bf16 patch / space-to-depth,
+      // split-K); those kernels stay chained, and because such calls work in the backend's one scratch buffer they are additionally
+      // kept in launch order among themselves -- single-kernel calls never touch the scratch
+      std::vector<size_t> first(n_calls), last(n_calls);
+      {
+        std::map<hipGraphNode_t, size_t> pos; for (size_t k = 0; k < nn; ++k) pos[order[k]] = k;
+        size_t prev_end = 0;
+        for (uint32_t i = 0; i < n_calls; ++i) {
+          if (nn == n_calls) { first[i] = last[i] = i; continue; }
+          if (i >= cap_last.size() || !cap_last[i] || !pos.count(cap_last[i])) rt_err("graph_end_deps: could not attribute the captured nodes to calls");
+          first[i] = prev_end; last[i] = pos[cap_last[i]];
+          if (last[i] < first[i]) rt_err("graph_end_deps: could not attribute the captured nodes to calls");
+          prev_end = last[i] + 1;
+        }
+        if (nn != n_calls && prev_end != nn) rt_err("graph_end_deps: captured nodes after the last call");
+      }
       if (ne) hip_err_chk(hipGraphRemoveDependencies(gr.g, ef.data(), et.data(), ne), "hipGraphRemoveDependencies");
       std::vector<hipGraphNode_t> nf, nt;
-      for (uint32_t i = 0; i < n_calls; ++i)
+      long prev_multi = -1;
+      for (uint32_t i = 0; i < n_calls; ++i) {
+        for (size_t k = first[i]; k < last[i]; ++k) { nf.push_back(order[k]); nt.push_back(order[k + 1]); }
+        if (last[i] > first[i]) { if (prev_multi >= 0) { nf.push_back(order[last[prev_multi]]); nt.push_back(order[first[i]]); } prev_multi = i; }
         for (uint32_t k = dep_ptr[i]; k < dep_ptr[i + 1]; ++k) {
           if (dep_idx[k] >= i) rt_err("graph_end_deps: call " + std::to_string(i) + " depends on call " + std::to_string(dep_idx[k]) + " (must be an earlier call)");
-          nf.push_back(order[dep_idx[k]]); nt.push_back(order[i]);
+          nf.push_back(order[last[dep_idx[k]]]); nt.push_back(order[first[i]]);
         }
+      }
+      { // (a stated dependency may coincide with a scratch-order edge: every edge once)
+        std::set<std::pair<hipGraphNode_t, hipGraphNode_t>> seen; size_t w = 0;
+        for (size_t k = 0; k < nf.size(); ++k) if (seen.insert({nf[k], nt[k]}).second) { nf[w] = nf[k]; nt[w] = nt[k]; ++w; }
+        nf.resize(w); nt.resize(w);
+      }
       if (!nf.empty()) hip_err_chk(hipGraphAddDependencies(gr.g, nf.data(), nt.data(), nf.size()), "hipGraphAddDependencies");
       hip_err_chk(hipGraphInstantiate(&gr.exec, gr.g, nullptr, nullptr, 0), "hipGraphInstantiate");
     } catch (...) { (void)hipGraphDestroy(gr.g); throw; }

@@ -195,3 +195,28 @@ def test_full_net_forward_bf16_operands(rtc, net, batch):
             assert nrms < 3e-2, (op.top, nrms)
     finally:
         fwd.release()
+
+
+def test_dependency_graph_with_multi_kernel_calls_bf16(rtc):
+    """bf16 convs launch two or more kernels per call (filter re-layout + patch kernel, space-to-depth, split-K) over the backend's one
+    scratch buffer: the dependency-wired graph keeps each call's kernels chained and the scratch users in launch order, and replays
+    to the same outputs as the call-by-call pass."""
+    from boda_amd.cnn_op import OpTune
+    cp = googlenet_conv(2)
+    params = _params(cp)
+    data = bo.gen_conv_in(*cp.nodes["data"].sizes)
+    fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16"))
+    fwd.init(cp, op_params=params)
+    try:
+        out = cp.out_node()
+        io = {"data": data}
+        fwd.run_fwd(["data"], io, [out])
+        want = io[out].copy()
+        n = fwd.capture_graph(parallel=True)
+        assert n == len(fwd.fwd_calls)
+        rtc.set_var_to_zero(out)
+        fwd.run_graph(); fwd.run_graph()
+        got = rtc.copy_var_to_nda(out)
+        assert np.array_equal(want, got) and float(np.abs(got).max()) > 0
+    finally:
+        fwd.release()
