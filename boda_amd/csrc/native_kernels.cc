@@ -196,19 +196,24 @@ static bool plan_k1_stream(conv_geom_t const &g, int num_cus, string const &spec
 }
 
 // bf16 variant (kernels/gemm_conv_bf16.hip): BK = 32, 32x32x16 MFMA only, chunked staging
-static void bf16_cfg(tile_cfg_t &c, bool gather, long tiles_hint = 0, long K = 0, int num_cus = 0, bool explicit_tile = false) {
+static void bf16_cfg(tile_cfg_t &c, bool gather, long Mi = 0, long Nj = 0, long K = 0, int num_cus = 0, bool explicit_tile = false) {
   if (c.MT != 32) { c.MT = 32; c.BI = 64; c.BJ = 64; c.WI = 2; c.WJ = 2; }
   if (c.BK != 32 && c.BK != 64) c.BK = 32;
   c.PF = 1;
-  // split-K by default for tile-starved shapes with a long K loop (fully-connected layers: AlexNet fc6 = 256 tiles x 288 K steps):
-  // aim at ~4 workgroups per CU, keep >= 8 K steps per slice.  (The bf16 path has no order-exactness to lose.)
+  // split-K by default for tile-starved shapes with a long K loop (fully-connected layers: AlexNet fc6 = 4096 x 256 outputs, K = 9216):
+  // the bf16 path has no order-exactness to lose.  Such shapes take 128x128 tiles (the LDS reuse the bf16 MFMA rate needs) and enough
+  // K slices for ~2 workgroups per CU with >= 8 K steps each.  Measured (AlexNet B=256, us): fc6 / fc7 64x64 unsplit 326 / 145,
+  // 64x64 x4 169 / 90, 128x128 x8 114 / 70; mid-size layers lose (ResNet res4 1x1 1024->256, 196 tiles x 32 steps: 47 split vs 42).
   if (!explicit_tile) {
     c.SPLITK = 1;
-    if (tiles_hint > 0 && num_cus > 0 && getenv("BODAHIP_NO_BF16_SPLITK") == nullptr) {
+    if (Mi > 0 && num_cus > 0 && getenv("BODAHIP_NO_BF16_SPLITK") == nullptr) {
       long const nkt = (K + c.BK - 1) / c.BK;
-      long s = std::min<long>(16, (4l * num_cus + tiles_hint - 1) / tiles_hint);
-      s = std::min<long>(s, nkt / 8);
-      if (s >= 2 && nkt >= 64 && tiles_hint <= num_cus) c.SPLITK = (int)s;   // (ResNet res4 1x1 1024->256, 196 tiles x 32 K steps: 47 us split vs 42 not)
+      long const tiles = ((Mi + c.BI - 1) / c.BI) * ((Nj + c.BJ - 1) / c.BJ), tiles128 = ((Mi + 127) / 128) * ((Nj + 127) / 128);
+      if (tiles <= num_cus && nkt >= 64) {
+        long s = std::min<long>(16, (2l * num_cus + tiles128 - 1) / tiles128);
+        s = std::min<long>(s, nkt / 8);
+        if (s >= 2) { c.BI = 128; c.BJ = 128; c.WI = 2; c.WJ = 2; c.MINW = 2; c.SPLITK = (int)s; }
+      }
     }
   }
   int const nt = c.threads();
@@ -224,8 +229,7 @@ static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string
   p.cfg = choose_cfg((int)M, (int)std::min<uint64_t>((uint64_t)N * batch, 0x7fffffffull), (int)K, num_cus, false, bf16); // (a batch deals batch x the tiles)
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad sgemm_tile '" + tile + "'"); }
   if (bf16) {
-    long const tiles = (long)((M + p.cfg.BI - 1) / p.cfg.BI) * ((N + p.cfg.BJ - 1) / p.cfg.BJ);
-    bf16_cfg(p.cfg, false, tiles, K, num_cus, !tile.empty());
+    bf16_cfg(p.cfg, false, M, N, K, num_cus, !tile.empty());
     p.defs = cfg_defs(p.cfg); p.defs.push_back("-DI_MODE=0"); p.defs.push_back("-DJ_MODE=0"); p.defs.push_back("-DEPI=0");
     if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
     return p;
@@ -337,7 +341,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
     }
   }
   if (p.patch && tile.empty()) p.cfg.PF = pf_for(p.cfg);
-  if (bf16) bf16_cfg(p.cfg, !p.ipconv, (long)((g.OC + p.cfg.BI - 1) / p.cfg.BI) * ((Nj + p.cfg.BJ - 1) / p.cfg.BJ), Kt, allow_splitk ? num_cus : 0, !tile.empty());
+  if (bf16) bf16_cfg(p.cfg, !p.ipconv, g.OC, Nj, Kt, allow_splitk ? num_cus : 0, !tile.empty());
   else check_cfg(p.cfg, !p.ipconv && !p.patch);
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0 && p.cfg.BK % 4 == 0) ? "2" : ((p.patch && Kt % 2 == 0) ? "4" : "3")));
