@@ -114,8 +114,8 @@ constexpr int kTI = BI / (WI * 32);
 constexpr int kTJ = BJ / (WJ * 32);
 static_assert(BI % (WI * 32) == 0 && BJ % (WJ * 32) == 0, "tile must be a multiple of the MFMA tile per wave");
 constexpr int kTaps = KH * KW, kWp = CW + 2 * PX;
-constexpr int kNP = CG * kTaps;                                    // k-slots (of 8 channels) per K step
-static_assert(kNP % 2 == 0, "an MFMA consumes two k-slots: CG*KH*KW must be even");
+constexpr int kNPr = CG * kTaps;                                   // k-slots (of 8 channels) per K step ...
+constexpr int kNP = kNPr + (kNPr & 1);                             // ... padded to whole MFMAs (two slots each): an odd count gets one all-zero filter slot
 static_assert(KH >= SY, "patch slots assume overlapping or abutting windows in y");
 constexpr int kRowsMax = (BJ - 2) / COW + 2;                       // output rows a BJ-pel tile can touch
 constexpr int kSegFull = (COH - 1) * SY + KH;                      // slots of a whole image
@@ -131,7 +131,7 @@ __device__ __forceinline__ rsrc_t make_rsrc(void const *p, unsigned bytes) { ret
 __device__ __forceinline__ float bload1(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
 __device__ __forceinline__ f32x4 bload4(rsrc_t r, int voff) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0)); }
 // chunk offset of k-slot q = (g, ky, kx) inside the patch, relative to a lane's output position
-constexpr int slot_off(int q) { return (q / kTaps) * kCS + ((q % kTaps) / KW) * kWp + (q % KW); }
+constexpr int slot_off(int q) { return (q >= kNPr) ? 0 : ((q / kTaps) * kCS + ((q % kTaps) / KW) * kWp + (q % KW)); } // (the pad slot reads tap 0: its filter row is zero)
 } // namespace
 
 extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p) {
@@ -203,7 +203,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     for (int e = 0; e < kIE; ++e) {
       int const el = tid + e * kNT, q = el / BI, i = el - q * BI;             // k-slot q = (g, tap) of this step, out_chan i0 + i
       int const g = q / kTaps, tap = q - g * kTaps, cg = cg0 + g;
-      bool const ok = (el < kNP * BI) && (cg < ncg) && (i0 + i < p.Mi);
+      bool const ok = (el < kNP * BI) && (q < kNPr) && (cg < ncg) && (i0 + i < p.Mi);
       rf[e] = bload4(rI, ok ? (int)((((unsigned)cg * kTaps + tap) * (unsigned)p.Mi + (unsigned)(i0 + i)) * 16u) : kOOB);
     }
   };

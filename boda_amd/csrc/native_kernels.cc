@@ -248,14 +248,16 @@ static bool plan_patch_bf16(conv_geom_t const &g, int num_cus, plan_t &p) {
   int const taps = g.KH * g.KW;
   if (!(g.SX == 1 && taps >= 2 && g.KH >= g.SY && g.C % 8 == 0 && g.C >= 16)) return false;
   if (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W) return false; // ("ipconv" shapes stay on the j-major path)
-  int cg = 1; while ((cg * taps) % 2 || cg * taps < 16) ++cg;                 // k-slots per K step: even, >= 16
-  if (cg > 4) return false;
+  int cg = 1; while (cg * taps < 16) ++cg;                                    // k-slots per K step: >= 16 (an odd count is padded with one zero slot)
+  if (char const *e = getenv("BODAHIP_PATCH16_CG")) { if (atoi(e) > 0) cg = atoi(e); }   // (experiments)
+  if (cg > 8) return false;
+  int const np = cg * taps + ((cg * taps) & 1);
   long const Nj = (long)g.B * g.OH * g.OW;
   int const wp = g.W + 2 * g.PX;
   auto lds = [&](int bi, int bj) {
     int const rows_max = (bj - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
     long const cs = (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp;
-    return 16l * ((long)cg * taps * bi + cg * cs);
+    return 16l * ((long)np * bi + cg * cs);
   };
   struct cand_t { int bi, bj, wi, wj; };
   static cand_t const cands[] = {{128, 128, 2, 2}, {96, 128, 1, 4}, {64, 128, 1, 4}, {64, 64, 2, 2}};
