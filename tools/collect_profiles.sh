@@ -30,6 +30,8 @@ for w in googlenet resnet50; do python bench.py --workload $w --batch 256 --no-c
 python bench.py --workload googlenet-net --graph --no-cpu-baseline > $O/bench_googlenet-net_graph.json 2>/dev/null
 python bench.py --workload googlenet-net --graph --parallel-branches --no-cpu-baseline > $O/bench_googlenet-net_graph_parallel.json 2>/dev/null
 for w in googlenet resnet50; do python bench.py --workload $w --graph --no-cpu-baseline > $O/bench_${w}_graph.json 2>/dev/null; done
+python bench.py --workload googlenet-net --dtype bf16 --graph --parallel-branches --no-cpu-baseline > $O/bench_googlenet-net_bf16_graph_parallel.json 2>/dev/null
+python bench.py --workload resnet50 --conv-algo winograd --graph --no-cpu-baseline > $O/bench_resnet50_winograd_graph.json 2>/dev/null
 python bench.py --workload nin-net --batch 128 --no-cpu-baseline > $O/bench_nin-net_b128.json 2>/dev/null
 python bench.py --workload nin --batch 128 --no-cpu-baseline > $O/bench_nin_b128.json 2>/dev/null
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
