@@ -118,6 +118,8 @@ def add_codegen_annotations(op: Op, tune: OpTune) -> Op:
             raise UnsupErr(f"sgemm variants of use_be={tune.use_be!r} are generated by the reference's CUCL code generator")
     else:
         raise UnsupErr(f"op type {t!r} is not on the conv_fwd / sgemm hot path")
+    if tune.hip_tile and native and not tune.use_culibs:
+        a.str_vals["hip_tile"] = tune.hip_tile   # travels with the function: the backend applies it to this function's calls only
     return a
 
 

@@ -306,6 +306,9 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   }
   // 1x1 kernel, no padding (any stride): the reference's k1conv case -- one add per gathered element, no table
   p.k1 = !p.ipconv && g.KH == 1 && g.KW == 1 && g.PY == 0 && g.PX == 0;
+  // long-K 1x1 layers on 64x64 tiles: a 32-deep K step (tools/tune_tiles.py over GoogLeNet / ResNet-50 at B=64: every 1x1 layer with
+  // >= 480 input channels gains 4-6 % over the 16-deep step; with 256 channels and fewer it does not)
+  if (p.k1 && !bf16 && tile.empty() && p.cfg.BI == 64 && p.cfg.BJ == 64 && p.cfg.MT == 32 && p.cfg.BK == 16 && g.C >= 448) p.cfg.BK = 32;
   // SX == 1, more than one tap: LDS input patch (J_MODE 7) -- a K step is CB whole input channels, staged as padded input rows
   // (coalesced, ~KH*KW x fewer loads than an im2col image) and read by the MFMAs in place.  Needs compile-time plane sizes.
   p.patch = false;
@@ -328,7 +331,11 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
       // MI355X (B=256 AlexNet conv2-5, TF/s): 64x256 126-131 | 128x256 125-131 | 32x256 110-129 | 64x64 116-122 | 128x128 109-120;
       // the score is that base rate x tile padding x how evenly the tiles deal out over the CUs.
       struct cand_t { int bi, bj, wi, wj, minw; double base; };
-      static cand_t const cands[] = {{64, 256, 1, 4, 2, 1.00}, {128, 256, 2, 4, 1, 0.99}, {32, 256, 1, 4, 2, 0.90}, {64, 64, 2, 2, 2, 0.93}, {128, 128, 2, 2, 2, 0.92}, {32, 128, 1, 2, 2, 0.80}};
+      // tools/tune_tiles.py over every distinct GoogLeNet / ResNet-50 layer at B=64 (ten candidate tiles each) corrected two entries: with a
+      // short K loop (< 2048: 64-192 input channels) the 64x64 tile is worth 0.82, not 0.93, of a 64x256 one (GoogLeNet conv2 3x3 64->192
+      // @56x56: 471 vs 380 us), and the 32x128 tile wants four waves (one 32x32 block each), not two (3x3 / 5x5 layers with 32-224 out_chans:
+      // 13-57 % faster).  What the sweep still finds after that is within a few percent of the planner's choice.
+      static cand_t const cands[] = {{64, 256, 1, 4, 2, 1.00}, {128, 256, 2, 4, 1, 0.99}, {32, 256, 1, 4, 2, 0.90}, {64, 64, 2, 2, 2, 0.93}, {128, 128, 2, 2, 2, 0.92}, {32, 128, 1, 4, 2, 0.80}};
       double best = -1;
       for (cand_t const &cd : cands) {
         tile_cfg_t c = p.cfg; c.BI = cd.bi; c.BJ = cd.bj; c.WI = cd.wi; c.WJ = cd.wj; c.MINW = cd.minw; c.BK = bk; c.MT = 32; c.SPLITK = 1;
@@ -336,7 +343,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
         long const ti = (g.OC + c.BI - 1) / c.BI, tj = (Nj + c.BJ - 1) / c.BJ, tiles = ti * tj;
         double const pad = ((double)g.OC / (double)(ti * c.BI)) * ((double)Nj / (double)(tj * c.BJ));
         double const bal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
-        double score = cd.base * pad * bal;
+        double score = cd.base * pad * bal * ((cd.bi == 64 && cd.bj == 64 && Kt < 2048) ? (0.82 / 0.93) : 1.0);
         if (2.0 * g.OC * (double)Nj * Kt < 2.4e10) { double const x = (double)tiles / num_cus; score *= x / (x + 0.6); } // short launches: see choose_cfg
         if (score > best) { best = score; p.cfg = c; p.patch = true; }
       }
@@ -731,6 +738,19 @@ static void need_float(dims_t const &d, char const *an) {
   if (d.tn != "float") unsup_err(string("native hip kernels: arg '") + an + "' has type " + d.tn + "; only float storage is supported");
 }
 
+// a function may carry its own tile (str_val hip_tile of the annotated op: per-layer tuned tiles, the op_tune_t-per-op analogue of the
+// reference's wisdom files); it overrides the backend-wide tune for that call only
+struct tile_override_t {
+  native_kernels_t::impl_t *impl; char const *key; bool active = false, had = false; string old;
+  tile_override_t(native_kernels_t::impl_t *impl_, char const *key_, op_base_t const &op) : impl(impl_), key(key_) {
+    auto it = op.str_vals.find("hip_tile");
+    if (it == op.str_vals.end() || it->second.empty()) return;
+    active = true; auto t = impl->tune.find(key); had = (t != impl->tune.end()); if (had) old = t->second;
+    impl->tune[key] = it->second;
+  }
+  ~tile_override_t() { if (!active) return; if (had) impl->tune[key] = old; else impl->tune.erase(key); }
+};
+
 void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &am) {
   string const &fn = fi.op.get_func_name();
   bool const bf16 = (fn == "hip_sgemm_bf16" || fn == "hip_conv_bf16");
@@ -743,6 +763,7 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     assert_st(a.sz() == 2 && b.sz() == 2 && c.sz() == 2);
     assert_st(a.names(0) == "K" && a.names(1) == "M" && b.names(0) == "K" && b.names(1) == "N" && c.names(0) == "M" && c.names(1) == "N");
     assert_st(b.dsz("K") == K); assert_st(c.dsz("M") == M); assert_st(c.dsz("N") == N);
+    tile_override_t const tov(impl, "sgemm_tile", fi.op);
     sgemm((float const *)host->nh_var_ptr(an), (float const *)host->nh_var_ptr(bn), (float *)host->nh_var_ptr(cn), M, N, K, bf16);
     return;
   }
@@ -770,6 +791,7 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     if (!g.SY || !g.SX) rt_err("hip_conv: zero stride");
     // out = (in + 2*pad - k)/stride + 1, floor (src/conv_util.cc:167-173)
     if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW) rt_err("hip_conv: out dims do not match in/filts/stride/in_pad");
+    tile_override_t const tov(impl, "conv_tile", fi.op);
     conv((float const *)host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), (float const *)host->nh_var_ptr(inm), (float *)host->nh_var_ptr(onm), g, bf16, out_ctot, out_coff,
          (fn == "hip_conv_winograd") ? "winograd_all" : nullptr); // hip_conv_winograd: the F(2x2,3x3) path for this function (3x3 / stride 1; others: direct)
     return;

@@ -785,3 +785,32 @@ def test_winograd_by_func_name_through_op_tune(be):
     assert np.array_equal(outs["out"], bo.conv_fwd(bo.gen_conv_in(2, 6, 12, 12), bo.gen_conv_filts(10, 6, 5, 5), bo.gen_conv_biases(10), (2, 2), (1, 1), True))
     outs, _ = _run(be, _conv_op(2, 6, 12, 12, 10, 3, 3, 1, 1))
     assert rtc.last_launch()["kernel"] == "bodahip_conv_f32" and np.array_equal(outs["out"], want)
+
+
+def test_tile_travels_with_the_function(be):
+    """op_tune hip_tile is carried by the annotated op (str_val hip_tile): the backend applies it to that function's calls only -- per-layer
+    tuned tiles (tools/tune_tiles.py, the op-tuner idea of src/op-tuner.cc) need no backend-wide state -- and results stay bit-exact."""
+    rtc = be.rtc
+    op = _conv_op(4, 24, 14, 14, 48, 3, 3, 1, 1)
+    x = bo.gen_conv_in(4, 24, 14, 14); f = bo.gen_conv_filts(48, 24, 3, 3); b = bo.gen_conv_biases(48)
+    want = bo.conv_fwd(x, f, b, (1, 1), (1, 1), True)
+    for vn, d, arr in (("tt_in", op.get_dims("in"), x), ("tt_f", op.get_dims("filts"), f), ("tt_b", op.get_dims("biases"), b), ("tt_out", op.get_dims("out"), None)):
+        rtc.create_var_with_dims(vn, d)
+        if arr is not None: rtc.copy_nda_to_var(vn, arr)
+    try:
+        cfgs = {}
+        for name, tune in (("tt_tiled", OpTune(hip_tile="32x128x16x1x4x2")), ("tt_auto", OpTune())):
+            anno = add_codegen_annotations(op, tune)
+            assert ("hip_tile" in anno.str_vals) == (name == "tt_tiled")
+            rtc.compile([RtcFuncInfo(name, "", [a for a, _ in NATIVE_ARGS[anno.get_func_name()]], anno)])
+        am = {"in": RtcArg.var("tt_in"), "filts": RtcArg.var("tt_f"), "biases": RtcArg.var("tt_b"), "out": RtcArg.var("tt_out"),
+              "stride": RtcArg.ref(op.get_dims("stride")), "in_pad": RtcArg.ref(op.get_dims("in_pad"))}
+        for name in ("tt_tiled", "tt_auto", "tt_tiled"):
+            rtc.set_var_to_zero("tt_out")
+            rtc.run(RtcFuncCall(name, am)); rtc.finish_and_sync()
+            cfgs.setdefault(name, []).append(rtc.last_launch()["cfg"])
+            assert np.array_equal(rtc.copy_var_to_nda("tt_out"), want), name
+        assert all(c.startswith("32x128x") and c.endswith("_w1x4") for c in cfgs["tt_tiled"]) and not cfgs["tt_auto"][0].startswith("32x128x")
+    finally:
+        for vn in ("tt_in", "tt_f", "tt_b", "tt_out"): rtc.release_var(vn)
+        rtc.release_func("tt_tiled"); rtc.release_func("tt_auto"); rtc.release_per_call_id_data()
