@@ -799,7 +799,7 @@ def test_tile_travels_with_the_function(be):
         if arr is not None: rtc.copy_nda_to_var(vn, arr)
     try:
         cfgs = {}
-        for name, tune in (("tt_tiled", OpTune(hip_tile="32x128x16x1x4x2")), ("tt_auto", OpTune())):
+        for name, tune in (("tt_tiled", OpTune(hip_tile="128x128x16x2x2x2")), ("tt_auto", OpTune())):
             anno = add_codegen_annotations(op, tune)
             assert ("hip_tile" in anno.str_vals) == (name == "tt_tiled")
             rtc.compile([RtcFuncInfo(name, "", [a for a, _ in NATIVE_ARGS[anno.get_func_name()]], anno)])
@@ -810,7 +810,7 @@ def test_tile_travels_with_the_function(be):
             rtc.run(RtcFuncCall(name, am)); rtc.finish_and_sync()
             cfgs.setdefault(name, []).append(rtc.last_launch()["cfg"])
             assert np.array_equal(rtc.copy_var_to_nda("tt_out"), want), name
-        assert all(c.startswith("32x128x") and c.endswith("_w1x4") for c in cfgs["tt_tiled"]) and not cfgs["tt_auto"][0].startswith("32x128x")
+        assert all(c.startswith("128x128x") and c.endswith("_w2x2") for c in cfgs["tt_tiled"]) and not cfgs["tt_auto"][0].startswith("128x128x")
     finally:
         for vn in ("tt_in", "tt_f", "tt_b", "tt_out"): rtc.release_var(vn)
         rtc.release_func("tt_tiled"); rtc.release_func("tt_auto"); rtc.release_per_call_id_data()
