@@ -814,3 +814,28 @@ def test_tile_travels_with_the_function(be):
     finally:
         for vn in ("tt_in", "tt_f", "tt_b", "tt_out"): rtc.release_var(vn)
         rtc.release_func("tt_tiled"); rtc.release_func("tt_auto"); rtc.release_per_call_id_data()
+
+
+@pytest.mark.parametrize("net", ["googlenet_conv", "resnet-50"])
+def test_config5_layers_at_bench_batch_prefix_invariance(be, net):
+    """Full-size property at BASELINE config 5's per-GPU batch (64): the planner picks other tiles / kernels there than at batch 2
+    (32x256 and 32x128 four-wave patch tiles, the streaming 1x1 kernel, 64x64 with a 32-deep K step ...), so every distinct layer is run
+    at B=64 and out[:2] must equal the oracle's B=2 result bit for bit (inputs are a hash of the flat index: the first two images of
+    the B=64 input are the B=2 input); the last image must be finite and not all zero."""
+    import bench
+    big = {}
+    for op in bench.net_conv_ops(net, 64):
+        big.setdefault(op.to_str(), op)
+    small = {}
+    for op in bench.net_conv_ops(net, 2):
+        small.setdefault(op.to_str(), op)
+    assert len(big) == len(small) >= 20
+    kernels = set()
+    for ob, os_ in zip(big.values(), small.values()):
+        outs, prc = _run(be, ob, 5)
+        want = bo.run_op(os_, 5)["out"]
+        assert np.array_equal(want, outs["out"][:2]), (ob.to_str(), prc.launch["kernel"], prc.launch["cfg"], SsdsDiff.of(want, outs["out"][:2]).basic_str())
+        last = outs["out"][-1]
+        assert np.isfinite(last).all() and last.max() > 0
+        kernels.add(prc.launch["kernel"] + " " + prc.launch["cfg"].split("x")[0] + "x" + prc.launch["cfg"].split("x")[1])
+    assert len(kernels) >= 3, kernels
