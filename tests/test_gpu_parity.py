@@ -816,20 +816,21 @@ def test_tile_travels_with_the_function(be):
         rtc.release_func("tt_tiled"); rtc.release_func("tt_auto"); rtc.release_per_call_id_data()
 
 
-@pytest.mark.parametrize("net", ["googlenet_conv", "resnet-50"])
-def test_config5_layers_at_bench_batch_prefix_invariance(be, net):
+@pytest.mark.parametrize("net,batch", [("googlenet_conv", 64), ("resnet-50", 64), ("nin", 128)])
+def test_config5_layers_at_bench_batch_prefix_invariance(be, net, batch):
     """Full-size property at BASELINE config 5's per-GPU batch (64): the planner picks other tiles / kernels there than at batch 2
     (32x256 and 32x128 four-wave patch tiles, the streaming 1x1 kernel, 64x64 with a 32-deep K step ...), so every distinct layer is run
     at B=64 and out[:2] must equal the oracle's B=2 result bit for bit (inputs are a hash of the flat index: the first two images of
     the B=64 input are the B=2 input); the last image must be finite and not all zero."""
     import bench
+    ops_of = (lambda b: bench.nin_ops(b)) if net == "nin" else (lambda b: bench.net_conv_ops(net, b))   # (nin at 128: config 4's per-GPU batch)
     big = {}
-    for op in bench.net_conv_ops(net, 64):
+    for op in ops_of(batch):
         big.setdefault(op.to_str(), op)
     small = {}
-    for op in bench.net_conv_ops(net, 2):
+    for op in ops_of(2):
         small.setdefault(op.to_str(), op)
-    assert len(big) == len(small) >= 20
+    assert len(big) == len(small) >= 9
     kernels = set()
     for ob, os_ in zip(big.values(), small.values()):
         outs, prc = _run(be, ob, 5)
@@ -838,4 +839,4 @@ def test_config5_layers_at_bench_batch_prefix_invariance(be, net):
         last = outs["out"][-1]
         assert np.isfinite(last).all() and last.max() > 0
         kernels.add(prc.launch["kernel"] + " " + prc.launch["cfg"].split("x")[0] + "x" + prc.launch["cfg"].split("x")[1])
-    assert len(kernels) >= 3, kernels
+    assert len(kernels) >= 2, kernels
