@@ -76,10 +76,14 @@ class ConvPipe:
         elif op.type == "Pooling":
             if op.kern_sz is None:   # global pooling
                 op.kern_sz, op.stride, op.in_pad = (H, W), (1, 1), (0, 0)
-            def osz(i, k, s, p):
-                pin = i + 2 * p
-                return 1 if pin < k else -(-(pin - k) // s) + 1
-            out = Dims.make("float", img=B, chan=C, y=osz(H, op.kern_sz[0], op.stride[0], op.in_pad[0]), x=osz(W, op.kern_sz[1], op.stride[1], op.in_pad[1]))
+            # Caffe CEIL convention; when EITHER padded dim is smaller than the kernel the reference yields (1,1) for both
+            # (pad_in_sz.both_dims_ge, src/conv_util.cc:201-203)
+            piy, pix = H + 2 * op.in_pad[0], W + 2 * op.in_pad[1]
+            if piy < op.kern_sz[0] or pix < op.kern_sz[1]:
+                oy = ox = 1
+            else:
+                oy = -(-(piy - op.kern_sz[0]) // op.stride[0]) + 1; ox = -(-(pix - op.kern_sz[1]) // op.stride[1]) + 1
+            out = Dims.make("float", img=B, chan=C, y=oy, x=ox)
         elif op.type in ("ReLU", "LRN", "Dropout"):
             out = d
         elif op.type == "Concat":          # channel concatenation of same-sized maps (src/conv_util.cc:437-446)
@@ -361,13 +365,16 @@ class ConvPipeFwd:
                     for b in (o.bots or (o.bot,)):
                         readers[b] = readers.get(b, 0) + 1
             conv_tops = {o.top for o in cp.ops if o.type == "Convolution"}
+            # a top that an un-fused in-place op (a ReLU that is not the conv's immediate successor, an in-place LRN) still works on
+            # must exist as a var of its own: it is not eliminated
+            inplace_targets = {o.top for o in cp.ops if o.in_place and o.tag not in fused and o.type != "Dropout"}
             for o in cp.ops:
                 if o.type != "Concat":
                     continue
                 c_done = 0
                 for b in o.bots:
                     ch = cp.nodes[b].dsz("chan")
-                    if b in conv_tops and readers.get(b, 0) == 1 and o.bots.count(b) == 1:
+                    if b in conv_tops and b not in inplace_targets and readers.get(b, 0) == 1 and o.bots.count(b) == 1:
                         self.slices[b] = (o.top, c_done, ch)
                     c_done += ch
         # vars: the source node, then one per op output (in-place ops and Dropout reuse their input var)
@@ -571,24 +578,3 @@ class ConvPipeFwd:
         for v in self._vars:
             rtc.release_var(v)
         self._funcs, self._vars, self.fwd_calls = [], [], []
-
-
-def oracle_forward(cp: ConvPipe, data: np.ndarray, params: Dict[str, np.ndarray], bo) -> Dict[str, np.ndarray]:
-    """Reference-order forward of `cp` with the CPU oracle module `bo` (TESTS ONLY: the caller passes oracle.boda_oracle).
-    Returns every node after its in-place ops (what the device vars hold after run_fwd)."""
-    vals = {cp.in_node: data}
-    for op in cp.ops:
-        x = vals[op.bot]
-        if op.type == "Convolution":
-            vals[op.top] = bo.conv_fwd(x, params[op.tag + "_filts"], params[op.tag + "_biases"], op.stride, op.in_pad, relu=False)
-        elif op.type == "ReLU":
-            vals[op.top] = bo.relu(x)
-        elif op.type == "Pooling":
-            vals[op.top] = bo.pool_fwd(x, op.kern_sz, op.stride, op.in_pad, bool(op.avg_pool))
-        elif op.type == "LRN":
-            vals[op.top] = bo.lrn_fwd(x, *op.lrn)
-        elif op.type == "Dropout":
-            vals[op.top] = x
-        elif op.type == "Concat":
-            vals[op.top] = np.concatenate([vals[b] for b in op.bots], axis=1)
-    return vals

@@ -122,7 +122,7 @@ int bodahip_get_device_info(bodahip_ctx *ctx, char *arch_buf, size_t n, int *num
   native_kernels_t *nk = hip_compute_native(&R(ctx)); (void)nk;
   native_host_t *h = dynamic_cast<native_host_t *>(&R(ctx)); if (!h) rt_err("not a hip backend");
   put_str(arch_buf, n, h->nh_arch(), "arch"); if (num_cus) *num_cus = h->nh_num_cus();
-  if (clock_khz) { int khz = 0; int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev); *clock_khz = khz; }
+  if (clock_khz) { int khz = 0; (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, h->nh_device()); *clock_khz = khz; } // (the ctx's device, not the thread's current one)
   ABI_CATCH }
 int bodahip_set_tune(bodahip_ctx *ctx, const char *key, const char *value) { ABI_TRY hip_compute_native(&R(ctx))->set_tune(S(key, "key"), value ? value : ""); ABI_CATCH }
 int bodahip_last_launch(bodahip_ctx *ctx, char *kbuf, size_t kn, char *cbuf, size_t cn, uint32_t *grid, uint32_t *block, double *flops, double *algo_bytes) {

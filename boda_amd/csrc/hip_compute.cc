@@ -324,6 +324,7 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
   // ---- native_host_t: what the native kernels need from the backend
   hipStream_t nh_stream() override { return stream; }
   bool nh_capturing() override { return capturing; }
+  int nh_live_graphs() override { int n = 0; for (auto const &gr : graphs) if (gr.exec) ++n; return n; }
 
   // ---- hipGraph capture of a call list (launch-bound inner loops, e.g. the ~120 small kernels of a GoogLeNet forward at batch 64):
   // graph_begin() ... run() x N ... graph_end() records the launches (arguments frozen as passed) instead of executing them;
@@ -393,13 +394,17 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
         std::map<hipGraphNode_t, size_t> pos; for (size_t k = 0; k < nn; ++k) pos[order[k]] = k;
         size_t prev_end = 0;
         for (uint32_t i = 0; i < n_calls; ++i) {
-          if (nn == n_calls) { first[i] = last[i] = i; continue; }
-          if (i >= cap_last.size() || !cap_last[i] || !pos.count(cap_last[i])) rt_err("graph_end_deps: could not attribute the captured nodes to calls");
-          first[i] = prev_end; last[i] = pos[cap_last[i]];
+          // always from the node each call left as the capture's tail (never from counts: a call that launched nothing -- a conv
+          // with no output positions -- next to one that launched two would keep the counts equal and shift every later call)
+          if (i >= cap_last.size()) rt_err("graph_end_deps: could not attribute the captured nodes to calls");
+          hipGraphNode_t const tail = cap_last[i], prev_tail = i ? cap_last[i - 1] : nullptr;
+          if (tail == prev_tail) rt_err("graph_end_deps: captured call " + std::to_string(i) + " launched no kernel; such calls cannot carry dependencies");
+          if (!tail || !pos.count(tail)) rt_err("graph_end_deps: could not attribute the captured nodes to calls");
+          first[i] = prev_end; last[i] = pos[tail];
           if (last[i] < first[i]) rt_err("graph_end_deps: could not attribute the captured nodes to calls");
           prev_end = last[i] + 1;
         }
-        if (nn != n_calls && prev_end != nn) rt_err("graph_end_deps: captured nodes after the last call");
+        if (prev_end != nn) rt_err("graph_end_deps: captured nodes after the last call");
       }
       if (ne) hip_err_chk(hipGraphRemoveDependencies(gr.g, ef.data(), et.data(), ne), "hipGraphRemoveDependencies");
       std::vector<hipGraphNode_t> nf, nt;
@@ -445,6 +450,7 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
   }
   string const &nh_arch() override { return arch; }
   int nh_num_cus() override { return props.multiProcessorCount; }
+  int nh_device() override { return device_ordinal; }
   void *nh_var_ptr(string const &vn) override { return must_find(vis, vn).buf->p; }
   dims_t nh_var_dims(string const &vn) override { return must_find(vis, vn).dims; }
   rtc_compute_t &nh_rtc() override { return *this; }

@@ -31,6 +31,7 @@ struct native_kernels_t::impl_t {
   std::map<string, kernel_t> kernels; // key = option string
   std::map<string, string> tune;
   void *ws = nullptr; size_t ws_bytes = 0; // split-K partial-sum slabs (grow-only scratch, like the reference's cudnn scratch var)
+  std::vector<void *> ws_retired;          // outgrown scratch buffers that captured graphs may still point into (freed with the backend)
   std::map<string, void *> ktabs;           // im2col gather tables, one per (C,H,W,KH,KW) (device memory)
   hipModule_t wino_mod = nullptr; hipFunction_t wino_filt = nullptr, wino_in = nullptr, wino_out = nullptr; // kernels/winograd_f32.hip
 };
@@ -45,6 +46,7 @@ native_kernels_t::~native_kernels_t() {
   for (auto &kv : impl->kernels) { if (kv.second.mod) (void)hipModuleUnload(kv.second.mod); }
   if (impl->wino_mod) (void)hipModuleUnload(impl->wino_mod);
   if (impl->ws) (void)hipFree(impl->ws);
+  for (void *r : impl->ws_retired) (void)hipFree(r);
   for (auto &kv : impl->ktabs) (void)hipFree(kv.second);
   delete impl;
 }
@@ -377,7 +379,14 @@ static std::vector<char> compile_plan(plan_t const &p, string const &arch, strin
 static void ensure_ws(native_kernels_t::impl_t *impl, native_host_t *host, size_t need) {
   if (impl->ws_bytes >= need) return;
   if (host->nh_capturing()) rt_err("graph capture: kernel workspace not allocated yet -- run the call list once before capturing it");
-  if (impl->ws) { hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize"); hip_err_chk(hipFree(impl->ws), "hipFree"); impl->ws = nullptr; impl->ws_bytes = 0; }
+  if (impl->ws) {
+    hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize");
+    // a captured hipGraph has the scratch pointer frozen into its kernel arguments (split-K slabs, Winograd U/V/M, bf16 filter
+    // re-layout, space-to-depth buffers): while any graph is alive the outgrown buffer is retired, not freed, so that replaying
+    // an older graph after a later call grew the scratch still works on valid memory
+    if (host->nh_live_graphs() > 0) impl->ws_retired.push_back(impl->ws); else hip_err_chk(hipFree(impl->ws), "hipFree");
+    impl->ws = nullptr; impl->ws_bytes = 0;
+  }
   hip_err_chk(hipMalloc(&impl->ws, need), "hipMalloc(kernel scratch)"); impl->ws_bytes = need;
 }
 static void setup_splitk(native_kernels_t::impl_t *impl, native_host_t *host, gemm_args_t &ga, tile_cfg_t const &cfg, size_t out_elems) {
@@ -464,7 +473,9 @@ void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t 
   ga.Mi = (int)M; ga.Nj = (int)N; ga.K = (int)K; ga.ldI = (int)M; ga.ldJ = (int)N; ga.ldD = (int)N;
   if ((uint64_t)K * M * 4 > 0x80000000ull || (uint64_t)K * N * 4 > 0x80000000ull) unsup_err("hip_sgemm: operands larger than 2 GiB are not supported (32-bit buffer offsets)");
   ga.I_bytes = (unsigned)((uint64_t)K * M * 4); ga.J_bytes = (unsigned)((uint64_t)K * N * 4);
-  if ((uint64_t)M * N * 4 >= 0xfffffff0ull) unsup_err("hip_sgemm: c of 4 GiB or more is not supported (32-bit store offsets)");
+  // (outputs share the operands' 2 GiB limit: the epilogue masks lanes past the last column with byte offset 0x80000000, which the
+  //  buffer range check only drops while the output itself ends below that offset)
+  if ((uint64_t)M * N * 4 >= 0x7ffffff0ull) unsup_err("hip_sgemm: c of 2 GiB or more is not supported (32-bit store offsets, masked lanes use offset 2^31)");
   ga.D_bytes = (unsigned)((uint64_t)M * N * 4);
   ga.tiles_i = (int)((M + cfg.BI - 1) / cfg.BI); ga.tiles_j = (int)((N + cfg.BJ - 1) / cfg.BJ);
   setup_splitk(impl, host, ga, cfg, (size_t)M * N);
@@ -624,7 +635,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
       ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = g2.C * g2.KH * g2.KW; ga.C = g2.C; ga.H = g2.H; ga.W = g2.W; ga.OH = g.OH; ga.OW = g.OW;
       ga.J_bytes = (unsigned)(in2 * 4);
       uint64_t const out_bytes = (uint64_t)Nj * out_ctot * 4;
-      if (out_bytes >= 0xfffffff0ull) unsup_err("hip_conv: out of 4 GiB or more is not supported (32-bit store offsets)");
+      if (out_bytes >= 0x7ffffff0ull) unsup_err("hip_conv: out of 2 GiB or more is not supported (32-bit store offsets, masked lanes use offset 2^31)");
       ga.D_bytes = (unsigned)out_bytes; ga.out_ctot = out_ctot; ga.out_coff = out_coff;
       ga.tiles_i = (g.OC + p2.cfg.BI - 1) / p2.cfg.BI; ga.tiles_j = (int)((Nj + p2.cfg.BJ - 1) / p2.cfg.BJ); ga.splitk = 1;
       launch_patch16(impl, host, p2, k2, ga, (float const *)((char *)impl->ws + off_f2), g2, off_fp);
@@ -647,7 +658,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   uint64_t const out_bytes = (uint64_t)Nj * out_ctot * 4;
   if (cfg.SPLITK > 1 && out_ctot != g.OC) unsup_err("hip_conv: split-K tiles cannot write a channel slice of a wider output");
   ga.out_ctot = out_ctot; ga.out_coff = out_coff;
-  if (out_bytes >= 0xfffffff0ull) unsup_err("hip_conv: out of 4 GiB or more is not supported (32-bit store offsets)");
+  if (out_bytes >= 0x7ffffff0ull) unsup_err("hip_conv: out of 2 GiB or more is not supported (32-bit store offsets, masked lanes use offset 2^31)");
   ga.D_bytes = (unsigned)out_bytes;
   if (p.rows) { ktab_t const kt = get_rtab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
   else if (!p.ipconv && !p.k1 && !p.patch && !p.stream && !p.patch16) { ktab_t const kt = get_ktab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }

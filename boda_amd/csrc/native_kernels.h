@@ -25,8 +25,10 @@ struct native_host_t {
   virtual ~native_host_t() {}
   virtual hipStream_t nh_stream() = 0;
   virtual bool nh_capturing() = 0; // stream capture (hipGraph) in progress: nothing may be compiled / allocated / synchronised
+  virtual int nh_live_graphs() = 0; // captured graphs not yet destroyed (their kernel arguments may point into the kernel scratch)
   virtual string const &nh_arch() = 0;
   virtual int nh_num_cus() = 0;
+  virtual int nh_device() = 0;      // HIP device ordinal this backend runs on
   virtual void *nh_var_ptr(string const &vn) = 0;
   virtual dims_t nh_var_dims(string const &vn) = 0;
   virtual rtc_compute_t &nh_rtc() = 0;

@@ -9,11 +9,12 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from boda_amd.conv_pipe import ConvPipe, ConvPipeFwd, PipeOp, alexnet_ng_conv, googlenet_conv, nin_imagenet, oracle_forward
+from boda_amd.conv_pipe import ConvPipe, ConvPipeFwd, PipeOp, alexnet_ng_conv, googlenet_conv, nin_imagenet
 from boda_amd.digest import SsdsDiff
 from boda_amd.op import Dims
 from boda_amd.rtc import make_rtc
 from oracle import boda_oracle as bo
+from oracle.net_forward import oracle_forward
 
 FULLNET_MRD = 5e-4
 
@@ -72,7 +73,7 @@ def test_full_net_forward_matches_oracle(rtc, net, batch, tmp_path):
         # (2) end to end against the oracle's own layer-by-layer forward, at the reference's full-net tolerance.  GoogLeNet is 22
         #     conv layers deep and the hash-random weights let the ulp-level LRN / avg-pool differences grow (measured 5.5e-4 at
         #     icp5 with every op exact in isolation), so its end-to-end bound only guards against gross errors.
-        want = oracle_forward(cp, data, params, bo)
+        want = oracle_forward(cp, data, params)
         tol = 5e-3 if net == "googlenet" else FULLNET_MRD
         for op in cp.ops:
             if op.type in ("ReLU", "Dropout"):
@@ -144,7 +145,7 @@ def test_concat_copies_into_channel_ranges(rtc):
         fwd.run_fwd(["data"], io, ["pa", "pb", "cat"])
         assert [c.func for c in fwd.fwd_calls].count("fwd_copy") == 3 and io["cat"].shape == (3, 15, 6, 7)
         assert np.array_equal(io["cat"], np.concatenate([io["pa"], data, io["pb"]], axis=1))
-        assert np.array_equal(io["pa"], oracle_forward(cp, data, {}, bo)["pa"])
+        assert np.array_equal(io["pa"], oracle_forward(cp, data, {})["pa"])
     finally:
         fwd.release()
 
@@ -160,7 +161,7 @@ def test_pool_lrn_relu_kernels_vs_oracle(rtc):
     try:
         io = {"data": data}
         fwd.run_fwd(["data"], io, ["p_pad", "n", "g"])
-        want = oracle_forward(cp, data, {}, bo)
+        want = oracle_forward(cp, data, {})
         assert np.array_equal(want["p_pad"], io["p_pad"]) and (io["p_pad"] >= 0).all()  # max-pool (ceil sizes, padding) + un-fused ReLU
         assert io["p_pad"].shape == (2, 7, 7, 6) and io["g"].shape == (2, 7, 1, 1)
         assert SsdsDiff.of(want["n"], io["n"]).mrd < 1e-5 and SsdsDiff.of(want["g"], io["g"]).mrd < 1e-5
@@ -185,7 +186,7 @@ def test_full_net_forward_bf16_operands(rtc, net, batch):
         nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
         io = {"data": data}
         fwd.run_fwd(["data"], io, nodes)
-        want = oracle_forward(cp, data, params, bo)
+        want = oracle_forward(cp, data, params)
         for op in cp.ops:
             if op.type in ("ReLU", "Dropout"):
                 continue
