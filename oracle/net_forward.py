@@ -9,14 +9,17 @@ import numpy as np
 from . import boda_oracle as bo
 
 
-def oracle_forward(cp, data: np.ndarray, params: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+def oracle_forward(cp, data: np.ndarray, params: Dict[str, np.ndarray], bf16: bool = False) -> Dict[str, np.ndarray]:
     """Reference-order forward of `cp` with the CPU oracle.
     Returns every node after its in-place ops (what the device vars hold after run_fwd)."""
     vals = {cp.in_node: data}
     for op in cp.ops:
         x = vals[op.bot]
         if op.type == "Convolution":
-            vals[op.top] = bo.conv_fwd(x, params[op.tag + "_filts"], params[op.tag + "_biases"], op.stride, op.in_pad, relu=False)
+            f = params[op.tag + "_filts"]
+            if bf16:   # what the bf16 kernels do: both operands rounded to bf16 (RNE) on the way in, fp32 accumulate, fp32 bias
+                x, f = bo.to_bf16(x), bo.to_bf16(f)
+            vals[op.top] = bo.conv_fwd(x, f, params[op.tag + "_biases"], op.stride, op.in_pad, relu=False)
         elif op.type == "ReLU":
             vals[op.top] = bo.relu(x)
         elif op.type == "Pooling":

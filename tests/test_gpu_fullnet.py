@@ -172,8 +172,14 @@ def test_pool_lrn_relu_kernels_vs_oracle(rtc):
 @pytest.mark.parametrize("net,batch", [("nin", 2), ("googlenet", 2)])
 def test_full_net_forward_bf16_operands(rtc, net, batch):
     """op_tune hip_dtype=bf16 through the full-net driver (config 5's arithmetic on whole nets): every conv goes to a bf16 kernel
-    (channel-innermost LDS patch / gather / 1x1, incl. writes into Concat channel slices); parity is unpinned for bf16 (the reference
-    has none) -- stated bound: normalised RMS error of every node < 3e-2 against the exact fp32 oracle forward, no NaNs."""
+    (channel-innermost LDS patch / gather / 1x1, incl. writes into Concat channel slices).  Parity is unpinned for bf16 (the reference
+    has none); the stated bounds, per node:
+      (1) against the oracle's forward with the SAME operand rounding (both conv operands to bf16, RNE; fp32 accumulate): normalised RMS
+          error < 1e-3 -- what is left is accumulation order plus the few values a 1e-6 difference pushes over a bf16 rounding boundary
+          in the next layer; a dropped K-slice or tap on any layer is 10-100x that;
+      (2) against the exact fp32 forward: < 3.5e-3 * sqrt(conv depth of the node) -- operand rounding is a relative error of
+          ~2^-9 / sqrt(3) per operand that accumulates like a random walk over the convs on the path (measured with the oracle alone:
+          at most 2.9e-3 * sqrt(depth) over every node of NiN and GoogLeNet)."""
     from boda_amd.cnn_op import OpTune
     cp = {"nin": nin_imagenet, "googlenet": googlenet_conv}[net](batch)
     params = _params(cp)
@@ -186,14 +192,25 @@ def test_full_net_forward_bf16_operands(rtc, net, batch):
         nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
         io = {"data": data}
         fwd.run_fwd(["data"], io, nodes)
-        want = oracle_forward(cp, data, params)
+        want_b = oracle_forward(cp, data, params, bf16=True)
+        want_x = oracle_forward(cp, data, params)
+        depth = {cp.in_node: 0}
+        for op in cp.ops:
+            depth[op.top] = max(depth[b] for b in (op.bots or (op.bot,))) + (1 if op.type == "Convolution" else 0)
+        def nrms(w, g):
+            w = w.astype(np.float64); g = g.astype(np.float64)
+            return float(np.sqrt(np.mean((w - g) ** 2)) / max(1e-30, np.sqrt(np.mean(w ** 2))))
+        worst_b = worst_x = 0.0
         for op in cp.ops:
             if op.type in ("ReLU", "Dropout"):
                 continue
-            w = want[op.top].astype(np.float64); g = io[op.top].astype(np.float64)
+            g = io[op.top]
             assert np.isfinite(g).all(), op.top
-            nrms = float(np.sqrt(np.mean((w - g) ** 2)) / max(1e-30, np.sqrt(np.mean(w ** 2))))
-            assert nrms < 3e-2, (op.top, nrms)
+            eb, ex = nrms(want_b[op.top], g), nrms(want_x[op.top], g)
+            worst_b = max(worst_b, eb); worst_x = max(worst_x, ex / np.sqrt(max(1, depth[op.top])))
+            assert eb < 1e-3, (op.top, "vs bf16-rounded oracle forward", eb)
+            assert ex < 3.5e-3 * np.sqrt(max(1, depth[op.top])), (op.top, depth[op.top], "vs exact fp32 forward", ex)
+        print(f"{net}: worst nRMS vs bf16 oracle forward {worst_b:.2e}; vs exact / sqrt(depth) {worst_x:.2e}")
     finally:
         fwd.release()
 

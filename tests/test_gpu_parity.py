@@ -840,3 +840,90 @@ def test_config5_layers_at_bench_batch_prefix_invariance(be, net, batch):
         assert np.isfinite(last).all() and last.max() > 0
         kernels.add(prc.launch["kernel"] + " " + prc.launch["cfg"].split("x")[0] + "x" + prc.launch["cfg"].split("x")[1])
     assert len(kernels) >= 2, kernels
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bf16 kernels at the BENCHED sizes (BASELINE config 5: 64 images per GPU; config 3's fc layers at 256; sgemm-ops-full >= 2048).
+# Parity is unpinned for bf16 by construction (the reference has none): the stated bound is  mrd < 1e-3 * max(1, sqrt(K/2400))
+# against the oracle fed the same bf16-rounded operands, enforced here where the bench runs.
+# ---------------------------------------------------------------------------------------------------------------
+def _bf16_bound(K):
+    return MRD_BF16 * max(1.0, (K / 2400.0) ** 0.5)
+
+
+def _bf16_prefix_check(be, big_op, small_op):
+    """big_op through hip_conv_bf16 at the benched batch; out[:2] against the oracle's batch-2 result on bf16-rounded operands (the
+    inputs are a hash of the flat index: the first two images of the big input ARE the batch-2 input; filters / biases are equal)."""
+    outs, prc = _run(be, big_op, 5, tune=OpTune(hip_dtype="bf16"))
+    assert prc.op.get_func_name() == "hip_conv_bf16"
+    g = small_op.conv_geom()
+    ins = bo.run_op(small_op, 5)
+    want = bo.conv_fwd(bo.to_bf16(ins["in"]), bo.to_bf16(ins["filts"]), ins["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
+    got = outs["out"][:2]
+    sd = SsdsDiff.of(want, got)
+    K = g["C"] * g["KH"] * g["KW"]
+    assert not sd.has_nan() and sd.mrd < _bf16_bound(K), (big_op.to_str(), prc.launch["kernel"], prc.launch["cfg"], K, sd.basic_str())
+    assert _nrms(ins["out"], got) < 1e-2            # and informationally against the exact fp32 result
+    last = outs["out"][-1]
+    assert np.isfinite(last).all() and last.max() > 0
+    return prc.launch, sd.mrd / _bf16_bound(K)
+
+
+@pytest.mark.parametrize("net", ["googlenet_conv", "resnet-50"])
+def test_config5_every_layer_bf16_at_bench_batch(be, net):
+    """Every distinct GoogLeNet / ResNet-50 layer at B=64 through hip_conv_bf16.  At this size the bf16 planner takes paths the small
+    edge shapes never reach: default split-K on tile-starved long-K layers, 128x128 patch16 tiles, the space-to-depth conv1 front end,
+    the 1x1 / table gathers -- each must have been taken at least once over the two nets."""
+    import bench
+    big, small = {}, {}
+    for op in bench.net_conv_ops(net, 64):
+        big.setdefault(op.to_str(), op)
+    for op in bench.net_conv_ops(net, 2):
+        small.setdefault(op.to_str(), op)
+    assert len(big) == len(small) >= 20
+    seen, worst = set(), 0.0
+    for ob, os_ in zip(big.values(), small.values()):
+        launch, rel = _bf16_prefix_check(be, ob, os_)
+        worst = max(worst, rel)
+        seen.add(launch["kernel"] + ("+splitk" if "_s" in launch["cfg"] else ""))
+    print(f"{net}: bf16 kernels taken at B=64: {sorted(seen)}; worst mrd / bound = {worst:.3f}")
+    assert any(k.startswith("bodahip_conv_patch_bf16") and "s2d" not in k for k in seen), seen      # channel-innermost LDS patch (3x3 / 5x5)
+    assert any("s2d" in k for k in seen), seen                                                       # conv1 through space-to-depth
+    assert any(k.startswith("bodahip_conv_bf16") for k in seen), seen                                # 1x1 / table gather kernel
+    if net == "googlenet_conv":
+        assert any(k.endswith("+splitk") for k in seen), seen                                        # inception 5a/5b 1x1 on 7x7 maps, aux heads
+
+
+@pytest.mark.parametrize("layer", ALEXNET_B256[5:])
+def test_alexnet_fc_layers_bf16_at_b256(be, layer):
+    """AlexNet fc6 / fc7 / fc8 at B=256 in bf16: the ipconv-shaped operands, split over K by default (K = 9216 / 4096)."""
+    C, H, W, OC, K, S, P = layer
+    launch, rel = _bf16_prefix_check(be, _conv_op(256, C, H, W, OC, K, K, S, P), _conv_op(2, C, H, W, OC, K, K, S, P))
+    assert launch["kernel"].startswith("bodahip_conv_bf16")
+    if C * K * K >= 4096:
+        assert "_s" in launch["cfg"], launch
+
+
+@pytest.mark.parametrize("n", [2048, 3072, 4096, 5120, 6144, 7168, 8192, 10240, 12288])
+def test_sgemm_full_sizes_bf16_row_sample(be, n):
+    """The sgemm-ops-full sizes >= 2048 through hip_sgemm_bf16 on the reference's mode-5 data (mode 600's exact answer 1000 m + n needs
+    more than bf16's 8 bits from 256 up): 16 rows of c spread over the matrix (first / last rows of the first, a middle and the last
+    tile row) against an fp64 contraction of the bf16-rounded operands."""
+    outs, prc = _run(be, _sgemm_op(n, n, n), 5, tune=OpTune(hip_dtype="bf16"))
+    assert prc.op.get_func_name() == "hip_sgemm_bf16"
+    rows = sorted({0, 1, 31, 32, 127, 128, 255, 256, n // 2 - 1, n // 2, n // 2 + 37, n - 257, n - 256, n - 129, n - 2, n - 1})
+    a = bo.to_bf16(bo.gen_sgemm_a(n, n, 5)[:, rows]).astype(np.float64); b = bo.to_bf16(bo.gen_sgemm_b(n, n, 5)).astype(np.float64)
+    want = (a.T @ b).astype(np.float32)
+    got = outs["c"][rows]
+    sd = SsdsDiff.of(want, got)
+    print(f"sgemm bf16 {n}^3 [{prc.launch['cfg']}]: mrd {sd.mrd:.3e} (bound {_bf16_bound(n):.3e})")
+    assert not sd.has_nan() and sd.mrd < _bf16_bound(n), (n, prc.launch["cfg"], sd.basic_str())
+    assert float(np.abs(outs["c"][-1]).max()) > 0 and np.isfinite(outs["c"]).all()
+
+
+def test_outputs_of_2gib_or_more_are_unsupported(be):
+    """The epilogue masks lanes past the last column with byte offset 2^31, which the buffer range check only drops while the output
+    ends below it: outputs of 2 GiB or more are refused (unsup_err), not silently corrupted."""
+    op = _sgemm_op(23200, 23200, 4)   # c = 2.15 GB
+    with pytest.raises(UnsupErr):
+        _run(be, op, 5)
