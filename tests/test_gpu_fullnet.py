@@ -17,6 +17,7 @@ from oracle import boda_oracle as bo
 from oracle.net_forward import oracle_forward
 
 FULLNET_MRD = 5e-4
+BF16_VS_BF16_ORACLE = 1e-2
 
 
 @pytest.fixture(scope="module")
@@ -173,11 +174,14 @@ def test_pool_lrn_relu_kernels_vs_oracle(rtc):
 def test_full_net_forward_bf16_operands(rtc, net, batch):
     """op_tune hip_dtype=bf16 through the full-net driver (config 5's arithmetic on whole nets): every conv goes to a bf16 kernel
     (channel-innermost LDS patch / gather / 1x1, incl. writes into Concat channel slices).  Parity is unpinned for bf16 (the reference
-    has none); the stated bounds, per node:
-      (1) against the oracle's forward with the SAME operand rounding (both conv operands to bf16, RNE; fp32 accumulate): normalised RMS
-          error < 1e-3 -- what is left is accumulation order plus the few values a 1e-6 difference pushes over a bf16 rounding boundary
-          in the next layer; a dropped K-slice or tap on any layer is 10-100x that;
-      (2) against the exact fp32 forward: < 3.5e-3 * sqrt(conv depth of the node) -- operand rounding is a relative error of
+    has none); the stated bounds:
+      (1) every conv IN ISOLATION -- the oracle, fed the bf16-rounded input the device conv actually consumed and the bf16-rounded
+          filters: mrd < 1e-3 * max(1, sqrt(K/2400)) (the per-layer bound of DESIGN.md section 3.3); a bound with no depth in it;
+      (2) per node against the oracle's forward with the same operand rounding: normalised RMS error < 1e-2.  Two forwards that round
+          to bf16 at every conv do not stay bit-close: a 1e-6 accumulation-order difference pushes a few values per layer over a bf16
+          rounding boundary (1 bf16 ulp = 4e-3 relative each) -- measured worst node: NiN 3.6e-3 (cccp8), GoogLeNet 5.1e-3; at GoogLeNet's
+          last layer; a dropped K-slice or tap on any layer is 0.1 and more;
+      (3) per node against the exact fp32 forward: < 3.5e-3 * sqrt(conv depth of the node): operand rounding is a relative error of
           ~2^-9 / sqrt(3) per operand that accumulates like a random walk over the convs on the path (measured with the oracle alone:
           at most 2.9e-3 * sqrt(depth) over every node of NiN and GoogLeNet)."""
     from boda_amd.cnn_op import OpTune
@@ -200,7 +204,20 @@ def test_full_net_forward_bf16_operands(rtc, net, batch):
         def nrms(w, g):
             w = w.astype(np.float64); g = g.astype(np.float64)
             return float(np.sqrt(np.mean((w - g) ** 2)) / max(1e-30, np.sqrt(np.mean(w ** 2))))
+        relu_after = {o.bot for o in cp.ops if o.type == "ReLU" and o.in_place}
+        worst_iso = 0.0
+        for op in cp.ops:
+            if op.type != "Convolution":
+                continue
+            x = io.get(op.bot, data if op.bot == "data" else None)
+            f = params[op.tag + "_filts"]
+            w = bo.conv_fwd(bo.to_bf16(x), bo.to_bf16(f), params[op.tag + "_biases"], op.stride, op.in_pad, relu=(op.top in relu_after))
+            K = f.shape[1] * f.shape[2] * f.shape[3]
+            sd = SsdsDiff.of(w, io[op.top]); bound = 1e-3 * max(1.0, (K / 2400.0) ** 0.5)
+            worst_iso = max(worst_iso, sd.mrd / bound)
+            assert not sd.has_nan() and sd.mrd < bound, (op.tag, K, sd.basic_str())
         worst_b = worst_x = 0.0
+        rows = []
         for op in cp.ops:
             if op.type in ("ReLU", "Dropout"):
                 continue
@@ -208,9 +225,12 @@ def test_full_net_forward_bf16_operands(rtc, net, batch):
             assert np.isfinite(g).all(), op.top
             eb, ex = nrms(want_b[op.top], g), nrms(want_x[op.top], g)
             worst_b = max(worst_b, eb); worst_x = max(worst_x, ex / np.sqrt(max(1, depth[op.top])))
-            assert eb < 1e-3, (op.top, "vs bf16-rounded oracle forward", eb)
-            assert ex < 3.5e-3 * np.sqrt(max(1, depth[op.top])), (op.top, depth[op.top], "vs exact fp32 forward", ex)
-        print(f"{net}: worst nRMS vs bf16 oracle forward {worst_b:.2e}; vs exact / sqrt(depth) {worst_x:.2e}")
+            rows.append((op.top, depth[op.top], eb, ex))
+        table = "\n".join(f"{t:24s} depth {d:2d}  vs bf16 oracle {eb:.2e}  vs exact {ex:.2e}" for t, d, eb, ex in rows)
+        print(f"{net}: convs in isolation worst mrd / bound {worst_iso:.3f}; worst nRMS vs bf16 oracle forward {worst_b:.2e}; vs exact / sqrt(depth) {worst_x:.2e}")
+        for t, d, eb, ex in rows:
+            assert eb < BF16_VS_BF16_ORACLE, (t, "vs bf16-rounded oracle forward", eb, table)
+            assert ex < 3.5e-3 * np.sqrt(max(1, d)), (t, d, "vs exact fp32 forward", ex, table)
     finally:
         fwd.release()
 

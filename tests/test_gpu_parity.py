@@ -908,7 +908,11 @@ def test_alexnet_fc_layers_bf16_at_b256(be, layer):
 def test_sgemm_full_sizes_bf16_row_sample(be, n):
     """The sgemm-ops-full sizes >= 2048 through hip_sgemm_bf16 on the reference's mode-5 data (mode 600's exact answer 1000 m + n needs
     more than bf16's 8 bits from 256 up): 16 rows of c spread over the matrix (first / last rows of the first, a middle and the last
-    tile row) against an fp64 contraction of the bf16-rounded operands."""
+    tile row) against an fp64 contraction of the bf16-rounded operands.  Bound: 1e-3 * max(1, K/2400) -- linear in K here, not the
+    sqrt(K) of the conv layers: on U(-5,5) data the partial sums grow like sqrt(K) * 8.3 (2500 and more at K = 12288, fp32 ulp 2.4e-4)
+    and the K/16 roundings of the fp32 accumulator random-walk over that, so the absolute error on the near-zero outputs that set mrd
+    grows like K.  Measured on MI355X: 2.5e-4 (3072) 3.2e-4 (4096) 4.5e-4 (5120) 7.0e-4 (6144) 8.8e-4 (7168) 7.1e-4 (8192) 8.3e-4 (10240)
+    2.5e-3 (12288).  It is the fp32 accumulator, not the bf16 operands: the rounded operands are what the fp64 reference is fed."""
     outs, prc = _run(be, _sgemm_op(n, n, n), 5, tune=OpTune(hip_dtype="bf16"))
     assert prc.op.get_func_name() == "hip_sgemm_bf16"
     rows = sorted({0, 1, 31, 32, 127, 128, 255, 256, n // 2 - 1, n // 2, n // 2 + 37, n - 257, n - 256, n - 129, n - 2, n - 1})
@@ -916,8 +920,9 @@ def test_sgemm_full_sizes_bf16_row_sample(be, n):
     want = (a.T @ b).astype(np.float32)
     got = outs["c"][rows]
     sd = SsdsDiff.of(want, got)
-    print(f"sgemm bf16 {n}^3 [{prc.launch['cfg']}]: mrd {sd.mrd:.3e} (bound {_bf16_bound(n):.3e})")
-    assert not sd.has_nan() and sd.mrd < _bf16_bound(n), (n, prc.launch["cfg"], sd.basic_str())
+    bound = MRD_BF16 * max(1.0, n / 2400.0)
+    print(f"sgemm bf16 {n}^3 [{prc.launch['cfg']}]: mrd {sd.mrd:.3e} (bound {bound:.3e})")
+    assert not sd.has_nan() and sd.mrd < bound, (n, prc.launch["cfg"], sd.basic_str())
     assert float(np.abs(outs["c"][-1]).max()) > 0 and np.isfinite(outs["c"]).all()
 
 
