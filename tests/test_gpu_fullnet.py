@@ -179,8 +179,8 @@ def test_full_net_forward_bf16_operands(rtc, net, batch):
           filters: mrd < 1e-3 * max(1, sqrt(K/2400)) (the per-layer bound of DESIGN.md section 3.3); a bound with no depth in it;
       (2) per node against the oracle's forward with the same operand rounding: normalised RMS error < 1e-2.  Two forwards that round
           to bf16 at every conv do not stay bit-close: a 1e-6 accumulation-order difference pushes a few values per layer over a bf16
-          rounding boundary (1 bf16 ulp = 4e-3 relative each) -- measured worst node: NiN 3.6e-3 (cccp8), GoogLeNet 5.1e-3; at GoogLeNet's
-          last layer; a dropped K-slice or tap on any layer is 0.1 and more;
+          rounding boundary (1 bf16 ulp = 4e-3 relative each) -- measured worst node: NiN 3.6e-3 (cccp8), GoogLeNet 5.1e-3;
+          a dropped K-slice or tap on any layer is 0.1 and more;
       (3) per node against the exact fp32 forward: < 3.5e-3 * sqrt(conv depth of the node): operand rounding is a relative error of
           ~2^-9 / sqrt(3) per operand that accumulates like a random walk over the convs on the path (measured with the oracle alone:
           at most 2.9e-3 * sqrt(depth) over every node of NiN and GoogLeNet)."""
