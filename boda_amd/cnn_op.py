@@ -32,6 +32,9 @@ class OpTune:
     ipconv: int = 0
     hip_dtype: str = ""  # extension: "" / "f32" = exact fp32 MFMA path; "bf16" = bf16 operands, fp32 accumulate (BASELINE config 5)
     hip_algo: str = ""  # extension: "" = the bit-exact direct kernels; "winograd": func hip_conv_winograd (3x3 / stride-1 layers through F(2x2,3x3), mrd <= ~2e-3)
+    hip_layout: str = ""  # extension (with hip_dtype=bf16): "nhwc" = channels-last bf16 STORAGE for in / filts / out: func hip_conv_nhwc on transposed operands,
+    # the originals kept as <arg>_ref and filled / read back by xpose functions outside the timed call -- the reference's own k1conv / tconv protocol (boda_amd/nhwc.py)
+    hip_out: str = ""  # extension (with hip_layout=nhwc): "f32" = the kernel writes float instead of bfloat16
     hip_tile: str = ""  # extension: workgroup tile of the native kernels "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF]]]]" ("" = heuristic)
 
     _ALWAYS = ("MNt", "MNb", "tconv_max_ksz")  # u32_pt_t fields print as "8 8" != default text "8:8": always dumped
@@ -51,7 +54,7 @@ class OpTune:
                 if len(parts) != 2:
                     raise RtErr(f"op_tune: {k} needs two values")
                 setattr(t, k, (int(parts[0]), int(parts[1])))
-            elif k in ("use_be", "hip_tile", "hip_dtype", "hip_algo"):
+            elif k in ("use_be", "hip_tile", "hip_dtype", "hip_algo", "hip_layout", "hip_out"):
                 setattr(t, k, str(v))
             else:
                 setattr(t, k, int(v))
@@ -103,6 +106,9 @@ def add_codegen_annotations(op: Op, tune: OpTune) -> Op:
         a.set_u32("conv_has_relu", 1)  # every Convolution under ops-prof (src/cnn_op.cc:337)
         if tune.use_culibs:
             a.set_func_name("cudnn_conv")
+        elif native and not (tune.k1conv or tune.tconv or tune.ipconv) and tune.hip_dtype == "bf16" and tune.hip_layout == "nhwc":
+            from . import nhwc
+            nhwc.annotate(a, "float" if tune.hip_out == "f32" else "bfloat16")
         elif native and not (tune.k1conv or tune.tconv or tune.ipconv):
             a.set_func_name("hip_conv_bf16" if tune.hip_dtype == "bf16" else ("hip_conv_winograd" if tune.hip_algo == "winograd" else "hip_conv"))
         else:
@@ -132,4 +138,5 @@ NATIVE_ARGS: Dict[str, tuple] = {
     "hip_conv": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
     "cudnn_conv": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
     "hip_conv_winograd": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
+    "hip_conv_nhwc": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
 }

@@ -53,12 +53,13 @@ native_kernels_t::~native_kernels_t() {
 uint32_t native_kernels_t::num_specialisations() const { return (uint32_t)impl->kernels.size(); }
 
 bool native_kernels_t::is_native_func_name(string const &fn) {
+  if (fn.find("_xpose_") != string::npos) return false; // (layout passes are generated CUCL functions, as the reference's <func>_xpose_<arg>)
   return fn == "hip_sgemm" || fn == "hip_conv" || fn == "cublas_sgemm" || fn == "cudnn_conv" || startswith(fn, "hip_");
 }
 void native_kernels_t::check_compile_time(rtc_func_info_t const &fi) {
   string const &fn = fi.op.get_func_name();
   if (fn == "hip_sgemm" || fn == "cublas_sgemm" || fn == "hip_sgemm_bf16") return;
-  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
+  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd" || fn == "hip_conv_nhwc") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
   rt_err("unknown/unhandled native hip function: " + fn);
 }
 void native_kernels_t::set_tune(string const &key, string const &val) {
@@ -157,7 +158,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(hipModuleLaunchKernel(k.func, grid, 1, 1, (uint32_t)c.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, patch16 = false; int rows = 0, cg = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, patch16 = false, nhwc = false; int rows = 0, cg = 0; };
 
 // Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
 //   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
@@ -287,6 +288,79 @@ static bool plan_patch_bf16(conv_geom_t const &g, int num_cus, plan_t &p) {
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
   return true;
 }
+
+// Channels-last bf16 convolution (kernels/conv_nhwc_bf16.hip): implicit GEMM D[oc][pel], operands straight from HBM into LDS
+// (buffer_load ... lds), 32x32x16 bf16 MFMA.  g.C is the STORED channel count (a multiple of 8).  tile: "BIxBJxBKxWIxWJ[xMINW]" or "".
+static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &tile, bool out_f32) {
+  if (g.C % 8) unsup_err("hip_conv_nhwc: in_chan of a channels-last bf16 tensor must be a multiple of 8 (the layout pass pads)");
+  if (g.H >= 32768 || g.W >= 32768) unsup_err("hip_conv_nhwc: planes of 32768 rows / columns or more are not supported");
+  long const Nj = (long)g.B * g.OH * g.OW;
+  int const cg = g.C / 8, kc = cg * g.KH * g.KW;
+  plan_t p; p.nhwc = true; p.bf16 = true; p.kname = "bodahip_conv_nhwc_bf16";
+  tile_cfg_t c; c.MT = 32; c.SPLITK = 1; c.PF = 1;
+  // K step: 64 (8 chunks) when a tap's chunks divide into it -- or when K is long anyway; 32 otherwise
+  c.BK = (cg % 8 == 0) ? 64 : ((cg % 4 == 0) ? 32 : (kc >= 32 ? 64 : 32));
+  // short K (<= 512): a 32-deep step -- half the LDS per ring slot, so a deeper ring and more workgroups per CU for what are HBM-bound
+  // launches (measured at 64 images: 1x1 layers with 64-512 input channels 5-10 % faster, the 7x7 / 2 conv1 on 8 stored channels 93 -> 75 us;
+  // from 1024 channels up and on 3x3 layers the 64-deep step wins)
+  if (kc <= 64) c.BK = 32;
+  int nbuf = 0;   // LDS ring depth (the tile string's 9th field; 0 = choose below)
+  if (!tile.empty()) {
+    if (!parse_tile(tile, c)) rt_err("bad conv_tile '" + tile + "'");
+    { int nf = 1; for (char ch : tile) if (ch == 'x' || ch == ':') ++nf; if (nf >= 9) nbuf = c.PF; }
+    c.MT = 32; c.PF = 1;
+    if (c.SPLITK < 1 || c.SPLITK > 64) unsup_err("hip_conv_nhwc: unsupported K split " + std::to_string(c.SPLITK));
+  } else {
+    // score = base rate of the tile x fraction of the padded tile grid that is real work x how evenly the tiles deal out over the CUs
+    // (the rule of choose_cfg); base rates are first MI355X measurements of this kernel relative to 128x128
+    // Tile and K split by a small time model (us), calibrated on MI355X (tools/nhwc_sweep.py, ResNet-50 / GoogLeNet at 64 images):
+    //   * the K loop is bound by the L2 -> LDS operand stream, not by the MFMAs: one K step of a workgroup costs ~0.7 us per 32 KB of
+    //     operand tiles (128x128x64), workgroups that share a CU share that rate -> t_main = ceil(wgs / CUs) * steps * 0.7 * (BI + BJ) * BK / 16384;
+    //   * ~4 us per launch of ramp-up, prologue and epilogue;
+    //   * K slices (tile-starved layers with a long K loop: 7x7-map layers, fully-connected layers; this path has no summation order to
+    //     keep) cost a second launch (~3 us) and the fp32 partial tiles written and read once each at ~5 TB/s.
+    struct cand_t { int bi, bj, wi, wj, minw; };
+    static cand_t const cands[] = {{128, 128, 2, 2, 2}, {64, 128, 1, 4, 2}, {64, 64, 2, 2, 2}, {32, 128, 1, 4, 2}, {32, 64, 1, 2, 2}};
+    long const nk = (kc + c.BK / 8 - 1) / (c.BK / 8);
+    bool const may_split = getenv("BODAHIP_NO_NHWC_SPLITK") == nullptr;
+    double best = 1e30;
+    for (cand_t const &cd : cands) {
+      long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
+      double const tau = 0.7 * (double)(cd.bi + cd.bj) * c.BK / 16384.0;
+      for (int sk = 1; sk <= 16; sk *= 2) {
+        if (sk > 1 && (!may_split || nk / sk < 4)) break;
+        long const wgs = tiles * sk, steps = (nk + sk - 1) / sk;
+        double t = (double)((wgs + num_cus - 1) / num_cus) * (double)steps * tau + 4.0;
+        if (sk > 1) t += 3.0 + 2.0 * sk * (double)Nj * g.OC * 4.0 / 5e6;
+        if (t < best) { best = t; c.BI = cd.bi; c.BJ = cd.bj; c.WI = cd.wi; c.WJ = cd.wj; c.MINW = cd.minw; c.SPLITK = sk; }
+      }
+    }
+  }
+  int const cpr = c.BK / 8, nt = c.threads();
+  {
+    // ring depth: 3 (one K step of loads in flight across each barrier) where every wave issues the same number of loads per step and two
+    // workgroups still fit a CU's LDS; 2 otherwise
+    bool const even = c.WI > 0 && c.WJ > 0 && ((c.BI * cpr / 64) % (c.WI * c.WJ) == 0) && ((c.BJ * cpr / 64) % (c.WI * c.WJ) == 0);
+    long const per_buf = (long)(c.BI + c.BJ) * c.BK * 2;
+    if (!nbuf) nbuf = (even && c.BK == 32 && 4 * per_buf <= 48 * 1024) ? 4 : ((even && 3 * per_buf <= 80 * 1024) ? 3 : 2);
+    if (nbuf < 2 || nbuf > 4 || (nbuf > 2 && !even)) unsup_err("hip_conv_nhwc: unsupported LDS ring depth " + std::to_string(nbuf) + " for tile " + c.str());
+    c.PF = nbuf;   // (reported as _pN in the launch info)
+  }
+  bool ok = (c.BK == 32 || c.BK == 64) && c.BI > 0 && c.BJ > 0 && c.WI > 0 && c.WJ > 0 && nt <= 1024 && (c.BI % (c.WI * 32) == 0) && (c.BJ % (c.WJ * 32) == 0) &&
+            ((c.BI * cpr) % 64 == 0) && ((c.BJ * cpr) % 64 == 0) && (c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) * 16 <= 256 && c.MINW >= 1;
+  long const lds = std::max<long>((long)nbuf * (c.BI + c.BJ) * c.BK * 2, out_f32 ? 0 : (long)c.BJ * (c.BI * 2 + 16));
+  ok = ok && lds <= 160 * 1024;
+  if (!ok) unsup_err("hip_conv_nhwc: unsupported tile configuration " + c.str());
+  p.cfg = c;
+  p.defs = {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI), "-DWJ=" + std::to_string(c.WJ),
+            "-DMINW=" + std::to_string(c.MINW), "-DCIN=" + std::to_string(g.C), "-DKH=" + std::to_string(g.KH), "-DKW=" + std::to_string(g.KW),
+            "-DSY=" + std::to_string(g.SY), "-DSX=" + std::to_string(g.SX), "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX),
+            "-DCH=" + std::to_string(g.H), "-DCW=" + std::to_string(g.W), "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW),
+            string("-DRELU=") + (g.relu ? "1" : "0"), string("-DOUT_F32=") + (out_f32 ? "1" : "0"), "-DNBUF=" + std::to_string(nbuf)};
+  if (c.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return p;
+}
 static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false, string const &k1s = string(), bool allow_splitk = true) {
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   plan_t p;
@@ -372,7 +446,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
 }
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
-  return hiprtc_compile(p.patch16 ? k_src_conv_patch_bf16 : (p.stream ? k_src_k1_stream_f32 : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
+  return hiprtc_compile(p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.stream ? k_src_k1_stream_f32 : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
 }
 
 // grow-only scratch shared by the split-K slabs and the Winograd-domain tensors (like the reference's cudnn scratch var)
@@ -690,6 +764,45 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
 }
 
+
+void native_kernels_t::conv_nhwc(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, bool out_f32, int out_ctot, int out_coff) {
+  if (out_ctot <= 0) { out_ctot = g.OC; out_coff = 0; }
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  if (!Nj || !g.OC) return;
+  if (Nj > 0x7fffffffl || Kt > 0x7fffffffl) unsup_err("hip_conv_nhwc: dims exceed int32");
+  plan_t const p = plan_conv_nhwc(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), out_f32);
+  tile_cfg_t const &cfg = p.cfg;
+  kernel_t &k = get_kernel(impl, host, p);
+  gemm_args_t ga; memset(&ga, 0, sizeof(ga));
+  uint64_t const in_bytes = (uint64_t)g.B * g.C * g.H * g.W * 2, f_bytes = (uint64_t)g.OC * Kt * 2, out_bytes = (uint64_t)Nj * out_ctot * (out_f32 ? 4 : 2);
+  if (in_bytes >= 0x7ffffff0ull || f_bytes >= 0x7ffffff0ull || out_bytes >= 0x7ffffff0ull) unsup_err("hip_conv_nhwc: tensors of 2 GiB or more are not supported (32-bit buffer offsets)");
+  ga.I = (float const *)filts; ga.J = (float const *)in; ga.D = (float *)out; ga.bias = biases;
+  ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
+  ga.I_bytes = (unsigned)f_bytes; ga.J_bytes = (unsigned)in_bytes; ga.D_bytes = (unsigned)out_bytes;
+  ga.out_ctot = out_ctot; ga.out_coff = out_coff; ga.splitk = 1;
+  ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
+  if (cfg.SPLITK > 1) {
+    long const nk = ((long)(g.C / 8) * g.KH * g.KW + cfg.BK / 8 - 1) / (cfg.BK / 8);
+    size_t const slab = ((size_t)Nj * g.OC + 3) & ~size_t(3);
+    if (slab * 4 >= 0x7ffffff0ull) unsup_err("hip_conv_nhwc: split-K slab of 2 GiB or more");
+    ensure_ws(impl, host, slab * (size_t)cfg.SPLITK * sizeof(float));
+    ga.splitk = cfg.SPLITK; ga.kt_per = (int)((nk + cfg.SPLITK - 1) / cfg.SPLITK); ga.ws = (float *)impl->ws; ga.ws_slab = (long)slab;
+  }
+  void *params[] = {&ga};
+  hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j * ga.splitk), 1, 1, (uint32_t)cfg.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(conv_nhwc_bf16)");
+  if (cfg.SPLITK > 1) {
+    plan_t rp; rp.nhwc = true; rp.bf16 = true; rp.kname = "bodahip_nhwc_splitk_reduce";
+    rp.defs = {"-DREDUCE_ONLY=1", string("-DRELU=") + (g.relu ? "1" : "0"), string("-DOUT_F32=") + (out_f32 ? "1" : "0")};
+    kernel_t &rk = get_kernel(impl, host, rp);
+    bool const v4 = (g.OC % 4 == 0) && (((out_ctot | out_coff) & 3) == 0);
+    long const n = v4 ? Nj * g.OC / 4 : Nj * g.OC;
+    hip_err_chk(hipModuleLaunchKernel(rk.func, (uint32_t)((n + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(nhwc_splitk_reduce)");
+  }
+  last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(ga.tiles_i * ga.tiles_j * ga.splitk); last_launch.block = cfg.threads();
+  last_launch.flops = 2.0 * Nj * g.OC * Kt;   // (as stored: zero pad channels of a conv1-type layer count as work done, not as credit -- bench.py credits the op's own 2MNK)
+  last_launch.algo_bytes = 2.0 * ((double)g.B * g.C * g.H * g.W + (double)g.OC * Kt) + (out_f32 ? 4.0 : 2.0) * (double)Nj * g.OC + 4.0 * g.OC;
+}
+
 static conv_geom_t geom_from_dims(dims_t const &f, dims_t const &in, dims_t const &out, dims_t const &stride, dims_t const &in_pad, bool relu) {
   conv_geom_t g;
   g.B = in.dsz("img"); g.C = in.dsz("chan"); g.H = in.dsz("y"); g.W = in.dsz("x");
@@ -710,7 +823,8 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
     conv_geom_t const g = geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims("out"), op.get_dims("stride"), op.get_dims("in_pad"), relu);
     conv_geom_t g2; int pry = 0, prx = 0;
-    if (bf16 && tile.empty() && s2d_geom(g, g2, pry, prx) && plan_patch_bf16(g2, num_cus, p)) { // conv1-type layers: space-to-depth front end (see conv())
+    if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc") p = plan_conv_nhwc(g, num_cus, tile, op.get_dims("out").tn == "float");
+    else if (bf16 && tile.empty() && s2d_geom(g, g2, pry, prx) && plan_patch_bf16(g2, num_cus, p)) { // conv1-type layers: space-to-depth front end (see conv())
       s2d = "s2d(" + std::to_string(g2.C) + "x" + std::to_string(g2.H) + "x" + std::to_string(g2.W) + ",k" + std::to_string(g2.KH) + "x" + std::to_string(g2.KW) + ")+";
       if (!arch.empty()) { plan_t sp; sp.patch16 = true; sp.bf16 = true; sp.kname = "bodahip_s2d"; sp.defs = {"-DS2D_ONLY=1"}; compile_plan(sp, arch, &log); }
     } else p = plan_conv(g, num_cus, tile, bf16);
@@ -719,7 +833,12 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
   if (arch.empty()) return 0;
   size_t const n = compile_plan(p, arch, &log).size();
   if (p.patch16) { plan_t fp; fp.patch16 = true; fp.bf16 = true; fp.kname = "bodahip_filt_bf16"; fp.defs = {"-DFILT_ONLY=1"}; compile_plan(fp, arch, &log); }
-  if (p.cfg.SPLITK > 1) { // the matching second-pass kernel
+  if (p.cfg.SPLITK > 1 && p.nhwc) {
+    plan_t rp; rp.nhwc = true; rp.bf16 = true; rp.kname = "bodahip_nhwc_splitk_reduce";
+    bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
+    rp.defs = {"-DREDUCE_ONLY=1", string("-DRELU=") + (relu ? "1" : "0"), string("-DOUT_F32=") + ((op.get_dims("out").tn == "float") ? "1" : "0")};
+    compile_plan(rp, arch, &log);
+  } else if (p.cfg.SPLITK > 1) { // the matching second-pass kernel
     plan_t r; r.kname = "bodahip_splitk_reduce"; bool const epi = (t == "Convolution");
     bool const relu = epi && (op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true);
     r.defs = {"-DREDUCE_ONLY=1", string("-DRED_EPI=") + (epi ? "1" : "0"), string("-DRED_RELU=") + (relu ? "1" : "0")};
@@ -778,6 +897,36 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     assert_st(b.dsz("K") == K); assert_st(c.dsz("M") == M); assert_st(c.dsz("N") == N);
     tile_override_t const tov(impl, "sgemm_tile", fi.op);
     sgemm((float const *)host->nh_var_ptr(an), (float const *)host->nh_var_ptr(bn), (float *)host->nh_var_ptr(cn), M, N, K, bf16);
+    return;
+  }
+  if (fn == "hip_conv_nhwc") {
+    // channels-last bf16 tensors: filts out_chan:y:x:in_chan, in / out img:y:x:chan (out bf16 or float), biases float
+    string const fnm = var_of(am, "filts"), bnm = var_of(am, "biases"), inm = var_of(am, "in"), onm = var_of(am, "out");
+    dims_t const f = host->nh_var_dims(fnm), bi = host->nh_var_dims(bnm), in = host->nh_var_dims(inm), out = host->nh_var_dims(onm);
+    need_float(bi, "biases");
+    if (f.tn != "bfloat16" || in.tn != "bfloat16") unsup_err("hip_conv_nhwc: filts / in must have type bfloat16 (got " + f.tn + " / " + in.tn + ")");
+    if (out.tn != "bfloat16" && out.tn != "float") unsup_err("hip_conv_nhwc: out must have type bfloat16 or float (got " + out.tn + ")");
+    assert_st(f.sz() == 4 && in.sz() == 4 && out.sz() == 4 && bi.sz() == 1);
+    if (!(f.names(0) == "out_chan" && f.names(1) == "y" && f.names(2) == "x" && f.names(3) == "in_chan")) rt_err("hip_conv_nhwc: filts must be out_chan:y:x:in_chan, got " + f.pretty_str());
+    for (dims_t const *d : {&in, &out}) if (!(d->names(0) == "img" && d->names(1) == "y" && d->names(2) == "x" && d->names(3) == "chan")) rt_err("hip_conv_nhwc: in / out must be img:y:x:chan, got " + d->pretty_str());
+    auto si = am.find("stride"), pi = am.find("in_pad");
+    if (si == am.end() || pi == am.end()) rt_err("hip_conv_nhwc: 'stride' and 'in_pad' REF args are required");
+    dims_t const stride = si->second.get_dims(host->nh_rtc()), in_pad = pi->second.get_dims(host->nh_rtc());
+    assert_st(stride.sz() == 2); assert_st(in_pad.sz() == 2);
+    conv_geom_t g = geom_from_dims(f, in, out, stride, in_pad, fi.op.get_u32("conv_has_relu") != 0);
+    if (f.dsz("in_chan") != (uint32_t)g.C) rt_err("hip_conv_nhwc: filts.in_chan != in.chan");
+    int out_ctot = 0, out_coff = 0;
+    auto oi = am.find("out_chan_off");
+    if (oi != am.end()) {
+      if (oi->second.is_var() || !oi->second.v || !oi->second.v->rp_elems()) rt_err("hip_conv_nhwc: out_chan_off must be a by-value uint32");
+      out_coff = (int)*(uint32_t const *)oi->second.v->rp_elems(); out_ctot = (int)out.dsz("chan");
+      if (out_coff < 0 || out_coff + g.OC > out_ctot) rt_err("hip_conv_nhwc: out_chan_off + out_chan exceeds the channels of out");
+    }
+    if (bi.dsz("out_chan") != (uint32_t)g.OC || (!out_ctot && out.dsz("chan") != (uint32_t)g.OC) || out.dsz("img") != (uint32_t)g.B) rt_err("hip_conv_nhwc: inconsistent biases/out dims");
+    if (!g.SY || !g.SX) rt_err("hip_conv_nhwc: zero stride");
+    if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW) rt_err("hip_conv_nhwc: out dims do not match in/filts/stride/in_pad");
+    tile_override_t const tov(impl, "conv_tile", fi.op);
+    conv_nhwc(host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), host->nh_var_ptr(inm), host->nh_var_ptr(onm), g, out.tn == "float", out_ctot, out_coff);
     return;
   }
   if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd") {

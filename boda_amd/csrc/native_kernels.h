@@ -6,6 +6,9 @@
 //     hip_sgemm  (alias cublas_sgemm)   args a:K:M  b:K:N  c:M:N                      test/rtc/cublas_sgemm.cucl:1-4
 //     hip_conv   (alias cudnn_conv)     args filts biases in stride(REF) in_pad(REF) out   test/rtc/cudnn_conv.cucl:1-7
 //     hip_sgemm_bf16 / hip_conv_bf16    same contracts; bf16 operands (converted while staging), fp32 accumulate (config 5)
+//     hip_conv_nhwc                     Convolution on channels-last bf16 tensors (filts out_chan:y:x:in_chan, in / out img:y:x:chan, type bfloat16;
+//                                       out may be float): the layout the bf16 matrix cores want -- reached through xpose functions like the
+//                                       reference's k1conv / tconv (src/rtc_prof.cc:92-121)
 //     hip_conv_winograd                 same contract as hip_conv; 3x3 / stride-1 layers through F(2x2,3x3) Winograd (mrd <= ~2e-3)
 // and lands them on kernels/gemm_conv_f32.hip (and, for short-K 1x1 convs with a long pel axis, kernels/k1_stream_f32.hip),
 // specialised with hiprtc per shape class at first use.
@@ -60,6 +63,8 @@ struct native_kernels_t {
   void conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16 = false, int out_ctot = 0, int out_coff = 0,
             char const *algo = nullptr);
 
+  // channels-last bf16 tensors (kernels/conv_nhwc_bf16.hip): filts out_chan:y:x:in_chan, in / out img:y:x:chan; g.C = stored channels (multiple of 8)
+  void conv_nhwc(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, bool out_f32, int out_ctot = 0, int out_coff = 0);
   void conv_winograd(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, int out_ctot, int out_coff);
 
   // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"; key "k1_stream" -> "off" | "WIxWJxOCBxCB[xMINW]";

@@ -42,7 +42,7 @@ inline bool startswith(string const &s, string const &p) { return s.size() >= p.
 
 // ---- dims_t -------------------------------------------------------------------------------------------------------
 inline uint64_t tn_size(string const &tn) {
-  if (tn == "none") return 0; if (tn == "half") return 2; if (tn == "float") return 4; if (tn == "double") return 8;
+  if (tn == "none") return 0; if (tn == "half") return 2; if (tn == "bfloat16") return 2; if (tn == "float") return 4; if (tn == "double") return 8;
   if (tn == "int32_t") return 4; if (tn == "uint32_t") return 4; if (tn == "uint16_t") return 2; if (tn == "uint8_t") return 1;
   rt_err("unknown type name '" + tn + "'");
 }

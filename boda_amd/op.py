@@ -11,7 +11,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple, Union
 
-TYPE_SIZES = {"none": 0, "half": 2, "float": 4, "double": 8, "int32_t": 4, "uint32_t": 4, "uint16_t": 2, "uint8_t": 1}
+TYPE_SIZES = {"none": 0, "half": 2, "bfloat16": 2, "float": 4, "double": 8, "int32_t": 4, "uint32_t": 4, "uint16_t": 2, "uint8_t": 1}
 
 
 class RtErr(RuntimeError):

@@ -82,6 +82,10 @@ def profile_rcg_call(be: OpsBackend, anno_op: Op, gen_mode: Optional[int], gen_v
     created: List[str] = []
     outs: Dict[str, np.ndarray] = {}
     tune_key = "sgemm_tile" if anno_op.get_type() == "sgemm" else "conv_tile"
+    # an arg whose annotated dims differ from its reference dims (<arg>_ref) lives twice: data is generated in / read back from the
+    # reference-layout var "<arg>_ref", a layout pass (run outside the timed call) fills / reads the kernel's var (src/rtc_prof.cc:92-121)
+    def ref_dims_of(an):
+        return anno_op.get_dims(an + "_ref") if anno_op.has(an + "_ref") else anno_op.get_dims(an)
     try:
         for an, io in NATIVE_ARGS[fn]:
             if io == "REF":
@@ -91,13 +95,22 @@ def profile_rcg_call(be: OpsBackend, anno_op: Op, gen_mode: Optional[int], gen_v
             rtc.create_var_with_dims(an, dims)  # zero-filled
             created.append(an)
             arg_map[an] = RtcArg.var(an)
+            if ref_dims_of(an) != dims:
+                rtc.create_var_with_dims(an + "_ref", ref_dims_of(an)); created.append(an + "_ref")
+        if any(anno_op.has(an + "_ref") for an, _ in NATIVE_ARGS[fn]):
+            from . import nhwc
+            nhwc.ensure_compiled(rtc)
         if gen_mode is not None:
             for an, io in NATIVE_ARGS[fn]:
                 if io != "IN":
                     continue
-                rtc.run(gd.gen_call(anno_op.get_type(), an, an, anno_op.get_dims(an), gen_mode, gen_vi))
+                dims, rdims = anno_op.get_dims(an), ref_dims_of(an)
+                gen_vn = an if rdims == dims else an + "_ref"
+                rtc.run(gd.gen_call(anno_op.get_type(), an, gen_vn, rdims, gen_mode, gen_vi))
+                if gen_vn != an:
+                    rtc.run(nhwc.xpose_call(an, gen_vn, an, rdims, dims))
                 if include_ins and want_outs:
-                    outs[an] = rtc.create_nda_from_var(an)
+                    outs[an] = rtc.create_nda_from_var(gen_vn)
         rtc.set_tune(tune_key, tile)
         rfc = RtcFuncCall(gen_fn, arg_map)
         ids = [rtc.run(rfc) for _ in range(run_iter)]
@@ -105,7 +118,12 @@ def profile_rcg_call(be: OpsBackend, anno_op: Op, gen_mode: Optional[int], gen_v
         if want_outs:
             for an, io in NATIVE_ARGS[fn]:
                 if io == "OUT":
-                    outs[an] = rtc.create_nda_from_var(an)
+                    dims, rdims = anno_op.get_dims(an), ref_dims_of(an)
+                    if rdims != dims:
+                        rtc.run(nhwc.xpose_call(an, an + "_ref", an, rdims, dims))
+                        outs[an] = rtc.create_nda_from_var(an + "_ref")
+                    else:
+                        outs[an] = rtc.create_nda_from_var(an)
         rtc.finish_and_sync()
         secs = [rtc.get_dur(i, i) / 1000.0 for i in ids]
         return outs, PrcRet(anno_op, secs[-1], secs, launch)

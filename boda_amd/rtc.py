@@ -109,7 +109,7 @@ def _cdims(d: Dims):
 
 
 _NP = {"float": np.float32, "double": np.float64, "int32_t": np.int32, "uint32_t": np.uint32, "uint16_t": np.uint16,
-       "uint8_t": np.uint8, "half": np.float16}
+       "uint8_t": np.uint8, "half": np.float16, "bfloat16": np.uint16}   # (numpy has no bf16: the raw 16-bit patterns)
 
 
 @dataclass
@@ -361,7 +361,7 @@ class HipCompute:
         import torch
         d = self.get_var_dims(vn)
         ptr = self.get_var_raw_native_pointer(vn)
-        tstr = {"float": "<f4", "half": "<f2", "int32_t": "<i4", "uint32_t": "<u4", "uint8_t": "|u1"}[d.tn]
+        tstr = {"float": "<f4", "half": "<f2", "bfloat16": "<u2", "int32_t": "<i4", "uint32_t": "<u4", "uint8_t": "|u1"}[d.tn]
 
         class _Holder:
             __cuda_array_interface__ = {"shape": tuple(d.sizes), "typestr": tstr, "data": (ptr, False), "version": 3, "strides": None}

@@ -1,0 +1,136 @@
+"""Parity tests (-m gpu) of the channels-last bf16 convolution (func hip_conv_nhwc, kernels/conv_nhwc_bf16.hip), through the C ABI and the
+reference's `<arg>_ref` + xpose protocol (boda_amd/ops_prof.py, src/rtc_prof.cc:92-121): data is generated in the reference layout,
+layout passes fill the kernel's bf16 tensors, the result is transposed back and compared with the CPU oracle fed the same bf16-rounded
+operands.  The reference has no bf16: parity is UNPINNED by construction; the stated bounds are
+    float output:     mrd < 1e-3 * max(1, sqrt(K / 2400))                       (the per-layer bound of every bf16 kernel here)
+    bfloat16 output:  the float result rounded once more: |got - want| <= 2^-8 * |want| + the float bound
+Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from boda_amd.cnn_op import OpTune, add_codegen_annotations
+from boda_amd.digest import SsdsDiff
+from boda_amd.op import parse_op
+from boda_amd.ops_prof import OpsBackend, profile_rcg_call
+from boda_amd.rtc import make_rtc
+from oracle import boda_oracle as bo
+
+NHWC_F32 = dict(hip_dtype="bf16", hip_layout="nhwc", hip_out="f32")
+NHWC = dict(hip_dtype="bf16", hip_layout="nhwc")
+
+
+@pytest.fixture(scope="module")
+def be():
+    rtc = make_rtc("(be=hip)", 0)
+    rtc.init()
+    b = OpsBackend(rtc)
+    yield b
+    rtc.finish_and_sync()
+    rtc.close()
+
+
+def _conv_op(B, C, H, W, OC, KH, KW, S, P):
+    OH = (H + 2 * P - KH) // S + 1; OW = (W + 2 * P - KW) // S + 1
+    return parse_op(f"(str_vals=(type=Convolution),nda_vals=(biases=(dims=(out_chan={OC})),filts=(dims=(out_chan={OC},in_chan={C},y={KH},x={KW})),"
+                    f"in=(dims=(img={B},chan={C},y={H},x={W})),in_pad=(tn=none,dims=(y={P},x={P})),kern_sz=(tn=none,dims=(y={KH},x={KW})),"
+                    f"out=(dims=(img={B},chan={OC},y={OH},x={OW})),out_chans=(tn=uint32_t,v={OC}),stride=(tn=none,dims=(y={S},x={S}))))")
+
+
+def _bound(K):
+    return 1e-3 * max(1.0, (K / 2400.0) ** 0.5)
+
+
+def _run(be, op, tune):
+    anno = add_codegen_annotations(op, tune)
+    assert anno.get_func_name() == "hip_conv_nhwc"
+    return profile_rcg_call(be, anno, 5, 0.0, 1, include_ins=True, tile=tune.hip_tile)
+
+
+def _want(op, outs):
+    g = op.conv_geom()
+    return bo.conv_fwd(bo.to_bf16(outs["in"]), bo.to_bf16(outs["filts"]), outs["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True), g["C"] * g["KH"] * g["KW"]
+
+
+def _check_f32(op, outs, prc):
+    want, K = _want(op, outs)
+    sd = SsdsDiff.of(want, outs["out"])
+    assert not sd.has_nan() and sd.mrd < _bound(K), (op.to_str(), prc.launch["cfg"], K, sd.basic_str())
+    return sd.mrd / _bound(K)
+
+
+def _check_bf16(op, outs, prc):
+    want, K = _want(op, outs)
+    got = outs["out"]
+    assert np.array_equal(bo.to_bf16(got), got)          # every value is a bf16
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    lim = 2.0 ** -8 * np.abs(want.astype(np.float64)) + _bound(K) * np.maximum(1.0, np.abs(want.astype(np.float64)))
+    assert np.isfinite(got).all() and (err <= lim).all(), (op.to_str(), prc.launch["cfg"], float((err / lim).max()))
+
+
+EDGE = [  # B, C, H, W, OC, KH, KW, S, P : 1x1 (stride 1 / 2, padded), 3x3, 5x5 / 2, 7x7 / 2, 11x11 / 4, whole-input kernels, ragged channels and maps
+    (2, 19, 11, 11, 40, 1, 1, 1, 0), (3, 64, 14, 14, 128, 1, 1, 2, 0), (2, 8, 7, 7, 16, 1, 1, 1, 1), (1, 3, 12, 12, 16, 3, 3, 1, 1),
+    (2, 5, 17, 13, 7, 5, 5, 2, 2), (3, 4, 9, 9, 33, 1, 1, 1, 0), (1, 8, 6, 6, 40, 6, 6, 1, 0), (2, 3, 35, 35, 96, 11, 11, 4, 0),
+    (1, 16, 14, 14, 130, 7, 7, 2, 3), (5, 32, 7, 7, 64, 1, 1, 2, 0), (2, 6, 10, 10, 12, 3, 3, 1, 0), (1, 1, 5, 5, 1, 5, 5, 1, 2),
+    (4, 20, 8, 8, 100, 3, 3, 1, 1), (2, 3, 40, 40, 16, 7, 7, 2, 3), (3, 4, 33, 31, 20, 5, 5, 1, 2), (2, 3, 64, 64, 24, 11, 11, 4, 5),
+    (4, 96, 27, 27, 256, 5, 5, 1, 2), (3, 256, 13, 13, 384, 3, 3, 1, 1), (8, 256, 6, 6, 512, 6, 6, 1, 0), (3, 528, 14, 14, 160, 1, 1, 1, 0),
+    (2, 112, 14, 14, 224, 3, 3, 1, 1), (2, 24, 28, 28, 64, 5, 5, 1, 2), (2, 832, 7, 7, 1000, 1, 1, 1, 0)]
+
+
+@pytest.mark.parametrize("shape", EDGE, ids=lambda s: "x".join(str(v) for v in s))
+def test_nhwc_conv_float_out_vs_oracle(be, shape):
+    op = _conv_op(*shape)
+    outs, prc = _run(be, op, OpTune(**NHWC_F32))
+    assert prc.launch["kernel"] == "bodahip_conv_nhwc_bf16"
+    _check_f32(op, outs, prc)
+
+
+@pytest.mark.parametrize("shape", EDGE[::2], ids=lambda s: "x".join(str(v) for v in s))
+def test_nhwc_conv_bf16_out_vs_oracle(be, shape):
+    op = _conv_op(*shape)
+    outs, prc = _run(be, op, OpTune(**NHWC))
+    _check_bf16(op, outs, prc)
+
+
+@pytest.mark.parametrize("tile", ["128x128x64x2x2", "128x128x32x2x2", "64x128x64x1x4", "64x64x32x2x2", "32x128x32x1x4", "32x64x64x1x2", "64x256x32x2x4x1", "256x128x32x4x2x1",
+                                  "128x128x64x2x2x2x1x32x3", "64x128x32x1x4x2x1x32x4", "64x64x64x2x2x2x3", "128x128x32x2x2x2x2x32x3", "32x64x32x1x2x2x5"])
+def test_nhwc_conv_tiles_agree_with_oracle(be, tile):
+    for shape in [(3, 40, 15, 15, 100, 3, 3, 1, 1), (2, 64, 9, 9, 200, 1, 1, 1, 0), (2, 3, 33, 33, 48, 7, 7, 2, 3)]:
+        op = _conv_op(*shape)
+        outs, prc = _run(be, op, OpTune(hip_tile=tile, **NHWC_F32))
+        assert prc.launch["cfg"].startswith(tile.split("x")[0] + "x" + tile.split("x")[1] + "x" + tile.split("x")[2]), prc.launch
+        if len(tile.split("x")) >= 7 and int(tile.split("x")[6]) > 1:
+            assert f"_s{tile.split('x')[6]}" in prc.launch["cfg"], prc.launch     # K slices + the reduce pass
+        _check_f32(op, outs, prc)
+        outs, prc = _run(be, op, OpTune(hip_tile=tile, **NHWC))
+        _check_bf16(op, outs, prc)
+
+
+@pytest.mark.parametrize("net", ["googlenet_conv", "resnet-50"])
+def test_config5_every_layer_nhwc_at_bench_batch(be, net):
+    """BASELINE config 5 as benched (bench.py --workload googlenet|resnet50 --dtype bf16): every distinct layer at 64 images per GPU through
+    hip_conv_nhwc; out[:2] against the oracle's batch-2 result on bf16-rounded operands (inputs are a hash of the flat index, so the first
+    two images of the big input ARE the batch-2 input)."""
+    import bench
+    big, small = {}, {}
+    for op in bench.net_conv_ops(net, 64):
+        big.setdefault(op.to_str(), op)
+    for op in bench.net_conv_ops(net, 2):
+        small.setdefault(op.to_str(), op)
+    assert len(big) == len(small) >= 20
+    cfgs, worst = set(), 0.0
+    for ob, os_ in zip(big.values(), small.values()):
+        anno = add_codegen_annotations(ob, OpTune(**NHWC_F32))
+        outs, prc = profile_rcg_call(be, anno, 5, 0.0, 1)
+        ins = bo.run_op(os_, 5)
+        g = os_.conv_geom(); K = g["C"] * g["KH"] * g["KW"]
+        want = bo.conv_fwd(bo.to_bf16(ins["in"]), bo.to_bf16(ins["filts"]), ins["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
+        sd = SsdsDiff.of(want, outs["out"][:2])
+        assert not sd.has_nan() and sd.mrd < _bound(K), (ob.to_str(), prc.launch["cfg"], K, sd.basic_str())
+        worst = max(worst, sd.mrd / _bound(K))
+        last = outs["out"][-1]
+        assert np.isfinite(last).all() and last.max() > 0
+        cfgs.add(prc.launch["cfg"])
+    print(f"{net}: hip_conv_nhwc tiles taken at B=64: {sorted(cfgs)}; worst mrd / bound = {worst:.3f}")
+    assert len(cfgs) >= 2
