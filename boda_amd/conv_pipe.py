@@ -334,6 +334,12 @@ class ConvPipeFwd:
         self._vars: List[str] = []
         self._funcs: List[str] = []
         self.concat_elim = True      # convs write straight into their channel range of a Concat output where legal
+        # op_tune (hip_dtype=bf16, hip_layout=nhwc): EVERY node lives as a channels-last bf16 tensor (channels padded to a multiple of 8), convs
+        # run hip_conv_nhwc, the other ops their channels-last kernels (boda_amd/nhwc.py); the caller's input is transposed by the first call of
+        # the pass, filters once at init, outputs when they are fetched -- the reference keeps k1conv / tconv intermediates in the consumer's
+        # transposed format the same way (src/rtc_fwd.cc:229-243,495-503)
+        self.nhwc = (self.op_tune.hip_dtype == "bf16" and self.op_tune.hip_layout == "nhwc")
+        self.in_var = ""             # the var that takes the caller's input (reference layout)
 
     # -- init: annotate, fuse, create vars, generate calls, upload params
     def init(self, cp: ConvPipe, op_params: Optional[Dict[str, np.ndarray]] = None, gen_mode: int = 5) -> None:
@@ -381,12 +387,25 @@ class ConvPipeFwd:
         alias: Dict[str, str] = {}
         def vn(node: str) -> str:
             return alias.get(node, node)
-        rtc.create_var_with_dims(cp.in_node, cp.nodes[cp.in_node]); self._vars.append(cp.in_node)
+        if self.nhwc:
+            from . import nhwc as _nhwc
+            _nhwc.ensure_fwd_compiled(rtc)
+            for o in cp.ops:
+                if o.type == "Concat" and any(cp.nodes[b].dsz("chan") % 8 for b in o.bots):
+                    raise UnsupErr(f"channels-last bf16 nets: Concat {o.tag} of inputs whose channel counts are not multiples of 8")
+        vd = (lambda node: _nhwc.nhwc_dims(cp.nodes[node])) if self.nhwc else (lambda node: cp.nodes[node])   # dims a node's var is created with
+        self._vd = vd
+        rtc.create_var_with_dims(cp.in_node, vd(cp.in_node)); self._vars.append(cp.in_node)
+        self.in_var = cp.in_node
+        if self.nhwc:   # the caller's input arrives in the reference layout; the first call of every pass transposes it
+            self.in_var = cp.in_node + "_ref"
+            rtc.create_var_with_dims(self.in_var, cp.nodes[cp.in_node]); self._vars.append(self.in_var)
+            self.fwd_calls.append(FwdCall("xpose_" + cp.in_node, _nhwc.xpose_call("in", self.in_var, cp.in_node, cp.nodes[cp.in_node], vd(cp.in_node)), "nhwc_xpose_in"))
         for pn, pd in cp.params.items():
-            rtc.create_var_with_dims(pn, pd); self._vars.append(pn); self.op_param_names.append(pn)
+            rtc.create_var_with_dims(pn, _nhwc.ohwi_dims(pd) if (self.nhwc and pn.endswith("_filts")) else pd); self._vars.append(pn); self.op_param_names.append(pn)
         made = set()
         for cat in sorted({t for (t, _, _) in self.slices.values()}):   # Concat outputs that convs write into exist before those convs
-            rtc.create_var_with_dims(cat, cp.nodes[cat]); self._vars.append(cat); made.add(cat)
+            rtc.create_var_with_dims(cat, vd(cat)); self._vars.append(cat); made.add(cat)
         for op in cp.ops:
             if op.tag in fused:
                 continue
@@ -395,7 +414,7 @@ class ConvPipeFwd:
                     alias[op.top] = vn(op.bot)
                 continue
             if not op.in_place and op.top not in made and op.top not in self.slices:
-                rtc.create_var_with_dims(op.top, cp.nodes[op.top]); self._vars.append(op.top)
+                rtc.create_var_with_dims(op.top, vd(op.top)); self._vars.append(op.top)
             if op.type == "Convolution":
                 cop = cp.conv_op(op)
                 anno = add_codegen_annotations(cop, self.op_tune)
@@ -407,7 +426,21 @@ class ConvPipeFwd:
                 if op.top in self.slices:
                     cat, c_off, _ = self.slices[op.top]
                     am["out"] = RtcArg.var(cat); am["out_chan_off"] = _u32(c_off)
+                elif self.nhwc and vd(op.top).dsz("chan") != op.out_chans:
+                    am["out_chan_off"] = _u32(0)     # (the var carries zero pad channels: the conv writes the first out_chans of each row)
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(gen_fn, am), fn, cop.flops()))
+            elif self.nhwc and op.type == "Pooling":
+                self.fwd_calls.append(FwdCall(op.tag, _nhwc.pool_call(vn(op.bot), op.top, vd(op.bot), vd(op.top), op.kern_sz, op.stride, op.in_pad, int(op.avg_pool)), "nhwc_pool"))
+            elif self.nhwc and op.type == "LRN":
+                self.fwd_calls.append(FwdCall(op.tag, _nhwc.lrn_call(vn(op.bot), op.top, vd(op.bot), *op.lrn), "nhwc_lrn"))
+            elif self.nhwc and op.type == "ReLU":
+                self.fwd_calls.append(FwdCall(op.tag, _nhwc.relu_call(vn(op.bot), vd(op.top)), "nhwc_relu"))
+            elif self.nhwc and op.type == "Concat":
+                c_done = 0
+                for bi, b in enumerate(op.bots):
+                    if b not in self.slices:        # (else: already written in place by its conv)
+                        self.fwd_calls.append(FwdCall(f"{op.tag}.{bi}", _nhwc.copy_call(vn(b), op.top, vd(b), vd(op.top), c_done), "nhwc_copy"))
+                    c_done += cp.nodes[b].dsz("chan")
             elif op.type == "Pooling":
                 i, o = cp.nodes[op.bot], cp.nodes[op.top]
                 none = lambda yx: Nda(Dims(("y", "x"), tuple(yx), "none"), "none")
@@ -457,11 +490,16 @@ class ConvPipeFwd:
         self._alias = alias
         # params: given arrays (copy_ndas_to_vars, src/rtc_fwd.cc:524) or the deterministic on-device pattern
         for pn in self.op_param_names:
+            dst = pn
+            if self.nhwc and pn.endswith("_filts"):   # filters: uploaded / generated in the reference layout, transposed once (src/rtc_fwd.cc:229-243 does the same at init)
+                dst = pn + "_ref"; rtc.create_var_with_dims(dst, cp.params[pn])
             if op_params is not None and pn in op_params:
-                rtc.copy_nda_to_var(pn, op_params[pn])
+                rtc.copy_nda_to_var(dst, op_params[pn])
             else:
                 arg = "filts" if pn.endswith("_filts") else "biases"
-                rtc.run(gd.gen_call("Convolution", arg, pn, cp.params[pn], gen_mode, 0.0))
+                rtc.run(gd.gen_call("Convolution", arg, dst, cp.params[pn], gen_mode, 0.0))
+            if dst != pn:
+                rtc.run(_nhwc.xpose_call("filts", dst, pn, cp.params[pn], _nhwc.ohwi_dims(cp.params[pn]))); rtc.finish_and_sync(); rtc.release_var(dst)
         rtc.finish_and_sync()
         rtc.release_per_call_id_data()
 
@@ -476,7 +514,7 @@ class ConvPipeFwd:
                 rtc.run(c.rfc)
         rtc.finish_and_sync()
         for v in to_set_vns:
-            rtc.copy_nda_to_var(self.var_of(v), fwd[v])
+            rtc.copy_nda_to_var(self.in_var if (self.nhwc and v == self.cp.in_node) else self.var_of(v), fwd[v])
         rtc.finish_and_sync()
         for c in self.fwd_calls:
             c.call_id = rtc.run(c.rfc)
@@ -484,9 +522,9 @@ class ConvPipeFwd:
         for v in to_get_vns:
             if v in self.slices:     # a conv output that only exists as a channel range of its Concat output
                 cat, c_off, ch = self.slices[v]
-                fwd[v] = np.ascontiguousarray(rtc.copy_var_to_nda(cat)[:, c_off:c_off + ch])
+                fwd[v] = np.ascontiguousarray(self._fetch(cat)[:, c_off:c_off + ch])
             else:
-                fwd[v] = rtc.copy_var_to_nda(self.var_of(v))
+                fwd[v] = self._fetch(v)
         self.compute_dur_ms = rtc.get_dur(self.fwd_calls[0].call_id, self.fwd_calls[-1].call_id) if self.fwd_calls else 0.0
         self.per_call_ms = [(c.tag, c.func, rtc.get_dur(c.call_id, c.call_id), c.flops) for c in self.fwd_calls]
         if self.per_call_fn:
@@ -495,6 +533,23 @@ class ConvPipeFwd:
                 for tag, func, ms, _ in self.per_call_ms:
                     f.write(f"per_layer_time['{tag}']=per_layer_time.get('{tag}',0.0) + {ms / 1000.0} # {func} \n")
         rtc.release_per_call_id_data()
+
+    def _fetch(self, node: str) -> np.ndarray:
+        """A node's value in the reference layout (img:chan:y:x float)."""
+        rtc = self.rtc
+        if not self.nhwc:
+            return rtc.copy_var_to_nda(self.var_of(node))
+        from . import nhwc as _nhwc
+        ref = self.cp.nodes[node]; tmp = "__fetch_tmp"
+        rtc.create_var_with_dims(tmp, ref)
+        try:
+            d = self._vd(node)
+            if d.dsz("chan") != ref.dsz("chan"):   # padded channels: read through a channel count of the stored row
+                raise UnsupErr(f"fetch of node {node!r} with padded channels is not supported")
+            rtc.run(_nhwc.xpose_call("out", tmp, self.var_of(node), ref, d)); rtc.finish_and_sync()
+            return rtc.copy_var_to_nda(tmp)
+        finally:
+            rtc.release_var(tmp)
 
     def run_fwd_device_only(self) -> float:
         """Run all calls once with inputs already resident (benchmarks); -> ms first-call-start to last-call-end."""
@@ -537,7 +592,9 @@ class ConvPipeFwd:
             am = c.rfc.arg_map
             rd = [am[a].n for a in ("in", "inout") if a in am and am[a].is_var()]
             wr = [am[a].n for a in ("out", "inout") if a in am and am[a].is_var()]
-            partial = c.func == "fwd_copy" or "out_chan_off" in am   # writers of disjoint channel ranges of one var: unordered among themselves
+            if c.func == "nhwc_xpose_in":     # (the layout pass of the net's input: reads <in>_ref, writes <in>)
+                rd, wr = [am["in_ref"].n], [am["in"].n]
+            partial = c.func in ("fwd_copy", "nhwc_copy") or ("out_chan_off" in am and c.tag in getattr(self, "slices", {}))   # writers of disjoint channel ranges of one var: unordered among themselves
             d = set()
             for v in rd:
                 d.update(writers.get(v, []))

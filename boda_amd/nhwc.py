@@ -117,3 +117,104 @@ def xpose_call(arg: str, ref_vn: str, vn: str, ref_dims: Dims, dims: Dims) -> Rt
         am = {"out": RtcArg.var(vn), "out_ref": RtcArg.var(ref_vn), "n": _u32(n), "C": _u32(ref_dims.dsz("chan")), "HW": _u32(ref_dims.dsz("y") * ref_dims.dsz("x"))}
         return RtcFuncCall(fn, am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
     raise ValueError(arg)
+
+
+# ------------------------------------------------------------------------------------------------
+# non-conv forward kernels on channels-last bf16 tensors (full-net driver, boda_amd/conv_pipe.py): semantics of test/rtc/{pool,lrn,relu,
+# copy}.cucl, 8 channels (one 16-byte chunk) per thread.  Arithmetic in fp32, results rounded to bf16 once (RNE) when stored.
+# ------------------------------------------------------------------------------------------------
+FWD_SRC = """
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// pooling: one thread per (img, oy, ox, 8 channels); the window is clipped to the plane (padding never takes part; an average divides by
+// the clipped area), taps column by column as the reference sums an average (test/rtc/pool.cucl)
+CUCL_GLOBAL_KERNEL void nhwc_pool( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n, uint32_t const C8, uint32_t const H,
+                                   uint32_t const W, uint32_t const OH, uint32_t const OW, uint32_t const KH, uint32_t const KW, uint32_t const SY,
+                                   uint32_t const SX, uint32_t const PY, uint32_t const PX, uint32_t const avg_pool ) {
+  uint32_t const i = GLOB_ID_1D;
+  if( i >= n ) { return; }
+  uint32_t const c = i % C8, ox = ( i / C8 ) % OW, oy = ( i / ( C8*OW ) ) % OH, img = i / ( C8*OW*OH );
+  int32_t const y0 = (int32_t)( oy*SY ) - (int32_t)PY, x0 = (int32_t)( ox*SX ) - (int32_t)PX;
+  int32_t const ya = ( y0 < 0 ) ? 0 : y0, xa = ( x0 < 0 ) ? 0 : x0;
+  int32_t const yb = ( y0 + (int32_t)KH > (int32_t)H ) ? (int32_t)H : y0 + (int32_t)KH, xb = ( x0 + (int32_t)KW > (int32_t)W ) ? (int32_t)W : x0 + (int32_t)KW;
+  float acc[8];
+  for( int32_t e = 0; e != 8; ++e ) { acc[e] = avg_pool ? 0.0f : -FLT_MAX; }
+  for( int32_t x = xa; x < xb; ++x ) {
+    for( int32_t y = ya; y < yb; ++y ) {
+      bf16x8_t const v = in[( ( img*H + y )*W + x )*C8 + c];
+      for( int32_t e = 0; e != 8; ++e ) { float const f = (float)v[e]; acc[e] = avg_pool ? ( acc[e] + f ) : ( ( f > acc[e] ) ? f : acc[e] ); }
+    }
+  }
+  float const area = (float)( ( ( yb > ya ) ? yb - ya : 0 ) * ( ( xb > xa ) ? xb - xa : 0 ) );
+  bf16x8_t r;
+  for( int32_t e = 0; e != 8; ++e ) { r[e] = (__bf16)( avg_pool ? acc[e] / area : acc[e] ); }
+  out[i] = r;
+}
+// across-channel LRN (test/rtc/lrn.cucl): out[c] = in[c] * ( k + alpha/local_size * sum_{|d| <= local_size/2} in[c+d]^2 ) ^ -beta; one thread per element
+CUCL_GLOBAL_KERNEL void nhwc_lrn( GASQ __bf16 const * const in, GASQ __bf16 * const out, uint32_t const n, uint32_t const C, uint32_t const local_size,
+                                  float const alpha, float const beta, float const k ) {
+  uint32_t const i = GLOB_ID_1D;
+  if( i >= n ) { return; }
+  int32_t const c = i % C, half = local_size / 2;
+  float sumsq = 0.0f;
+  for( int32_t d = -half; d <= half; ++d ) {
+    if( c + d >= 0 && c + d < (int32_t)C ) { float const v = (float)in[(int32_t)i + d]; sumsq += v*v; }
+  }
+  out[i] = (__bf16)( (float)in[i] * powf( k + sumsq * ( alpha / (float)local_size ), -beta ) );
+}
+// stand-alone ReLU (one that could not be fused into its conv)
+CUCL_GLOBAL_KERNEL void nhwc_relu( GASQ __bf16 * const inout, uint32_t const n ) {
+  uint32_t const i = GLOB_ID_1D;
+  if( i < n ) { if( (float)inout[i] <= 0.0f ) { inout[i] = (__bf16)0.0f; } }
+}
+// Concat: copy one input (C8_in chunks per position) into its channel range of the output (src/rtc_fwd.cc:267-280)
+CUCL_GLOBAL_KERNEL void nhwc_copy( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n, uint32_t const C8_in, uint32_t const C8_out,
+                                   uint32_t const off8 ) {
+  uint32_t const i = GLOB_ID_1D;
+  if( i >= n ) { return; }
+  uint32_t const pel = i / C8_in;
+  out[pel*C8_out + off8 + ( i - pel*C8_in )] = in[i];
+}
+"""
+FWD_FUNCS: Dict[str, List[str]] = {
+    "nhwc_pool": ["in", "out", "n", "C8", "H", "W", "OH", "OW", "KH", "KW", "SY", "SX", "PY", "PX", "avg_pool"],
+    "nhwc_lrn": ["in", "out", "n", "C", "local_size", "alpha", "beta", "k"],
+    "nhwc_relu": ["inout", "n"],
+    "nhwc_copy": ["in", "out", "n", "C8_in", "C8_out", "off8"],
+}
+_f32 = lambda v: RtcArg.scalar(float(v), "float")
+
+
+def ensure_fwd_compiled(rtc) -> None:
+    ensure_compiled(rtc)
+    if getattr(rtc, "_nhwc_fwd_compiled", False):
+        return
+    infos = [RtcFuncInfo(fn, FWD_SRC if i == 0 else "", args, Op({"type": "fwd", "func_name": fn}, {})) for i, (fn, args) in enumerate(FWD_FUNCS.items())]
+    rtc.compile(infos)
+    rtc._nhwc_fwd_compiled = True
+
+
+def pool_call(in_vn: str, out_vn: str, i: Dims, o: Dims, kern, stride, pad, avg: int) -> RtcFuncCall:
+    """i / o: the channels-last dims of the vars (img:y:x:chan, chan a multiple of 8)."""
+    c8 = i.dsz("chan") // 8; n = o.dsz("img") * o.dsz("y") * o.dsz("x") * c8
+    am = {"in": RtcArg.var(in_vn), "out": RtcArg.var(out_vn), "n": _u32(n), "C8": _u32(c8), "H": _u32(i.dsz("y")), "W": _u32(i.dsz("x")), "OH": _u32(o.dsz("y")),
+          "OW": _u32(o.dsz("x")), "KH": _u32(kern[0]), "KW": _u32(kern[1]), "SY": _u32(stride[0]), "SX": _u32(stride[1]), "PY": _u32(pad[0]), "PX": _u32(pad[1]),
+          "avg_pool": _u32(avg)}
+    return RtcFuncCall("nhwc_pool", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
+
+
+def lrn_call(in_vn: str, out_vn: str, d: Dims, local_size: int, alpha: float, beta: float, k: float) -> RtcFuncCall:
+    n = d.dims_prod()
+    am = {"in": RtcArg.var(in_vn), "out": RtcArg.var(out_vn), "n": _u32(n), "C": _u32(d.dsz("chan")), "local_size": _u32(local_size), "alpha": _f32(alpha),
+          "beta": _f32(beta), "k": _f32(k)}
+    return RtcFuncCall("nhwc_lrn", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
+
+
+def relu_call(vn: str, d: Dims) -> RtcFuncCall:
+    n = d.dims_prod()
+    return RtcFuncCall("nhwc_relu", {"inout": RtcArg.var(vn), "n": _u32(n)}, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
+
+
+def copy_call(in_vn: str, out_vn: str, i: Dims, o: Dims, chan_off: int) -> RtcFuncCall:
+    n = i.dims_prod() // 8
+    am = {"in": RtcArg.var(in_vn), "out": RtcArg.var(out_vn), "n": _u32(n), "C8_in": _u32(i.dsz("chan") // 8), "C8_out": _u32(o.dsz("chan") // 8), "off8": _u32(chan_off // 8)}
+    return RtcFuncCall("nhwc_copy", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)

@@ -9,10 +9,12 @@ import numpy as np
 from . import boda_oracle as bo
 
 
-def oracle_forward(cp, data: np.ndarray, params: Dict[str, np.ndarray], bf16: bool = False) -> Dict[str, np.ndarray]:
-    """Reference-order forward of `cp` with the CPU oracle.
+def oracle_forward(cp, data: np.ndarray, params: Dict[str, np.ndarray], bf16: bool = False, store_bf16: bool = False) -> Dict[str, np.ndarray]:
+    """Reference-order forward of `cp` with the CPU oracle.  bf16: conv operands rounded to bf16 (RNE) on the way in; store_bf16: every node
+    is additionally STORED as bf16 (the channels-last bf16 nets: one more rounding per op output; implies bf16).
     Returns every node after its in-place ops (what the device vars hold after run_fwd)."""
-    vals = {cp.in_node: data}
+    vals = {cp.in_node: bo.to_bf16(data) if store_bf16 else data}
+    bf16 = bf16 or store_bf16
     for op in cp.ops:
         x = vals[op.bot]
         if op.type == "Convolution":
@@ -30,4 +32,6 @@ def oracle_forward(cp, data: np.ndarray, params: Dict[str, np.ndarray], bf16: bo
             vals[op.top] = x
         elif op.type == "Concat":
             vals[op.top] = np.concatenate([vals[b] for b in op.bots], axis=1)
+        if store_bf16:
+            vals[op.top] = bo.to_bf16(vals[op.top])
     return vals

@@ -258,3 +258,77 @@ def test_dependency_graph_with_multi_kernel_calls_bf16(rtc):
         assert np.array_equal(want, got) and float(np.abs(got).max()) > 0
     finally:
         fwd.release()
+
+
+@pytest.mark.parametrize("net,batch", [("nin", 2), ("alexnet", 2), ("googlenet", 2)])
+def test_full_net_forward_channels_last_bf16(rtc, net, batch):
+    """op_tune (hip_dtype=bf16, hip_layout=nhwc) through the full-net driver: every node is a channels-last bf16 tensor in HBM, convs run
+    hip_conv_nhwc (incl. writes into Concat channel slices), pools / LRN their channels-last kernels; the input is transposed by the first
+    call, filters once at init.  Parity is unpinned (the reference has no bf16); stated bounds:
+      (1) every op IN ISOLATION on the values the device op actually consumed: convs against the oracle (bf16 filters, fp32 accumulate)
+          within one bf16 rounding of the result (2^-8 relative) plus the per-layer float bound 1e-3 * max(1, sqrt(K/2400)); max-pools and
+          Concats exact; average pools / LRN within one bf16 rounding;
+      (2) per node against the oracle forward that rounds like the device (conv operands and every stored node to bf16): nRMS < 1.5e-2;
+      (3) per node against the exact fp32 forward: nRMS < 4.5e-3 * sqrt(conv depth) (oracle alone: at most 3.5e-3 * sqrt(depth))."""
+    from boda_amd.cnn_op import OpTune
+    cp = {"nin": nin_imagenet, "alexnet": alexnet_ng_conv, "googlenet": googlenet_conv}[net](batch)
+    params = _params(cp)
+    data = bo.gen_conv_in(*cp.nodes["data"].sizes)
+    fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc"))
+    fwd.init(cp, op_params=params)
+    try:
+        funcs = [c.func for c in fwd.fwd_calls]
+        assert funcs[0] == "nhwc_xpose_in" and funcs.count("hip_conv_nhwc") == sum(o.type == "Convolution" for o in cp.ops)
+        assert not any(f.startswith("fwd_") or f == "hip_conv" for f in funcs)
+        nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
+        io = {"data": data}
+        fwd.run_fwd(["data"], io, nodes)
+        io["data"] = bo.to_bf16(data)     # what the first conv consumed
+        ulp = 2.0 ** -8
+        def close_to_rounded(w, g, extra):
+            w = w.astype(np.float64); g = g.astype(np.float64)
+            return bool((np.abs(g - w) <= ulp * np.abs(w) + extra * np.maximum(1.0, np.abs(w))).all())
+        relu_after = {o.bot for o in cp.ops if o.type == "ReLU" and o.in_place}
+        for op in cp.ops:
+            x = io.get(op.bot)
+            g = io.get(op.top)
+            if op.type in ("ReLU", "Dropout"):
+                continue
+            assert np.isfinite(g).all() and np.array_equal(bo.to_bf16(g), g), op.tag       # finite bf16 values
+            if op.type == "Convolution":
+                f = params[op.tag + "_filts"]; K = f.shape[1] * f.shape[2] * f.shape[3]
+                w = bo.conv_fwd(x, bo.to_bf16(f), params[op.tag + "_biases"], op.stride, op.in_pad, relu=(op.top in relu_after))
+                assert close_to_rounded(w, g, 1e-3 * max(1.0, (K / 2400.0) ** 0.5)), (op.tag, K, SsdsDiff.of(w, g).basic_str())
+            elif op.type == "Pooling":
+                w = bo.pool_fwd(x, op.kern_sz, op.stride, op.in_pad, bool(op.avg_pool))
+                assert (close_to_rounded(w, g, 1e-6) if op.avg_pool else np.array_equal(w, g)), op.tag
+            elif op.type == "LRN":
+                assert close_to_rounded(bo.lrn_fwd(x, *op.lrn), g, 1e-5), op.tag
+            elif op.type == "Concat":
+                assert np.array_equal(g, np.concatenate([io[b] for b in op.bots], axis=1)), op.tag
+        want_b = oracle_forward(cp, data, params, store_bf16=True)
+        want_x = oracle_forward(cp, data, params)
+        depth = {cp.in_node: 0}
+        for op in cp.ops:
+            depth[op.top] = max(depth[b] for b in (op.bots or (op.bot,))) + (1 if op.type == "Convolution" else 0)
+        def nrms(w, g):
+            w = w.astype(np.float64); g = g.astype(np.float64)
+            return float(np.sqrt(np.mean((w - g) ** 2)) / max(1e-30, np.sqrt(np.mean(w ** 2))))
+        worst_b = worst_x = 0.0
+        for op in cp.ops:
+            if op.type in ("ReLU", "Dropout"):
+                continue
+            eb, ex = nrms(want_b[op.top], io[op.top]), nrms(want_x[op.top], io[op.top])
+            worst_b = max(worst_b, eb); worst_x = max(worst_x, ex / np.sqrt(max(1, depth[op.top])))
+            assert eb < 1.5e-2, (op.top, "vs the oracle forward with the device's roundings", eb)
+            assert ex < 4.5e-3 * np.sqrt(max(1, depth[op.top])), (op.top, depth[op.top], "vs exact fp32 forward", ex)
+        print(f"{net} channels-last bf16: worst nRMS vs rounding oracle forward {worst_b:.2e}; vs exact / sqrt(depth) {worst_x:.2e}")
+        assert io[cp.out_node()].shape[:2] == (batch, 1000)
+        # graph replay (true dependencies) reproduces the call-by-call outputs
+        out = cp.out_node(); want = io[out]
+        n = fwd.capture_graph(parallel=True)
+        assert n == len(fwd.fwd_calls)
+        rtc.set_var_to_zero(fwd.var_of(out)); fwd.run_graph(); fwd.run_graph()
+        assert np.array_equal(fwd._fetch(out), want)
+    finally:
+        fwd.release()
