@@ -34,6 +34,7 @@ class OpTune:
     hip_algo: str = ""  # extension: "" = the bit-exact direct kernels; "winograd": func hip_conv_winograd (3x3 / stride-1 layers through F(2x2,3x3), mrd <= ~2e-3)
     hip_layout: str = ""  # extension (with hip_dtype=bf16): "nhwc" = channels-last bf16 STORAGE for in / filts / out: func hip_conv_nhwc on transposed operands,
     # the originals kept as <arg>_ref and filled / read back by xpose functions outside the timed call -- the reference's own k1conv / tconv protocol (boda_amd/nhwc.py)
+    hip_s2d: int = 1  # extension (with hip_layout=nhwc): 1 = conv1-type layers (stride >= 2 on <= 8 channels) run space-to-depth, the regrouping done by the layout pass of `in` (boda_amd/nhwc.py)
     hip_out: str = ""  # extension (with hip_layout=nhwc): "f32" = the kernel writes float instead of bfloat16
     hip_tile: str = ""  # extension: workgroup tile of the native kernels "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF]]]]" ("" = heuristic)
 
@@ -108,7 +109,7 @@ def add_codegen_annotations(op: Op, tune: OpTune) -> Op:
             a.set_func_name("cudnn_conv")
         elif native and not (tune.k1conv or tune.tconv or tune.ipconv) and tune.hip_dtype == "bf16" and tune.hip_layout == "nhwc":
             from . import nhwc
-            nhwc.annotate(a, "float" if tune.hip_out == "f32" else "bfloat16")
+            nhwc.annotate(a, "float" if tune.hip_out == "f32" else "bfloat16", allow_s2d=bool(tune.hip_s2d))
         elif native and not (tune.k1conv or tune.tconv or tune.ipconv):
             a.set_func_name("hip_conv_bf16" if tune.hip_dtype == "bf16" else ("hip_conv_winograd" if tune.hip_algo == "winograd" else "hip_conv"))
         else:

@@ -393,16 +393,32 @@ class ConvPipeFwd:
             for o in cp.ops:
                 if o.type == "Concat" and any(cp.nodes[b].dsz("chan") % 8 for b in o.bots):
                     raise UnsupErr(f"channels-last bf16 nets: Concat {o.tag} of inputs whose channel counts are not multiples of 8")
-        vd = (lambda node: _nhwc.nhwc_dims(cp.nodes[node])) if self.nhwc else (lambda node: cp.nodes[node])   # dims a node's var is created with
+        # annotated convs up front (channels-last nets: a conv1-type layer that is the ONLY reader of the net's input runs space-to-depth, the
+        # regrouping done by the input's layout pass; everywhere else intermediates are plain img:y:x:chan)
+        import dataclasses
+        annos: Dict[str, Op] = {}
+        in_readers = [o for o in cp.ops if cp.in_node in (o.bots or (o.bot,))]
+        for o in cp.ops:
+            if o.type == "Convolution":
+                s2d_ok = self.nhwc and len(in_readers) == 1 and in_readers[0] is o
+                annos[o.tag] = add_codegen_annotations(cp.conv_op(o), dataclasses.replace(self.op_tune, hip_s2d=int(s2d_ok)) if self.nhwc else self.op_tune)
+        in_anno = annos[in_readers[0].tag] if (self.nhwc and len(in_readers) == 1 and in_readers[0].type == "Convolution") else None
+        def vd(node: str) -> Dims:   # dims a node's var is created with
+            if not self.nhwc:
+                return cp.nodes[node]
+            if node == cp.in_node and in_anno is not None:
+                return in_anno.get_dims("in")
+            return _nhwc.nhwc_dims(cp.nodes[node])
         self._vd = vd
         rtc.create_var_with_dims(cp.in_node, vd(cp.in_node)); self._vars.append(cp.in_node)
         self.in_var = cp.in_node
         if self.nhwc:   # the caller's input arrives in the reference layout; the first call of every pass transposes it
             self.in_var = cp.in_node + "_ref"
             rtc.create_var_with_dims(self.in_var, cp.nodes[cp.in_node]); self._vars.append(self.in_var)
-            self.fwd_calls.append(FwdCall("xpose_" + cp.in_node, _nhwc.xpose_call("in", self.in_var, cp.in_node, cp.nodes[cp.in_node], vd(cp.in_node)), "nhwc_xpose_in"))
+            self.fwd_calls.append(FwdCall("xpose_" + cp.in_node, _nhwc.xpose_call("in", self.in_var, cp.in_node, cp.nodes[cp.in_node], vd(cp.in_node), in_anno), "nhwc_xpose_in"))
+        pdims = lambda pn: annos[pn[:-len("_filts")]].get_dims("filts") if (self.nhwc and pn.endswith("_filts")) else cp.params[pn]   # (as stored)
         for pn, pd in cp.params.items():
-            rtc.create_var_with_dims(pn, _nhwc.ohwi_dims(pd) if (self.nhwc and pn.endswith("_filts")) else pd); self._vars.append(pn); self.op_param_names.append(pn)
+            rtc.create_var_with_dims(pn, pdims(pn)); self._vars.append(pn); self.op_param_names.append(pn)
         made = set()
         for cat in sorted({t for (t, _, _) in self.slices.values()}):   # Concat outputs that convs write into exist before those convs
             rtc.create_var_with_dims(cat, vd(cat)); self._vars.append(cat); made.add(cat)
@@ -417,7 +433,7 @@ class ConvPipeFwd:
                 rtc.create_var_with_dims(op.top, vd(op.top)); self._vars.append(op.top)
             if op.type == "Convolution":
                 cop = cp.conv_op(op)
-                anno = add_codegen_annotations(cop, self.op_tune)
+                anno = annos[op.tag]
                 anno.nda_vals["conv_has_relu"].v = (has_relu[op.tag],)
                 fn = anno.get_func_name(); gen_fn = f"{fn}__{cp.name}_{op.tag}"
                 rtc.compile([RtcFuncInfo(gen_fn, "", [a for a, _ in NATIVE_ARGS[fn]], anno)]); self._funcs.append(gen_fn)
@@ -499,7 +515,7 @@ class ConvPipeFwd:
                 arg = "filts" if pn.endswith("_filts") else "biases"
                 rtc.run(gd.gen_call("Convolution", arg, dst, cp.params[pn], gen_mode, 0.0))
             if dst != pn:
-                rtc.run(_nhwc.xpose_call("filts", dst, pn, cp.params[pn], _nhwc.ohwi_dims(cp.params[pn]))); rtc.finish_and_sync(); rtc.release_var(dst)
+                rtc.run(_nhwc.xpose_call("filts", dst, pn, cp.params[pn], pdims(pn), annos[pn[:-len("_filts")]])); rtc.finish_and_sync(); rtc.release_var(dst)
         rtc.finish_and_sync()
         rtc.release_per_call_id_data()
 

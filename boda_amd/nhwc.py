@@ -18,7 +18,7 @@ generic hiprtc path like the reference's own `xpose_*` kernels.
 from __future__ import annotations
 from typing import Dict, List, Tuple
 
-from .op import Dims, Nda, Op
+from .op import Dims, Nda, Op, UnsupErr
 from .rtc import RtcArg, RtcFuncCall, RtcFuncInfo
 
 FUNC = "hip_conv_nhwc"
@@ -40,32 +40,85 @@ def ohwi_dims(d: Dims, tn: str = "bfloat16") -> Dims:
     return Dims(("out_chan", "y", "x", "in_chan"), (d.dsz("out_chan"), d.dsz("y"), d.dsz("x"), pad8(d.dsz("in_chan"))), tn)
 
 
-def annotate(a: Op, out_tn: str = "bfloat16") -> None:
-    """In place: the `hip_conv_nhwc` form of an annotated Convolution -- kernel dims for in / filts / out, the originals as <arg>_ref."""
-    for an, conv in (("in", lambda d: nhwc_dims(d)), ("filts", ohwi_dims), ("out", lambda d: nhwc_dims(d, out_tn, pad=False))):
+def s2d_geom(g: dict):
+    """Space-to-depth form of a conv1-type layer (stride s in both axes on <= 8 channels, kernel wider than the stride: 11x11 / 4, 7x7 / 2 on
+    3 channels): an s x s block of input pixels becomes s*s channels,
+        in2[b][Y][X][c*s*s + dy*s + dx]   = in[b][c][s*Y + dy - Pry][s*X + dx - Prx]                    (zero outside; Pr = pad rounded up to a multiple of s)
+        f2 [oc][a][b][c*s*s + dy*s + dx]  = filts[oc][c][s*a + dy - (Pry - PY)][s*b + dx - (Prx - PX)]  (zero outside)
+    and the layer is the stride-1, unpadded KH2 x KW2 convolution of in2 with f2 -- the same sums term for term, with C*s*s contiguous
+    channels per position instead of C (8 stored) and ceil-ed kernel extents.  -> dict or None."""
+    s = g["SY"]
+    if not (2 <= s <= 4 and g["SX"] == s and g["KH"] > s and g["KW"] > s and g["C"] <= 8 and g["C"] * s * s <= 64):
+        return None
+    pry, prx = (g["PY"] + s - 1) // s * s, (g["PX"] + s - 1) // s * s
+    kh2, kw2 = (g["KH"] + (pry - g["PY"]) + s - 1) // s, (g["KW"] + (prx - g["PX"]) + s - 1) // s
+    return dict(S=s, PRY=pry, PRX=prx, KH2=kh2, KW2=kw2, C2=g["C"] * s * s, H2=g["OH"] + kh2 - 1, W2=g["OW"] + kw2 - 1)
+
+
+def annotate(a: Op, out_tn: str = "bfloat16", allow_s2d: bool = True) -> None:
+    """In place: the `hip_conv_nhwc` form of an annotated Convolution -- kernel dims for in / filts / out, the originals as <arg>_ref.
+    conv1-type layers additionally go space-to-depth (s2d_geom): the kernel then sees a stride-1, unpadded convolution; the original
+    stride / in_pad / kern_sz stay as <arg>_ref and the scalars nhwc_s2d{,_pry,_prx} tell the layout passes how `in` / `filts` are filled."""
+    g = a.conv_geom()
+    sd = s2d_geom(g) if allow_s2d else None
+    for an in ("in", "filts", "out"):
         ref = a.get_dims(an)
         a.nda_vals[an + "_ref"] = Nda(dims=ref, tn=ref.tn)
-        a.nda_vals[an] = Nda(dims=conv(ref), tn=conv(ref).tn)
+    i, f, o = a.get_dims("in_ref"), a.get_dims("filts_ref"), a.get_dims("out_ref")
+    if sd is None:
+        a.nda_vals["in"] = Nda(dims=nhwc_dims(i), tn="bfloat16")
+        a.nda_vals["filts"] = Nda(dims=ohwi_dims(f), tn="bfloat16")
+    else:
+        c2p = pad8(sd["C2"])
+        a.nda_vals["in"] = Nda(dims=Dims(("img", "y", "x", "chan"), (g["B"], sd["H2"], sd["W2"], c2p), "bfloat16"), tn="bfloat16")
+        a.nda_vals["filts"] = Nda(dims=Dims(("out_chan", "y", "x", "in_chan"), (g["OC"], sd["KH2"], sd["KW2"], c2p), "bfloat16"), tn="bfloat16")
+        none = lambda y, x: Nda(Dims(("y", "x"), (y, x), "none"), "none")
+        for an, v in (("stride", none(1, 1)), ("in_pad", none(0, 0)), ("kern_sz", none(sd["KH2"], sd["KW2"]))):
+            if a.has(an):
+                a.nda_vals[an + "_ref"] = a.nda_vals[an]
+            a.nda_vals[an] = v
+        a.set_u32("nhwc_s2d", sd["S"]); a.set_u32("nhwc_s2d_pry", sd["PRY"]); a.set_u32("nhwc_s2d_prx", sd["PRX"])
+    a.nda_vals["out"] = Nda(dims=nhwc_dims(o, out_tn, pad=False), tn=out_tn)
     a.set_func_name(FUNC)
 
 
 # layout passes (one thread per element of the destination; sizes by value).  `__bf16` conversions round to nearest even.
 XPOSE_SRC = """
-// in_ref img:chan:y:x float -> in img:y:x:chan(padded) bf16
-CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_in( GASQ float const * const in_ref, GASQ __bf16 * const in, uint32_t const n, uint32_t const C,
-                                                 uint32_t const CP, uint32_t const HW ) {
+typedef __bf16 xp_bf16x8_t __attribute__((ext_vector_type(8)));
+// in_ref img:chan:y:x float -> in img:y:x:chan bf16, one thread per 16-byte chunk (8 channels) of the destination.  With S > 1 the
+// destination is the space-to-depth tensor: channel c2 = c*S*S + dy*S + dx of position (Y, X) is pixel (S*Y + dy - PRY, S*X + dx - PRX) of
+// channel c (zero outside the plane); S = 1, PR = 0 is the plain transposition.  Channels >= C2 are zero pad.
+CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_in( GASQ float const * const in_ref, GASQ xp_bf16x8_t * const in, uint32_t const n, uint32_t const C,
+                                                 uint32_t const H, uint32_t const W, uint32_t const C2, uint32_t const C8, uint32_t const H2,
+                                                 uint32_t const W2, uint32_t const S, uint32_t const PRY, uint32_t const PRX ) {
   uint32_t const i = GLOB_ID_1D;
   if( i >= n ) { return; }
-  uint32_t const c = i % CP, pel = ( i / CP ) % HW, img = i / ( CP * HW );
-  in[i] = ( c < C ) ? (__bf16)in_ref[( img*C + c )*HW + pel] : (__bf16)0.0f;
+  uint32_t const q = i % C8, X = ( i / C8 ) % W2, Y = ( i / ( C8*W2 ) ) % H2, img = i / ( C8*W2*H2 );
+  xp_bf16x8_t r;
+  for( uint32_t e = 0; e != 8; ++e ) {
+    uint32_t const c2 = 8*q + e, c = c2 / ( S*S ), dy = ( c2 / S ) % S, dx = c2 % S;
+    int32_t const y = (int32_t)( S*Y + dy ) - (int32_t)PRY, x = (int32_t)( S*X + dx ) - (int32_t)PRX;
+    bool const ok = ( c2 < C2 ) && ( y >= 0 ) && ( y < (int32_t)H ) && ( x >= 0 ) && ( x < (int32_t)W );
+    r[e] = (__bf16)( ok ? in_ref[( ( img*C + c )*H + y )*W + x] : 0.0f );
+  }
+  in[i] = r;
 }
-// filts_ref out_chan:in_chan:y:x float -> filts out_chan:y:x:in_chan(padded) bf16
-CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_filts( GASQ float const * const filts_ref, GASQ __bf16 * const filts, uint32_t const n, uint32_t const C,
-                                                    uint32_t const CP, uint32_t const HW ) {
+// filts_ref out_chan:in_chan:y:x float -> filts out_chan:y:x:in_chan bf16 (S > 1: the space-to-depth filters; tap (a, b), channel c2 is tap
+// (S*a + dy - OFY, S*b + dx - OFX) of channel c, zero outside the kernel)
+CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_filts( GASQ float const * const filts_ref, GASQ xp_bf16x8_t * const filts, uint32_t const n, uint32_t const C,
+                                                    uint32_t const KH, uint32_t const KW, uint32_t const C2, uint32_t const C8, uint32_t const KH2,
+                                                    uint32_t const KW2, uint32_t const S, uint32_t const OFY, uint32_t const OFX ) {
   uint32_t const i = GLOB_ID_1D;
   if( i >= n ) { return; }
-  uint32_t const c = i % CP, tap = ( i / CP ) % HW, oc = i / ( CP * HW );
-  filts[i] = ( c < C ) ? (__bf16)filts_ref[( oc*C + c )*HW + tap] : (__bf16)0.0f;
+  uint32_t const q = i % C8, b = ( i / C8 ) % KW2, a = ( i / ( C8*KW2 ) ) % KH2, oc = i / ( C8*KW2*KH2 );
+  xp_bf16x8_t r;
+  for( uint32_t e = 0; e != 8; ++e ) {
+    uint32_t const c2 = 8*q + e, c = c2 / ( S*S ), dy = ( c2 / S ) % S, dx = c2 % S;
+    int32_t const y = (int32_t)( S*a + dy ) - (int32_t)OFY, x = (int32_t)( S*b + dx ) - (int32_t)OFX;
+    bool const ok = ( c2 < C2 ) && ( y >= 0 ) && ( y < (int32_t)KH ) && ( x >= 0 ) && ( x < (int32_t)KW );
+    r[e] = (__bf16)( ok ? filts_ref[( ( oc*C + c )*KH + y )*KW + x] : 0.0f );
+  }
+  filts[i] = r;
 }
 // out img:y:x:chan (bf16 / float) -> out_ref img:chan:y:x float
 CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_out_bf16( GASQ __bf16 const * const out, GASQ float * const out_ref, uint32_t const n, uint32_t const C, uint32_t const HW ) {
@@ -82,8 +135,8 @@ CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_out_f32( GASQ float const * const ou
 }
 """
 XPOSE_FUNCS: Dict[str, List[str]] = {
-    "hip_conv_nhwc_xpose_in": ["in_ref", "in", "n", "C", "CP", "HW"],
-    "hip_conv_nhwc_xpose_filts": ["filts_ref", "filts", "n", "C", "CP", "HW"],
+    "hip_conv_nhwc_xpose_in": ["in_ref", "in", "n", "C", "H", "W", "C2", "C8", "H2", "W2", "S", "PRY", "PRX"],
+    "hip_conv_nhwc_xpose_filts": ["filts_ref", "filts", "n", "C", "KH", "KW", "C2", "C8", "KH2", "KW2", "S", "OFY", "OFX"],
     "hip_conv_nhwc_xpose_out_bf16": ["out", "out_ref", "n", "C", "HW"],
     "hip_conv_nhwc_xpose_out_f32": ["out", "out_ref", "n", "C", "HW"],
 }
@@ -99,17 +152,26 @@ def ensure_compiled(rtc) -> None:
     rtc._nhwc_xpose_compiled = True
 
 
-def xpose_call(arg: str, ref_vn: str, vn: str, ref_dims: Dims, dims: Dims) -> RtcFuncCall:
-    """The layout pass between `<arg>_ref` (reference layout, float) and `<arg>` (kernel layout): in / filts forward, out backward."""
+def xpose_call(arg: str, ref_vn: str, vn: str, ref_dims: Dims, dims: Dims, anno: Op = None) -> RtcFuncCall:
+    """The layout pass between `<arg>_ref` (reference layout, float) and `<arg>` (kernel layout): in / filts forward, out backward.  `anno`:
+    the annotated op (its nhwc_s2d scalars select the space-to-depth form of in / filts)."""
+    s = pry = prx = ofy = ofx = 0
+    if anno is not None and anno.has("nhwc_s2d"):
+        s, pry, prx = anno.get_u32("nhwc_s2d"), anno.get_u32("nhwc_s2d_pry"), anno.get_u32("nhwc_s2d_prx")
+        pad = anno.get_dims("in_pad_ref"); ofy, ofx = pry - pad.dsz("y"), prx - pad.dsz("x")
     if arg == "in":
-        n = dims.dims_prod()
-        am = {"in_ref": RtcArg.var(ref_vn), "in": RtcArg.var(vn), "n": _u32(n), "C": _u32(ref_dims.dsz("chan")), "CP": _u32(dims.dsz("chan")),
-              "HW": _u32(dims.dsz("y") * dims.dsz("x"))}
+        n = dims.dims_prod() // 8
+        C = ref_dims.dsz("chan")
+        am = {"in_ref": RtcArg.var(ref_vn), "in": RtcArg.var(vn), "n": _u32(n), "C": _u32(C), "H": _u32(ref_dims.dsz("y")), "W": _u32(ref_dims.dsz("x")),
+              "C2": _u32(C * (s * s if s else 1)), "C8": _u32(dims.dsz("chan") // 8), "H2": _u32(dims.dsz("y")), "W2": _u32(dims.dsz("x")), "S": _u32(s or 1),
+              "PRY": _u32(pry), "PRX": _u32(prx)}
         return RtcFuncCall("hip_conv_nhwc_xpose_in", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
     if arg == "filts":
-        n = dims.dims_prod()
-        am = {"filts_ref": RtcArg.var(ref_vn), "filts": RtcArg.var(vn), "n": _u32(n), "C": _u32(ref_dims.dsz("in_chan")), "CP": _u32(dims.dsz("in_chan")),
-              "HW": _u32(dims.dsz("y") * dims.dsz("x"))}
+        n = dims.dims_prod() // 8
+        C = ref_dims.dsz("in_chan")
+        am = {"filts_ref": RtcArg.var(ref_vn), "filts": RtcArg.var(vn), "n": _u32(n), "C": _u32(C), "KH": _u32(ref_dims.dsz("y")), "KW": _u32(ref_dims.dsz("x")),
+              "C2": _u32(C * (s * s if s else 1)), "C8": _u32(dims.dsz("in_chan") // 8), "KH2": _u32(dims.dsz("y")), "KW2": _u32(dims.dsz("x")), "S": _u32(s or 1),
+              "OFY": _u32(ofy), "OFX": _u32(ofx)}
         return RtcFuncCall("hip_conv_nhwc_xpose_filts", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
     if arg == "out":
         n = ref_dims.dims_prod()
@@ -149,17 +211,28 @@ CUCL_GLOBAL_KERNEL void nhwc_pool( GASQ bf16x8_t const * const in, GASQ bf16x8_t
   for( int32_t e = 0; e != 8; ++e ) { r[e] = (__bf16)( avg_pool ? acc[e] / area : acc[e] ); }
   out[i] = r;
 }
-// across-channel LRN (test/rtc/lrn.cucl): out[c] = in[c] * ( k + alpha/local_size * sum_{|d| <= local_size/2} in[c+d]^2 ) ^ -beta; one thread per element
-CUCL_GLOBAL_KERNEL void nhwc_lrn( GASQ __bf16 const * const in, GASQ __bf16 * const out, uint32_t const n, uint32_t const C, uint32_t const local_size,
+// across-channel LRN (test/rtc/lrn.cucl): out[c] = in[c] * ( k + alpha/local_size * sum_{|d| <= local_size/2} in[c+d]^2 ) ^ -beta.  One thread per
+// 16-byte chunk (8 channels): it loads its own chunk and the two neighbours (local_size/2 <= 8), squares them once and slides the window.
+CUCL_GLOBAL_KERNEL void nhwc_lrn( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n, uint32_t const C8, uint32_t const local_size,
                                   float const alpha, float const beta, float const k ) {
   uint32_t const i = GLOB_ID_1D;
   if( i >= n ) { return; }
-  int32_t const c = i % C, half = local_size / 2;
-  float sumsq = 0.0f;
-  for( int32_t d = -half; d <= half; ++d ) {
-    if( c + d >= 0 && c + d < (int32_t)C ) { float const v = (float)in[(int32_t)i + d]; sumsq += v*v; }
+  int32_t const q = i % C8, half = local_size / 2;
+  float v[24];
+  bf16x8_t const mid = in[i];
+  for( int32_t e = 0; e != 8; ++e ) { v[8 + e] = (float)mid[e]; v[e] = 0.0f; v[16 + e] = 0.0f; }
+  if( q > 0 ) { bf16x8_t const lo = in[i - 1]; for( int32_t e = 0; e != 8; ++e ) { v[e] = (float)lo[e]; } }
+  if( q + 1 < (int32_t)C8 ) { bf16x8_t const hi = in[i + 1]; for( int32_t e = 0; e != 8; ++e ) { v[16 + e] = (float)hi[e]; } }
+  float sq[24];
+  for( int32_t e = 0; e != 24; ++e ) { sq[e] = v[e]*v[e]; }
+  float const per_elem = alpha / (float)local_size;
+  bf16x8_t r;
+  for( int32_t e = 0; e != 8; ++e ) {
+    float sumsq = 0.0f;
+    for( int32_t d = -8; d <= 8; ++d ) { if( d >= -half && d <= half ) { sumsq += sq[8 + e + d]; } }
+    r[e] = (__bf16)( v[8 + e] * powf( k + sumsq * per_elem, -beta ) );
   }
-  out[i] = (__bf16)( (float)in[i] * powf( k + sumsq * ( alpha / (float)local_size ), -beta ) );
+  out[i] = r;
 }
 // stand-alone ReLU (one that could not be fused into its conv)
 CUCL_GLOBAL_KERNEL void nhwc_relu( GASQ __bf16 * const inout, uint32_t const n ) {
@@ -177,7 +250,7 @@ CUCL_GLOBAL_KERNEL void nhwc_copy( GASQ bf16x8_t const * const in, GASQ bf16x8_t
 """
 FWD_FUNCS: Dict[str, List[str]] = {
     "nhwc_pool": ["in", "out", "n", "C8", "H", "W", "OH", "OW", "KH", "KW", "SY", "SX", "PY", "PX", "avg_pool"],
-    "nhwc_lrn": ["in", "out", "n", "C", "local_size", "alpha", "beta", "k"],
+    "nhwc_lrn": ["in", "out", "n", "C8", "local_size", "alpha", "beta", "k"],
     "nhwc_relu": ["inout", "n"],
     "nhwc_copy": ["in", "out", "n", "C8_in", "C8_out", "off8"],
 }
@@ -203,8 +276,10 @@ def pool_call(in_vn: str, out_vn: str, i: Dims, o: Dims, kern, stride, pad, avg:
 
 
 def lrn_call(in_vn: str, out_vn: str, d: Dims, local_size: int, alpha: float, beta: float, k: float) -> RtcFuncCall:
-    n = d.dims_prod()
-    am = {"in": RtcArg.var(in_vn), "out": RtcArg.var(out_vn), "n": _u32(n), "C": _u32(d.dsz("chan")), "local_size": _u32(local_size), "alpha": _f32(alpha),
+    if local_size // 2 > 8:
+        raise UnsupErr("channels-last LRN: local_size above 17")
+    n = d.dims_prod() // 8
+    am = {"in": RtcArg.var(in_vn), "out": RtcArg.var(out_vn), "n": _u32(n), "C8": _u32(d.dsz("chan") // 8), "local_size": _u32(local_size), "alpha": _f32(alpha),
           "beta": _f32(beta), "k": _f32(k)}
     return RtcFuncCall("nhwc_lrn", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
 

@@ -108,7 +108,7 @@ def profile_rcg_call(be: OpsBackend, anno_op: Op, gen_mode: Optional[int], gen_v
                 gen_vn = an if rdims == dims else an + "_ref"
                 rtc.run(gd.gen_call(anno_op.get_type(), an, gen_vn, rdims, gen_mode, gen_vi))
                 if gen_vn != an:
-                    rtc.run(nhwc.xpose_call(an, gen_vn, an, rdims, dims))
+                    rtc.run(nhwc.xpose_call(an, gen_vn, an, rdims, dims, anno_op))
                 if include_ins and want_outs:
                     outs[an] = rtc.create_nda_from_var(gen_vn)
         rtc.set_tune(tune_key, tile)
@@ -120,7 +120,7 @@ def profile_rcg_call(be: OpsBackend, anno_op: Op, gen_mode: Optional[int], gen_v
                 if io == "OUT":
                     dims, rdims = anno_op.get_dims(an), ref_dims_of(an)
                     if rdims != dims:
-                        rtc.run(nhwc.xpose_call(an, an + "_ref", an, rdims, dims))
+                        rtc.run(nhwc.xpose_call(an, an + "_ref", an, rdims, dims, anno_op))
                         outs[an] = rtc.create_nda_from_var(an + "_ref")
                     else:
                         outs[an] = rtc.create_nda_from_var(an)

@@ -16,7 +16,7 @@ def _conv_op(B, C, H, W, OC, KH, KW, S, P):
 
 def test_annotation_gives_kernel_dims_and_keeps_reference_dims():
     op = _conv_op(64, 3, 224, 224, 64, 7, 7, 2, 3)
-    a = add_codegen_annotations(op, OpTune(hip_dtype="bf16", hip_layout="nhwc"))
+    a = add_codegen_annotations(op, OpTune(hip_dtype="bf16", hip_layout="nhwc", hip_s2d=0))
     assert a.get_func_name() == "hip_conv_nhwc" and "hip_conv_nhwc" in NATIVE_ARGS
     assert a.get_dims("in") == Dims(("img", "y", "x", "chan"), (64, 224, 224, 8), "bfloat16")          # 3 channels stored as 8 (zero pad)
     assert a.get_dims("filts") == Dims(("out_chan", "y", "x", "in_chan"), (64, 7, 7, 8), "bfloat16")
@@ -29,6 +29,17 @@ def test_annotation_gives_kernel_dims_and_keeps_reference_dims():
     assert f.get_dims("out").tn == "float"
     # the C++ op-line parser of the backend takes the annotated line (new type name included) and gives the same canonical text back
     assert rtc.parse_op_native(a.to_str()) == a.to_str()
+    # conv1-type layers (stride 2 on 3 channels) go space-to-depth by default: 2x2 pixel blocks -> 12 (stored: 16) channels, the 7x7 / 2 / pad 3
+    # layer becomes a 4x4 / 1 / pad 0 one on a 115 x 115 map (pad 3 rounded up to 4: 224 + 4 + ... -> (112 + 4 - 1)); originals kept as <arg>_ref
+    s = add_codegen_annotations(op, OpTune(hip_dtype="bf16", hip_layout="nhwc"))
+    assert s.get_dims("in") == Dims(("img", "y", "x", "chan"), (64, 115, 115, 16), "bfloat16")
+    assert s.get_dims("filts") == Dims(("out_chan", "y", "x", "in_chan"), (64, 4, 4, 16), "bfloat16")
+    assert s.get_dims("stride").sizes == (1, 1) and s.get_dims("in_pad").sizes == (0, 0) and s.get_dims("kern_sz").sizes == (4, 4)
+    assert s.get_dims("stride_ref").sizes == (2, 2) and s.get_dims("in_pad_ref").sizes == (3, 3) and s.get_dims("kern_sz_ref").sizes == (7, 7)
+    assert (s.get_u32("nhwc_s2d"), s.get_u32("nhwc_s2d_pry"), s.get_u32("nhwc_s2d_prx")) == (2, 4, 4)
+    s.conv_geom()   # (the annotated op is itself a consistent convolution)
+    # a 3x3 / 2 layer on 64 channels is not a conv1-type layer
+    assert not add_codegen_annotations(_conv_op(2, 64, 14, 14, 128, 3, 3, 2, 1), OpTune(hip_dtype="bf16", hip_layout="nhwc")).has("nhwc_s2d")
     # without the layout knob nothing changes: fp32 NCHW tensors, operands rounded while staging
     assert add_codegen_annotations(op, OpTune(hip_dtype="bf16")).get_func_name() == "hip_conv_bf16"
 
