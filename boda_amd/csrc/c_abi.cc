@@ -48,6 +48,12 @@ const char *bodahip_last_error(void) { return g_last_error.c_str(); }
 
 int bodahip_create(bodahip_ctx **out, int device_ordinal) {
   ABI_TRY if (!out) rt_err("null out"); *out = new bodahip_ctx{make_hip_compute(device_ordinal)}; ABI_CATCH }
+int bodahip_create_be(bodahip_ctx **out, const char *be, int device_ordinal) {
+  ABI_TRY if (!out) rt_err("null out"); string const b = S(be, "be");
+  if (b == "hip") *out = new bodahip_ctx{make_hip_compute(device_ordinal)};
+  else if (b == "cpu") *out = new bodahip_ctx{make_cpu_compute()};
+  else rt_err("unknown rtc back-end '" + b + "' (this library provides be=hip and be=cpu)");
+  ABI_CATCH }
 void bodahip_destroy(bodahip_ctx *ctx) { try { delete ctx; } catch (...) {} }
 int bodahip_set_gen_src(bodahip_ctx *ctx, uint32_t gen_src, const char *dir) {
   ABI_TRY R(ctx).gen_src = gen_src; if (dir) R(ctx).gen_src_output_dir = dir; ABI_CATCH }

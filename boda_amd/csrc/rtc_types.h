@@ -224,5 +224,7 @@ string op_to_str(op_base_t const &op);
 
 // factory for the MI355X backend (hip_compute.cc)
 p_rtc_compute_t make_hip_compute(int device_ordinal);
+// factory for be=cpu, the host-cores backend behind the same contract (cpu_compute.cc; the CPU baseline of SURVEY.md section 8d)
+p_rtc_compute_t make_cpu_compute();
 
 } // namespace bodahip

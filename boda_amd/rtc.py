@@ -51,6 +51,7 @@ ABI = {  # symbol -> (restype, argtypes); every symbol include/bodahip.h declare
     "bodahip_abi_version": (C.c_int, []),
     "bodahip_last_error": (C.c_char_p, []),
     "bodahip_create": (C.c_int, [C.POINTER(_ctxp), C.c_int]),
+    "bodahip_create_be": (C.c_int, [C.POINTER(_ctxp), C.c_char_p, C.c_int]),
     "bodahip_destroy": (None, [_ctxp]),
     "bodahip_set_gen_src": (C.c_int, [_ctxp, C.c_uint32, C.c_char_p]),
     "bodahip_init": (C.c_int, [_ctxp]),
@@ -167,9 +168,10 @@ class HipCompute:
     """`rtc_compute_t` with be=hip.  One instance per GPU (one process per GPU in multi-GPU runs)."""
     be = "hip"
 
-    def __init__(self, device_ordinal: int = 0):
+    def __init__(self, device_ordinal: int = 0, be: str = "hip"):
         self._ctx = _ctxp()
-        _chk(_lib.bodahip_create(C.byref(self._ctx), device_ordinal))
+        self.be = be
+        _chk(_lib.bodahip_create_be(C.byref(self._ctx), be.encode(), device_ordinal))
         self.device_ordinal = device_ordinal
         self._init_done = False
 
@@ -403,6 +405,6 @@ def make_rtc(spec: str = "(be=hip)", device_ordinal: int = 0) -> HipCompute:
     """NESI-style factory: '(be=hip)' -> backend (the reference creates backends from such lexps, src/rtc_prof.cc:204-217)."""
     from .op import parse_lexp
     kv = dict(parse_lexp(spec))
-    if kv.get("be") != "hip":
-        raise RtErr(f"unknown rtc back-end {kv.get('be')!r}; this package provides be=hip only")
-    return HipCompute(device_ordinal)
+    if kv.get("be") not in ("hip", "cpu"):
+        raise RtErr(f"unknown rtc back-end {kv.get('be')!r}; this package provides be=hip (and be=cpu, the host-cores baseline behind the same contract)")
+    return HipCompute(device_ordinal, kv["be"])

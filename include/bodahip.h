@@ -68,6 +68,10 @@ const char *bodahip_last_error(void);
 
 /* construction: NESI would create the backend from "(be=hip)"; device_ordinal selects the GPU (one process per GPU) */
 int bodahip_create(bodahip_ctx **out, int device_ordinal);
+/* the same by NESI type id: be = "hip" (as above) | "cpu" -- the host-cores backend behind the same contract (blocked, vectorised, OpenMP sgemm /
+ * conv + bias + ReLU on reference-layout tensors; native function names only; the CPU baseline timed beside the GPU, SURVEY.md section 8d: the
+ * reference itself has no CPU path, src/rtc_fwd.cc:43-44, its one precedent is a cblas_sgemm loop, src/qblas-test.cc:33-41) */
+int bodahip_create_be(bodahip_ctx **out, const char *be, int device_ordinal);
 void bodahip_destroy(bodahip_ctx *ctx);
 int bodahip_set_gen_src(bodahip_ctx *ctx, uint32_t gen_src, const char *gen_src_output_dir); /* fields gen_src, gen_src_output_dir (:39-40) */
 
