@@ -15,6 +15,9 @@ uint32_t hip_compute_graph_num_calls(rtc_compute_t *rtc, uint32_t id);
 void hip_compute_graph_destroy(rtc_compute_t *rtc, uint32_t id);
 uint32_t hip_compute_graph_end_deps(rtc_compute_t *rtc, uint32_t n, uint32_t const *ptr, uint32_t const *idx);
 native_kernels_t *hip_compute_native(rtc_compute_t *rtc);
+p_rtc_compute_t make_hip_multi_compute(std::vector<int> const &device_ordinals);
+rtc_compute_t *hip_multi_sub(rtc_compute_t *rtc, uint32_t i);
+uint32_t hip_multi_num_devices(rtc_compute_t *rtc);
 extern char const *const k_src_gemm_conv_f32_ptr;
 }
 
@@ -48,6 +51,10 @@ const char *bodahip_last_error(void) { return g_last_error.c_str(); }
 
 int bodahip_create(bodahip_ctx **out, int device_ordinal) {
   ABI_TRY if (!out) rt_err("null out"); *out = new bodahip_ctx{make_hip_compute(device_ordinal)}; ABI_CATCH }
+int bodahip_create_multi(bodahip_ctx **out, uint32_t n_devices, const int *device_ordinals) {
+  ABI_TRY if (!out || !device_ordinals || !n_devices) rt_err("null / empty argument");
+  *out = new bodahip_ctx{make_hip_multi_compute(std::vector<int>(device_ordinals, device_ordinals + n_devices))}; ABI_CATCH }
+int bodahip_num_devices(bodahip_ctx *ctx, uint32_t *n) { ABI_TRY if (!n) rt_err("null out"); *n = hip_multi_num_devices(&R(ctx)); ABI_CATCH }
 int bodahip_create_be(bodahip_ctx **out, const char *be, int device_ordinal) {
   ABI_TRY if (!out) rt_err("null out"); string const b = S(be, "be");
   if (b == "hip") *out = new bodahip_ctx{make_hip_compute(device_ordinal)};
@@ -122,18 +129,19 @@ int bodahip_graph_end_deps(bodahip_ctx *ctx, uint32_t n_calls, const uint32_t *d
   ABI_TRY if (!graph_id || !dep_ptr) rt_err("null argument"); static uint32_t const none = 0;
   *graph_id = hip_compute_graph_end_deps(&R(ctx), n_calls, dep_ptr, dep_idx ? dep_idx : &none); ABI_CATCH }
 int bodahip_graph_destroy(bodahip_ctx *ctx, uint32_t graph_id) { ABI_TRY hip_compute_graph_destroy(&R(ctx), graph_id); ABI_CATCH }
-int bodahip_get_stream(bodahip_ctx *ctx, void **s) { ABI_TRY if (!s) rt_err("null out"); *s = hip_compute_stream(&R(ctx)); ABI_CATCH }
+int bodahip_get_stream(bodahip_ctx *ctx, void **s) { ABI_TRY if (!s) rt_err("null out"); *s = hip_compute_stream(hip_multi_sub(&R(ctx), 0)); ABI_CATCH }
 int bodahip_get_device_info(bodahip_ctx *ctx, char *arch_buf, size_t n, int *num_cus, int *clock_khz) {
   ABI_TRY
-  native_kernels_t *nk = hip_compute_native(&R(ctx)); (void)nk;
-  native_host_t *h = dynamic_cast<native_host_t *>(&R(ctx)); if (!h) rt_err("not a hip backend");
+  native_kernels_t *nk = hip_compute_native(hip_multi_sub(&R(ctx), 0)); (void)nk;
+  native_host_t *h = dynamic_cast<native_host_t *>(hip_multi_sub(&R(ctx), 0)); if (!h) rt_err("not a hip backend");
   put_str(arch_buf, n, h->nh_arch(), "arch"); if (num_cus) *num_cus = h->nh_num_cus();
   if (clock_khz) { int khz = 0; (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, h->nh_device()); *clock_khz = khz; } // (the ctx's device, not the thread's current one)
   ABI_CATCH }
-int bodahip_set_tune(bodahip_ctx *ctx, const char *key, const char *value) { ABI_TRY hip_compute_native(&R(ctx))->set_tune(S(key, "key"), value ? value : ""); ABI_CATCH }
+int bodahip_set_tune(bodahip_ctx *ctx, const char *key, const char *value) {
+  ABI_TRY for (uint32_t i = 0; i < hip_multi_num_devices(&R(ctx)); ++i) hip_compute_native(hip_multi_sub(&R(ctx), i))->set_tune(S(key, "key"), value ? value : ""); ABI_CATCH }
 int bodahip_last_launch(bodahip_ctx *ctx, char *kbuf, size_t kn, char *cbuf, size_t cn, uint32_t *grid, uint32_t *block, double *flops, double *algo_bytes) {
   ABI_TRY
-  launch_info_t const &li = hip_compute_native(&R(ctx))->last_launch;
+  launch_info_t const &li = hip_compute_native(hip_multi_sub(&R(ctx), 0))->last_launch;   // (a multi-device backend: device 0's)
   put_str(kbuf, kn, li.kernel, "kernel"); put_str(cbuf, cn, li.cfg.str(), "cfg");
   if (grid) *grid = li.grid; if (block) *block = li.block; if (flops) *flops = li.flops; if (algo_bytes) *algo_bytes = li.algo_bytes;
   ABI_CATCH }

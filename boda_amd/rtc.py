@@ -52,6 +52,8 @@ ABI = {  # symbol -> (restype, argtypes); every symbol include/bodahip.h declare
     "bodahip_last_error": (C.c_char_p, []),
     "bodahip_create": (C.c_int, [C.POINTER(_ctxp), C.c_int]),
     "bodahip_create_be": (C.c_int, [C.POINTER(_ctxp), C.c_char_p, C.c_int]),
+    "bodahip_create_multi": (C.c_int, [C.POINTER(_ctxp), C.c_uint32, C.POINTER(C.c_int)]),
+    "bodahip_num_devices": (C.c_int, [_ctxp, C.POINTER(C.c_uint32)]),
     "bodahip_destroy": (None, [_ctxp]),
     "bodahip_set_gen_src": (C.c_int, [_ctxp, C.c_uint32, C.c_char_p]),
     "bodahip_init": (C.c_int, [_ctxp]),
@@ -168,10 +170,15 @@ class HipCompute:
     """`rtc_compute_t` with be=hip.  One instance per GPU (one process per GPU in multi-GPU runs)."""
     be = "hip"
 
-    def __init__(self, device_ordinal: int = 0, be: str = "hip"):
+    def __init__(self, device_ordinal: int = 0, be: str = "hip", devices: Optional[Sequence[int]] = None):
         self._ctx = _ctxp()
         self.be = be
-        _chk(_lib.bodahip_create_be(C.byref(self._ctx), be.encode(), device_ordinal))
+        self.devices = list(devices) if devices else None
+        if self.devices:   # N GPUs behind this one backend: vars sharded on img / M, weights replicated (include/bodahip.h: bodahip_create_multi)
+            arr = (C.c_int * len(self.devices))(*self.devices)
+            _chk(_lib.bodahip_create_multi(C.byref(self._ctx), len(self.devices), arr)); device_ordinal = self.devices[0]
+        else:
+            _chk(_lib.bodahip_create_be(C.byref(self._ctx), be.encode(), device_ordinal))
         self.device_ordinal = device_ordinal
         self._init_done = False
 
@@ -407,4 +414,13 @@ def make_rtc(spec: str = "(be=hip)", device_ordinal: int = 0) -> HipCompute:
     kv = dict(parse_lexp(spec))
     if kv.get("be") not in ("hip", "cpu"):
         raise RtErr(f"unknown rtc back-end {kv.get('be')!r}; this package provides be=hip (and be=cpu, the host-cores baseline behind the same contract)")
-    return HipCompute(device_ordinal, kv["be"])
+    devs = None
+    if "devices" in kv:   # "(be=hip,devices=0:1:2:3)" | "(be=hip,devices=all)": one backend over several GPUs (one host thread, one stream per GPU)
+        if kv["be"] != "hip":
+            raise RtErr("devices=... needs be=hip")
+        if kv["devices"] == "all":
+            import torch
+            devs = list(range(max(1, torch.cuda.device_count())))
+        else:
+            devs = [int(x) for x in str(kv["devices"]).split(":")]
+    return HipCompute(device_ordinal, kv["be"], devs)

@@ -72,6 +72,13 @@ int bodahip_create(bodahip_ctx **out, int device_ordinal);
  * conv + bias + ReLU on reference-layout tensors; native function names only; the CPU baseline timed beside the GPU, SURVEY.md section 8d: the
  * reference itself has no CPU path, src/rtc_fwd.cc:43-44, its one precedent is a cblas_sgemm loop, src/qblas-test.cc:33-41) */
 int bodahip_create_be(bodahip_ctx **out, const char *be, int device_ordinal);
+/* N GPUs behind ONE context ("one logical var <-> N shards", one host thread, one stream per device; the surface that hides it
+ * is src/rtc_compute.H:48-80): vars with a leading dim `img` (sgemm: dim `M`) are split into n_devices contiguous chunks, everything else is
+ * replicated (H2D once + peer-to-peer fan-out); copy_to_var scatters, copy_from_var gathers, run() of a native function enqueues on every device,
+ * get_dur() is the slowest device's.  Generated CUCL functions run only on replicated vars (BODAHIP_UNSUPPORTED on sharded ones).  Ordinals
+ * may repeat ({0,0}: two shards on one GPU).  No collective on the data path. */
+int bodahip_create_multi(bodahip_ctx **out, uint32_t n_devices, const int *device_ordinals);
+int bodahip_num_devices(bodahip_ctx *ctx, uint32_t *n_devices_out);
 void bodahip_destroy(bodahip_ctx *ctx);
 int bodahip_set_gen_src(bodahip_ctx *ctx, uint32_t gen_src, const char *gen_src_output_dir); /* fields gen_src, gen_src_output_dir (:39-40) */
 
