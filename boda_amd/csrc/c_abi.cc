@@ -15,6 +15,7 @@ uint32_t hip_compute_graph_num_calls(rtc_compute_t *rtc, uint32_t id);
 void hip_compute_graph_destroy(rtc_compute_t *rtc, uint32_t id);
 uint32_t hip_compute_graph_end_deps(rtc_compute_t *rtc, uint32_t n, uint32_t const *ptr, uint32_t const *idx);
 native_kernels_t *hip_compute_native(rtc_compute_t *rtc);
+void hip_compute_compile_code_object(rtc_compute_t *rtc, void const *code, size_t code_sz, vect_rtc_func_info_t const &fis);
 p_rtc_compute_t make_hip_multi_compute(std::vector<int> const &device_ordinals);
 rtc_compute_t *hip_multi_sub(rtc_compute_t *rtc, uint32_t i);
 uint32_t hip_multi_num_devices(rtc_compute_t *rtc);
@@ -93,6 +94,27 @@ int bodahip_compile(bodahip_ctx *ctx, uint32_t n, const bodahip_func_info *funcs
   }
   rtc_compile_opts_t o; if (opts) { o.show_compile_log = opts->show_compile_log; o.enable_lineinfo = opts->enable_lineinfo; o.show_func_attrs = opts->show_func_attrs; o.show_rtc_calls = opts->show_rtc_calls; }
   R(ctx).compile(fis, o);
+  ABI_CATCH }
+int bodahip_compile_code_object(bodahip_ctx *ctx, const void *code, size_t code_sz, uint32_t n, const bodahip_func_info *funcs) {
+  ABI_TRY
+  vect_rtc_func_info_t fis;
+  for (uint32_t i = 0; i < n; ++i) {
+    rtc_func_info_t fi; fi.func_name = S(funcs[i].func_name, "func_name");
+    for (uint32_t a = 0; a < funcs[i].n_args; ++a) fi.arg_names.push_back(S(funcs[i].arg_names[a], "arg name"));
+    if (funcs[i].op && funcs[i].op[0]) fi.op = parse_op_lexp(funcs[i].op);
+    fis.push_back(std::move(fi));
+  }
+  if (hip_multi_num_devices(&R(ctx)) != 1) unsup_err("compile_code_object: single-device be=hip contexts only");
+  hip_compute_compile_code_object(&R(ctx), code, code_sz, fis);
+  ABI_CATCH }
+int bodahip_compile_to_file(const char *src, const char *arch, int add_prelude, const char *out_path) {
+  ABI_TRY
+  string log;
+  std::vector<char> const code = hiprtc_compile((add_prelude ? cucl_prelude() : string()) + S(src, "src"), "to_file", S(arch, "arch"), {"-ffast-math"}, &log, false);
+  FILE *f = fopen(S(out_path, "out_path").c_str(), "wb");
+  if (!f) rt_err(string("cannot write ") + out_path);
+  size_t const w = fwrite(code.data(), 1, code.size(), f); fclose(f);
+  if (w != code.size()) rt_err(string("short write to ") + out_path);
   ABI_CATCH }
 int bodahip_release_func(bodahip_ctx *ctx, const char *fn) { ABI_TRY R(ctx).release_func(S(fn, "func_name")); ABI_CATCH }
 int bodahip_release_all_funcs(bodahip_ctx *ctx) { ABI_TRY R(ctx).release_all_funcs(); ABI_CATCH }

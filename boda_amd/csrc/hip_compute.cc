@@ -256,6 +256,22 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
     }
     ++compile_call_ix;
   }
+  // compile()'s second half for functions that arrive as a ready code object (gfx950 .hsaco) instead of CUCL source -- e.g. generated
+  // functions compiled ahead of time on a machine that has the templates (oracle/ref_cucl.py); same registration, same run() marshalling
+  void compile_code_object(void const *code, size_t code_sz, vect_rtc_func_info_t const &func_infos) {
+    assert_st(init_done); use_dev();
+    if (!code || !code_sz) rt_err("compile_code_object: empty code object");
+    for (auto const &fi : func_infos) if (funcs.count(fi.func_name)) rt_err("compile: function '" + fi.func_name + "' already exists");
+    std::vector<char> copy((char const *)code, (char const *)code + code_sz);
+    hipModule_t m;
+    hip_err_chk(hipModuleLoadData(&m, copy.data()), "hipModuleLoadData(code object)");
+    std::shared_ptr<hipModule_t> mod(new hipModule_t(m), [](hipModule_t *pm) { (void)hipModuleUnload(*pm); delete pm; });
+    for (auto const &fi : func_infos) {
+      hip_func_t hf; hf.info = fi; hf.mod = mod;
+      hip_err_chk(hipModuleGetFunction(&hf.func, *mod, fi.func_name.c_str()), ("hipModuleGetFunction(" + fi.func_name + ")").c_str());
+      funcs.emplace(fi.func_name, std::move(hf));
+    }
+  }
   void release_func(string const &func_name) override { must_erase(funcs, func_name); }
   void release_all_funcs() override { finish_and_sync(); funcs.clear(); finish_and_sync(); }
 
@@ -464,6 +480,7 @@ uint32_t hip_compute_graph_launch(rtc_compute_t *rtc, uint32_t id) { return as_h
 uint32_t hip_compute_graph_num_calls(rtc_compute_t *rtc, uint32_t id) { return as_hip(rtc).graph_num_calls(id); }
 void hip_compute_graph_destroy(rtc_compute_t *rtc, uint32_t id) { as_hip(rtc).graph_destroy(id); }
 uint32_t hip_compute_graph_end_deps(rtc_compute_t *rtc, uint32_t n, uint32_t const *ptr, uint32_t const *idx) { return as_hip(rtc).graph_end_deps(n, ptr, idx); }
+void hip_compute_compile_code_object(rtc_compute_t *rtc, void const *code, size_t code_sz, vect_rtc_func_info_t const &fis) { as_hip(rtc).compile_code_object(code, code_sz, fis); }
 void *hip_compute_stream(rtc_compute_t *rtc) { hip_compute_t *h = dynamic_cast<hip_compute_t *>(rtc); if (!h) rt_err("not a hip_compute_t"); return (void *)h->stream; }
 native_kernels_t *hip_compute_native(rtc_compute_t *rtc) { hip_compute_t *h = dynamic_cast<hip_compute_t *>(rtc); if (!h || !h->native) rt_err("hip backend not initialised"); return h->native.get(); }
 

@@ -191,9 +191,48 @@ def _strides(sizes: Tuple[int, ...]) -> List[int]:
     return list(reversed(st))
 
 
-def instantiate(t: Template, op: Op, gen_fn: str) -> Instance:
-    """rtc_call_gen_t::init + instantiate_template for a fully static op."""
+class CallGen:
+    """What a custom code-generation hook sees of the call being generated (the public face of rtc_call_gen_t, src/rtc_func_gen.H:120-170):
+    the op, the launch geometry fixed by the template's index declarations, `set(var, val)` for template variables and `line(section, text)`
+    for bulk sections, plus insert_nda_ix_exprs for index expressions over the dims of a declared IX."""
+
+    def __init__(self, op: Op, tsvs: Dict[str, str], all_ix_dims: Dict[str, Tuple[Tuple[str, ...], Tuple[int, ...]]], tpb: int, blks: int):
+        self.op, self.tsvs, self.all_ix_dims, self.tpb, self.blks = op, tsvs, all_ix_dims, tpb, blks
+        self.cgs: Dict[str, List[str]] = {}
+
+    def get_arg_dims_by_name(self, vn: str) -> Dims:
+        if vn not in self.op.nda_vals:
+            raise RtErr(f"referenced arg '{vn}' not present in dims_vals")
+        return self.op.get_dims(vn)
+
+    def set(self, var: str, val: str) -> None:
+        if var in self.tsvs:
+            raise RtErr(f"template variable '{var}' defined twice")
+        self.tsvs[var] = val
+
+    def line(self, sec: str, text: str) -> None:
+        self.cgs.setdefault(sec, [f"// begin {sec}"]).append("   " + text)
+
+    def insert_nda_ix_exprs(self, ix_vn: str, ix_dims: Tuple[Tuple[str, ...], Tuple[int, ...]], ix_expr: str = "") -> None:
+        """src/rtc_func_gen.cc:220-239: <ix>_<dim> = ((expr / stride) %% size), the outermost dim left to overflow."""
+        names, sizes = ix_dims
+        e = ix_expr or ix_vn
+        st = _strides(tuple(sizes)); prod = 1
+        for i, (n, sz, sd) in enumerate(zip(names, sizes, st)):
+            v = f"({e}/{sd})" if sd > 1 else e
+            self.set(f"{ix_vn}_{n}_nomod", v)
+            if i:
+                v = f"({v}%%{sz})" if sz > 1 else "0"
+            self.set(f"{ix_vn}_{n}", v)
+            prod *= sz
+        self.set(f"{ix_vn}_dims_prod", str(prod))
+
+
+def instantiate(t: Template, op: Op, gen_fn: str, custom=None) -> Instance:
+    """rtc_call_gen_t::init + instantiate_template for a fully static op.  `custom(CallGen, template name)`: the custom_codegen_t hook, called
+    after the index declarations and before the arguments are processed, as the reference does (src/rtc_func_gen.cc:386)."""
     tsvs: Dict[str, str] = {"rtc_func_name": gen_fn}
+    all_ix_dims: Dict[str, Tuple[Tuple[str, ...], Tuple[int, ...]]] = {}
     tpb = int(op.nda_vals["tpb"].v[0]) if "tpb" in op.nda_vals and op.nda_vals["tpb"].v is not None else 0
     blks = 0
     errs: List[str] = []
@@ -257,6 +296,7 @@ def instantiate(t: Template, op: Op, gen_fn: str) -> Instance:
             names, sizes = [names[i] for i in sel], [sizes[i] for i in sel]
         if not names or any(s == 0 for s in sizes):
             raise UnsupErr(f"CUCL template {t.name}: IX {ix.ix_vn} over dynamically sized arg")
+        all_ix_dims[ix.ix_vn] = (tuple(names), tuple(sizes))
         st = _strides(tuple(sizes)); prod = 1
         for s in sizes:
             prod *= s
@@ -281,6 +321,10 @@ def instantiate(t: Template, op: Op, gen_fn: str) -> Instance:
                 raise RtErr("CUCL error: LOC_ID_1D IX encoutered after setting tpb (some other way)")
             tpb = prod
 
+    cg = None
+    if custom is not None:
+        cg = CallGen(op, tsvs, all_ix_dims, tpb, blks)
+        custom(cg, t.name)
     arg_names: List[str] = []
     for ad in t.arg_decls:
         arg_names.append(ad.vn)
@@ -319,12 +363,33 @@ def instantiate(t: Template, op: Op, gen_fn: str) -> Instance:
     elif "cucl_arg_info_decls" not in tsvs:
         tsvs["cucl_arg_info_decls"] = ""
 
-    def sub(m: "re.Match") -> str:
-        k = m.group(1)
-        if k not in tsvs:
-            raise RtErr(f"CUCL template {t.name}: unknown template variable %({k})")
-        return tsvs[k]
-    src = re.sub(r"%\(([A-Za-z0-9_]+)\)", sub, t.text).replace("%%", "%")
+    if cg is not None:      # terminate and emit the bulk sections (src/rtc_func_gen.cc:478-481)
+        for sec, lines in cg.cgs.items():
+            if sec in tsvs:
+                raise RtErr(f"template variable '{sec}' defined twice")
+            tsvs[sec] = "\n".join(lines) + f"\n    // end {sec}\n"
+
+    def expand(text: str, depth: int = 0) -> str:
+        """%(name) -> the (itself expanded) value, %% -> % : values may refer to other template variables (generated lines do)."""
+        if depth > 16:
+            raise RtErr(f"CUCL template {t.name}: template variables nest deeper than 16 levels (a cycle?)")
+        out: List[str] = []; i = 0; n = len(text)
+        while i < n:
+            c = text[i]
+            if c != "%" or i + 1 >= n:
+                out.append(c); i += 1; continue
+            if text[i + 1] == "%":
+                out.append("%"); i += 2; continue
+            if text[i + 1] == "(":
+                j = text.find(")", i + 2)
+                k = text[i + 2:j] if j > 0 else ""
+                if j > 0 and re.fullmatch(r"[A-Za-z0-9_]+", k):
+                    if k not in tsvs:
+                        raise RtErr(f"CUCL template {t.name}: unknown template variable %({k})")
+                    out.append(expand(tsvs[k], depth + 1)); i = j + 1; continue
+            out.append(c); i += 1
+        return "".join(out)
+    src = expand(t.text)
     if not tpb:
         raise RtErr(f"CUCL template {t.name}: launch geometry not determined (no GLOB_ID_1D / LOC_ID_1D index)")
     return Instance(gen_fn, src, arg_names + cai_names, tpb, blks, dyn_vars)

@@ -64,6 +64,8 @@ ABI = {  # symbol -> (restype, argtypes); every symbol include/bodahip.h declare
     "bodahip_get_var_dims": (C.c_int, [_ctxp, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t]),
     "bodahip_set_var_to_zero": (C.c_int, [_ctxp, C.c_char_p]),
     "bodahip_compile": (C.c_int, [_ctxp, C.c_uint32, C.POINTER(_CFuncInfo), C.POINTER(_CCompileOpts)]),
+    "bodahip_compile_code_object": (C.c_int, [_ctxp, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(_CFuncInfo)]),
+    "bodahip_compile_to_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p]),
     "bodahip_release_func": (C.c_int, [_ctxp, C.c_char_p]),
     "bodahip_release_all_funcs": (C.c_int, [_ctxp]),
     "bodahip_run": (C.c_int, [_ctxp, C.c_char_p, C.c_uint32, C.POINTER(_CArg), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
@@ -236,6 +238,16 @@ class HipCompute:
         co = _CCompileOpts(o.show_compile_log, o.enable_lineinfo, o.show_func_attrs, o.show_rtc_calls)
         _chk(_lib.bodahip_compile(self._ctx, n, arr, C.byref(co)))
 
+    def compile_code_object(self, code: bytes, func_infos: Sequence[RtcFuncInfo]) -> None:
+        """compile() for functions that arrive as a gfx950 code object (func_src of the infos is ignored)."""
+        n = len(func_infos)
+        arr = (_CFuncInfo * max(1, n))(); keep = []
+        for i, fi in enumerate(func_infos):
+            an = (C.c_char_p * max(1, len(fi.arg_names)))(*[a.encode() for a in fi.arg_names]); keep.append(an)
+            arr[i] = _CFuncInfo(fi.func_name.encode(), b"", len(fi.arg_names), C.cast(an, C.POINTER(C.c_char_p)), fi.op.to_str().encode())
+        buf = C.create_string_buffer(code, len(code))
+        _chk(_lib.bodahip_compile_code_object(self._ctx, C.cast(buf, C.c_void_p), len(code), n, arr))
+
     def release_func(self, func_name: str) -> None:
         _chk(_lib.bodahip_release_func(self._ctx, func_name.encode()))
 
@@ -385,6 +397,11 @@ def compile_offline(src_or_opts: str, native_template: Optional[str] = None, arc
                                       1 if add_prelude else 0, 1 if use_cache else 0, C.byref(sz), log, 1 << 16)
     _chk(rc)
     return int(sz.value)
+
+
+def compile_to_file(src: str, out_path: str, arch: str = "gfx950", add_prelude: bool = True) -> None:
+    """hiprtc-compile CUCL-dialect source to a code object file, without a device."""
+    _chk(_lib.bodahip_compile_to_file(src.encode(), arch.encode(), 1 if add_prelude else 0, out_path.encode()))
 
 
 def explain_plan(op: Op, num_cus: int = 256, tile: str = "") -> str:

@@ -134,6 +134,12 @@ int bodahip_last_launch(bodahip_ctx *ctx, char *kernel_buf, size_t kernel_buf_sz
 int bodahip_compile_offline(const char *src_or_opts, const char *native_template_or_null, const char *arch, int add_prelude, int use_cache,
                             size_t *code_size_out, char *log_buf, size_t log_buf_sz);
 
+/* ::compile() for functions that arrive as a ready gfx950 code object instead of CUCL source (func_src of the infos is ignored): same
+ * registration, arg marshalling and run() as source-compiled functions.  bodahip_compile_to_file writes such a code object from CUCL-dialect
+ * source without a device (ahead-of-time generation on a machine that holds the templates; see oracle/ref_cucl.py). */
+int bodahip_compile_code_object(bodahip_ctx *ctx, const void *code, size_t code_sz, uint32_t n_funcs, const bodahip_func_info *funcs);
+int bodahip_compile_to_file(const char *src, const char *arch, int add_prelude, const char *out_path);
+
 /* parse one op line (op_base_t lexp, current or legacy form -- what bodahip_compile does with bodahip_func_info.op) and
  * write it back in canonical form (sorted str_vals / nda_vals, as NESI prints std::map).  Host-only; for tests/tools. */
 int bodahip_parse_op(const char *op_lexp, char *canon_buf, size_t canon_buf_sz);

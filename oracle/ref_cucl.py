@@ -1,0 +1,86 @@
+"""oracle/ref_cucl.py -- TEST INFRASTRUCTURE: builds the reference's OWN convolution / sgemm kernels for gfx950 into oracle/_ref/cucl/.
+
+The reference's arithmetic exists only as CUCL templates (test/rtc/{sgemm,conv,k1conv,tconv,xpose_filts,k1conv_xpose_in,tconv_xpose_in}.cucl
+of a Boda checkout) that its code generator instantiates per op and hands to NVRTC / OpenCL.  Where a checkout is present (the build
+container: /root/reference), this recipe instantiates them with this repository's restatement of that generator
+(boda_amd/cucl_template.py + boda_amd/cnn_codegen.py), compiles each generated function with hiprtc for gfx950, and writes
+    oracle/_ref/cucl/<function>.hsaco      code objects (git-ignored; they travel to the GPU box like any built .so)
+    oracle/_ref/cucl/manifest.json         per op: the op line, the tune, per function its name, argument list and kinds, tpb, blks
+Nothing of the reference's text is kept: the generated sources exist only in memory.  On the GPU box tests/test_gpu_ref_cucl.py loads the
+code objects through be=hip (bodahip_compile_code_object), runs the reference's layout passes and kernels on the reference's
+deterministic data and holds the results to the oracle -- the real reference, checked and timed on the same silicon as the native kernels.
+Only tests/ and __graft_entry__.build() use this module."""
+from __future__ import annotations
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(HERE, "_ref", "cucl")
+REF_RTC_DIR = "/root/reference/test/rtc"
+
+
+def workloads():
+    """(tag, op, tune) of everything that is built: BASELINE config 2 sizes for sgemm, configs 3 / 4 layers for the conv variants, and the small
+    ops whose reference digests the repository holds (tests/golden/wisdom/conv-debug.wis)."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    from boda_amd.cnn_op import OpTune
+    from boda_amd.op import read_ops
+    res = []
+    for op in bench.sgemm_full_ops():
+        n = op.sgemm_geom()["M"]
+        if n in (256, 2048, 4096, 8192):
+            res.append((f"sgemm{n}", op, OpTune()))
+    kt = OpTune(k1conv=1, tconv=1)
+    for b in (2, 256):
+        for i, op in enumerate(bench.alexnet_b256_ops(b)):
+            res.append((f"alexnet_b{b}_l{i}", op, kt))
+        for i, op in enumerate(bench.nin_ops(b)):
+            if i in (1, 4, 7, 10):      # the 1x1 layers the reference runs as k1conv (cccp1 / 3 / 5 / 7)
+                res.append((f"nin_b{b}_l{i}", op, kt))
+    for i, op in enumerate(read_ops(os.path.join(ROOT, "tests", "golden", "ops", "conv-ops-debug.txt"))):
+        res.append((f"debug{i}", op, kt)); res.append((f"debug{i}_plain", op, OpTune()))
+    return res
+
+
+def build(rtc_dir: str = REF_RTC_DIR, verbose: bool = False) -> int:
+    """-> number of code objects written (0 when no Boda checkout is present: the prebuilt files, if any, are left alone)."""
+    if not os.path.isdir(rtc_dir):
+        return 0
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from boda_amd import cnn_codegen as cc, rtc
+    from boda_amd.cucl_template import load_template
+    os.makedirs(OUT, exist_ok=True)
+    manifest, n = [], 0
+
+    def emit(fn_name: str, template: str, anno):
+        nonlocal n
+        inst = cc.instantiate_ref(rtc_dir, template, anno, fn_name)
+        path = os.path.join(OUT, fn_name + ".hsaco")
+        rtc.compile_to_file(inst.src, path)
+        n += 1
+        t = load_template(rtc_dir, template)
+        kinds = {ad.vn: ("SCALAR" if ad.loi == 0 else ad.io_type) for ad in t.arg_decls}
+        return {"func": fn_name, "template": template, "arg_names": inst.arg_names, "arg_kinds": [kinds[a] for a in inst.arg_names], "tpb": inst.tpb,
+                "blks": inst.blks, "file": os.path.basename(path)}
+
+    for tag, op, tune in workloads():
+        anno = cc.annotate_ref(op, tune)
+        entry = {"tag": tag, "op": op.to_str(), "tune": tune.to_str(), "variant": anno.get_func_name(), "xposes": []}
+        for tname, src_arg, dst_arg, xop in cc.xpose_ops(anno):
+            e = emit(f"{tag}__{tname}", tname, xop); e.update(src=src_arg, dst=dst_arg); entry["xposes"].append(e)
+        entry["main"] = emit(f"{tag}__{anno.get_func_name()}", anno.get_func_name(), anno)
+        manifest.append(entry)
+        if verbose:
+            print(tag, entry["variant"], entry["main"]["tpb"], entry["main"]["blks"])
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+    return n
+
+
+if __name__ == "__main__":
+    print(build(verbose=True), "code objects in", OUT)

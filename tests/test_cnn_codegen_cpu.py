@@ -1,0 +1,71 @@
+"""SURVEY.md section 8 F4, host side (no GPU): the restated blocking / variant annotations (src/cnn_op.cc, src/gbt_tile.H) against the launch
+geometries the survey probed from the reference's own fixtures, and -- where a Boda checkout is present (the build container) -- the
+reference's templates instantiated through the restated custom code generation (src/cnn_codegen.cc) and compiled for gfx950."""
+import os
+import pytest
+
+import bench
+from boda_amd import cnn_codegen as cc, rtc
+from boda_amd.cnn_op import OpTune
+from boda_amd.op import RtErr, UnsupErr
+
+REF_RTC = "/root/reference/test/rtc"
+have_ref = pytest.mark.skipif(not os.path.isdir(REF_RTC), reason="no Boda checkout on this machine (the templates are not part of this repository)")
+KT = OpTune(k1conv=1, tconv=1)
+
+
+def test_good_div_and_gbt_tile():
+    assert cc.good_div(7, 8) == 7 and cc.good_div(64, 8) == 8 and cc.good_div(55, 8) == 8    # 55 -> 7 chunks of 8: 1 of 56 wasted
+    assert cc.good_div(13, 8) == 7                                                             # 2 x 8 wastes 3 of 13 (>= 20 %): 2 x 7
+    g = cc.GbtTile((8, 8), 128, (256 * 55 * 55, 96))                                           # NiN cccp1 at batch 256
+    assert g.mn_per_thr == (8, 8) and g.thr_per_blk == (10, 12) and g.num_blk == (9680, 1)
+
+
+def test_annotations_reproduce_the_reference_geometries():
+    """variant + blocks of AlexNet and NiN layers at batch 256 with k1conv=1, tconv=1; sgemm blocks."""
+    al = [cc.annotate_ref(op, KT) for op in bench.alexnet_b256_ops()]
+    assert [a.get_func_name() for a in al] == ["tconv"] * 5 + ["conv"] * 3
+    w = al[0].get_dims("work")
+    assert (w.dsz("blk_y"), w.dsz("out_chan_tile")) == (10, 12) and w.dsz("blk_bline") * w.dsz("blk_bx") * w.dsz("out_chan_blk") == 9856
+    blks = lambda a: (a.get_dims("work").dsz("blk_bline") * a.get_dims("work").dsz("blk_bx") if a.get_func_name() == "tconv" else a.get_dims("work").dsz("pels_blk")) * a.get_dims("work").dsz("out_chan_blk")
+    assert [blks(a) for a in al] == [9856, 6912, 2496, 2496, 1664, 128, 128, 32]
+    nin = bench.nin_ops()
+    k1 = [cc.annotate_ref(nin[i], KT) for i in (1, 4, 7, 10)]
+    assert all(a.get_func_name() == "k1conv" for a in k1) and [blks(a) for a in k1] == [9680, 5832, 2028, 1152]
+    assert k1[0].get_dims("in").names == ("blk", "blk_iter", "blk_iter_chan", "blk_pel") and k1[0].get_dims("in_ref") == nin[1].get_dims("in")
+    assert k1[0].get_dims("filts").names == ("out_chan_blk", "in_chan", "y", "x", "out_chan_reg", "out_chan_tile")
+    # without the enables every conv is the general variant; 1x1 with padding falls back to it too (src/cnn_op.cc:51-53)
+    assert cc.annotate_ref(nin[1], OpTune()).get_func_name() == "conv"
+    sg = {op.sgemm_geom()["M"]: op for op in bench.sgemm_full_ops()}
+    w = cc.annotate_ref(sg[8192], OpTune()).get_dims("work")
+    assert (w.dsz("Mg"), w.dsz("Ng"), w.dsz("Mb"), w.dsz("Nb"), w.dsz("Kb"), w.dsz("Mt"), w.dsz("Nt")) == (128, 64, 8, 16, 8, 8, 8)
+    with pytest.raises(RtErr):          # the reference's default tune cannot run 64^3 (N = 64 is not a multiple of 128: src/cnn_op.cc:352-355)
+        cc.annotate_ref(sg[64], OpTune())
+    with pytest.raises(UnsupErr):
+        cc.annotate_ref(nin[1], OpTune(k1conv=1, use_local_mem=2))     # the _simd variants are not restated
+
+
+@have_ref
+@pytest.mark.parametrize("which", ["sgemm", "conv", "k1conv", "tconv"])
+def test_reference_templates_instantiate_and_compile(which):
+    op, tune = {"sgemm": ([o for o in bench.sgemm_full_ops() if o.sgemm_geom()["M"] == 2048][0], OpTune()),
+                "conv": (bench.alexnet_b256_ops(4)[5], KT), "k1conv": (bench.nin_ops(4)[4], KT), "tconv": (bench.alexnet_b256_ops(4)[1], KT)}[which]
+    anno = cc.annotate_ref(op, tune)
+    assert anno.get_func_name() == which
+    inst = cc.instantiate_ref(REF_RTC, which, anno, "t_" + which)
+    assert inst.tpb > 0 and inst.blks > 0 and "%(" not in inst.src
+    assert rtc.compile_offline(inst.src, use_cache=False) > 0
+    for tname, src, dst, xop in cc.xpose_ops(anno):
+        xi = cc.instantiate_ref(REF_RTC, tname, xop, "t_x_" + tname)
+        assert rtc.compile_offline(xi.src, use_cache=False) > 0
+
+
+@have_ref
+def test_build_recipe_writes_code_objects_and_manifest():
+    from oracle import ref_cucl
+    import json
+    if not os.path.exists(os.path.join(ref_cucl.OUT, "manifest.json")):
+        assert ref_cucl.build() > 0
+    man = json.load(open(os.path.join(ref_cucl.OUT, "manifest.json")))
+    assert len(man) >= 30 and all(os.path.getsize(os.path.join(ref_cucl.OUT, e["main"]["file"])) > 1000 for e in man)
+    assert {e["variant"] for e in man} == {"sgemm", "conv", "k1conv", "tconv"}

@@ -1,0 +1,127 @@
+"""-m gpu: the reference's OWN kernels under be=hip.  oracle/ref_cucl.py (run by __graft_entry__.build() where a Boda
+checkout exists) instantiated the reference's CUCL templates -- sgemm, conv, k1conv, tconv and their xpose passes -- with this repository's
+restatement of its code generator and compiled them for gfx950; here the code objects are loaded through the C ABI
+(bodahip_compile_code_object), the layout passes and kernels run on the reference's deterministic data exactly as ops-prof runs them
+(src/rtc_prof.cc:44-126: gen data in reference layout, xpose, main function, timing of the main function only), and the results are held
+to the oracle at the reference's own tolerance (mrd < 2e-4, src/rtc_prof.cc:161).  The launch geometries in the manifest are the ones the
+survey probed from the reference's fixtures (AlexNet conv1 tconv tpb 120 blks 9856, NiN cccp1 k1conv tpb 120 blks 9680, ...).
+Per-kernel times of the reference's kernels on the MI355X go to gpurun_out/ref_cucl_times.json (the reference-GPU column of DESIGN.md)."""
+import json
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from boda_amd import cnn_codegen as cc, gen_data as gd
+from boda_amd.cnn_op import OpTune
+from boda_amd.digest import SsdsDiff
+from boda_amd.op import Dims, parse_op
+from boda_amd.rtc import RtcArg, RtcFuncCall, RtcFuncInfo, make_rtc
+from oracle import boda_oracle as bo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CUCL = os.path.join(ROOT, "oracle", "_ref", "cucl")
+MRD = 2e-4
+
+
+def _manifest():
+    fn = os.path.join(CUCL, "manifest.json")
+    return json.load(open(fn)) if os.path.exists(fn) else []
+
+
+MAN = _manifest()
+
+
+@pytest.fixture(scope="module")
+def rtc():
+    r = make_rtc("(be=hip)", 0); r.init()
+    r.compile(gd.func_infos()); r._gen_data_compiled = True
+    yield r
+    r.finish_and_sync(); r.close()
+
+
+def test_manifest_present_and_geometries_match_the_reference_fixtures():
+    if not MAN:
+        pytest.skip("oracle/_ref/cucl not built (no Boda checkout on the build machine)")
+    geo = {e["tag"]: (e["variant"], e["main"]["tpb"], e["main"]["blks"]) for e in MAN}
+    # SURVEY.md section 8 a5 (probed from test/rtc_func_sigs.txt and good_tr/nin of the reference) and a4 (sgemm 8192^3 -> 8192 blocks)
+    assert geo["alexnet_b256_l0"] == ("tconv", 120, 9856) and geo["alexnet_b256_l1"] == ("tconv", 128, 6912)
+    assert geo["alexnet_b256_l2"][2] == geo["alexnet_b256_l3"][2] == 2496 and geo["alexnet_b256_l4"][2] == 1664
+    assert [geo[f"alexnet_b256_l{i}"][::2] for i in (5, 6, 7)] == [("conv", 128), ("conv", 128), ("conv", 32)]
+    assert geo["nin_b256_l1"] == ("k1conv", 120, 9680) and geo["nin_b256_l4"] == ("k1conv", 128, 5832)
+    assert geo["nin_b256_l7"][2] == 2028 and geo["nin_b256_l10"][2] == 1152
+    assert geo["sgemm8192"] == ("sgemm", 128, 8192)
+
+
+def _run_entry(rtc, e, iters=3):
+    op = parse_op(e["op"]); tune = OpTune.parse(e["tune"])
+    anno = cc.annotate_ref(op, tune)
+    assert anno.get_func_name() == e["variant"]
+    funcs = e["xposes"] + [e["main"]]
+    made, loaded = [], []
+    try:
+        for f in funcs:
+            rtc.compile_code_object(open(os.path.join(CUCL, f["file"]), "rb").read(), [RtcFuncInfo(f["func"], "", f["arg_names"], anno)]); loaded.append(f["func"])
+        names = {}
+        for f in funcs:
+            for an, kind in zip(f["arg_names"], f["arg_kinds"]):
+                if kind in ("IN", "OUT", "INOUT"):
+                    names[an] = anno.get_dims(an)
+        for an, d in names.items():
+            rtc.create_var_with_dims(an, d); made.append(an)
+        is_conv = op.get_type() == "Convolution"
+        # deterministic inputs in the reference layout (the <arg>_ref var when the variant transposes that arg)
+        for an in (("in", "filts", "biases") if is_conv else ("a", "b")):
+            tgt = an + "_ref" if (an + "_ref") in names else an
+            rtc.run(gd.gen_call(op.get_type(), an, tgt, names[tgt], 5, 0.0))
+        def call(f):
+            am = {}
+            for an, kind in zip(f["arg_names"], f["arg_kinds"]):
+                am[an] = RtcArg.var(an) if kind in ("IN", "OUT", "INOUT") else (RtcArg.scalar(0, "uint32_t") if kind == "SCALAR" else RtcArg.ref(anno.get_dims(an)))
+            return RtcFuncCall(f["func"], am, tpb=f["tpb"], blks=f["blks"])
+        for f in e["xposes"]:
+            rtc.run(call(f))
+        main = call(e["main"])
+        ids = [rtc.run(main) for _ in range(iters)]
+        rtc.finish_and_sync()
+        ms = min(rtc.get_dur(i, i) for i in ids)
+        res = {an: rtc.copy_var_to_nda(an) for an in ((("in_ref" if "in_ref" in names else "in"), ("filts_ref" if "filts_ref" in names else "filts"), "biases", "out") if is_conv else ("a", "b", "c"))}
+        return op, res, ms
+    finally:
+        rtc.finish_and_sync()
+        for vn in made:
+            rtc.release_var(vn)
+        for fn in loaded:
+            rtc.release_func(fn)
+        rtc.release_per_call_id_data()
+
+
+TIMES = {}
+
+
+@pytest.mark.parametrize("e", MAN, ids=[e["tag"] for e in MAN])
+def test_reference_kernel_matches_oracle(rtc, e):
+    op, res, ms = _run_entry(rtc, e)
+    if op.get_type() == "sgemm":
+        want, got = bo.sgemm(res["a"], res["b"]), res["c"]
+    else:
+        g = op.conv_geom()
+        i = res["in_ref"] if "in_ref" in res else res["in"]; f = res["filts_ref"] if "filts_ref" in res else res["filts"]
+        nb = min(2, g["B"])       # conv is per image: the first images of a large batch against the oracle on those images
+        want = bo.conv_fwd(i[:nb], f, res["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True); got = res["out"][:nb]
+        last = res["out"][-1]
+        assert np.isfinite(last).all() and last.max() > 0
+    sd = SsdsDiff.of(want, got)
+    assert not sd.has_nan() and sd.mrd < MRD, (e["tag"], e["variant"], sd.basic_str())
+    TIMES[e["tag"]] = {"variant": e["variant"], "tpb": e["main"]["tpb"], "blks": e["main"]["blks"], "ms": round(ms, 5), "tflops": round(op.flops() / ms / 1e9, 2),
+                       "bit_exact_vs_oracle": bool(np.array_equal(want, got))}
+
+
+def test_zz_write_reference_kernel_times():
+    if not TIMES:
+        pytest.skip("no reference kernels ran")
+    out = os.path.join(ROOT, "gpurun_out"); os.makedirs(out, exist_ok=True)
+    json.dump(TIMES, open(os.path.join(out, "ref_cucl_times.json"), "w"), indent=1)
+    big = {k: v for k, v in TIMES.items() if "b256" in k or k.startswith("sgemm")}
+    print("reference CUCL kernels on this GPU (TF/s):", {k: v["tflops"] for k, v in big.items()})
