@@ -54,6 +54,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define SPLITK 0 // 1: the grid is tiles x p.splitk; slice s runs K steps [s*kt_per, (s+1)*kt_per) and stores its raw fp32 partial tile to slab s of p.ws
 #endif           // ([pel][oc], row pitch Mi); bodahip_nhwc_splitk_reduce (REDUCE_ONLY) sums the slabs and applies bias / ReLU / the output type.  For
                  // tile-starved layers with a long K (7x7-map layers at 64 images, fully-connected layers): this path has no summation order to keep.
+#ifndef ABLATE
+#define ABLATE 0   // measurement only (wrong results): 1 = no operand loads, 2 = no fragment reads / MFMAs, 3 = fragment reads but no MFMAs
+#endif
+#ifndef INTERLEAVE
+#define INTERLEAVE 0  // 1: spread the next step's LDS-DMA pieces between the MFMA groups of the current step instead of issuing them back to back at the top of
+#endif                // the step.  Measured on MI355X (ResNet-50 / GoogLeNet lists at 64 images): 35 % SLOWER (kernel time 1.51 -> 2.06 ms, res4 3x3 41 -> 64 us):
+                      // an LDS-DMA issued among MFMAs and ds_reads costs far more than one issued in a run of its own.  Kept for the record, off.
 #ifndef NBUF
 #define NBUF 2   // LDS ring depth: the loads of K step s + NBUF - 1 are issued before the MFMAs of step s (NBUF - 2 steps of loads stay in flight across a barrier)
 #endif
@@ -184,28 +191,31 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     if (kNoPad && !ok) jbase[s] = kOOB;
   }
 
-  auto stage = [&](int step, int buf) {
+  // One K step's operand loads are kISlots + kJSlots 1-KB pieces per wave.  `piece` issues piece pc of step `step` into ring slot `buf`.
+  struct step_ctx_t { int ky, kx, cg0; };
+  auto step_ctx = [&](int step) {
+    step_ctx_t c{0, 0, step * kCPR};
+    if constexpr (kFast) { int const tap = step / (kCG / kCPR); c.cg0 = (step - tap * (kCG / kCPR)) * kCPR; c.ky = tap / KW; c.kx = tap - c.ky * KW; }
+    return c;
+  };
+  auto piece = [&](int step, step_ctx_t const &c, int buf, int pc) {
+    if (ABLATE == 1) return;
     char *const Ib = smem + buf * (kIImg + kJImg), *const Jb = Ib + kIImg;
-    int tap = 0, cg0 = step * kCPR, ky = 0, kx = 0;
-    if constexpr (kFast) { tap = step / (kCG / kCPR); cg0 = (step - tap * (kCG / kCPR)) * kCPR; ky = tap / KW; kx = tap - ky * KW; }
-#pragma unroll
-    for (int s = 0; s < kISlots; ++s) {
-      int const q = s * kNW + wave;
-      if (kIInst % kNW != 0 && q >= kIInst) break;
+    if (pc < kISlots) {
+      int const s = pc, q = s * kNW + wave;
+      if (kIInst % kNW != 0 && q >= kIInst) return;
       int const kc = step * kCPR + ichunk[s];
       int off = ibase[s] + kc * 16;
       if ((kKC % kCPR != 0 && kc >= kKC) || ibase[s] == kOOB) off = kOOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rI, (lds_t)(Ib + q * 1024), 16, off, 0, 0, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < kJSlots; ++s) {
-      int const q = s * kNW + wave;
-      if (kJInst % kNW != 0 && q >= kJInst) break;
+    } else {
+      int const s = pc - kISlots, q = s * kNW + wave;
+      if (kJInst % kNW != 0 && q >= kJInst) return;
       int off; bool ok = true;
       int const iy0 = jyx[s] >> 16, ix0 = (int)(short)(jyx[s] & 0xffff);
       if constexpr (kFast) {
-        off = jbase[s] + ((ky * CW + kx) * CIN + (cg0 + jchunk[s]) * 8) * 2;
-        if constexpr (!kNoPad) ok = ((unsigned)(iy0 + ky) < (unsigned)CH) && ((unsigned)(ix0 + kx) < (unsigned)CW);
+        off = jbase[s] + ((c.ky * CW + c.kx) * CIN + (c.cg0 + jchunk[s]) * 8) * 2;
+        if constexpr (!kNoPad) ok = ((unsigned)(iy0 + c.ky) < (unsigned)CH) && ((unsigned)(ix0 + c.kx) < (unsigned)CW);
       } else {
         int const kc = step * kCPR + jchunk[s];
         int const t = kc / kCG, cg = kc - t * kCG, y = t / KW, x = t - y * KW;
@@ -216,6 +226,12 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
       if (kNoPad) { if (jbase[s] == kOOB) ok = false; }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rJ, (lds_t)(Jb + q * 1024), 16, ok ? off : kOOB, 0, 0, 0);
     }
+  };
+  constexpr int kPieces = kISlots + kJSlots;
+  auto stage = [&](int step, int buf) {
+    step_ctx_t const c = step_ctx(step);
+#pragma unroll
+    for (int pc = 0; pc < kPieces; ++pc) piece(step, c, buf, pc);
   };
 
   f32x16 acc[kTI][kTJ];
@@ -242,7 +258,8 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     else if (in_flight_steps == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerStep) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kLoadsPerStep) : "memory");
   };
-  auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
+  auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };   // (the step's last MFMAs, which the compiler may sink below it, only read registers;
+  // their ds_reads were issued -- queued in the LDS, in order -- before this wave arrived, i.e. before any other wave can issue the DMA that refills the slot)
 #if SPLITK
   int const k_begin = (int)(blockIdx.x % p.splitk) * p.kt_per, nk = max(0, min(kNK, k_begin + p.kt_per) - k_begin);   // this slice's K steps
 #else
@@ -255,19 +272,37 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   int cur = 0;
   for (int step = 0; step < nk; ++step) {
     int const nxt = (cur == 0) ? NBUF - 1 : cur - 1;   // == (step + NBUF - 1) % NBUF
-    if (step + NBUF - 1 < nk) stage(k_begin + step + NBUF - 1, nxt);
+    bool const more = step + NBUF - 1 < nk;
+    step_ctx_t const nc = step_ctx(k_begin + step + NBUF - 1);
+#if !INTERLEAVE
+    if (more) stage(k_begin + step + NBUF - 1, nxt);
+#endif
     char const *const Ib = smem + cur * (kIImg + kJImg), *const Jb = Ib + kIImg;
+    constexpr int kKK = BK / 16, kPP = (kPieces + kKK - 1) / kKK;   // pieces of the next step issued per MFMA group
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
+    for (int kk = 0; kk < kKK; ++kk) {
+      if (ABLATE == 2) break;
       bf16x8 a[kTI], b[kTJ];
 #pragma unroll
       for (int t = 0; t < kTI; ++t) a[t] = *reinterpret_cast<bf16x8 const *>(Ib + arow + t * (32 * BK * 2) + xo[kk]);
 #pragma unroll
       for (int t = 0; t < kTJ; ++t) b[t] = *reinterpret_cast<bf16x8 const *>(Jb + brow + t * (32 * BK * 2) + xo[kk]);
+#if INTERLEAVE
+      if (more) {
+#pragma unroll
+        for (int pc = kk * kPP; pc < (kk + 1) * kPP && pc < kPieces; ++pc) piece(k_begin + step + NBUF - 1, nc, nxt, pc);
+      }
+#endif
 #pragma unroll
       for (int ta = 0; ta < kTI; ++ta)
 #pragma unroll
-        for (int tb = 0; tb < kTJ; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        for (int tb = 0; tb < kTJ; ++tb) {
+          if (ABLATE == 3) { asm volatile("" ::"v"(a[ta]), "v"(b[tb])); continue; }   // (keeps the reads alive)
+          acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        }
+#if INTERLEAVE
+      __builtin_amdgcn_sched_barrier(0);   // keep the groups in program order: reads | loads | MFMAs
+#endif
     }
     // loads still wanted in flight after this wait: those of steps step + 2 .. step + NBUF - 1 that exist
     int const newest = (nk - 1 < step + NBUF - 1) ? nk - 1 : step + NBUF - 1;
