@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""gpurun_out/<dir>/{stats,fetch,write,sq}_<workload>/p_results.db + calib -> profiles/r01_*.txt + profiles/pmc_summary.json"""
+"""gpurun_out/<dir>/{stats,fetch,write,sq}_<key>/p_results.db + calib -> profiles/<tag>_*.txt + profiles/pmc_summary.json (each entry carries the
+kernel-source hash it was measured with: bench.py reports roofline.traffic only while that hash is current)"""
 import json, os, sqlite3, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "final")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
 summ = os.path.join(ROOT, "tools", "rocprof_summary.py")
@@ -19,14 +20,18 @@ known = 1 << 30
 factor = known / (cal * 1024.0)
 res = {"_fetch_size_calibration": {"known_bytes": known, "FETCH_SIZE_KB": cal, "bytes_per_reported_byte": round(factor, 4),
                                    "note": "16 B/lane coalesced stream; FETCH_SIZE under-reports by this factor on gfx950 (guide: exactly 2)"}}
-for w in ("sgemm-ops-full", "alexnet", "nin"):
+hash_fn = os.path.join(src, "kernel_src_hash.txt")
+khash = open(hash_fn).read().strip() if os.path.exists(hash_fn) else ""
+WORK = {"sgemm-ops-full": ("--workload sgemm-ops-full", "bodahip_sgemm_f32"), "alexnet": ("--workload alexnet", "bodahip_conv_f32"), "nin": ("--workload nin", "bodahip_conv_f32"),
+        "googlenet-bf16-nhwc": ("--workload googlenet --dtype bf16 --layout nhwc", "bodahip_conv_nhwc_bf16"),
+        "resnet50-bf16-nhwc": ("--workload resnet50 --dtype bf16 --layout nhwc", "bodahip_conv_nhwc_bf16")}
+for w, (cmdargs, kern) in WORK.items():
     sdb = os.path.join(src, f"stats_{w}", "p_results.db")
     if not os.path.exists(sdb):
         continue
     with open(os.path.join(out, f"{tag}_{w}_kernel_stats.txt"), "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --workload {w} --steps 5 --warmup 2 --no-cpu-baseline\n")
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py {cmdargs} --steps 5 --warmup 2 --no-cpu-baseline\n")
         f.write(subprocess.check_output([sys.executable, summ, sdb, "--by-grid"], text=True))
-    kern = "bodahip_sgemm_f32" if w.startswith("sgemm") else "bodahip_conv_f32"
     rows = {}
     for cn, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         for g, v in q(os.path.join(src, f"{sub}_{w}", "p_results.db"), f"select grid_size, sum(value) from counters_collection where counter_name='{cn}' and kernel_name='{kern}' group by grid_size"):
@@ -35,7 +40,7 @@ for w in ("sgemm-ops-full", "alexnet", "nin"):
     for g, cn, v, dur in q(os.path.join(src, f"sq_{w}", "p_results.db"), f"select grid_size, counter_name, sum(value), sum(end-start) from counters_collection where kernel_name='{kern}' group by grid_size, counter_name"):
         sq.setdefault(g, {})[cn] = v; sq[g]["_dur_ns"] = dur
     with open(os.path.join(out, f"{tag}_{w}_pmc.txt"), "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload {w} --steps 1 --warmup 0   (separate passes: FETCH_SIZE | WRITE_SIZE | SQ set)\n")
+        f.write(f"# rocprofv3 --kernel-trace --pmc <set> -- python bench.py {cmdargs} --steps 1 --warmup 0   (separate passes: FETCH_SIZE | WRITE_SIZE | SQ set); kernel {kern}; kernel sources {khash}\n")
         f.write(f"# HBM bytes = FETCH_SIZE_KB*1024*{factor:.3f} (calibrated, see pmc_summary.json) + WRITE_SIZE_KB*1024 ; summed over launches of the same grid size\n")
         f.write("# grid(threads)  fetch_MB(corrected)  write_MB  | mfma_busy%  clock_GHz  waves  wave_cycles: wait_inst% wait_any% active%\n")
         tot_f = tot_w = 0.0
@@ -51,12 +56,10 @@ for w in ("sgemm-ops-full", "alexnet", "nin"):
                          f"  {100*s.get('SQ_WAIT_INST_ANY',0)/wc:6.1f} {100*s.get('SQ_WAIT_ANY',0)/wc:6.1f} {100*s.get('SQ_ACTIVE_INST_ANY',0)/wc:6.1f}")
             f.write(line + "\n")
         f.write(f"# total per step: fetch {tot_f/1e9:.3f} GB (corrected), write {tot_w/1e9:.3f} GB\n")
-    res[w] = {"hbm_bytes_per_step": int(tot_f + tot_w), "fetch_bytes_corrected": int(tot_f), "write_bytes": int(tot_w)}
-for w, cmd in (("alexnet_winograd", "--workload alexnet --conv-algo winograd"), ("alexnet_bf16", "--workload alexnet --dtype bf16")):   # kernel stats only
-    sdb = os.path.join(src, f"stats_{w}", "p_results.db")
-    if os.path.exists(sdb):
-        with open(os.path.join(out, f"{tag}_{w}_kernel_stats.txt"), "w") as f:
-            f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py {cmd} --steps 5 --warmup 2 --no-cpu-baseline\n")
-            f.write(subprocess.check_output([sys.executable, summ, sdb, "--by-grid"], text=True))
+    res[w] = {"hbm_bytes_per_step": int(tot_f + tot_w), "fetch_bytes_corrected": int(tot_f), "write_bytes": int(tot_w), "kernel_src_hash": khash, "file": f"{tag}_{w}_pmc.txt"}
+import glob, shutil
+for fn in glob.glob(os.path.join(src, "bench_*.json")):   # the bench lines of the same box
+    if os.path.getsize(fn) > 10:
+        shutil.copy(fn, os.path.join(out, f"{tag}_" + os.path.basename(fn)))
 json.dump(res, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
