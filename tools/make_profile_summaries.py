@@ -37,8 +37,8 @@ for w, (cmdargs, kern) in WORK.items():
         for g, v in q(os.path.join(src, f"{sub}_{w}", "p_results.db"), f"select grid_size, sum(value) from counters_collection where counter_name='{cn}' and kernel_name='{kern}' group by grid_size"):
             rows.setdefault(g, {})[cn] = v
     sq = {}
-    for g, cn, v, dur in q(os.path.join(src, f"sq_{w}", "p_results.db"), f"select grid_size, counter_name, sum(value), sum(end-start) from counters_collection where kernel_name='{kern}' group by grid_size, counter_name"):
-        sq.setdefault(g, {})[cn] = v; sq[g]["_dur_ns"] = dur
+    for g, cn, v, dur, nn in q(os.path.join(src, f"sq_{w}", "p_results.db"), f"select grid_size, counter_name, sum(value), sum(end-start), count(*) from counters_collection where kernel_name='{kern}' group by grid_size, counter_name"):
+        sq.setdefault(g, {})[cn] = v; sq[g]["_dur_ns"] = dur; sq[g]["_n"] = nn
     with open(os.path.join(out, f"{tag}_{w}_pmc.txt"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --pmc <set> -- python bench.py {cmdargs} --steps 1 --warmup 0   (separate passes: FETCH_SIZE | WRITE_SIZE | SQ set); kernel {kern}; kernel sources {khash}\n")
         f.write(f"# HBM bytes = FETCH_SIZE_KB*1024*{factor:.3f} (calibrated, see pmc_summary.json) + WRITE_SIZE_KB*1024 ; summed over launches of the same grid size\n")
@@ -52,7 +52,8 @@ for w, (cmdargs, kern) in WORK.items():
             if s.get("GRBM_GUI_ACTIVE"):
                 cyc = s["GRBM_GUI_ACTIVE"] / 8.0
                 wc = s.get("SQ_WAVE_CYCLES", 0) or 1
-                line += (f"  | {100*s.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/1024/cyc:9.1f}  {cyc/s['_dur_ns']:9.2f}  {int(s.get('SQ_WAVES',0)):6d}"
+                long_enough = s["_dur_ns"] / max(1, s.get("_n", 1)) > 2e5   # (GRBM_GUI_ACTIVE spans the dispatch gaps of short launches: clock / busy only for >= 200 us)
+                line += (f"  | " + (f"{100*s.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/1024/cyc:9.1f}  {cyc/s['_dur_ns']:9.2f}" if long_enough else "        -          -") + f"  {int(s.get('SQ_WAVES',0)):6d}"
                          f"  {100*s.get('SQ_WAIT_INST_ANY',0)/wc:6.1f} {100*s.get('SQ_WAIT_ANY',0)/wc:6.1f} {100*s.get('SQ_ACTIVE_INST_ANY',0)/wc:6.1f}")
             f.write(line + "\n")
         f.write(f"# total per step: fetch {tot_f/1e9:.3f} GB (corrected), write {tot_w/1e9:.3f} GB\n")
