@@ -29,7 +29,7 @@
 // Numerics: bf16 products are exact in fp32; the MFMA sums 16 of them per instruction in an order of its own, so results are NOT
 // bit-comparable with a CPU loop; parity is stated against the oracle fed the same bf16 operands (tests), unpinned by construction.
 //
-// -D parameters: KNAME BI BJ BK(32|64) WI WJ MINW CIN KH KW SY SX PY PX CH CW COH COW RELU OUT_F32 NBUF(2..4)
+// -D parameters: KNAME BI BJ BK(32|64; f32: 16|32) WI WJ MINW CIN KH KW SY SX PY PX CH CW COH COW RELU OUT_F32 NBUF(2..8) [IN_F32 SPLITK]
 
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
@@ -50,6 +50,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef OUT_F32
 #define OUT_F32 0
 #endif
+#ifndef IN_F32
+#define IN_F32 0  // 1: float tensors (in / filts / out), exact fp32 MFMA (v_mfma_f32_32x32x2_f32): every output is ONE ascending-k fma chain -- bit-identical to the
+#endif            // reference's per-thread fmaf loop (and to gemm_conv_f32.hip).  A 16-byte chunk is 4 k; a lane reads its row's chunk with one ds_read_b128 and
+                  // feeds two MFMAs from it (lanes 0-31 supply k = 4c, 4c+2, lanes 32-63 k = 4c+1, 4c+3: the instruction adds its two k in ascending order).
+                  // Used by hip_conv for the shapes whose operands are k-contiguous in the REFERENCE layout already -- output 1x1, kernel == whole input
+                  // (AlexNet fc6-fc8: in[img][K], filts[oc][K]) -- where the tile-starved, one-workgroup-per-CU launch needs many K steps in flight
+                  // (a deep LDS-DMA ring) rather than registers.  Requires OUT_F32, no split-K (it would break the chain).
 #ifndef SPLITK
 #define SPLITK 0 // 1: the grid is tiles x p.splitk; slice s runs K steps [s*kt_per, (s+1)*kt_per) and stores its raw fp32 partial tile to slab s of p.ws
 #endif           // ([pel][oc], row pitch Mi); bodahip_nhwc_splitk_reduce (REDUCE_ONLY) sums the slabs and applies bias / ReLU / the output type.  For
@@ -119,11 +126,15 @@ namespace {
 constexpr int kNW = WI * WJ, kNT = kNW * 64;
 constexpr int kTI = BI / (WI * 32), kTJ = BJ / (WJ * 32);
 static_assert(BI % (WI * 32) == 0 && BJ % (WJ * 32) == 0, "tile must be a multiple of the 32x32 MFMA tile per wave");
-static_assert(BK == 32 || BK == 64, "BK must be 32 or 64");
-static_assert(CIN % 8 == 0, "channels-last bf16 tensors carry a multiple of 8 channels");
-constexpr int kCPR = BK / 8;                  // 16-byte chunks per LDS row
-constexpr int kRP = 256 / (BK * 2);           // LDS rows per 256 bytes (one pass over the 64 banks)
-constexpr int kCG = CIN / 8;                    // chunks per tap
+constexpr int kEB = IN_F32 ? 4 : 2;           // bytes per element
+constexpr int kCK = 16 / kEB;                 // k per 16-byte chunk
+static_assert(IN_F32 ? (BK == 16 || BK == 32) : (BK == 32 || BK == 64), "BK: 32 | 64 (bf16), 16 | 32 (f32)");
+static_assert(CIN % kCK == 0, "channels-last tensors carry a whole number of 16-byte chunks per position");
+static_assert(!IN_F32 || (OUT_F32 && !SPLITK), "the exact fp32 variant writes float and never splits K");
+constexpr int kRowB = BK * kEB;               // bytes per LDS row
+constexpr int kCPR = kRowB / 16;              // 16-byte chunks per LDS row
+constexpr int kRP = 256 / kRowB;              // LDS rows per 256 bytes (one pass over the 64 banks)
+constexpr int kCG = CIN / kCK;                // chunks per tap
 constexpr int kTaps = KH * KW;
 constexpr int kKC = kTaps * kCG;              // chunks along k
 constexpr int kNK = (kKC + kCPR - 1) / kCPR;  // K steps
@@ -132,10 +143,11 @@ constexpr bool kNoPad = (PY == 0 && PX == 0 && (COH - 1) * SY + KH <= CH && (COW
 constexpr int kIInst = BI * kCPR / 64, kJInst = BJ * kCPR / 64;   // 1-KB wave instructions per image
 static_assert((BI * kCPR) % 64 == 0 && (BJ * kCPR) % 64 == 0, "an image must be a whole number of 1-KB wave loads");
 constexpr int kISlots = (kIInst + kNW - 1) / kNW, kJSlots = (kJInst + kNW - 1) / kNW;
-static_assert(NBUF >= 2 && NBUF <= 4, "ring depth 2..4");
+static_assert(NBUF >= 2 && NBUF <= 8, "ring depth 2..8");
+static_assert((NBUF - 2) * (kISlots + kJSlots) <= 56, "loads kept in flight must fit the 6-bit vmcnt");
 static_assert(NBUF == 2 || (kIInst % kNW == 0 && kJInst % kNW == 0), "a ring deeper than 2 counts loads per wave: every wave must issue the same number");
 constexpr int kLoadsPerStep = kISlots + kJSlots;   // (per wave, when they divide evenly)
-constexpr int kIImg = BI * BK * 2, kJImg = BJ * BK * 2;          // bytes
+constexpr int kIImg = BI * kRowB, kJImg = BJ * kRowB;            // bytes
 constexpr int kEPitch = BI * 2 + 16;                               // epilogue tile [pel][oc] bf16, rows de-phased by 4 banks
 constexpr int kStage = NBUF * (kIImg + kJImg), kEpi = (OUT_F32 || SPLITK) ? 0 : BJ * kEPitch;
 constexpr int kSmem = kStage > kEpi ? kStage : kEpi;
@@ -186,7 +198,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     int const img = pel / (COH * COW), rem = pel - img * (COH * COW), oy = rem / COW, ox = rem - oy * COW;
     int const iy0 = oy * SY - PY, ix0 = ox * SX - PX;
     bool const ok = pel < p.Nj;
-    jbase[s] = ((img * CH + iy0) * CW + ix0) * (CIN * 2);
+    jbase[s] = ((img * CH + iy0) * CW + ix0) * (CIN * kEB);
     jyx[s] = ok ? ((iy0 << 16) | (ix0 & 0xffff)) : (int)0x80008000;   // (a row of no image: every tap fails the range test)
     if (kNoPad && !ok) jbase[s] = kOOB;
   }
@@ -214,12 +226,12 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
       int off; bool ok = true;
       int const iy0 = jyx[s] >> 16, ix0 = (int)(short)(jyx[s] & 0xffff);
       if constexpr (kFast) {
-        off = jbase[s] + ((c.ky * CW + c.kx) * CIN + (c.cg0 + jchunk[s]) * 8) * 2;
+        off = jbase[s] + ((c.ky * CW + c.kx) * CIN + (c.cg0 + jchunk[s]) * kCK) * kEB;
         if constexpr (!kNoPad) ok = ((unsigned)(iy0 + c.ky) < (unsigned)CH) && ((unsigned)(ix0 + c.kx) < (unsigned)CW);
       } else {
         int const kc = step * kCPR + jchunk[s];
         int const t = kc / kCG, cg = kc - t * kCG, y = t / KW, x = t - y * KW;
-        off = jbase[s] + ((y * CW + x) * CIN + cg * 8) * 2;
+        off = jbase[s] + ((y * CW + x) * CIN + cg * kCK) * kEB;
         ok = (kc < kKC);
         if constexpr (!kNoPad) ok = ok && ((unsigned)(iy0 + y) < (unsigned)CH) && ((unsigned)(ix0 + x) < (unsigned)CW);
       }
@@ -244,19 +256,33 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 
   // fragment reads: lane l holds row (l & 31), k-chunk (2*kk + (l >> 5)) of each 16-deep MFMA step, at the swizzled chunk position
   int const h = lane >> 5, fsw = swz(lane & 31);
-  int xo[BK / 16];
+#if IN_F32
+  constexpr int kKK = kCPR;   // one fragment read (4 k) per chunk, two MFMAs each
+  int xo[kKK];
 #pragma unroll
-  for (int kk = 0; kk < BK / 16; ++kk) xo[kk] = ((2 * kk + h) ^ fsw) * 16;
-  int const arow = (wi * (kTI * 32) + (lane & 31)) * (BK * 2), brow = (wj * (kTJ * 32) + (lane & 31)) * (BK * 2);
+  for (int kk = 0; kk < kKK; ++kk) xo[kk] = (kk ^ fsw) * 16;
+#else
+  constexpr int kKK = BK / 16;
+  int xo[kKK];
+#pragma unroll
+  for (int kk = 0; kk < kKK; ++kk) xo[kk] = ((2 * kk + h) ^ fsw) * 16;
+#endif
+  int const arow = (wi * (kTI * 32) + (lane & 31)) * kRowB, brow = (wj * (kTJ * 32) + (lane & 31)) * kRowB;
 
   // K loop over an NBUF-deep LDS ring.  Step s: issue the loads of step s + NBUF - 1 into the buffer step s - 1 has just released, run the
   // MFMAs of step s, wait until this wave's loads of step s + 1 have landed (a COUNTED vmcnt: the younger NBUF - 2 steps stay in flight),
   // then one barrier -- after it every wave's share of step s + 1 is in LDS and every wave is done reading step s.  The barrier is the
   // bare instruction: __syncthreads() would drain vmcnt to 0 while LDS-DMA is in flight.
-  auto wait_loads = [&](int in_flight_steps) {
-    if (in_flight_steps <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (in_flight_steps == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerStep) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kLoadsPerStep) : "memory");
+  auto wait_loads = [&](int in_flight_steps) {   // (the count is an immediate: one case per depth)
+    switch (in_flight_steps < 0 ? 0 : in_flight_steps) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoadsPerStep) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBUF > 3 ? 2 * kLoadsPerStep : 0) : "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBUF > 4 ? 3 * kLoadsPerStep : 0) : "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBUF > 5 ? 4 * kLoadsPerStep : 0) : "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBUF > 6 ? 5 * kLoadsPerStep : 0) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBUF > 7 ? 6 * kLoadsPerStep : 0) : "memory"); break;
+    }
   };
   auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };   // (the step's last MFMAs, which the compiler may sink below it, only read registers;
   // their ds_reads were issued -- queued in the LDS, in order -- before this wave arrived, i.e. before any other wave can issue the DMA that refills the slot)
@@ -267,7 +293,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #endif
 #pragma unroll
   for (int s0 = 0; s0 < NBUF - 1; ++s0) if (s0 < nk) stage(k_begin + s0, s0);
-  { int const pre = (nk < NBUF - 1 ? nk : NBUF - 1) - 1; if (pre <= 0) wait_loads(0); else if (pre == 1) wait_loads(1); else wait_loads(2); }
+  wait_loads((nk < NBUF - 1 ? nk : NBUF - 1) - 1);
   barrier();
   int cur = 0;
   for (int step = 0; step < nk; ++step) {
@@ -278,15 +304,34 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     if (more) stage(k_begin + step + NBUF - 1, nxt);
 #endif
     char const *const Ib = smem + cur * (kIImg + kJImg), *const Jb = Ib + kIImg;
-    constexpr int kKK = BK / 16, kPP = (kPieces + kKK - 1) / kKK;   // pieces of the next step issued per MFMA group
+    constexpr int kPP = (kPieces + kKK - 1) / kKK;   // pieces of the next step issued per MFMA group (INTERLEAVE only)
 #pragma unroll
     for (int kk = 0; kk < kKK; ++kk) {
       if (ABLATE == 2) break;
+#if IN_F32
+      f32x4 a[kTI], b[kTJ];
+#pragma unroll
+      for (int t = 0; t < kTI; ++t) a[t] = *reinterpret_cast<f32x4 const *>(Ib + arow + t * (32 * kRowB) + xo[kk]);
+#pragma unroll
+      for (int t = 0; t < kTJ; ++t) b[t] = *reinterpret_cast<f32x4 const *>(Jb + brow + t * (32 * kRowB) + xo[kk]);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {      // k = 4kk + 2*half (lanes 0-31) | + 1 (lanes 32-63)
+        float av[kTI], bw[kTJ];
+#pragma unroll
+        for (int t = 0; t < kTI; ++t) av[t] = h ? a[t][2 * half + 1] : a[t][2 * half];
+#pragma unroll
+        for (int t = 0; t < kTJ; ++t) bw[t] = h ? b[t][2 * half + 1] : b[t][2 * half];
+#pragma unroll
+        for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < kTJ; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ta], bw[tb], acc[ta][tb], 0, 0, 0);
+      }
+#else
       bf16x8 a[kTI], b[kTJ];
 #pragma unroll
-      for (int t = 0; t < kTI; ++t) a[t] = *reinterpret_cast<bf16x8 const *>(Ib + arow + t * (32 * BK * 2) + xo[kk]);
+      for (int t = 0; t < kTI; ++t) a[t] = *reinterpret_cast<bf16x8 const *>(Ib + arow + t * (32 * kRowB) + xo[kk]);
 #pragma unroll
-      for (int t = 0; t < kTJ; ++t) b[t] = *reinterpret_cast<bf16x8 const *>(Jb + brow + t * (32 * BK * 2) + xo[kk]);
+      for (int t = 0; t < kTJ; ++t) b[t] = *reinterpret_cast<bf16x8 const *>(Jb + brow + t * (32 * kRowB) + xo[kk]);
 #if INTERLEAVE
       if (more) {
 #pragma unroll
@@ -303,11 +348,12 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #if INTERLEAVE
       __builtin_amdgcn_sched_barrier(0);   // keep the groups in program order: reads | loads | MFMAs
 #endif
+#endif
     }
     // loads still wanted in flight after this wait: those of steps step + 2 .. step + NBUF - 1 that exist
     int const newest = (nk - 1 < step + NBUF - 1) ? nk - 1 : step + NBUF - 1;
     int const fl = newest - (step + 1);
-    if (NBUF == 2 || fl <= 0) wait_loads(0); else if (fl == 1) wait_loads(1); else wait_loads(2);
+    wait_loads(NBUF == 2 ? 0 : fl);
     barrier();
     cur = (cur + 1 == NBUF) ? 0 : cur + 1;
   }

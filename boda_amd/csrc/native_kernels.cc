@@ -361,9 +361,31 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
   return p;
 }
+// Exact fp32 convolutions whose operands are k-contiguous in the REFERENCE layout -- output 1x1, no padding, kernel == whole input (AlexNet
+// fc6-fc8: in[img][K], filts[out_chan][K]) -- through the LDS-DMA kernel's IN_F32 variant (kernels/conv_nhwc_bf16.hip): 64x64 tiles of four
+// waves, 32-deep K steps, an 8-slot LDS ring (six K steps of loads in flight).  Same ascending-k fma chain: bit-exact (tested).  MEASURED SLOWER
+// than the register-staged gather kernel on MI355X and therefore opt-in (BODAHIP_IPCONV_DMA=1): AlexNet fc6 / fc7 at 256 images 65.5 / 63.8 TF/s
+// with 8 ring slots (37 / 37 with 2 or 4) against 80.5 / 78.6 -- a workgroup alone on its CU streaming 16 KB per K step through LDS-DMA gets
+// ~16 GB/s however many steps are in flight (the per-CU LDS-DMA fill rate from HBM), less than two register-staged K-tiles deliver.
+static bool plan_ipconv_dma(conv_geom_t const &g, int num_cus, plan_t &p) {
+  if (!getenv("BODAHIP_IPCONV_DMA")) return false;
+  long const Kt = (long)g.C * g.KH * g.KW;
+  if (!(g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W)) return false;
+  if (Kt % 4 || Kt < 512) return false;
+  long const tiles = (long)((g.OC + 63) / 64) * ((g.B + 63) / 64);
+  if (tiles * 4 < num_cus * 3) return false;      // fewer workgroups than 3/4 of the CUs: finer (16x16-MFMA) tiles of the gather kernel do better
+  tile_cfg_t c; c.BI = 64; c.BJ = 64; c.BK = 32; c.WI = 2; c.WJ = 2; c.MINW = 1; c.SPLITK = 1; c.MT = 32; c.PF = 8;
+  if (char const *e = getenv("BODAHIP_IPCONV_DMA_NBUF")) c.PF = std::max(2, std::min(8, atoi(e)));
+  p = plan_t(); p.nhwc = true; p.kname = "bodahip_conv_nhwc_f32"; p.cfg = c;
+  p.defs = {"-DBI=64", "-DBJ=64", "-DBK=32", "-DWI=2", "-DWJ=2", "-DMINW=1", "-DCIN=" + std::to_string(Kt), "-DKH=1", "-DKW=1", "-DSY=1", "-DSX=1", "-DPY=0", "-DPX=0",
+            "-DCH=1", "-DCW=1", "-DCOH=1", "-DCOW=1", string("-DRELU=") + (g.relu ? "1" : "0"), "-DOUT_F32=1", "-DIN_F32=1", "-DNBUF=" + std::to_string(c.PF)};
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return true;
+}
 static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false, string const &k1s = string(), bool allow_splitk = true) {
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   plan_t p;
+  if (!bf16 && tile.empty() && plan_ipconv_dma(g, num_cus, p)) return p;
   if (!bf16 && tile.empty() && plan_k1_stream(g, num_cus, k1s, p)) return p;
   if (bf16 && tile.empty() && plan_patch_bf16(g, num_cus, p)) return p; p.kname = bf16 ? "bodahip_conv_bf16" : "bodahip_conv_f32"; p.bf16 = bf16;
   // output 1x1, no padding, kernel == whole input ("ipconv" case): the im2col row of image j is the contiguous image
@@ -722,6 +744,20 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   plan_t const p = plan_conv(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), bf16, tune_of(impl, "k1_stream"), out_ctot == g.OC);
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
+  if (p.nhwc) {   // (fp32 here: the k-contiguous shapes through the LDS-DMA kernel, plan_ipconv_dma)
+    gemm_args_t na; memset(&na, 0, sizeof(na));
+    uint64_t const ib = (uint64_t)g.B * Kt * 4, fb = (uint64_t)g.OC * Kt * 4, ob = (uint64_t)Nj * out_ctot * 4;
+    if (ib >= 0x7ffffff0ull || fb >= 0x7ffffff0ull || ob >= 0x7ffffff0ull) unsup_err("hip_conv: tensors of 2 GiB or more are not supported (32-bit buffer offsets)");
+    na.I = filts; na.J = in; na.D = out; na.bias = biases; na.Mi = g.OC; na.Nj = (int)Nj; na.K = (int)Kt; na.C = (int)Kt; na.H = 1; na.W = 1; na.OH = 1; na.OW = 1;
+    na.I_bytes = (unsigned)fb; na.J_bytes = (unsigned)ib; na.D_bytes = (unsigned)ob; na.out_ctot = out_ctot; na.out_coff = out_coff; na.splitk = 1;
+    na.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; na.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
+    void *nparams[] = {&na};
+    hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(na.tiles_i * na.tiles_j), 1, 1, (uint32_t)cfg.threads(), 1, 1, 0, host->nh_stream(), nparams, nullptr), "hipModuleLaunchKernel(conv_nhwc_f32)");
+    last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(na.tiles_i * na.tiles_j); last_launch.block = cfg.threads();
+    last_launch.flops = 2.0 * Nj * g.OC * Kt;
+    last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
+    return;
+  }
   gemm_args_t ga; memset(&ga, 0, sizeof(ga));
   uint64_t const in_bytes = (uint64_t)g.B * g.C * g.H * g.W * 4, f_bytes = (uint64_t)g.OC * Kt * 4;
   if (in_bytes >= 0x7ffffff0ull || f_bytes >= 0x7ffffff0ull) unsup_err("hip_conv: in / filts of 2 GiB or more are not supported (32-bit buffer offsets)");

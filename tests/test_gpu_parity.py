@@ -932,3 +932,22 @@ def test_outputs_of_2gib_or_more_are_unsupported(be):
     op = _sgemm_op(23200, 23200, 4)   # c = 2.15 GB
     with pytest.raises(UnsupErr):
         _run(be, op, 5)
+
+
+def test_ipconv_shapes_through_the_lds_dma_kernel_bit_exact(monkeypatch):
+    """The exact fp32 variant of the LDS-DMA kernel (kernels/conv_nhwc_bf16.hip, IN_F32: b128 fragment reads feeding two 32x32x2 MFMAs in ascending
+    k) on the shapes whose operands are k-contiguous in the reference layout (output 1x1, kernel == whole input).  Opt-in (measured slower than the
+    gather kernel, native_kernels.cc: plan_ipconv_dma) -- forced here and held to bit-exact equality with the oracle like every fp32 kernel."""
+    monkeypatch.setenv("BODAHIP_IPCONV_DMA", "1")
+    rtc = make_rtc("(be=hip)", 0); rtc.init()
+    b = OpsBackend(rtc)
+    try:
+        for shape in [(256, 64, 6, 6, 512, 6, 6, 1, 0), (200, 1024, 1, 1, 1000, 1, 1, 1, 0), (130, 37, 4, 4, 300, 4, 4, 1, 0)]:
+            op = _conv_op(*shape)
+            outs, prc = _run(b, op, 5, include_ins=True)
+            assert prc.launch["kernel"] == "bodahip_conv_nhwc_f32", prc.launch
+            g = op.conv_geom()
+            want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (1, 1), (0, 0), True)
+            assert np.array_equal(want, outs["out"]), (shape, SsdsDiff.of(want, outs["out"]).basic_str())
+    finally:
+        rtc.finish_and_sync(); rtc.close()
