@@ -62,7 +62,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #endif           // ([pel][oc], row pitch Mi); bodahip_nhwc_splitk_reduce (REDUCE_ONLY) sums the slabs and applies bias / ReLU / the output type.  For
                  // tile-starved layers with a long K (7x7-map layers at 64 images, fully-connected layers): this path has no summation order to keep.
 #ifndef ABLATE
-#define ABLATE 0   // measurement only (wrong results): 1 = no operand loads, 2 = no fragment reads / MFMAs, 3 = fragment reads but no MFMAs
+#define ABLATE 0   // measurement only (wrong results): 1 = no operand loads, 2 = no fragment reads / MFMAs, 3 = fragment reads but no MFMAs,
+                   // 4 = no K loop at all (prologue + epilogue), 5 = return at once (launch floor), 6 = K loop but no epilogue
 #endif
 #ifndef INTERLEAVE
 #define INTERLEAVE 0  // 1: spread the next step's LDS-DMA pieces between the MFMA groups of the current step instead of issuing them back to back at the top of
@@ -163,6 +164,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   int const tid = threadIdx.x, lane = tid & 63;
   int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int const wi = wave / WJ, wj = wave % WJ;
+  if (ABLATE == 5) return;
 
   int tile_i, tile_j; // XCD-aware workgroup -> tile map (as gemm_conv_f32.hip)
   {
@@ -289,7 +291,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #if SPLITK
   int const k_begin = (int)(blockIdx.x % p.splitk) * p.kt_per, nk = max(0, min(kNK, k_begin + p.kt_per) - k_begin);   // this slice's K steps
 #else
-  constexpr int k_begin = 0, nk = kNK;
+  constexpr int k_begin = 0, nk = (ABLATE == 4) ? 0 : kNK;
 #endif
 #pragma unroll
   for (int s0 = 0; s0 < NBUF - 1; ++s0) if (s0 < nk) stage(k_begin + s0, s0);
@@ -357,6 +359,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     barrier();
     cur = (cur + 1 == NBUF) ? 0 : cur + 1;
   }
+  if (ABLATE == 6) { if (acc[0][0][0] == 123.456f) p.D[0] = 1.f; return; }
   // ---- epilogue.  C/D layout of the 32x32 MFMA family: column j = lane & 31, rows i = 8*g + 4*(lane >> 5) + e for register 4*g + e:
   // a lane holds 4 consecutive out_chans of one pel per register quad
 #if SPLITK

@@ -18,7 +18,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         out.append(f"{float(np.median(prc.all_secs[2:]))*1e6:7.1f}")
     print(os.environ.get("BODAHIP_EXTRA_DEFS", "full").ljust(14), prc.launch["cfg"], " ".join(out), flush=True)
 else:
-    for ab in ("", "-DABLATE=1", "-DABLATE=2", "-DABLATE=3"):
+    for ab in ("", "-DABLATE=1", "-DABLATE=2", "-DABLATE=3", "-DABLATE=4", "-DABLATE=5", "-DABLATE=6"):
         env = dict(os.environ); env["BODAHIP_EXTRA_DEFS"] = ab
         if not ab: env.pop("BODAHIP_EXTRA_DEFS")
         env["BODAHIP_CACHE_DIR"] = "/tmp/kc_ablate" + ab.replace("-D", "_").replace("=", "")
