@@ -373,7 +373,7 @@ static bool plan_ipconv_dma(conv_geom_t const &g, int num_cus, plan_t &p) {
   if (!(g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W)) return false;
   if (Kt % 4 || Kt < 512) return false;
   long const tiles = (long)((g.OC + 63) / 64) * ((g.B + 63) / 64);
-  if (tiles * 4 < num_cus * 3) return false;      // fewer workgroups than 3/4 of the CUs: finer (16x16-MFMA) tiles of the gather kernel do better
+  if (tiles * 4 < num_cus * 3 && string(getenv("BODAHIP_IPCONV_DMA")) != "force") return false;   // fewer workgroups than 3/4 of the CUs: finer (16x16-MFMA) tiles of the gather kernel do better
   tile_cfg_t c; c.BI = 64; c.BJ = 64; c.BK = 32; c.WI = 2; c.WJ = 2; c.MINW = 1; c.SPLITK = 1; c.MT = 32; c.PF = 8;
   if (char const *e = getenv("BODAHIP_IPCONV_DMA_NBUF")) c.PF = std::max(2, std::min(8, atoi(e)));
   p = plan_t(); p.nhwc = true; p.kname = "bodahip_conv_nhwc_f32"; p.cfg = c;

@@ -212,25 +212,33 @@ CUCL_GLOBAL_KERNEL void nhwc_pool( GASQ bf16x8_t const * const in, GASQ bf16x8_t
   out[i] = r;
 }
 // across-channel LRN (test/rtc/lrn.cucl): out[c] = in[c] * ( k + alpha/local_size * sum_{|d| <= local_size/2} in[c+d]^2 ) ^ -beta.  One thread per
-// 16-byte chunk (8 channels): it loads its own chunk and the two neighbours (local_size/2 <= 8), squares them once and slides the window.
+// 16-byte chunk (8 channels) of one position; consecutive lanes hold consecutive chunks, so the halo -- the last `half` channels of the chunk
+// below and the first `half` of the chunk above (half = local_size/2 <= 8) -- comes from the neighbouring LANES (wave shuffles of the squares)
+// instead of from memory: every element is loaded once.  Lanes at a position's first / last chunk, and at the wave's edges, take zero / reload.
 CUCL_GLOBAL_KERNEL void nhwc_lrn( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n, uint32_t const C8, uint32_t const local_size,
                                   float const alpha, float const beta, float const k ) {
   uint32_t const i = GLOB_ID_1D;
-  if( i >= n ) { return; }
-  int32_t const q = i % C8, half = local_size / 2;
-  float v[24];
-  bf16x8_t const mid = in[i];
-  for( int32_t e = 0; e != 8; ++e ) { v[8 + e] = (float)mid[e]; v[e] = 0.0f; v[16 + e] = 0.0f; }
-  if( q > 0 ) { bf16x8_t const lo = in[i - 1]; for( int32_t e = 0; e != 8; ++e ) { v[e] = (float)lo[e]; } }
-  if( q + 1 < (int32_t)C8 ) { bf16x8_t const hi = in[i + 1]; for( int32_t e = 0; e != 8; ++e ) { v[16 + e] = (float)hi[e]; } }
-  float sq[24];
-  for( int32_t e = 0; e != 24; ++e ) { sq[e] = v[e]*v[e]; }
+  bool const live = i < n;
+  int32_t const q = live ? (int32_t)( i % C8 ) : 0, half = local_size / 2, lane = LOC_ID_1D & 63;
+  float v[8], sq[24];
+  bf16x8_t const mid = live ? in[i] : (bf16x8_t)0;
+  for( int32_t e = 0; e != 8; ++e ) { v[e] = (float)mid[e]; sq[8 + e] = v[e]*v[e]; }
+  for( int32_t e = 0; e != 8; ++e ) {          // squares of the chunk below (lane - 1) and above (lane + 1)
+    sq[e] = __shfl_up( sq[8 + e], 1, 64 );
+    sq[16 + e] = __shfl_down( sq[8 + e], 1, 64 );
+  }
+  bool const has_lo = q > 0, has_hi = q + 1 < (int32_t)C8;
+  if( has_lo && lane == 0 ) { bf16x8_t const lo = in[i - 1]; for( int32_t e = 0; e != 8; ++e ) { float const f = (float)lo[e]; sq[e] = f*f; } }
+  if( has_hi && live && ( lane == 63 || i + 1 >= n ) ) { bf16x8_t const hi = in[i + 1]; for( int32_t e = 0; e != 8; ++e ) { float const f = (float)hi[e]; sq[16 + e] = f*f; } }
+  if( !has_lo ) { for( int32_t e = 0; e != 8; ++e ) { sq[e] = 0.0f; } }
+  if( !has_hi ) { for( int32_t e = 0; e != 8; ++e ) { sq[16 + e] = 0.0f; } }
+  if( !live ) { return; }
   float const per_elem = alpha / (float)local_size;
   bf16x8_t r;
   for( int32_t e = 0; e != 8; ++e ) {
     float sumsq = 0.0f;
     for( int32_t d = -8; d <= 8; ++d ) { if( d >= -half && d <= half ) { sumsq += sq[8 + e + d]; } }
-    r[e] = (__bf16)( v[8 + e] * powf( k + sumsq * per_elem, -beta ) );
+    r[e] = (__bf16)( v[e] * powf( k + sumsq * per_elem, -beta ) );
   }
   out[i] = r;
 }
