@@ -320,13 +320,18 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
     //   * K slices (tile-starved layers with a long K loop: 7x7-map layers, fully-connected layers; this path has no summation order to
     //     keep) cost a second launch (~3 us) and the fp32 partial tiles written and read once each at ~5 TB/s.
     struct cand_t { int bi, bj, wi, wj, minw; };
-    static cand_t const cands[] = {{128, 128, 2, 2, 2}, {64, 128, 1, 4, 2}, {64, 64, 2, 2, 2}, {32, 128, 1, 4, 2}, {32, 64, 1, 2, 2}};
+    //   * large tiles (8 / 16 waves) move fewer operand bytes per flop but then meet the matrix pipes: a K step is never faster than its flops at
+    //     ~45 % of the CU's bf16 MFMA rate (AlexNet / NiN conv2, 5x5 96->256 at 256 images: 128x128 305, 128x256 254, 256x256 243 us).
+    static cand_t const cands[] = {{128, 128, 2, 2, 2}, {64, 128, 1, 4, 2}, {64, 64, 2, 2, 2}, {32, 128, 1, 4, 2}, {32, 64, 1, 2, 2}, {128, 256, 2, 4, 1}, {256, 256, 4, 4, 1}};
     long const nk = (kc + c.BK / 8 - 1) / (c.BK / 8);
     bool const may_split = getenv("BODAHIP_NO_NHWC_SPLITK") == nullptr;
     double best = 1e30;
     for (cand_t const &cd : cands) {
       long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
-      double const tau = 0.7 * (double)(cd.bi + cd.bj) * c.BK / 16384.0;
+      if (cd.bi * cd.bj > 128 * 128 && ((long)(cd.bi + cd.bj) * c.BK * 2 * 2 > 140 * 1024 || !getenv("BODAHIP_NHWC_BIG_TILES"))) continue;   // 128x256 / 256x256 at one workgroup per CU:
+      // opt-in.  Measured (MI355X, same box, A/B): NiN whole net +2 %, ResNet-50 / GoogLeNet lists and AlexNet net within noise, single layers both ways --
+      // the wider tile halves the operand re-reads per MFMA but leaves one workgroup per CU with nothing to hide its barriers behind.
+      double const tau = std::max(0.7 * (double)(cd.bi + cd.bj) * c.BK / 16384.0, 2.0 * cd.bi * cd.bj * c.BK / (0.45 * 2.5e9 / num_cus * 1e3));
       for (int sk = 1; sk <= 16; sk *= 2) {
         if (sk > 1 && (!may_split || nk / sk < 4)) break;
         long const wgs = tiles * sk, steps = (nk + sk - 1) / sk;

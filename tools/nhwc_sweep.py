@@ -15,7 +15,8 @@ TILES = [("" if t == "auto" else t) for t in os.environ.get("TILES", "").split()
     "128x64x64x2x2x2x1x32x3", "64x64x64x2x2x2x1x32x3", "64x64x32x2x2x2x1x32x4", "32x128x64x1x4x2x1x32x3", "256x128x32x4x2x1x1x32x3", "128x256x32x2x4x1x1x32x3", "128x256x64x2x4x1x1x32x2"]
 rtc = make_rtc("(be=hip)", 0); rtc.init(); be = OpsBackend(rtc)
 seen = {}
-for op in bench.net_conv_ops(net, int(os.environ.get("BATCH", "64"))):
+_b = int(os.environ.get("BATCH", "64"))
+for op in (bench.alexnet_b256_ops(_b) if net == "alexnet" else bench.nin_ops(_b) if net == "nin" else bench.net_conv_ops(net, _b)):
     seen.setdefault(op.to_str(), op)
 ops = list(seen.values())
 sel = os.environ.get("SEL")
