@@ -98,7 +98,7 @@ static void check_cfg(tile_cfg_t const &c, bool gather) {
 // the workgroups deal out over the CUs (tiles / (num_cus * ceil(tiles / num_cus)); with fewer tiles than CUs this is the fraction
 // of CUs that get one).  Base rates are steady-state MI355X measurements relative to 128x128 (sgemm 4096^3..12288^3, AlexNet /
 // NiN / GoogLeNet layers, tools/tile_sweep.py):
-//   128x128 w2x2 1.00 | 256x256 w4x4 1.02 (k-major operands only: halves the HBM re-reads) | 96x256 w1x4 0.95 (gathers; OC = 96-multiples)
+//   128x128 w2x2 1.00 | 256x256 w2x4 with two K-tiles in flight 1.02 (k-major operands only: halves the HBM re-reads; eight 128x64 waves, 8192^3: 140.7 TF/s vs 135.6 as sixteen 64x64 waves with one; BK32 137.7) | 96x256 w1x4 0.95 (gathers; OC = 96-multiples)
 //   64x64 w2x2 with two K-tiles in flight 0.93 (two-wave 64x128 / 32x128 workgroups measured 1.3-1.8x slower than this and are gone)
 //   32x64 as eight 16x16x4-MFMA waves 0.60 (thin out_chan / tile-starved: 2-2.7x faster than 32x128 there) | 32x32 m16 w2x2 0.45
 // Splitting K would fill the chip for tile-starved shapes too, but it re-associates the fp32 sum: the reference's golden digests
@@ -111,7 +111,7 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather, bo
     {128, 128, 32, 2, 2, 2, 32, 1, 1.00, true, true}, {256, 256, 32, 4, 4, 1, 32, 1, 1.35, false, true}, {128, 256, 32, 2, 4, 1, 32, 1, 1.15, true, false},
     {96, 128, 32, 1, 2, 2, 32, 1, 0.85, true, true},  {64, 64, 32, 2, 2, 2, 32, 1, 0.70, true, true}};
   static cand_t const cands_f32[] = {
-    {128, 128, 16, 2, 2, 2, 32, 1, 1.00, true, true},  {256, 256, 16, 4, 4, 1, 32, 1, 1.02, false, true}, {96, 256, 16, 1, 4, 2, 32, 1, 0.95, true, false},
+    {128, 128, 16, 2, 2, 2, 32, 1, 1.00, true, true},  {256, 256, 16, 2, 4, 1, 32, 2, 1.02, false, true}, {96, 256, 16, 1, 4, 2, 32, 1, 0.95, true, false},
     {96, 128, 16, 1, 2, 2, 32, 1, 0.90, false, true},  {64, 64, 16, 2, 2, 2, 32, 2, 0.93, true, true},    {32, 64, 32, 2, 4, 1, 16, 2, 0.60, true, true},
     {32, 32, 64, 2, 2, 1, 16, 2, 0.45, false, true}}; // (BK 64 + two K-tiles in flight: AlexNet fc8 24 -> 32 TF/s in sequence)
   tile_cfg_t best_c; double best = -1;
@@ -562,10 +562,72 @@ static ktab_t get_rtab(native_kernels_t::impl_t *impl, native_host_t *host, conv
 
 static string tune_of(native_kernels_t::impl_t *impl, char const *key) { auto t = impl->tune.find(key); return (t == impl->tune.end()) ? string() : t->second; }
 
+// Two-level tiling for the large fp32 sgemms.  A grid of 256x256 tiles runs one workgroup per CU, so a tile count that is not a
+// multiple of the CU count ends in a mostly idle round (7168^3: 784 tiles = 3 rounds + 16 tiles, measured 102 TF/s against 136 at
+// 8192^3 = 4 rounds exactly); 128x128 tiles quantise finer but run ~8 % slower per flop.  The split gives the first `m_main` rows of c
+// (whole rounds of 256x256 tiles) to the large tile and the remaining rows to a second launch of small tiles that fills the chip for
+// a fraction of a tile-time.  Each output is still ONE ascending-k chain in one thread: results are bit-identical to the unsplit launch.
+// Time model (units: one 256x256 tile on one CU at rate 1): a launch of n tiles of relative area a, s workgroups per CU, relative
+// rate r costs floor(n / (cus*s)) * s*a/r for its full rounds plus k*a/(r*eff) for the last, k = ceil(rest / cus) workgroups on the
+// busiest CU, eff = 0.6 for one of two co-resident workgroups running alone (its MFMAs no longer hide the other's barriers).
+struct sgemm_split_t { uint32_t m_main = 0; string tail_tile; double t_single = 0, t_split = 0; };
+static double launch_model(long n, double a, int s, double r, int cus) {
+  long const per = (long)cus * s, full = n / per, rest = n - full * per;
+  double t = (double)full * s * a / r;
+  if (rest) { long const k = (rest + cus - 1) / cus; double const eff = (k >= s) ? 1.0 : 0.6 + 0.4 * (double)(k - 1) / (double)(s - 1); t += (double)k * a / (r * eff); }
+  return t;
+}
+static char const *const kBigTile = "256x256x16x2x4x1x1x32x2";
+static sgemm_split_t plan_sgemm_split(uint32_t M, uint32_t N, uint32_t K, int num_cus) {
+  sgemm_split_t sp;
+  if (getenv("BODAHIP_NO_SGEMM_SPLIT") || M % 4 || N % 4 || K < 512 || M < 1024 || N < 1024) return sp;
+  long const ti = (M + 255) / 256, tj = (N + 255) / 256;
+  if (ti * tj < num_cus) return sp;
+  double const r_big = 1.04, r_mid = 1.0, r_small = 0.93;
+  auto small_n = [&](uint32_t rows, int b) { return (long)((rows + b - 1) / b) * (long)((N + b - 1) / b); };
+  sp.t_single = std::min(launch_model(ti * tj, 1.0, 1, r_big, num_cus), launch_model(small_n(M, 128), 0.25, 2, r_mid, num_cus));
+  double best = sp.t_single * 0.975;   // (a split must buy at least 2.5 %)
+  for (long R = 1; R < ti; ++R) {
+    uint32_t const m_main = (uint32_t)(R * 256), rows = M - m_main;
+    double const tm = launch_model(R * tj, 1.0, 1, r_big, num_cus);
+    double const t128 = tm + launch_model(small_n(rows, 128), 0.25, 2, r_mid, num_cus) + 0.004;
+    double const t64 = tm + launch_model(small_n(rows, 64), 0.0625, 2, r_small, num_cus) + 0.004;
+    char const *const force = getenv("BODAHIP_SGEMM_SPLIT_TAIL");   // (experiments: "128" | "64")
+    if (force && atoi(force) == 128) { if (t128 < best) { best = t128; sp.m_main = m_main; sp.tail_tile = "128x128x16x2x2x2"; } continue; }
+    if (force && atoi(force) == 64) { if (t64 < best) { best = t64; sp.m_main = m_main; sp.tail_tile = "64x64x32x2x2x2x1x32x2"; } continue; }
+    if (t128 < best) { best = t128; sp.m_main = m_main; sp.tail_tile = "128x128x16x2x2x2"; }
+    if (t64 < best) { best = t64; sp.m_main = m_main; sp.tail_tile = "64x64x32x2x2x2x1x32x2"; }
+  }
+  sp.t_split = best;
+  return sp;
+}
+
 void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16) {
   if (!M || !N) return;
   if (!K) { hip_err_chk(hipMemsetAsync(c, 0, (size_t)M * N * 4, host->nh_stream()), "hipMemsetAsync"); return; }
   if (M > 0x7fffffffu || N > 0x7fffffffu || K > 0x7fffffffu) unsup_err("hip_sgemm: dims exceed int32");
+  if (!bf16 && tune_of(impl, "sgemm_tile").empty()) {
+    sgemm_split_t const sp = plan_sgemm_split(M, N, K, host->nh_num_cus());
+    if (sp.m_main) {
+      if ((uint64_t)K * M * 4 > 0x80000000ull || (uint64_t)K * N * 4 > 0x80000000ull || (uint64_t)M * N * 4 >= 0x7ffffff0ull) unsup_err("hip_sgemm: operands / c of 2 GiB or more are not supported (32-bit buffer offsets)");
+      uint32_t grid = 0;
+      for (int part = 0; part < 2; ++part) {
+        uint32_t const m0 = part ? sp.m_main : 0, rows = part ? M - sp.m_main : sp.m_main;
+        plan_t const p = plan_sgemm(rows, N, K, host->nh_num_cus(), part ? sp.tail_tile : string(kBigTile), false);
+        kernel_t &k = get_kernel(impl, host, p);
+        gemm_args_t ga; memset(&ga, 0, sizeof(ga));
+        ga.I = a + m0; ga.J = b; ga.D = c + (size_t)m0 * N; ga.bias = nullptr;
+        ga.Mi = (int)rows; ga.Nj = (int)N; ga.K = (int)K; ga.ldI = (int)M; ga.ldJ = (int)N; ga.ldD = (int)N;
+        ga.I_bytes = (unsigned)(((uint64_t)K * M - m0) * 4); ga.J_bytes = (unsigned)((uint64_t)K * N * 4); ga.D_bytes = (unsigned)((uint64_t)rows * N * 4);
+        ga.tiles_i = (int)((rows + p.cfg.BI - 1) / p.cfg.BI); ga.tiles_j = (int)((N + p.cfg.BJ - 1) / p.cfg.BJ); ga.splitk = 1;
+        launch(host, k, ga, p.cfg);
+        grid += (uint32_t)ga.tiles_i * ga.tiles_j;
+        if (!part) { last_launch.kernel = p.kname; last_launch.cfg = p.cfg; last_launch.block = p.cfg.threads(); }
+      }
+      last_launch.grid = grid; last_launch.flops = 2.0 * M * N * K; last_launch.algo_bytes = 4.0 * ((double)K * M + (double)K * N + (double)M * N);
+      return;
+    }
+  }
   plan_t const p = plan_sgemm(M, N, K, host->nh_num_cus(), tune_of(impl, "sgemm_tile"), bf16);
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
@@ -859,7 +921,17 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
   string const &t = op.get_type();
   plan_t p; string log, s2d;
   bool const bf16 = op.has_func_name() && (op.get_func_name() == "hip_sgemm_bf16" || op.get_func_name() == "hip_conv_bf16");
-  if (t == "sgemm") { dims_t const &a = op.get_dims("a"), &b = op.get_dims("b"); p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, tile, bf16); }
+  if (t == "sgemm") {
+    dims_t const &a = op.get_dims("a"), &b = op.get_dims("b");
+    sgemm_split_t sp; if (!bf16 && tile.empty()) sp = plan_sgemm_split(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus);
+    if (sp.m_main) {   // two-level tiling: the large tile over the first m_main rows (reported), small tiles over the rest
+      plan_t const tp = plan_sgemm(a.dsz("M") - sp.m_main, b.dsz("N"), a.dsz("K"), num_cus, sp.tail_tile, false);
+      p = plan_sgemm(sp.m_main, b.dsz("N"), a.dsz("K"), num_cus, kBigTile, false);
+      s2d = "rows<" + std::to_string(sp.m_main) + ":" + p.cfg.str() + "+rest:";
+      if (!arch.empty()) compile_plan(p, arch, &log);
+      p = tp;
+    } else p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, tile, bf16);
+  }
   else if (t == "Convolution") {
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
     conv_geom_t const g = geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims("out"), op.get_dims("stride"), op.get_dims("in_pad"), relu);

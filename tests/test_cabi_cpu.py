@@ -124,6 +124,16 @@ def test_planner_sgemm_tiles_follow_problem_size():
     assert "-DI_MODE=1" in R.explain_plan(sg(130, 64, 50)) and "-DJ_MODE=1" in R.explain_plan(sg(128, 66, 50))     # scalar staging for ragged M / N
     assert R.explain_plan(sg(8192, 8192, 8192), tile="128x128x16x2x2x2x4").count("-DSPLITK=1") == 1           # split-K only as an explicit tune
     assert R.explain_plan(sg(4096, 4096, 4096, "hip_sgemm_bf16")).startswith("bodahip_sgemm_bf16 256x256")
+    # two-level tiling: 7168^3 is 784 tiles of 256x256 = 3 rounds of 256 CUs + 16 -> 27 tile rows (756 tiles) on the large tile, the last 256 rows on small
+    # tiles; 8192^3 (1024 = 4 rounds exactly) is not split; an explicit tile or BODAHIP_NO_SGEMM_SPLIT switches it off
+    sp = R.explain_plan(sg(7168, 7168, 7168))
+    assert sp.startswith("rows<6912:256x256x16_w2x4_p2+rest:bodahip_sgemm_f32 64x64x32_w2x2_p2"), sp
+    assert R.explain_plan(sg(10240, 10240, 10240)).startswith("rows<9728:") and not R.explain_plan(sg(12288, 12288, 12288)).startswith("rows<")
+    assert R.explain_plan(sg(7168, 7168, 7168), tile="128x128x16x2x2x2").startswith("bodahip_sgemm_f32 128x128")
+    assert not R.explain_plan(sg(7168, 7170, 7168)).startswith("rows<")        # ragged N: scalar staging, no split
+    os.environ["BODAHIP_NO_SGEMM_SPLIT"] = "1"
+    try: assert R.explain_plan(sg(7168, 7168, 7168)).startswith("bodahip_sgemm_f32 ")
+    finally: del os.environ["BODAHIP_NO_SGEMM_SPLIT"]
     # the tile heuristic balances tiles over the CUs it is told about: a 512^3 problem on 256 CUs takes the thin 16x16-MFMA tiles, on 16 CUs 64x64
     assert R.explain_plan(sg(512, 512, 512), num_cus=256).split()[1] == "32x32x64_w2x2_m16_p2"
     assert R.explain_plan(sg(512, 512, 512), num_cus=16).split()[1] == "64x64x32_w2x2_p2"

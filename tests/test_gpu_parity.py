@@ -597,6 +597,20 @@ def test_sgemm_random_shapes_bit_exact(be, tile):
         assert np.array_equal(want, outs["c"]), ((M, N, K), prc.launch["cfg"])
 
 
+def test_sgemm_two_level_tiling_bit_exact(be):
+    """The split launch (256x256 tiles over whole rounds of tile rows + small tiles over the remaining rows) == the unsplit launch == oracle,
+    on a shape where the remainder is not a multiple of any tile (M = 4540: 17 full tile rows of 16 -> 16 rows main, 444 rows tail)."""
+    M, N, K = 4540, 4096, 520
+    op = _sgemm_op(M, N, K)
+    outs, prc = _run(be, op, 5, include_ins=True)
+    assert prc.launch["cfg"].startswith("256x256") and prc.launch["grid"] > 256, prc.launch     # main tiles + tail tiles
+    os.environ["BODAHIP_NO_SGEMM_SPLIT"] = "1"
+    try: outs1, prc1 = _run(be, op, 5)
+    finally: del os.environ["BODAHIP_NO_SGEMM_SPLIT"]
+    assert np.array_equal(outs["c"], outs1["c"])
+    assert np.array_equal(bo.sgemm(outs["a"], outs["b"]), outs["c"])
+
+
 def test_cucl_template_dyn_dims_per_call(be):
     """A template with an OUT_DYN argument: one generated function serves any dims; the cai__* arguments and the launch geometry
     come from Instance.call_args per call (the reference's rcg_func_call_t::run flow)."""
