@@ -33,7 +33,7 @@ struct native_kernels_t::impl_t {
   void *ws = nullptr; size_t ws_bytes = 0; // split-K partial-sum slabs (grow-only scratch, like the reference's cudnn scratch var)
   std::vector<void *> ws_retired;          // outgrown scratch buffers that captured graphs may still point into (freed with the backend)
   std::map<string, void *> ktabs;           // im2col gather tables, one per (C,H,W,KH,KW) (device memory)
-  hipModule_t wino_mod = nullptr; hipFunction_t wino_filt = nullptr, wino_in = nullptr, wino_out = nullptr; // kernels/winograd_f32.hip
+  hipModule_t wino_mod = nullptr; hipFunction_t wino_filt = nullptr, wino_in = nullptr, wino_out = nullptr, wino_fused = nullptr, wino_filt_t = nullptr; // kernels/winograd_f32.hip
 };
 
 native_kernels_t::native_kernels_t(native_host_t *host_) : impl(new impl_t), host(host_) {
@@ -702,13 +702,41 @@ void native_kernels_t::conv_winograd(float const *filts, float const *biases, fl
   if (!impl->wino_mod) {
     if (host->nh_capturing()) rt_err("graph capture: Winograd transform kernels are not compiled yet -- run the call list once before capturing it");
     string log;
-    std::vector<char> code = hiprtc_compile(k_src_winograd_f32, "bodahip_winograd", host->nh_arch(), {}, &log, true);
+    vect_string wdefs; if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) wdefs.push_back(tok); } // (experiments)
+    std::vector<char> code = hiprtc_compile(k_src_winograd_f32, "bodahip_winograd", host->nh_arch(), wdefs, &log, true);
     hip_err_chk(hipModuleLoadData(&impl->wino_mod, code.data()), "hipModuleLoadData(winograd)");
     hip_err_chk(hipModuleGetFunction(&impl->wino_filt, impl->wino_mod, "bodahip_wino_filt"), "hipModuleGetFunction(wino_filt)");
     hip_err_chk(hipModuleGetFunction(&impl->wino_in, impl->wino_mod, "bodahip_wino_in"), "hipModuleGetFunction(wino_in)");
     hip_err_chk(hipModuleGetFunction(&impl->wino_out, impl->wino_mod, "bodahip_wino_out"), "hipModuleGetFunction(wino_out)");
+    hip_err_chk(hipModuleGetFunction(&impl->wino_fused, impl->wino_mod, "bodahip_wino_fused"), "hipModuleGetFunction(wino_fused)");
+    hip_err_chk(hipModuleGetFunction(&impl->wino_filt_t, impl->wino_mod, "bodahip_wino_filt_t"), "hipModuleGetFunction(wino_filt_t)");
   }
   int const TH = (g.OH + 1) / 2, TW = (g.OW + 1) / 2, tpi = TH * TW;
+  // Fused kernel (bodahip_wino_fused): transforms inside the MFMA kernel, only U goes through memory; same results bit for bit as the
+  // three-kernel pipeline below.  Opt-in (BODAHIP_WINO_FUSED=1) because it measures BEHIND the pipeline on MI355X (AlexNet conv3 / 4 / 5 at
+  // 256 images: 549 / 774 / 616 us against 474 / 668 / 489; direct kernel 578 / 855 / 661): sixteen 32x32 accumulators leave one wave per
+  // SIMD, and with the staging work taken out (ablations, -DWABLATE) its bare MFMA loop already takes 535 us for conv4 -- 1176 workgroups
+  // over 256 CUs are 5 rounds for 4.6 rounds of work, at the ~1.9 GHz the matrix pipes sustain -- so the ceiling is 1.25x over the pipeline,
+  // while the batched transform-domain sgemm runs 256x256 tiles at 120-130 TF/s.  Kept, tested and measurable; not the default.
+  if (g.OC % 4 == 0 && getenv("BODAHIP_WINO_FUSED") && (uint64_t)g.B * g.C * g.H * g.W * 4 < 0x3ff00000ull && (uint64_t)16 * g.C * g.OC * 4 < 0x7ffffff0ull &&
+      (uint64_t)g.B * tpi < 0x7fffffc0ull) {
+    size_t const nU = (size_t)16 * g.C * g.OC;
+    ensure_ws(impl, host, nU * sizeof(float));
+    wino_args_t wa; memset(&wa, 0, sizeof(wa));
+    wa.in = in; wa.filts = filts; wa.bias = biases; wa.out = out; wa.U = (float *)impl->ws;
+    wa.C = g.C; wa.H = g.H; wa.W = g.W; wa.OC = g.OC; wa.OH = g.OH; wa.OW = g.OW; wa.TH = TH; wa.TW = TW; wa.PY = g.PY; wa.PX = g.PX; wa.relu = g.relu ? 1 : 0;
+    wa.out_ctot = out_ctot; wa.out_coff = out_coff; wa.B0 = 0; wa.Bc = g.B; wa.Tc = (int)((long)g.B * tpi);
+    void *wparams[] = {&wa};
+    hip_err_chk(hipModuleLaunchKernel(impl->wino_filt_t, (uint32_t)(((long)g.C * g.OC + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), wparams, nullptr), "hipModuleLaunchKernel(wino_filt_t)");
+    uint32_t const grid = (uint32_t)((g.OC + 63) / 64) * (uint32_t)((wa.Tc + 63) / 64);
+    hip_err_chk(hipModuleLaunchKernel(impl->wino_fused, grid, 1, 1, 256, 1, 1, 0, host->nh_stream(), wparams, nullptr), "hipModuleLaunchKernel(wino_fused)");
+    tile_cfg_t fc; fc.BI = 64; fc.BJ = 64; fc.BK = 8; fc.WI = 2; fc.WJ = 2; fc.MINW = 1; fc.MT = 32; fc.PF = 1; fc.SPLITK = 1;
+    long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * 9;
+    last_launch.kernel = "bodahip_conv_winograd_fused_f32"; last_launch.cfg = fc; last_launch.grid = grid; last_launch.block = 256;
+    last_launch.flops = 2.0 * Nj * g.OC * Kt; // effective flops, as the reference credits any fast algorithm (src/latex-util.H:116-133)
+    last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
+    return;
+  }
   // images per chunk: bounds the scratch (V + M <= 1 GiB; BODAHIP_WINO_CHUNK_MB overrides); a multiple of 4 keeps the sgemm's N on its
   // vector-load path.  Measured: (a) chunks small enough to keep V and M inside the 256 MB Infinity Cache (96 / 192 MB) LOSE 5 % to
   // one big batched sgemm (AlexNet conv4 B=256: 713 / 715 vs 674 us) -- the shorter sgemms cost more than the HBM round trip saves;

@@ -740,6 +740,7 @@ def test_k1_stream_auto_choice_matches_tiled_kernel(be):
 
 WINO_CASES = [  # (B, C, H, W, OC, pad): odd and even planes, no / unit / double padding, 1-wide planes, ragged channel counts
     (3, 6, 10, 10, 12, 1), (2, 5, 13, 13, 7, 1), (5, 16, 7, 9, 33, 0), (1, 3, 3, 3, 4, 0), (2, 8, 4, 5, 8, 2), (9, 24, 14, 14, 40, 1), (2, 1, 6, 1, 2, 1),
+    (3, 19, 9, 11, 68, 1), (4, 40, 13, 13, 128, 1),   # several 8-channel stages (ragged last one), several 64-out_chan blocks and 64-tile blocks of the fused kernel
 ]
 
 
@@ -774,8 +775,17 @@ def test_winograd_conv_within_reference_tolerance(be, case, relu):
         want = bo.conv_fwd(x, f, b, (1, 1), (P, P), relu)
         sd = SsdsDiff.of(want, got[:, 1:1 + OC])
         assert not sd.has_nan() and sd.mrd < 2e-3, sd.basic_str()
-        assert sd.mrd < 5e-4, sd.basic_str()      # these small layers measure 6e-5 .. 1.4e-4 on the reference's U(-5,5) data (K = 9*in_chan <= 216 terms)
+        assert sd.mrd < 5e-4, sd.basic_str()      # these small layers measure 6e-5 .. 1.4e-4 on the reference's U(-5,5) data (K = 9*in_chan <= 360 terms)
         assert (got[:, :1] == 7).all() and (got[:, 1 + OC:] == 7).all()
+        if OC % 4 == 0:   # the opt-in fused kernel == the three-kernel pipeline bit for bit: same transform expressions, same ascending-in_chan MFMA chain per position
+            os.environ["BODAHIP_WINO_FUSED"] = "1"
+            try:
+                rtc.copy_nda_to_var("wn_out", names["out"][2])
+                rtc.run(RtcFuncCall("wino_conv", am)); rtc.finish_and_sync()
+                assert rtc.last_launch()["kernel"] == "bodahip_conv_winograd_fused_f32"
+                assert np.array_equal(got, rtc.copy_var_to_nda("wn_out"))
+            finally:
+                del os.environ["BODAHIP_WINO_FUSED"]
     finally:
         rtc.set_tune("conv_algo", "")
         for vn, _, _ in names.values():
