@@ -713,11 +713,12 @@ void native_kernels_t::conv_winograd(float const *filts, float const *biases, fl
   }
   int const TH = (g.OH + 1) / 2, TW = (g.OW + 1) / 2, tpi = TH * TW;
   // Fused kernel (bodahip_wino_fused): transforms inside the MFMA kernel, only U goes through memory; same results bit for bit as the
-  // three-kernel pipeline below.  Opt-in (BODAHIP_WINO_FUSED=1) because it measures BEHIND the pipeline on MI355X (AlexNet conv3 / 4 / 5 at
-  // 256 images: 549 / 774 / 616 us against 474 / 668 / 489; direct kernel 578 / 855 / 661): sixteen 32x32 accumulators leave one wave per
-  // SIMD, and with the staging work taken out (ablations, -DWABLATE) its bare MFMA loop already takes 535 us for conv4 -- 1176 workgroups
-  // over 256 CUs are 5 rounds for 4.6 rounds of work, at the ~1.9 GHz the matrix pipes sustain -- so the ceiling is 1.25x over the pipeline,
-  // while the batched transform-domain sgemm runs 256x256 tiles at 120-130 TF/s.  Kept, tested and measurable; not the default.
+  // three-kernel pipeline below.  Opt-in (BODAHIP_WINO_FUSED=1): on MI355X it measures level with the pipeline, not ahead of it -- AlexNet
+  // conv3 / 4 / 5 at 256 images 456 / 645 / 514 us against 474 / 668 / 489 (direct kernel 578 / 855 / 661); lists with winograd_all:
+  // AlexNet 136.7 vs 137.0 TF/s, NiN 127.1 vs 130.5, GoogLeNet@64 66.3 vs 64.0, ResNet-50@64 90.7 vs 90.4.  With all staging work taken
+  // out (ablations, -DWABLATE) the bare MFMA loop of conv4 already takes 529 us: 1176 workgroups over 256 CUs are 5 rounds for 4.6 rounds
+  // of work, one barrier per 8 channels costs ~0.5 us of drained matrix pipe per stage, 14x14 tiles cover a 13x13 plane -- while the batched
+  // transform-domain sgemm of the pipeline runs 256x256 tiles at 120-130 TF/s.  Kept, tested and measurable; not the default.
   if (g.OC % 4 == 0 && getenv("BODAHIP_WINO_FUSED") && (uint64_t)g.B * g.C * g.H * g.W * 4 < 0x3ff00000ull && (uint64_t)16 * g.C * g.OC * 4 < 0x7ffffff0ull &&
       (uint64_t)g.B * tpi < 0x7fffffc0ull) {
     size_t const nU = (size_t)16 * g.C * g.OC;
@@ -729,10 +730,10 @@ void native_kernels_t::conv_winograd(float const *filts, float const *biases, fl
     void *wparams[] = {&wa};
     hip_err_chk(hipModuleLaunchKernel(impl->wino_filt_t, (uint32_t)(((long)g.C * g.OC + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), wparams, nullptr), "hipModuleLaunchKernel(wino_filt_t)");
     uint32_t const grid = (uint32_t)((g.OC + 63) / 64) * (uint32_t)((wa.Tc + 63) / 64);
-    hip_err_chk(hipModuleLaunchKernel(impl->wino_fused, grid, 1, 1, 256, 1, 1, 0, host->nh_stream(), wparams, nullptr), "hipModuleLaunchKernel(wino_fused)");
-    tile_cfg_t fc; fc.BI = 64; fc.BJ = 64; fc.BK = 8; fc.WI = 2; fc.WJ = 2; fc.MINW = 1; fc.MT = 32; fc.PF = 1; fc.SPLITK = 1;
+    hip_err_chk(hipModuleLaunchKernel(impl->wino_fused, grid, 1, 1, 512, 1, 1, 0, host->nh_stream(), wparams, nullptr), "hipModuleLaunchKernel(wino_fused)");
+    tile_cfg_t fc; fc.BI = 64; fc.BJ = 64; fc.BK = 8; fc.WI = 2; fc.WJ = 4; fc.MINW = 1; fc.MT = 32; fc.PF = 1; fc.SPLITK = 1;
     long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * 9;
-    last_launch.kernel = "bodahip_conv_winograd_fused_f32"; last_launch.cfg = fc; last_launch.grid = grid; last_launch.block = 256;
+    last_launch.kernel = "bodahip_conv_winograd_fused_f32"; last_launch.cfg = fc; last_launch.grid = grid; last_launch.block = 512;
     last_launch.flops = 2.0 * Nj * g.OC * Kt; // effective flops, as the reference credits any fast algorithm (src/latex-util.H:116-133)
     last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
     return;
