@@ -37,6 +37,9 @@ for w in nin-net alexnet-net googlenet-net; do
   python bench.py --workload $w --dtype bf16 --no-cpu-baseline --graph --parallel-branches > $O/bench_${w}_bf16_graph.json 2>/dev/null
   python bench.py --workload $w --dtype bf16 --layout nhwc --no-cpu-baseline --graph --parallel-branches > $O/bench_${w}_bf16_nhwc_graph.json 2>/dev/null
 done
+python bench.py --workload alexnet --conv-algo winograd --no-cpu-baseline > $O/bench_alexnet_winograd.json 2>/dev/null
+BODAHIP_WINO_FUSED=1 python bench.py --workload alexnet --conv-algo winograd --no-cpu-baseline > $O/bench_alexnet_winograd_fused.json 2>/dev/null
+BODAHIP_NO_SGEMM_SPLIT=1 python bench.py --no-cpu-baseline > $O/bench_sgemm-ops-full_nosplit.json 2>/dev/null
 python bench.py --workload nin-net --batch 128 --no-cpu-baseline > $O/bench_nin-net_b128.json 2>/dev/null
 python bench.py --workload nin --batch 128 --no-cpu-baseline > $O/bench_nin_b128.json 2>/dev/null
 find $O -name "*.db" -size +30M -delete   # keep the merge-back under the 64 MiB cap
