@@ -331,7 +331,10 @@ def custom_codegen(cg: CallGen, template_name: str) -> None:
     """cnn_custom_codegen_t::gen_op (src/cnn_codegen.cc:11-27): templates without a hook pass through untouched."""
     if template_name in _EMITTERS:
         _EMITTERS[template_name](cg)
-    elif template_name in ("conv_simd", "k1conv_simd", "ipconv", "sgemm_no_local", "sgemm_simd", "sgemm_simd_local", "bconv", "bconv_fb", "reduce"):
+    elif template_name == "reduce":      # gen_op_reduce (src/cnn_codegen.cc:28-34): one accumulation line per member of the `ins` pack
+        for vn in cg.multi_args.get("ins", []):
+            cg.line("ins_ops", f"v += {vn}[GLOB_ID_1D];")
+    elif template_name in ("conv_simd", "k1conv_simd", "ipconv", "sgemm_no_local", "sgemm_simd", "sgemm_simd_local", "bconv", "bconv_fb"):
         raise UnsupErr(f"CUCL compatibility mode: the custom code generation of '{template_name}' is not restated")
 
 

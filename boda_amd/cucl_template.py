@@ -17,8 +17,9 @@ LOC_ID_1D -> tpb.  `_DYN` arguments keep their dims out of the generated source:
 trailing `int32_t cai__<arg>_<dim>_{dim,stride}` / `cai__<arg>_dims_prod` by-value arguments (declared through the template's
 `%(cucl_arg_info_decls)`), an index over such an argument likewise, and values and launch geometry are supplied per call
 (`Instance.call_args`; `add_dyn_nda_dims_sz`, `src/rtc_func_gen.cc:429-469`, `rcg_func_call_t::run`, `:496-584`).  `_multi`
-arguments and the convolution variants' custom code generation (`src/cnn_codegen.cc`) raise UnsupErr -- `be=hip` serves those ops
-through its native kernels instead.
+arguments (`float_multi const * const ins`: a pack of op[`ins_num`] arguments `ins_0` .. declared through `%(ins_decl)`, `src/rtc_func_gen.cc:24-41,
+143-151,388-391`) expand per op; custom code generation is a hook (`custom`), restated for the reference's sgemm / conv variants and `reduce` in
+`boda_amd/cnn_codegen.py`.
 """
 from __future__ import annotations
 import os
@@ -39,6 +40,7 @@ class ArgDecl:
     io_type: str       # IN | OUT | INOUT | REF
     ok_dims: List[Tuple[str, ...]]   # acceptable dim-name lists
     dyn: bool = False  # _DYN: dims arrive per call through cai__* arguments
+    multi: bool = False  # type <tn>_multi: stands for op[<vn>_num] arguments <vn>_0 .. <vn>_{n-1} (arg_decl_t::set_vn_tn, src/rtc_func_gen.cc:24-41)
 
 
 @dataclass
@@ -142,8 +144,9 @@ def parse_template(name: str, text: str, include_dir: Optional[str] = None) -> T
                 vn, tn, loi = _parse_arg_decl(line)
                 if dyn and loi == 0:
                     raise RtErr("invalid CUCL io var decl; by-value arguments must not be DYN")
-                if tn.endswith("_multi"):
-                    raise UnsupErr(f"CUCL template {name}: _multi argument '{vn}' is not supported by this restatement")
+                multi = tn.endswith("_multi")
+                if multi:
+                    tn = tn[:-len("_multi")]
                 if not tn:
                     raise RtErr("invalid CUCL io var decl; no var type found.")
                 if loi > 1:
@@ -158,7 +161,7 @@ def parse_template(name: str, text: str, include_dir: Optional[str] = None) -> T
                 for sp in specs:
                     if any(not d for d in sp):
                         raise RtErr("invalid (currently forbidden/unused) empty dim name in nda_spec")
-                arg_decls.append(ArgDecl(vn, tn, loi, cd, specs, dyn))
+                arg_decls.append(ArgDecl(vn, tn, loi, cd, specs, dyn, multi))
             elif cd == "INCLUDE":
                 if len(parts) != 3:
                     raise RtErr("invalid CUCL INCLUDE decl; must be exactly CUCL INCLUDE filename.h.")
@@ -199,6 +202,7 @@ class CallGen:
     def __init__(self, op: Op, tsvs: Dict[str, str], all_ix_dims: Dict[str, Tuple[Tuple[str, ...], Tuple[int, ...]]], tpb: int, blks: int):
         self.op, self.tsvs, self.all_ix_dims, self.tpb, self.blks = op, tsvs, all_ix_dims, tpb, blks
         self.cgs: Dict[str, List[str]] = {}
+        self.multi_args: Dict[str, List[str]] = {}   # _multi declaration -> the argument names it expands to for this op
 
     def get_arg_dims_by_name(self, vn: str) -> Dims:
         if vn not in self.op.nda_vals:
@@ -321,13 +325,26 @@ def instantiate(t: Template, op: Op, gen_fn: str, custom=None) -> Instance:
                 raise RtErr("CUCL error: LOC_ID_1D IX encoutered after setting tpb (some other way)")
             tpb = prod
 
-    cg = None
+    # a _multi declaration stands for op[<vn>_num] arguments <vn>_0 .. <vn>_{n-1} (vect_arg_decl_t::multi_iter, src/rtc_func_gen.H:69-86)
+    expanded: List[Tuple[ArgDecl, str]] = []
+    for ad in t.arg_decls:
+        if not ad.multi:
+            expanded.append((ad, ad.vn)); continue
+        num_vn = ad.vn + "_num"
+        if num_vn not in op.nda_vals or op.nda_vals[num_vn].v is None:
+            errs.append(f"multi arg '{ad.vn}' in template is missing required num field '{num_vn}' in op; "); continue
+        for mix in range(int(op.nda_vals[num_vn].v[0])):
+            expanded.append((ad, f"{ad.vn}_{mix}"))
+    cg = CallGen(op, tsvs, all_ix_dims, tpb, blks)
+    cg.multi_args = {ad.vn: [vn for a2, vn in expanded if a2 is ad] for ad in t.arg_decls if ad.multi}
     if custom is not None:
-        cg = CallGen(op, tsvs, all_ix_dims, tpb, blks)
         custom(cg, t.name)
     arg_names: List[str] = []
-    for ad in t.arg_decls:
-        arg_names.append(ad.vn)
+    for ad, vn_x in expanded:
+        arg_names.append(vn_x)
+        if ad.multi:      # the declaration line of this member of the pack (src/rtc_func_gen.cc:391)
+            cg.line(ad.vn + "_decl", f"GASQ {ad.tn} const * const {vn_x},")
+        ad = ad if not ad.multi else ArgDecl(vn_x, ad.tn, ad.loi, ad.io_type, ad.ok_dims, ad.dyn, True)
         if ad.vn not in op.nda_vals:
             errs.append(f"referenced {ad.io_type} arg '{ad.vn}' not present in dims_vals; "); continue
         nda = op.nda_vals[ad.vn]; d = nda.dims if nda.dims is not None else Dims((), (), nda.tn)
@@ -363,7 +380,7 @@ def instantiate(t: Template, op: Op, gen_fn: str, custom=None) -> Instance:
     elif "cucl_arg_info_decls" not in tsvs:
         tsvs["cucl_arg_info_decls"] = ""
 
-    if cg is not None:      # terminate and emit the bulk sections (src/rtc_func_gen.cc:478-481)
+    if True:                # terminate and emit the bulk sections (src/rtc_func_gen.cc:478-481)
         for sec, lines in cg.cgs.items():
             if sec in tsvs:
                 raise RtErr(f"template variable '{sec}' defined twice")

@@ -65,7 +65,10 @@ def build(rtc_dir: str = REF_RTC_DIR, verbose: bool = False) -> int:
         n += 1
         t = load_template(rtc_dir, template)
         kinds = {ad.vn: ("SCALAR" if ad.loi == 0 else ad.io_type) for ad in t.arg_decls}
-        return {"func": fn_name, "template": template, "arg_names": inst.arg_names, "arg_kinds": [kinds[a] for a in inst.arg_names], "tpb": inst.tpb,
+        multi = [ad.vn for ad in t.arg_decls if ad.multi]
+        def kind(a):      # (the members <vn>_<i> of a _multi pack carry their declaration's kind)
+            return kinds[a] if a in kinds else next(kinds[m] for m in multi if a.startswith(m + "_") and a[len(m) + 1:].isdigit())
+        return {"func": fn_name, "template": template, "arg_names": inst.arg_names, "arg_kinds": [kind(a) for a in inst.arg_names], "tpb": inst.tpb,
                 "blks": inst.blks, "file": os.path.basename(path)}
 
     for tag, op, tune in workloads():
@@ -77,6 +80,14 @@ def build(rtc_dir: str = REF_RTC_DIR, verbose: bool = False) -> int:
         manifest.append(entry)
         if verbose:
             print(tag, entry["variant"], entry["main"]["tpb"], entry["main"]["blks"])
+    # the one template of the reference with a `_multi` argument pack (test/rtc/reduce.cucl: out = sum of ins_num tensors; custom code generation
+    # src/cnn_codegen.cc:28-34): exercises the pack expansion of the template layer on the GPU
+    from boda_amd.op import Dims, Nda, Op
+    d = Dims.make("float", img=3, chan=5, y=7, x=9)
+    rvals = {"out": Nda(d), "ins_num": Nda(Dims((), (), "uint32_t"), "uint32_t", (3,))}
+    rvals.update({f"ins_{i}": Nda(d) for i in range(3)})
+    rop = Op({"type": "Reduce", "func_name": "reduce"}, rvals)
+    manifest.append({"tag": "reduce3", "op": rop.to_str(), "tune": "()", "variant": "reduce", "xposes": [], "main": emit("reduce3__reduce", "reduce", rop)})
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     return n

@@ -68,4 +68,17 @@ def test_build_recipe_writes_code_objects_and_manifest():
         assert ref_cucl.build() > 0
     man = json.load(open(os.path.join(ref_cucl.OUT, "manifest.json")))
     assert len(man) >= 30 and all(os.path.getsize(os.path.join(ref_cucl.OUT, e["main"]["file"])) > 1000 for e in man)
-    assert {e["variant"] for e in man} == {"sgemm", "conv", "k1conv", "tconv"}
+    assert {e["variant"] for e in man} >= {"sgemm", "conv", "k1conv", "tconv"}
+
+
+@have_ref
+def test_reference_reduce_template_multi_pack():
+    """test/rtc/reduce.cucl: `float_multi ins` + gen_op_reduce (src/cnn_codegen.cc:28-34) -> one pointer argument and one accumulation line per member."""
+    from boda_amd.op import Dims, Nda, Op
+    d = Dims.make("float", img=2, chan=3, y=4, x=5)
+    vals = {"out": Nda(d), "ins_num": Nda(Dims((), (), "uint32_t"), "uint32_t", (4,))}
+    vals.update({f"ins_{i}": Nda(d) for i in range(4)})
+    inst = cc.instantiate_ref(REF_RTC, "reduce", Op({"type": "Reduce", "func_name": "reduce"}, vals), "t_reduce")
+    assert inst.arg_names == ["ins_num", "ins_0", "ins_1", "ins_2", "ins_3", "out"] and inst.tpb == 256 and inst.blks == 1
+    assert inst.src.count("[GLOB_ID_1D];") == 4 and "%(" not in inst.src
+    assert rtc.compile_offline(inst.src, use_cache=False) > 0

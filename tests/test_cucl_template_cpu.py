@@ -55,8 +55,53 @@ def test_own_template_vars_geometry_and_offline_compile():
         instantiate(t, Op({"type": "own", "func_name": "own"}, dict(op.nda_vals, out=Nda(Dims.make("float", img=2, y=5, x=4)))), "x")
     with pytest.raises(RtErr):
         parse_template("dyn", "void f( float const a ) // CUCL IN_DYN :\n{}")      # by-value arguments must not be DYN
-    with pytest.raises(UnsupErr):
-        parse_template("multi", "void f( GASQ float_multi const * const ins ) // CUCL IN img:chan:y:x\n{}")
+
+
+MULTI = """
+CUCL_GLOBAL_KERNEL void %(rtc_func_name)(
+#if 0
+  GASQ float_multi const * const ins, // CUCL IN img:chan:y:x
+#endif
+  %(ins_decl)
+  float const scale, // CUCL IN :
+  GASQ float * const out ) // CUCL OUT img:chan:y:x
+{
+  // CUCL IX GLOB_ID_1D out
+  if( GLOB_ID_1D >= %(out_dims_prod) ) { return; }
+  float v = 0;
+  %(ins_ops);
+  out[GLOB_ID_1D] = v * scale + %(ins_2_chan_dim);
+}
+"""
+
+
+def _multi_op(n):
+    d = Dims.make("float", img=2, chan=3, y=4, x=5)
+    vals = {"out": Nda(d), "scale": Nda(None, "float", None), "ins_num": Nda(Dims((), (), "uint32_t"), "uint32_t", (n,))}
+    vals.update({f"ins_{i}": Nda(d) for i in range(n)})
+    return Op({"type": "own_multi", "func_name": "own_multi"}, vals)
+
+
+def _multi_hook(cg, name):
+    for vn in cg.multi_args["ins"]:
+        cg.line("ins_ops", f"v += {vn}[GLOB_ID_1D];")
+
+
+def test_multi_argument_pack_expands_to_num_arguments():
+    """`<type>_multi <vn>`: op[<vn>_num] arguments <vn>_0 .. (arg_decl_t::set_vn_tn / multi_iter, src/rtc_func_gen.cc:24-41,143-151,388-391): one
+    declaration line each in %(<vn>_decl), their dims as template variables, the custom hook sees the expanded names."""
+    t = parse_template("own_multi", MULTI)
+    assert [(a.vn, a.tn, a.multi) for a in t.arg_decls if a.vn == "ins"] == [("ins", "float", True)]
+    inst = instantiate(t, _multi_op(3), "own_multi__n3", custom=_multi_hook)
+    assert inst.arg_names == ["ins_0", "ins_1", "ins_2", "scale", "out"]      # (the pack expands at its DECLARATION's position in the arg list)
+    for i in range(3):
+        assert f"GASQ float const * const ins_{i}," in inst.src and f"v += ins_{i}[GLOB_ID_1D];" in inst.src
+    assert "+ 3;" in inst.src and inst.blks == 1 and "%(" not in inst.src
+    assert rtc.compile_offline(inst.src) > 0
+    with pytest.raises(RtErr, match="ins_num"):
+        instantiate(t, Op({"type": "own_multi", "func_name": "own_multi"}, {k: v for k, v in _multi_op(3).nda_vals.items() if k != "ins_num"}), "x", custom=lambda cg, n: None)
+    with pytest.raises(RtErr, match="ins_2"):
+        instantiate(t, Op({"type": "own_multi", "func_name": "own_multi"}, {k: v for k, v in _multi_op(3).nda_vals.items() if k != "ins_2"}), "x", custom=_multi_hook)
 
 
 DYN = """

@@ -100,7 +100,10 @@ def _run_entry(rtc, e, iters=3):
 TIMES = {}
 
 
-@pytest.mark.parametrize("e", MAN, ids=[e["tag"] for e in MAN])
+CONV_SGEMM = [e for e in MAN if e["variant"] != "reduce"]
+
+
+@pytest.mark.parametrize("e", CONV_SGEMM, ids=[e["tag"] for e in CONV_SGEMM])
 def test_reference_kernel_matches_oracle(rtc, e):
     op, res, ms = _run_entry(rtc, e)
     if op.get_type() == "sgemm":
@@ -116,6 +119,33 @@ def test_reference_kernel_matches_oracle(rtc, e):
     assert not sd.has_nan() and sd.mrd < MRD, (e["tag"], e["variant"], sd.basic_str())
     TIMES[e["tag"]] = {"variant": e["variant"], "tpb": e["main"]["tpb"], "blks": e["main"]["blks"], "ms": round(ms, 5), "tflops": round(op.flops() / ms / 1e9, 2),
                        "bit_exact_vs_oracle": bool(np.array_equal(want, got))}
+
+
+def test_reference_reduce_template_with_multi_argument_pack(rtc):
+    """test/rtc/reduce.cucl -- the reference's one template with a `_multi` argument pack (ins_num arguments ins_0 ..): generated by the restated template
+    layer + gen_op_reduce, compiled for gfx950 on the build machine, run here under be=hip; the sum in the generated order is exact in fp32."""
+    es = [e for e in MAN if e["variant"] == "reduce"]
+    if not es:
+        pytest.skip("oracle/_ref/cucl holds no reduce kernel")
+    e = es[0]; f = e["main"]; op = parse_op(e["op"])
+    assert f["arg_names"] == ["ins_num", "ins_0", "ins_1", "ins_2", "out"] and f["arg_kinds"] == ["SCALAR", "IN", "IN", "IN", "OUT"]
+    rtc.compile_code_object(open(os.path.join(CUCL, f["file"]), "rb").read(), [RtcFuncInfo(f["func"], "", f["arg_names"], op)])
+    made = []
+    try:
+        rng = np.random.default_rng(5); d = op.get_dims("out"); ins = []
+        for i in range(3):
+            rtc.create_var_with_dims(f"ins_{i}", d); made.append(f"ins_{i}")
+            ins.append(rng.standard_normal(d.sizes).astype(np.float32)); rtc.copy_nda_to_var(f"ins_{i}", ins[-1])
+        rtc.create_var_with_dims("out", d); made.append("out")
+        am = {f"ins_{i}": RtcArg.var(f"ins_{i}") for i in range(3)}
+        am["out"] = RtcArg.var("out"); am["ins_num"] = RtcArg.scalar(3, "uint32_t")
+        rtc.run(RtcFuncCall(f["func"], am, tpb=f["tpb"], blks=f["blks"])); rtc.finish_and_sync()
+        want = ((np.float32(0) + ins[0]) + ins[1]) + ins[2]
+        assert np.array_equal(want, rtc.copy_var_to_nda("out"))
+    finally:
+        for vn in made:
+            rtc.release_var(vn)
+        rtc.release_func(f["func"]); rtc.release_per_call_id_data()
 
 
 def test_zz_write_reference_kernel_times():
