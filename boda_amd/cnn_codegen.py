@@ -13,8 +13,8 @@ checkout exists (the build container), oracle/ref_cucl.py instantiates them for 
 oracle/_ref/ (code objects + a manifest of launch geometries) -- the reference's real kernels, timed and checked on the GPU box beside the
 native ones (tests/test_gpu_ref_cucl.py, bench.py's `ref_cucl_gpu` object).
 
-Only the fp32, local-memory variants the BASELINE configs use are covered (op_tune defaults + k1conv=1 / tconv=1); the `_simd` variants,
-`ipconv` and the backward ops raise UnsupErr.
+Only the fp32, local-memory variants are covered (op_tune defaults + k1conv=1 / tconv=1 / ipconv=1, and `reduce`); the `_simd` variants and the
+backward ops raise UnsupErr.
 """
 from __future__ import annotations
 import os
@@ -103,8 +103,8 @@ def annotate_ref(op: Op, tune: OpTune) -> Op:
         raise UnsupErr(f"CUCL compatibility mode: op type {t!r}")
     g = a.conv_geom()
     fn = ref_conv_func_name(a, tune)
-    if fn not in ("conv", "k1conv", "tconv"):
-        raise UnsupErr(f"CUCL compatibility mode: variant '{fn}' is not generated (conv / k1conv / tconv are)")
+    if fn not in ("conv", "k1conv", "tconv", "ipconv"):
+        raise UnsupErr(f"CUCL compatibility mode: variant '{fn}' is not generated (conv / k1conv / tconv / ipconv are)")
     a.set_func_name(fn)
     a.set_u32("conv_has_relu", 1)
     ni, no, filts = a.get_dims("in"), a.get_dims("out"), a.get_dims("filts")
@@ -131,9 +131,17 @@ def annotate_ref(op: Op, tune: OpTune) -> Op:
         work = _none_dims(pels_blk=bm, out_chan_blk=bn, pels_tile=tm, out_chan_tile=tn, pels=m_per, out_chan=n_per)
         if fn == "k1conv":
             in_dims = Dims(("blk", "blk_iter", "blk_iter_chan", "blk_pel"), (bm, _cdiv(g["C"], tune.Kb), tune.Kb, tm * m_per), ni.tn)
+    if fn == "ipconv":      # inner-product case (one output per channel and image): the reduction is tiled too, over fioc_tile lanes (src/cnn_op.cc:204-209)
+        fioc_tile = 4
+        while fioc_tile < 32 and fioc_tile * 2 * tm * tn <= 512:
+            fioc_tile *= 2
+        if g["C"] % fioc_tile:
+            raise RtErr(f"ipconv: in_chan={g['C']} must be a multiple of fioc_tile={fioc_tile}")
+        work = Dims(work.names + ("fioc_tile",), work.sizes + (fioc_tile,), "none")
     a.set_dims("work", work)
     a.reset_dims("in", in_dims)
-    a.reset_dims("filts", Dims(("out_chan_blk", "in_chan", "y", "x", "out_chan_reg", "out_chan_tile"), (bn, g["C"], g["KH"], g["KW"], n_per, tn), filts.tn))
+    if fn != "ipconv":      # (ipconv reads filts -- and in -- in the reference layout: no layout pass, src/cnn_op.cc:305-311)
+        a.reset_dims("filts", Dims(("out_chan_blk", "in_chan", "y", "x", "out_chan_reg", "out_chan_tile"), (bn, g["C"], g["KH"], g["KW"], n_per, tn), filts.tn))
     return a
 
 
@@ -324,7 +332,45 @@ def gen_tconv(cg: CallGen) -> None:
             cg.line("stores", f"if( (out_chan + {tx}) < %(out_chan_dim) ) {{ out_off[ {tx}*%(out_chan_stride) + {ty}*%(out_x_stride) ] = {_bias_relu(cg, work, tx, ty)}; }}")
 
 
-_EMITTERS: Dict[str, Callable[[CallGen], None]] = {"sgemm": gen_sgemm, "conv": gen_conv, "k1conv": gen_k1conv, "tconv": gen_tconv}
+def gen_ipconv(cg: CallGen) -> None:
+    """src/cnn_codegen.cc:217-283: the inner-product variant (output 1x1, no padding: AlexNet fc6-fc8).  in and filts are read in the reference
+    layout, where an image / a filter is one contiguous vector of in_chan*y*x elements; fioc_tile consecutive lanes share one (pels, out_chan)
+    register tile and each takes every fioc_tile-th element of the reduction; the partial sums meet through __shfl_down over groups of
+    fioc_tile lanes (a power of two <= 32: such groups never straddle a 64-wide wavefront), lane 0 of a group stores."""
+    work = cg.get_arg_dims_by_name("work")
+    P, OC, F = work.dsz("pels"), work.dsz("out_chan"), work.dsz("fioc_tile")
+    for what, arr, row_sz, row_stride in (("filts", "filts", work.dsz("out_chan_tile") * OC * F, "%(filts_out_chan_stride)"),
+                                          ("in", "in", work.dsz("pels_tile") * P * F, "%(in_img_stride)")):
+        cg.set(f"{what}_smem_sz", str(row_sz))
+        # element ix of the local buffer = (row ix / fioc_tile, lane % fioc_tile): row = ix / fioc_tile of the block's filters / images
+        _guarded(cg, f"{what}_smem_loads", row_sz,
+                 lambda i, ix, arr=arr, what=what, row_stride=row_stride:
+                 f"{what}_smem[{ix}] = {arr}[{what}_off+(( LOC_ID_1D/%(work_fioc_tile_dim) + %(tpb)/%(work_fioc_tile_dim)* {i})*{row_stride})];",
+                 f"%({what}_smem_sz)")
+    for tx in range(OC):
+        cg.line("loads", f"filts_strip[{tx}] = filts_smem_off[{tx}*%(work_fioc_tile_dim)];")
+    for ty in range(P):
+        cg.line("loads", f"in_strip[{ty}] = in_smem_off[{ty}*%(work_fioc_tile_dim)];")
+    _fma_tile(cg, "fmas", work, lambda ty: ty)
+    # the store loop runs over the thread's pels at run time: row work_pel of the register tile is copied into filts_strip first
+    cg.line("outs_to_filts_strip", "if( (in_pel+work_pel) >= %(in_img_dim) ) { return; } // this pel and the following are off-the-end pels, so don't store them.")
+    cg.line("outs_to_filts_strip", "switch(work_pel) { ")
+    for ty in range(P):
+        cg.line("outs_to_filts_strip", f"case {ty}:")
+        for tx in range(OC):
+            cg.line("outs_to_filts_strip", f"filts_strip[{tx}] = out_tile[{ty * OC + tx}];")
+        cg.line("outs_to_filts_strip", "break;")
+    cg.line("outs_to_filts_strip", "} ")
+    for tx in range(OC):
+        wb = F // 2
+        while wb:
+            cg.line("stores", f"filts_strip[{tx}] += __shfl_down( filts_strip[{tx}], {wb}, {F} );"); wb //= 2
+        v = f"(filts_strip[{tx}] + biases[ocix+{tx}])"
+        v = f"max(0.0f,{v})" if cg.op.get_u32("conv_has_relu") else v
+        cg.line("stores", f"if( (%(LOC_ID_1D_fioc_tile) == 0 ) && ((ocix + {tx}) < %(out_chan_dim)) ) {{ out[out_off + {tx}*%(out_chan_stride)] = {v}; }}")
+
+
+_EMITTERS: Dict[str, Callable[[CallGen], None]] = {"sgemm": gen_sgemm, "conv": gen_conv, "k1conv": gen_k1conv, "tconv": gen_tconv, "ipconv": gen_ipconv}
 
 
 def custom_codegen(cg: CallGen, template_name: str) -> None:
@@ -334,7 +380,7 @@ def custom_codegen(cg: CallGen, template_name: str) -> None:
     elif template_name == "reduce":      # gen_op_reduce (src/cnn_codegen.cc:28-34): one accumulation line per member of the `ins` pack
         for vn in cg.multi_args.get("ins", []):
             cg.line("ins_ops", f"v += {vn}[GLOB_ID_1D];")
-    elif template_name in ("conv_simd", "k1conv_simd", "ipconv", "sgemm_no_local", "sgemm_simd", "sgemm_simd_local", "bconv", "bconv_fb"):
+    elif template_name in ("conv_simd", "k1conv_simd", "sgemm_no_local", "sgemm_simd", "sgemm_simd_local", "bconv", "bconv_fb"):
         raise UnsupErr(f"CUCL compatibility mode: the custom code generation of '{template_name}' is not restated")
 
 

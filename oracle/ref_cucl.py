@@ -41,6 +41,13 @@ def workloads():
         for i, op in enumerate(bench.nin_ops(b)):
             if i in (1, 4, 7, 10):      # the 1x1 layers the reference runs as k1conv (cccp1 / 3 / 5 / 7)
                 res.append((f"nin_b{b}_l{i}", op, kt))
+    # the inner-product variant for the layers with a 1x1 output.  Its local-memory loads are unguarded in the reference ("can load garbage",
+    # src/cnn_codegen.cc:226,240): only blockings that divide images and out_chans exactly are safe -- fc6 / fc7 at 64 and 256 images (fc8's 1000
+    # out_chans would read 24 filters past the end of the tensor)
+    it = OpTune(k1conv=1, tconv=1, ipconv=1)
+    for b in (64, 256):
+        for i in (5, 6):
+            res.append((f"alexnet_b{b}_l{i}_ip", bench.alexnet_b256_ops(b)[i], it))
     for i, op in enumerate(read_ops(os.path.join(ROOT, "tests", "golden", "ops", "conv-ops-debug.txt"))):
         res.append((f"debug{i}", op, kt)); res.append((f"debug{i}_plain", op, OpTune()))
     return res

@@ -43,13 +43,20 @@ def test_annotations_reproduce_the_reference_geometries():
         cc.annotate_ref(sg[64], OpTune())
     with pytest.raises(UnsupErr):
         cc.annotate_ref(nin[1], OpTune(k1conv=1, use_local_mem=2))     # the _simd variants are not restated
+    # ipconv (1x1 output, no padding: fc6 at 256 images): the (pels, out_chan) blocking of conv plus fioc_tile lanes over the reduction -- the largest
+    # power of two <= 32 that keeps the block at <= 512 threads (src/cnn_op.cc:204-209); in / filts stay in the reference layout, no layout pass
+    ip = cc.annotate_ref(bench.alexnet_b256_ops()[5], OpTune(k1conv=1, tconv=1, ipconv=1))
+    w = ip.get_dims("work")
+    assert ip.get_func_name() == "ipconv" and w.names[-1] == "fioc_tile" and w.dsz("fioc_tile") * w.dsz("pels_tile") * w.dsz("out_chan_tile") <= 512
+    assert w.dsz("fioc_tile") in (4, 8, 16, 32) and ip.get_dims("filts").names == ("out_chan", "in_chan", "y", "x") and cc.xpose_ops(ip) == []
 
 
 @have_ref
-@pytest.mark.parametrize("which", ["sgemm", "conv", "k1conv", "tconv"])
+@pytest.mark.parametrize("which", ["sgemm", "conv", "k1conv", "tconv", "ipconv"])
 def test_reference_templates_instantiate_and_compile(which):
     op, tune = {"sgemm": ([o for o in bench.sgemm_full_ops() if o.sgemm_geom()["M"] == 2048][0], OpTune()),
-                "conv": (bench.alexnet_b256_ops(4)[5], KT), "k1conv": (bench.nin_ops(4)[4], KT), "tconv": (bench.alexnet_b256_ops(4)[1], KT)}[which]
+                "conv": (bench.alexnet_b256_ops(4)[5], KT), "k1conv": (bench.nin_ops(4)[4], KT), "tconv": (bench.alexnet_b256_ops(4)[1], KT),
+                "ipconv": (bench.alexnet_b256_ops(4)[6], OpTune(k1conv=1, tconv=1, ipconv=1))}[which]
     anno = cc.annotate_ref(op, tune)
     assert anno.get_func_name() == which
     inst = cc.instantiate_ref(REF_RTC, which, anno, "t_" + which)

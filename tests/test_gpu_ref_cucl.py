@@ -113,6 +113,21 @@ def test_reference_kernel_matches_oracle(rtc, e):
         i = res["in_ref"] if "in_ref" in res else res["in"]; f = res["filts_ref"] if "filts_ref" in res else res["filts"]
         nb = min(2, g["B"])       # conv is per image: the first images of a large batch against the oracle on those images
         want = bo.conv_fwd(i[:nb], f, res["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True); got = res["out"][:nb]
+        if e["variant"] == "ipconv":
+            # ipconv sums fioc_tile interleaved partial chains and joins them by a shuffle tree: not the oracle's single ascending chain.  With
+            # K = 9216 / 4096 products of magnitude <= 25 any fp32 order is ~1e-3 (mrd) from the exact inner products -- the oracle's chain
+            # included -- so the variant is held to the EXACT (fp64) result at least as tightly as the oracle's own chain is, and to the oracle
+            # at 2e-3 (the tolerance the reference applies where the summation order differs, src/rtc_prof.cc:317-319)
+            x64 = i[:nb].reshape(nb, -1).astype(np.float64); f64 = f.reshape(f.shape[0], -1).astype(np.float64)
+            exact = np.maximum(x64 @ f64.T + res["biases"].astype(np.float64), 0).reshape(got.shape)
+            err_ip, err_chain = float(np.abs(got - exact).max()), float(np.abs(want - exact).max())
+            assert err_ip <= 1.5 * err_chain, (e["tag"], err_ip, err_chain)
+            sd = SsdsDiff.of(want, got)
+            assert not sd.has_nan() and sd.mrd < 2e-3, (e["tag"], sd.basic_str())
+            want = got        # (recorded below as "not bit-exact": see bit_exact_vs_oracle)
+            TIMES[e["tag"]] = {"variant": e["variant"], "tpb": e["main"]["tpb"], "blks": e["main"]["blks"], "ms": round(ms, 5), "tflops": round(op.flops() / ms / 1e9, 2),
+                               "bit_exact_vs_oracle": False, "max_abs_err_vs_exact": err_ip, "oracle_chain_max_abs_err_vs_exact": err_chain}
+            return
         last = res["out"][-1]
         assert np.isfinite(last).all() and last.max() > 0
     sd = SsdsDiff.of(want, got)
