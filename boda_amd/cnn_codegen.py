@@ -13,8 +13,8 @@ checkout exists (the build container), oracle/ref_cucl.py instantiates them for 
 oracle/_ref/ (code objects + a manifest of launch geometries) -- the reference's real kernels, timed and checked on the GPU box beside the
 native ones (tests/test_gpu_ref_cucl.py, bench.py's `ref_cucl_gpu` object).
 
-Only the fp32, local-memory variants are covered (op_tune defaults + k1conv=1 / tconv=1 / ipconv=1, and `reduce`); the `_simd` variants and the
-backward ops raise UnsupErr.
+Covered: all four sgemm variants (use_local_mem 0..3; vector width 2 / 4), conv / k1conv / tconv / ipconv, reduce; conv_simd / k1conv_simd, sgemm_prof
+and the backward ops raise UnsupErr.
 """
 from __future__ import annotations
 import os
@@ -89,15 +89,18 @@ def annotate_ref(op: Op, tune: OpTune) -> Op:
     t = a.get_type()
     if t == "sgemm":
         g = a.sgemm_geom()
-        if tune.use_local_mem != 1 or tune.prof_variant:
-            raise UnsupErr("CUCL compatibility mode: only the local-memory `sgemm` variant is generated (use_local_mem=1)")
+        if tune.prof_variant:
+            raise UnsupErr("CUCL compatibility mode: the sgemm_prof variant is not generated")
+        variants = {0: "sgemm_no_local", 1: "sgemm", 2: "sgemm_simd", 3: "sgemm_simd_local"}      # src/cnn_op.cc:368-374
+        if tune.use_local_mem not in variants:
+            raise RtErr(f"unknonw value for op_tune.use_local_mem of {tune.use_local_mem}")
         mb, nb = tune.MNb[0] * tune.MNt[0], tune.MNb[1] * tune.MNt[1]
         for what, v, blk in (("M", g["M"], mb), ("N", g["N"], nb), ("K", g["K"], tune.Kb)):
             if v % blk:   # (the reference's own restriction, src/cnn_op.cc:349-360: its default tune cannot run sgemm 64^3)
                 raise RtErr(f"FIXME: currently, {what}={v} must be a multiple of {what}_blk={blk}")
         a.set_dims("work", _none_dims(Mg=g["M"] // mb, Ng=g["N"] // nb, Mb=tune.MNb[0], Nb=tune.MNb[1], Kb=tune.Kb, Mt=tune.MNt[0], Nt=tune.MNt[1]))
         a.set_u32("use_local_mem", tune.use_local_mem); a.set_u32("prof_variant", tune.prof_variant); a.set_u32("vw", tune.vw)
-        a.set_func_name("sgemm")
+        a.set_func_name(variants[tune.use_local_mem])
         return a
     if t != "Convolution":
         raise UnsupErr(f"CUCL compatibility mode: op type {t!r}")
@@ -227,6 +230,104 @@ def gen_sgemm(cg: CallGen) -> None:
     cg.line("outs_to_b_r", "} ")
     for n in range(Nt):
         cg.line("stores", f"c[c_off+{n}] = b_r[{n}];")
+
+
+def _sgemm_rows_to_c(cg: CallGen, work: Dims, b_r: Callable[[int], str], store: Callable[[int], str], n_stores: int) -> None:
+    """The store pattern all sgemm variants share: a run-time loop over the thread's Mt rows copies row Mt of the register tile into b_r, then stores it."""
+    Mt, Nt = work.dsz("Mt"), work.dsz("Nt")
+    cg.line("outs_to_b_r", "switch(Mt) { ")
+    for m in range(Mt):
+        cg.line("outs_to_b_r", f"case {m}:")
+        for n in range(Nt):
+            cg.line("outs_to_b_r", f"{b_r(n)} = c_r[{m * Nt + n}];")
+        cg.line("outs_to_b_r", "break;")
+    cg.line("outs_to_b_r", "} ")
+    for n in range(n_stores):
+        cg.line("stores", store(n))
+
+
+def _vec_elem(vw: int, ix: int) -> str:
+    """Element ix of an array of vw-wide vectors (gva, src/cnn_codegen.cc:284-290): .xyzw up to 4 lanes, .s0 .. .sf beyond (OpenCL only)."""
+    if vw > 16:
+        raise RtErr("vector width > 16")
+    return f"[{ix // vw}].{'xyzw'[ix % vw] if vw <= 4 else 's' + '0123456789abcdef'[ix % vw]}"
+
+
+def _sgemm_vw(cg: CallGen, work: Dims) -> int:
+    vw = cg.op.get_u32("vw")
+    if vw not in (2, 4):
+        raise UnsupErr(f"CUCL compatibility mode: vector width vw={vw}: HIP has float2 / float4 (the reference's default 8 is an OpenCL type)")
+    if work.dsz("Mt") % vw or work.dsz("Nt") % vw:
+        raise RtErr("sgemm_simd: Mt and Nt must be multiples of vw")
+    return vw
+
+
+def gen_sgemm_no_local(cg: CallGen) -> None:
+    """src/cnn_codegen.cc:387-406 (use_local_mem=0): every thread reads its own Mt + Nt operands of each k row straight from global memory."""
+    work = cg.get_arg_dims_by_name("work")
+    Kb, Mt, Nt = work.dsz("Kb"), work.dsz("Mt"), work.dsz("Nt")
+    ks = {vn: cg.get_arg_dims_by_name(vn).dstride("K") for vn in ("a", "b")}
+    for k in range(Kb):
+        for m in range(Mt):
+            cg.line("inner_loop_body", f"a_r[{m}] = a[a_off+{m + k * ks['a']}];")
+        for n in range(Nt):
+            cg.line("inner_loop_body", f"b_r[{n}] = b[b_off+{n + k * ks['b']}];")
+        for m in range(Mt):
+            for n in range(Nt):
+                cg.line("inner_loop_body", f"c_r[{m * Nt + n}] += a_r[{m}]*b_r[{n}];")
+    _sgemm_rows_to_c(cg, work, lambda n: f"b_r[{n}]", lambda n: f"c[c_off+{n}] = b_r[{n}];", Nt)
+
+
+def _sgemm_simd_body(cg: CallGen, work: Dims, vw: int, a_src: Callable[[int, int], str], b_src: Callable[[int, int], str]) -> None:
+    Kb, Mt, Nt = work.dsz("Kb"), work.dsz("Mt"), work.dsz("Nt")
+    for k in range(Kb):
+        for m in range(Mt // vw):
+            cg.line("inner_loop_body", f"a_r[{m}] = {a_src(m, k)};")
+        for n in range(Nt // vw):
+            cg.line("inner_loop_body", f"b_r[{n}] = {b_src(n, k)};")
+        for m in range(Mt):
+            for n in range(Nt):
+                cg.line("inner_loop_body", f"c_r[{m * Nt + n}] += a_r{_vec_elem(vw, m)}*b_r{_vec_elem(vw, n)};")
+    _sgemm_rows_to_c(cg, work, lambda n: f"b_r{_vec_elem(vw, n)}", lambda n: f"((GASQ float{vw} *)c)[c_off+{n}] = b_r[{n}];", Nt // vw)
+
+
+def gen_sgemm_simd(cg: CallGen) -> None:
+    """src/cnn_codegen.cc:343-385 (use_local_mem=2): as sgemm_no_local with vw-wide vector loads / stores."""
+    work = cg.get_arg_dims_by_name("work"); vw = _sgemm_vw(cg, work)
+    ks = {}
+    for vn in ("a", "b"):
+        st = cg.get_arg_dims_by_name(vn).dstride("K")
+        if st % vw:
+            raise RtErr(f"sgemm_simd: the K stride of {vn} must be a multiple of vw")
+        ks[vn] = st // vw
+    _sgemm_simd_body(cg, work, vw, lambda m, k: f"((GASQ float{vw} const *)a)[a_off+{m + k * ks['a']}]", lambda n, k: f"((GASQ float{vw} const *)b)[b_off+{n + k * ks['b']}]")
+
+
+def gen_sgemm_simd_local(cg: CallGen) -> None:
+    """src/cnn_codegen.cc:293-341,408-459 (use_local_mem=3): Kb rows of a / b into local memory as vw-wide vectors, vector register loads from there."""
+    work = cg.get_arg_dims_by_name("work"); vw = _sgemm_vw(cg, work)
+    Kb = work.dsz("Kb")
+    blk = {"a": work.dsz("Mb") * work.dsz("Mt") // vw, "b": work.dsz("Nb") * work.dsz("Nt") // vw}
+    for vn in ("a", "b"):
+        d = cg.get_arg_dims_by_name(vn)
+        if d.tn != "float":
+            raise UnsupErr("CUCL compatibility mode: sgemm on float tensors only")
+        if d.dstride("K") % vw:
+            raise RtErr(f"sgemm_simd_local: the K stride of {vn} must be a multiple of vw")
+        row_len, sm_sz, stride = blk[vn], blk[vn] * Kb, d.dstride("K") // vw
+        if stride < row_len:
+            raise RtErr("sgemm: a block row is longer than the matrix row")
+        pad = stride - row_len
+        cg.set(f"{vn}_sm_sz", str(sm_sz))
+        for i in range(_cdiv(sm_sz, cg.tpb)):
+            so = cg.tpb * i
+            row, row_off = so // row_len, so % row_len
+            extra = f"+(LOC_ID_1D+{row_off})/{row_len}*{pad}" if (pad and row_off + cg.tpb > row_len) else ""
+            tail = ""
+            if so + cg.tpb > sm_sz:
+                cg.line("sm_loads", f"if( (LOC_ID_1D+{so}) < {sm_sz} ) {{"); tail = "}"
+            cg.line("sm_loads", f"{vn}_sm[LOC_ID_1D+{so}] = ((GASQ %(a_tn){vw} const *)({vn}))[{vn}_off+{so + row * pad}{extra}];{tail}")
+    _sgemm_simd_body(cg, work, vw, lambda m, k: f"a_sm_off[{m + k * blk['a']}]", lambda n, k: f"b_sm_off[{n + k * blk['b']}]")
 
 
 def gen_conv(cg: CallGen) -> None:
@@ -370,7 +471,8 @@ def gen_ipconv(cg: CallGen) -> None:
         cg.line("stores", f"if( (%(LOC_ID_1D_fioc_tile) == 0 ) && ((ocix + {tx}) < %(out_chan_dim)) ) {{ out[out_off + {tx}*%(out_chan_stride)] = {v}; }}")
 
 
-_EMITTERS: Dict[str, Callable[[CallGen], None]] = {"sgemm": gen_sgemm, "conv": gen_conv, "k1conv": gen_k1conv, "tconv": gen_tconv, "ipconv": gen_ipconv}
+_EMITTERS: Dict[str, Callable[[CallGen], None]] = {"sgemm": gen_sgemm, "sgemm_no_local": gen_sgemm_no_local, "sgemm_simd": gen_sgemm_simd,
+                                                   "sgemm_simd_local": gen_sgemm_simd_local, "conv": gen_conv, "k1conv": gen_k1conv, "tconv": gen_tconv, "ipconv": gen_ipconv}
 
 
 def custom_codegen(cg: CallGen, template_name: str) -> None:
@@ -380,7 +482,7 @@ def custom_codegen(cg: CallGen, template_name: str) -> None:
     elif template_name == "reduce":      # gen_op_reduce (src/cnn_codegen.cc:28-34): one accumulation line per member of the `ins` pack
         for vn in cg.multi_args.get("ins", []):
             cg.line("ins_ops", f"v += {vn}[GLOB_ID_1D];")
-    elif template_name in ("conv_simd", "k1conv_simd", "sgemm_no_local", "sgemm_simd", "sgemm_simd_local", "bconv", "bconv_fb"):
+    elif template_name in ("conv_simd", "k1conv_simd", "bconv", "bconv_fb"):
         raise UnsupErr(f"CUCL compatibility mode: the custom code generation of '{template_name}' is not restated")
 
 

@@ -176,15 +176,15 @@ def parse_template(name: str, text: str, include_dir: Optional[str] = None) -> T
     return Template(name, "\n".join(out_lines), arg_decls, ix_decls)
 
 
-_C_SUFFIX = {"float": "f", "double": "", "uint32_t": "U", "int32_t": "", "uint16_t": "U", "uint8_t": "U", "half": "f"}
-
-
 def _scalar_const(nda: Nda) -> str:
+    """get_scalar_c_const_str (src/boda_base.cc:422-441): integers print plain (a template may paste them into identifiers -- `float%(vw)`), floats
+    as %#.9g with an f suffix."""
     v = nda.v[0] if nda.v is not None else None
-    if nda.tn in ("float", "double", "half"):
-        s = repr(float(v))
-        return s + ("f" if nda.tn != "double" else "")
-    return str(int(v)) + _C_SUFFIX.get(nda.tn, "")
+    if nda.tn in ("float", "half"):
+        return "%#.9gf" % float(v)
+    if nda.tn == "double":
+        return repr(float(v))
+    return str(int(v))
 
 
 def _strides(sizes: Tuple[int, ...]) -> List[int]:

@@ -34,6 +34,11 @@ def workloads():
         n = op.sgemm_geom()["M"]
         if n in (256, 2048, 4096, 8192):
             res.append((f"sgemm{n}", op, OpTune()))
+    for op in bench.sgemm_full_ops():      # the other sgemm variants (op_tune use_local_mem = 0 / 2 / 3; vw = 4: HIP has float4, not OpenCL's float8)
+        n = op.sgemm_geom()["M"]
+        if n in (256, 2048):
+            for lm, name in ((0, "nolocal"), (2, "simd"), (3, "simdlocal")):
+                res.append((f"sgemm{n}_{name}", op, OpTune(use_local_mem=lm, vw=4)))
     kt = OpTune(k1conv=1, tconv=1)
     for b in (2, 256):
         for i, op in enumerate(bench.alexnet_b256_ops(b)):

@@ -42,7 +42,8 @@ def test_annotations_reproduce_the_reference_geometries():
     with pytest.raises(RtErr):          # the reference's default tune cannot run 64^3 (N = 64 is not a multiple of 128: src/cnn_op.cc:352-355)
         cc.annotate_ref(sg[64], OpTune())
     with pytest.raises(UnsupErr):
-        cc.annotate_ref(nin[1], OpTune(k1conv=1, use_local_mem=2))     # the _simd variants are not restated
+        cc.annotate_ref(nin[1], OpTune(k1conv=1, use_local_mem=2))     # the convolutions' _simd variants are not restated
+    assert [cc.annotate_ref(sg[2048], OpTune(use_local_mem=lm, vw=4)).get_func_name() for lm in (0, 1, 2, 3)] == ["sgemm_no_local", "sgemm", "sgemm_simd", "sgemm_simd_local"]
     # ipconv (1x1 output, no padding: fc6 at 256 images): the (pels, out_chan) blocking of conv plus fioc_tile lanes over the reduction -- the largest
     # power of two <= 32 that keeps the block at <= 512 threads (src/cnn_op.cc:204-209); in / filts stay in the reference layout, no layout pass
     ip = cc.annotate_ref(bench.alexnet_b256_ops()[5], OpTune(k1conv=1, tconv=1, ipconv=1))
@@ -52,9 +53,11 @@ def test_annotations_reproduce_the_reference_geometries():
 
 
 @have_ref
-@pytest.mark.parametrize("which", ["sgemm", "conv", "k1conv", "tconv", "ipconv"])
+@pytest.mark.parametrize("which", ["sgemm", "sgemm_no_local", "sgemm_simd", "sgemm_simd_local", "conv", "k1conv", "tconv", "ipconv"])
 def test_reference_templates_instantiate_and_compile(which):
-    op, tune = {"sgemm": ([o for o in bench.sgemm_full_ops() if o.sgemm_geom()["M"] == 2048][0], OpTune()),
+    sg2048 = [o for o in bench.sgemm_full_ops() if o.sgemm_geom()["M"] == 2048][0]
+    op, tune = {"sgemm": (sg2048, OpTune()), "sgemm_no_local": (sg2048, OpTune(use_local_mem=0)), "sgemm_simd": (sg2048, OpTune(use_local_mem=2, vw=4)),
+                "sgemm_simd_local": (sg2048, OpTune(use_local_mem=3, vw=4)),
                 "conv": (bench.alexnet_b256_ops(4)[5], KT), "k1conv": (bench.nin_ops(4)[4], KT), "tconv": (bench.alexnet_b256_ops(4)[1], KT),
                 "ipconv": (bench.alexnet_b256_ops(4)[6], OpTune(k1conv=1, tconv=1, ipconv=1))}[which]
     anno = cc.annotate_ref(op, tune)

@@ -44,7 +44,7 @@ def test_own_template_vars_geometry_and_offline_compile():
     assert "void own__t0(" in s and "GLOB_ID_1D >= 120" in s
     assert "((GLOB_ID_1D/4)%5)*2" in s and "(GLOB_ID_1D%4)*2" in s           # y, x index expressions (stride 4 / 1) times the REF's dims
     assert "(GLOB_ID_1D/60)*189" in s and "((GLOB_ID_1D/20)%3)*63" in s      # outermost dim not wrapped; in strides 189 / 63
-    assert s.rstrip().endswith("}") and "+ 7U;" in s and "%(" not in s
+    assert s.rstrip().endswith("}") and "+ 7;" in s and "%(" not in s
     assert rtc.compile_offline(s) > 0                                         # compiles for gfx950 behind the CUCL prelude
     # a by-value scalar without a value stays an argument reference
     op2 = Op({"type": "own", "func_name": "own"}, dict(op.nda_vals, shift=Nda(None, "uint32_t", None)))

@@ -108,6 +108,18 @@ def test_reference_kernel_matches_oracle(rtc, e):
     op, res, ms = _run_entry(rtc, e)
     if op.get_type() == "sgemm":
         want, got = bo.sgemm(res["a"], res["b"]), res["c"]
+        if e["variant"] != "sgemm" and not np.array_equal(want, got):
+            # the variants without a barrier in the K loop (no_local, simd) are compiled with fast-math, as the reference compiles them
+            # (--use_fast_math / -cl-fast-relaxed-math): the compiler may re-associate the k sum, so they are held to the exact fp64 product at
+            # least as tightly as the oracle's own ascending chain is, and to the oracle at 2e-3
+            exact = res["a"].astype(np.float64).T @ res["b"].astype(np.float64)
+            err_v, err_chain = float(np.abs(got - exact).max()), float(np.abs(want - exact).max())
+            assert err_v <= 1.5 * err_chain, (e["tag"], err_v, err_chain)
+            sd = SsdsDiff.of(want, got)
+            assert not sd.has_nan() and sd.mrd < 2e-3, (e["tag"], sd.basic_str())
+            TIMES[e["tag"]] = {"variant": e["variant"], "tpb": e["main"]["tpb"], "blks": e["main"]["blks"], "ms": round(ms, 5), "tflops": round(op.flops() / ms / 1e9, 2),
+                               "bit_exact_vs_oracle": False, "max_abs_err_vs_exact": err_v, "oracle_chain_max_abs_err_vs_exact": err_chain}
+            return
     else:
         g = op.conv_geom()
         i = res["in_ref"] if "in_ref" in res else res["in"]; f = res["filts_ref"] if "filts_ref" in res else res["filts"]
