@@ -597,10 +597,12 @@ def test_sgemm_random_shapes_bit_exact(be, tile):
         assert np.array_equal(want, outs["c"]), ((M, N, K), prc.launch["cfg"])
 
 
-def test_sgemm_two_level_tiling_bit_exact(be):
+@pytest.mark.parametrize("shape", [(4540, 4096, 520), (4100, 4096, 516), (4348, 4100, 600), (6144, 6144, 512)], ids=lambda s: "x".join(map(str, s)))
+def test_sgemm_two_level_tiling_bit_exact(be, shape):
     """The split launch (256x256 tiles over whole rounds of tile rows + small tiles over the remaining rows) == the unsplit launch == oracle,
-    on a shape where the remainder is not a multiple of any tile (M = 4540: 17 full tile rows of 16 -> 16 rows main, 444 rows tail)."""
-    M, N, K = 4540, 4096, 520
+    on shapes where the remainder is not a multiple of any tile (M = 4540: 17 full tile rows of 16 -> 16 rows main, 444 rows tail), is a single
+    4-row sliver (4100), meets a ragged last tile column (N = 4100), and on one of the benchmark's own sizes (6144^2, K cut to 512)."""
+    M, N, K = shape
     op = _sgemm_op(M, N, K)
     outs, prc = _run(be, op, 5, include_ins=True)
     assert prc.launch["cfg"].startswith("256x256") and prc.launch["grid"] > 256, prc.launch     # main tiles + tail tiles
