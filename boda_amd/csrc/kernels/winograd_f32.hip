@@ -134,8 +134,9 @@ extern "C" __global__ __launch_bounds__(256) void bodahip_wino_filt_t(wino_args_
 //
 // A workgroup of eight waves owns 64 out_chans x 64 tiles for ALL 16 transform positions xn.  Wave (wi, wj, xh) owns the 32 x 32 block
 // (wi, wj) for the eight positions xn = 8 xh .. 8 xh + 7 (transform rows xi = 2 xh, 2 xh + 1) as eight 32x32 accumulators: 128 registers,
-// TWO waves per SIMD -- a lone wave cannot keep the matrix pipe busy (measured: a bare loop of independent 32x32x2 MFMAs from one wave per
-// SIMD runs at 82 cycles per MFMA, not 64), and the second wave's MFMAs cover the first one's staging work.
+// TWO waves per SIMD: issue is in order, so whatever a wave issues between two of its MFMAs beyond the 64 cycles the first one runs is pipe time lost;
+// a second wave's MFMAs fill those gaps (a first version -- sixteen accumulators, one wave per SIMD -- measured the same bare-loop floor but hid
+// less of its staging work: 769 vs 645 us on AlexNet conv4).
 // Output transform: A^T M A = rows of (M A) combined over xi.  A wave forms s[xi][x] = (M A)[xi][x] for its two xi lane-locally; the xh = 1
 // wave hands its s[2], s[3] to its xh = 0 partner through LDS (the operand buffers are free by then), which finishes
 // (s0 + s1) + s2 and (s1 - s2) - s3 -- the association of the three-kernel pipeline -- adds the bias and stores.  No M tensor.
