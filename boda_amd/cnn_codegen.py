@@ -13,7 +13,7 @@ checkout exists (the build container), oracle/ref_cucl.py instantiates them for 
 oracle/_ref/ (code objects + a manifest of launch geometries) -- the reference's real kernels, timed and checked on the GPU box beside the
 native ones (tests/test_gpu_ref_cucl.py, bench.py's `ref_cucl_gpu` object).
 
-Covered: all four sgemm variants (use_local_mem 0..3; vector width 2 / 4), conv / k1conv / tconv / ipconv, reduce; conv_simd / k1conv_simd, sgemm_prof
+Covered: all four sgemm variants (use_local_mem 0..3; vector width 2 / 4), conv / k1conv / k1conv_simd / tconv / ipconv, reduce; conv_simd, sgemm_prof
 and the backward ops raise UnsupErr.
 """
 from __future__ import annotations
@@ -106,8 +106,8 @@ def annotate_ref(op: Op, tune: OpTune) -> Op:
         raise UnsupErr(f"CUCL compatibility mode: op type {t!r}")
     g = a.conv_geom()
     fn = ref_conv_func_name(a, tune)
-    if fn not in ("conv", "k1conv", "tconv", "ipconv"):
-        raise UnsupErr(f"CUCL compatibility mode: variant '{fn}' is not generated (conv / k1conv / tconv / ipconv are)")
+    if fn not in ("conv", "k1conv", "tconv", "ipconv", "k1conv_simd"):
+        raise UnsupErr(f"CUCL compatibility mode: variant '{fn}' is not generated (conv / k1conv / tconv / ipconv / k1conv_simd are)")
     a.set_func_name(fn)
     a.set_u32("conv_has_relu", 1)
     ni, no, filts = a.get_dims("in"), a.get_dims("out"), a.get_dims("filts")
@@ -134,6 +134,19 @@ def annotate_ref(op: Op, tune: OpTune) -> Op:
         work = _none_dims(pels_blk=bm, out_chan_blk=bn, pels_tile=tm, out_chan_tile=tn, pels=m_per, out_chan=n_per)
         if fn == "k1conv":
             in_dims = Dims(("blk", "blk_iter", "blk_iter_chan", "blk_pel"), (bm, _cdiv(g["C"], tune.Kb), tune.Kb, tm * m_per), ni.tn)
+    if fn == "k1conv_simd":      # vector loads / stores, no local memory (src/cnn_op.cc:226-245): in, filts AND out transposed to (chan, pel) forms padded to the blocking
+        vw = tune.vw
+        if vw not in (2, 4):
+            raise UnsupErr(f"CUCL compatibility mode: vector width vw={vw}: HIP has float2 / float4 (the reference's default 8 is an OpenCL type)")
+        if m_per % vw or n_per % vw:
+            raise UnsupErr("k1conv_simd only supports work.pels and work.out_chan being multiples of vw")
+        a.set_u32("vw", vw); a.set_u32("Kb", tune.Kb)
+        pels_pad, oc_pad = bm * tm * m_per, bn * tn * n_per
+        a.set_dims("work", work)
+        a.reset_dims("in", Dims(("chan", "pel"), (g["C"], pels_pad), ni.tn))
+        a.reset_dims("filts", Dims(("in_chan", "y", "x", "out_chan"), (g["C"], g["KH"], g["KW"], oc_pad), filts.tn))
+        a.reset_dims("out", Dims(("chan", "pel"), (oc_pad, pels_pad), no.tn))
+        return a
     if fn == "ipconv":      # inner-product case (one output per channel and image): the reduction is tiled too, over fioc_tile lanes (src/cnn_op.cc:204-209)
         fioc_tile = 4
         while fioc_tile < 32 and fioc_tile * 2 * tm * tn <= 512:
@@ -471,7 +484,40 @@ def gen_ipconv(cg: CallGen) -> None:
         cg.line("stores", f"if( (%(LOC_ID_1D_fioc_tile) == 0 ) && ((ocix + {tx}) < %(out_chan_dim)) ) {{ out[out_off + {tx}*%(out_chan_stride)] = {v}; }}")
 
 
-_EMITTERS: Dict[str, Callable[[CallGen], None]] = {"sgemm": gen_sgemm, "sgemm_no_local": gen_sgemm_no_local, "sgemm_simd": gen_sgemm_simd,
+def gen_k1conv_simd(cg: CallGen) -> None:
+    """src/cnn_codegen.cc:514-562 (k1conv with use_local_mem=2): no local memory; per in_chan a thread reads pels/vw + out_chan/vw vectors of the
+    (chan, pel) input and the (in_chan, ..., out_chan) filters, Kb in_chans per loop trip; biases arrive in filts_strip, ReLU in the store rows."""
+    work = cg.get_arg_dims_by_name("work")
+    vw = cg.op.get_u32("vw"); Kb = cg.op.get_u32("Kb")
+    P, OC = work.dsz("pels"), work.dsz("out_chan")
+    if P % vw or OC % vw:
+        raise RtErr("k1conv_simd: work.pels and work.out_chan must be multiples of vw")
+    ics, fics = cg.get_arg_dims_by_name("in").dstride("chan"), cg.get_arg_dims_by_name("filts").dstride("in_chan")
+    if ics % vw or fics % vw:
+        raise RtErr("k1conv_simd: the chan strides of in / filts must be multiples of vw")
+    ics //= vw; fics //= vw
+    for k in range(Kb):
+        for tx in range(P // vw):
+            cg.line("inner_loop_body", f"in_strip[{tx}] = ((GASQ float{vw} const *)in)[in_off+{tx + k * ics}];")
+        for ty in range(OC // vw):
+            cg.line("inner_loop_body", f"filts_strip[{ty}] = ((GASQ float{vw} const *)filts)[filts_off+{ty + k * fics}];")
+        for tx in range(P):
+            for ty in range(OC):
+                cg.line("inner_loop_body", f"out_tile[{tx * OC + ty}] += in_strip{_vec_elem(vw, tx)}*filts_strip{_vec_elem(vw, ty)};")
+    relu = cg.op.get_u32("conv_has_relu")
+    cg.line("outs_to_in_strip", "switch(ty) { ")
+    for ty in range(OC):
+        cg.line("outs_to_in_strip", f"case {ty}:")
+        for tx in range(P):
+            v = f"(out_tile[{tx * OC + ty}]+filts_strip{_vec_elem(vw, ty)})"
+            cg.line("outs_to_in_strip", f"in_strip{_vec_elem(vw, tx)} = {('max(0.0f,' + v + ')') if relu else v};")
+        cg.line("outs_to_in_strip", "break;")
+    cg.line("outs_to_in_strip", "} ")
+    for tx in range(P // vw):
+        cg.line("stores", f"((GASQ float{vw} *)out)[out_off+{tx}] = in_strip[{tx}];")
+
+
+_EMITTERS: Dict[str, Callable[[CallGen], None]] = {"k1conv_simd": gen_k1conv_simd, "sgemm": gen_sgemm, "sgemm_no_local": gen_sgemm_no_local, "sgemm_simd": gen_sgemm_simd,
                                                    "sgemm_simd_local": gen_sgemm_simd_local, "conv": gen_conv, "k1conv": gen_k1conv, "tconv": gen_tconv, "ipconv": gen_ipconv}
 
 
@@ -482,7 +528,7 @@ def custom_codegen(cg: CallGen, template_name: str) -> None:
     elif template_name == "reduce":      # gen_op_reduce (src/cnn_codegen.cc:28-34): one accumulation line per member of the `ins` pack
         for vn in cg.multi_args.get("ins", []):
             cg.line("ins_ops", f"v += {vn}[GLOB_ID_1D];")
-    elif template_name in ("conv_simd", "k1conv_simd", "bconv", "bconv_fb"):
+    elif template_name in ("conv_simd", "bconv", "bconv_fb"):
         raise UnsupErr(f"CUCL compatibility mode: the custom code generation of '{template_name}' is not restated")
 
 
@@ -498,7 +544,14 @@ def xpose_ops(anno: Op) -> List[Tuple[str, str, str, Op]]:
         res.append(("xpose_filts", "filts_ref", "filts", anno))
     if fn in ("k1conv", "tconv"):
         res.append((fn + "_xpose_in", "in_ref", "in", anno))
+    if fn == "k1conv_simd":
+        res.append(("k1conv_simd_xpose_filts", "filts_ref", "filts", anno)); res.append(("k1conv_simd_xpose_in", "in_ref", "in", anno))
     return res
+
+
+def post_xpose_ops(anno: Op) -> List[Tuple[str, str, str, Op]]:
+    """Layout passes AFTER the main function (src/rtc_prof.cc:117-120): variants that write a transposed `out` get <func>_xpose_out (out -> out_ref)."""
+    return [("k1conv_simd_xpose_out", "out", "out_ref", anno)] if anno.get_func_name() == "k1conv_simd" else []
 
 
 def instantiate_ref(rtc_dir: str, template_name: str, anno: Op, gen_fn: str) -> Instance:

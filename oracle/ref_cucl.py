@@ -49,6 +49,10 @@ def workloads():
     # the inner-product variant for the layers with a 1x1 output.  Its local-memory loads are unguarded in the reference ("can load garbage",
     # src/cnn_codegen.cc:226,240): only blockings that divide images and out_chans exactly are safe -- fc6 / fc7 at 64 and 256 images (fc8's 1000
     # out_chans would read 24 filters past the end of the tensor)
+    st = OpTune(k1conv=1, tconv=1, use_local_mem=2, vw=4)      # k1conv_simd: vector loads, no local memory, in / filts / out as padded (chan, pel) matrices
+    for b in (2, 256):
+        for i in (4, 7):
+            res.append((f"nin_b{b}_l{i}_simd", bench.nin_ops(b)[i], st))
     it = OpTune(k1conv=1, tconv=1, ipconv=1)
     for b in (64, 256):
         for i in (5, 6):
@@ -89,6 +93,9 @@ def build(rtc_dir: str = REF_RTC_DIR, verbose: bool = False) -> int:
         for tname, src_arg, dst_arg, xop in cc.xpose_ops(anno):
             e = emit(f"{tag}__{tname}", tname, xop); e.update(src=src_arg, dst=dst_arg); entry["xposes"].append(e)
         entry["main"] = emit(f"{tag}__{anno.get_func_name()}", anno.get_func_name(), anno)
+        entry["post"] = []
+        for tname, src_arg, dst_arg, xop in cc.post_xpose_ops(anno):      # (variants that write a transposed out: <func>_xpose_out afterwards)
+            e = emit(f"{tag}__{tname}", tname, xop); e.update(src=src_arg, dst=dst_arg); entry["post"].append(e)
         manifest.append(entry)
         if verbose:
             print(tag, entry["variant"], entry["main"]["tpb"], entry["main"]["blks"])

@@ -42,7 +42,14 @@ def test_annotations_reproduce_the_reference_geometries():
     with pytest.raises(RtErr):          # the reference's default tune cannot run 64^3 (N = 64 is not a multiple of 128: src/cnn_op.cc:352-355)
         cc.annotate_ref(sg[64], OpTune())
     with pytest.raises(UnsupErr):
-        cc.annotate_ref(nin[1], OpTune(k1conv=1, use_local_mem=2))     # the convolutions' _simd variants are not restated
+        cc.annotate_ref(nin[1], OpTune(k1conv=1, use_local_mem=2))     # vw defaults to 8: an OpenCL vector type, HIP has float2 / float4
+    with pytest.raises(UnsupErr):
+        cc.annotate_ref(bench.alexnet_b256_ops()[1], OpTune(use_local_mem=2, vw=4))     # conv_simd is not restated
+    ks = cc.annotate_ref(nin[4], OpTune(k1conv=1, tconv=1, use_local_mem=2, vw=4))      # k1conv_simd: in / filts / out as (chan, pel) matrices padded to the blocking
+    w = ks.get_dims("work")
+    assert ks.get_func_name() == "k1conv_simd" and ks.get_dims("in").names == ("chan", "pel") and ks.get_dims("out").names == ("chan", "pel")
+    assert ks.get_dims("out").sizes == (w.dsz("out_chan_blk") * w.dsz("out_chan_tile") * w.dsz("out_chan"), w.dsz("pels_blk") * w.dsz("pels_tile") * w.dsz("pels"))
+    assert [x[0] for x in cc.xpose_ops(ks)] == ["k1conv_simd_xpose_filts", "k1conv_simd_xpose_in"] and [x[0] for x in cc.post_xpose_ops(ks)] == ["k1conv_simd_xpose_out"]
     assert [cc.annotate_ref(sg[2048], OpTune(use_local_mem=lm, vw=4)).get_func_name() for lm in (0, 1, 2, 3)] == ["sgemm_no_local", "sgemm", "sgemm_simd", "sgemm_simd_local"]
     # ipconv (1x1 output, no padding: fc6 at 256 images): the (pels, out_chan) blocking of conv plus fioc_tile lanes over the reduction -- the largest
     # power of two <= 32 that keeps the block at <= 512 threads (src/cnn_op.cc:204-209); in / filts stay in the reference layout, no layout pass
@@ -53,19 +60,19 @@ def test_annotations_reproduce_the_reference_geometries():
 
 
 @have_ref
-@pytest.mark.parametrize("which", ["sgemm", "sgemm_no_local", "sgemm_simd", "sgemm_simd_local", "conv", "k1conv", "tconv", "ipconv"])
+@pytest.mark.parametrize("which", ["sgemm", "sgemm_no_local", "sgemm_simd", "sgemm_simd_local", "conv", "k1conv", "k1conv_simd", "tconv", "ipconv"])
 def test_reference_templates_instantiate_and_compile(which):
     sg2048 = [o for o in bench.sgemm_full_ops() if o.sgemm_geom()["M"] == 2048][0]
     op, tune = {"sgemm": (sg2048, OpTune()), "sgemm_no_local": (sg2048, OpTune(use_local_mem=0)), "sgemm_simd": (sg2048, OpTune(use_local_mem=2, vw=4)),
                 "sgemm_simd_local": (sg2048, OpTune(use_local_mem=3, vw=4)),
-                "conv": (bench.alexnet_b256_ops(4)[5], KT), "k1conv": (bench.nin_ops(4)[4], KT), "tconv": (bench.alexnet_b256_ops(4)[1], KT),
+                "conv": (bench.alexnet_b256_ops(4)[5], KT), "k1conv": (bench.nin_ops(4)[4], KT), "tconv": (bench.alexnet_b256_ops(4)[1], KT), "k1conv_simd": (bench.nin_ops(4)[4], OpTune(k1conv=1, tconv=1, use_local_mem=2, vw=4)),
                 "ipconv": (bench.alexnet_b256_ops(4)[6], OpTune(k1conv=1, tconv=1, ipconv=1))}[which]
     anno = cc.annotate_ref(op, tune)
     assert anno.get_func_name() == which
     inst = cc.instantiate_ref(REF_RTC, which, anno, "t_" + which)
     assert inst.tpb > 0 and inst.blks > 0 and "%(" not in inst.src
     assert rtc.compile_offline(inst.src, use_cache=False) > 0
-    for tname, src, dst, xop in cc.xpose_ops(anno):
+    for tname, src, dst, xop in cc.xpose_ops(anno) + cc.post_xpose_ops(anno):
         xi = cc.instantiate_ref(REF_RTC, tname, xop, "t_x_" + tname)
         assert rtc.compile_offline(xi.src, use_cache=False) > 0
 

@@ -58,7 +58,7 @@ def _run_entry(rtc, e, iters=3):
     op = parse_op(e["op"]); tune = OpTune.parse(e["tune"])
     anno = cc.annotate_ref(op, tune)
     assert anno.get_func_name() == e["variant"]
-    funcs = e["xposes"] + [e["main"]]
+    funcs = e["xposes"] + [e["main"]] + e.get("post", [])
     made, loaded = [], []
     try:
         for f in funcs:
@@ -86,7 +86,12 @@ def _run_entry(rtc, e, iters=3):
         ids = [rtc.run(main) for _ in range(iters)]
         rtc.finish_and_sync()
         ms = min(rtc.get_dur(i, i) for i in ids)
-        res = {an: rtc.copy_var_to_nda(an) for an in ((("in_ref" if "in_ref" in names else "in"), ("filts_ref" if "filts_ref" in names else "filts"), "biases", "out") if is_conv else ("a", "b", "c"))}
+        for f in e.get("post", []):      # a variant that writes a transposed out: its <func>_xpose_out pass puts the result into out_ref (reference layout)
+            rtc.run(call(f))
+        rtc.finish_and_sync()
+        res = {an: rtc.copy_var_to_nda(an) for an in ((("in_ref" if "in_ref" in names else "in"), ("filts_ref" if "filts_ref" in names else "filts"), "biases") if is_conv else ("a", "b", "c"))}
+        if is_conv:
+            res["out"] = rtc.copy_var_to_nda("out_ref" if e.get("post") else "out")
         return op, res, ms
     finally:
         rtc.finish_and_sync()
