@@ -13,8 +13,8 @@ checkout exists (the build container), oracle/ref_cucl.py instantiates them for 
 oracle/_ref/ (code objects + a manifest of launch geometries) -- the reference's real kernels, timed and checked on the GPU box beside the
 native ones (tests/test_gpu_ref_cucl.py, bench.py's `ref_cucl_gpu` object).
 
-Covered: all four sgemm variants (use_local_mem 0..3; vector width 2 / 4), conv / k1conv / k1conv_simd / tconv / ipconv, reduce; conv_simd, sgemm_prof
-and the backward ops raise UnsupErr.
+Covered: all four sgemm variants (use_local_mem 0..3; vector width 2 / 4), conv / conv_simd / k1conv / k1conv_simd / tconv / ipconv, reduce; sgemm_prof and the
+backward ops raise UnsupErr.
 """
 from __future__ import annotations
 import os
@@ -106,8 +106,8 @@ def annotate_ref(op: Op, tune: OpTune) -> Op:
         raise UnsupErr(f"CUCL compatibility mode: op type {t!r}")
     g = a.conv_geom()
     fn = ref_conv_func_name(a, tune)
-    if fn not in ("conv", "k1conv", "tconv", "ipconv", "k1conv_simd"):
-        raise UnsupErr(f"CUCL compatibility mode: variant '{fn}' is not generated (conv / k1conv / tconv / ipconv / k1conv_simd are)")
+    if fn not in ("conv", "k1conv", "tconv", "ipconv", "k1conv_simd", "conv_simd"):
+        raise UnsupErr(f"CUCL compatibility mode: variant '{fn}' is not generated")
     a.set_func_name(fn)
     a.set_u32("conv_has_relu", 1)
     ni, no, filts = a.get_dims("in"), a.get_dims("out"), a.get_dims("filts")
@@ -134,6 +134,32 @@ def annotate_ref(op: Op, tune: OpTune) -> Op:
         work = _none_dims(pels_blk=bm, out_chan_blk=bn, pels_tile=tm, out_chan_tile=tn, pels=m_per, out_chan=n_per)
         if fn == "k1conv":
             in_dims = Dims(("blk", "blk_iter", "blk_iter_chan", "blk_pel"), (bm, _cdiv(g["C"], tune.Kb), tune.Kb, tm * m_per), ni.tn)
+    if fn == "conv_simd":      # the general vector variant (src/cnn_op.cc:246-292): input planes padded to (in + pad) rounded up to the stride, the output
+        # computed on the (padded plane / stride) grid -- a superset of the real output positions -- so that in_pel = out_pel * stride is linear
+        vw = tune.vw
+        if vw not in (2, 4):
+            raise UnsupErr(f"CUCL compatibility mode: vector width vw={vw}: HIP has float2 / float4 (the reference's default 8 is an OpenCL type)")
+        if tune.Kb != 1:
+            raise RtErr("conv_simd: Kb must be 1 (no inner-loop unrolling in this variant, src/cnn_op.cc:246)")
+        if g["SY"] != g["SX"]:
+            raise RtErr("conv_simd: uniform x / y stride only")
+        a.set_u32("vw", vw); a.set_u32("Kb", tune.Kb)
+        st = g["SY"]
+        iy, ix = _cdiv(g["H"] + g["PY"], st) * st, _cdiv(g["W"] + g["PX"], st) * st
+        in_pels = _none_dims(img=g["B"], y=iy, x=ix); out_pels = _none_dims(img=g["B"], y=iy // st, x=ix // st)
+        a.set_dims("in_pels", in_pels); a.set_dims("out_pels", out_pels)
+        gb = GbtTile(tune.MNt, tune.MNb[0] * tune.MNb[1], (out_pels.dims_prod(), g["OC"]))
+        (m_per, n_per), (tm, tn), (bm, bn) = gb.mn_per_thr, gb.thr_per_blk, gb.num_blk
+        if m_per % vw or n_per % vw:
+            raise UnsupErr("conv_simd only supports work.pels and work.out_chan being multiples of vw")
+        pels_pad, oc_pad = bm * tm * m_per, bn * tn * n_per
+        fy, fx = max(g["KH"] - st, g["PY"]), max(g["KW"] - st, g["PX"])      # pels the last output position may hang off the last image
+        in_pels_pad = _cdiv(in_pels.dims_prod() + fy * in_pels.dstride("y") + fx * in_pels.dstride("x"), vw) * vw
+        a.set_dims("work", _none_dims(pels_blk=bm, out_chan_blk=bn, pels_tile=tm, out_chan_tile=tn, pels=m_per, out_chan=n_per))
+        a.reset_dims("in", Dims(("chan", "pel"), (g["C"], in_pels_pad), ni.tn))
+        a.reset_dims("filts", Dims(("in_chan", "y", "x", "out_chan"), (g["C"], g["KH"], g["KW"], oc_pad), filts.tn))
+        a.reset_dims("out", Dims(("chan", "pel"), (oc_pad, pels_pad), no.tn))
+        return a
     if fn == "k1conv_simd":      # vector loads / stores, no local memory (src/cnn_op.cc:226-245): in, filts AND out transposed to (chan, pel) forms padded to the blocking
         vw = tune.vw
         if vw not in (2, 4):
@@ -517,7 +543,42 @@ def gen_k1conv_simd(cg: CallGen) -> None:
         cg.line("stores", f"((GASQ float{vw} *)out)[out_off+{tx}] = in_strip[{tx}];")
 
 
-_EMITTERS: Dict[str, Callable[[CallGen], None]] = {"k1conv_simd": gen_k1conv_simd, "sgemm": gen_sgemm, "sgemm_no_local": gen_sgemm_no_local, "sgemm_simd": gen_sgemm_simd,
+def gen_conv_simd(cg: CallGen) -> None:
+    """src/cnn_codegen.cc:564-623 (the general conv with use_local_mem=2): one (in_chan, ky, kx) element per loop trip; the thread's pels are consecutive
+    positions of the padded output grid, their inputs stride_x apart (plus a row jump where the run wraps, for stride > 1); filters as vectors."""
+    work, in_pels, stride = cg.get_arg_dims_by_name("work"), cg.get_arg_dims_by_name("in_pels"), cg.get_arg_dims_by_name("stride")
+    vw = cg.op.get_u32("vw")
+    P, OC = work.dsz("pels"), work.dsz("out_chan")
+    if P % vw or OC % vw:
+        raise RtErr("conv_simd: work.pels and work.out_chan must be multiples of vw")
+    if cg.op.get_u32("Kb") != 1 or stride.dsz("y") != stride.dsz("x"):
+        raise RtErr("conv_simd: Kb == 1 and a uniform stride are required")
+    fics = cg.get_arg_dims_by_name("filts").dstride("in_chan")
+    if fics % vw:
+        raise RtErr("conv_simd: the in_chan stride of filts must be a multiple of vw")
+    row_extra = (stride.dsz("y") - 1) * in_pels.dstride("y")
+    for tx in range(P):
+        reo = f"+((out_x + {tx})/%(out_pels_x_dim)*{row_extra})" if row_extra else ""
+        cg.line("inner_loop_body", f"in_strip{_vec_elem(vw, tx)} = in[in_off+{tx * stride.dsz('x')} {reo}];")
+    for ty in range(OC // vw):
+        cg.line("inner_loop_body", f"filts_strip[{ty}] = ((GASQ float{vw} const *)filts)[filts_off+{ty}];")
+    for tx in range(P):
+        for ty in range(OC):
+            cg.line("inner_loop_body", f"out_tile[{tx * OC + ty}] += in_strip{_vec_elem(vw, tx)}*filts_strip{_vec_elem(vw, ty)};")
+    relu = cg.op.get_u32("conv_has_relu")
+    cg.line("outs_to_in_strip", "switch(ty) { ")
+    for ty in range(OC):
+        cg.line("outs_to_in_strip", f"case {ty}:")
+        for tx in range(P):
+            v = f"(out_tile[{tx * OC + ty}]+filts_strip{_vec_elem(vw, ty)})"
+            cg.line("outs_to_in_strip", f"in_strip{_vec_elem(vw, tx)} = {('max(0.0f,' + v + ')') if relu else v};")
+        cg.line("outs_to_in_strip", "break;")
+    cg.line("outs_to_in_strip", "} ")
+    for tx in range(P // vw):
+        cg.line("stores", f"((GASQ float{vw} *)out)[out_off+{tx}] = in_strip[{tx}];")
+
+
+_EMITTERS: Dict[str, Callable[[CallGen], None]] = {"k1conv_simd": gen_k1conv_simd, "conv_simd": gen_conv_simd, "sgemm": gen_sgemm, "sgemm_no_local": gen_sgemm_no_local, "sgemm_simd": gen_sgemm_simd,
                                                    "sgemm_simd_local": gen_sgemm_simd_local, "conv": gen_conv, "k1conv": gen_k1conv, "tconv": gen_tconv, "ipconv": gen_ipconv}
 
 
@@ -528,7 +589,7 @@ def custom_codegen(cg: CallGen, template_name: str) -> None:
     elif template_name == "reduce":      # gen_op_reduce (src/cnn_codegen.cc:28-34): one accumulation line per member of the `ins` pack
         for vn in cg.multi_args.get("ins", []):
             cg.line("ins_ops", f"v += {vn}[GLOB_ID_1D];")
-    elif template_name in ("conv_simd", "bconv", "bconv_fb"):
+    elif template_name in ("bconv", "bconv_fb"):
         raise UnsupErr(f"CUCL compatibility mode: the custom code generation of '{template_name}' is not restated")
 
 
@@ -544,14 +605,15 @@ def xpose_ops(anno: Op) -> List[Tuple[str, str, str, Op]]:
         res.append(("xpose_filts", "filts_ref", "filts", anno))
     if fn in ("k1conv", "tconv"):
         res.append((fn + "_xpose_in", "in_ref", "in", anno))
-    if fn == "k1conv_simd":
-        res.append(("k1conv_simd_xpose_filts", "filts_ref", "filts", anno)); res.append(("k1conv_simd_xpose_in", "in_ref", "in", anno))
+    if fn in ("k1conv_simd", "conv_simd"):
+        res.append((fn + "_xpose_filts", "filts_ref", "filts", anno)); res.append((fn + "_xpose_in", "in_ref", "in", anno))
     return res
 
 
 def post_xpose_ops(anno: Op) -> List[Tuple[str, str, str, Op]]:
     """Layout passes AFTER the main function (src/rtc_prof.cc:117-120): variants that write a transposed `out` get <func>_xpose_out (out -> out_ref)."""
-    return [("k1conv_simd_xpose_out", "out", "out_ref", anno)] if anno.get_func_name() == "k1conv_simd" else []
+    fn = anno.get_func_name()
+    return [(fn + "_xpose_out", "out", "out_ref", anno)] if fn in ("k1conv_simd", "conv_simd") else []
 
 
 def instantiate_ref(rtc_dir: str, template_name: str, anno: Op, gen_fn: str) -> Instance:

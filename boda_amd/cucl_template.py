@@ -360,7 +360,7 @@ def instantiate(t: Template, op: Op, gen_fn: str, custom=None) -> Instance:
             dyn_vars.append((ad.vn, ad.vn, ()))
             add_dyn(ad.vn, d.names, True)
             continue
-        dims_only = ad.io_type == "REF" and nda.tn == "none"
+        dims_only = False      # (insert_nda_dims_sz leaves strides out only for dims without them; the dims an annotation builds all carry strides -- conv_simd reads %(in_pels_x_stride) of a REF)
         st = _strides(tuple(d.sizes))
         for n, s, sd in zip(d.names, d.sizes, st):
             put(f"{ad.vn}_{n}_dim", str(s))

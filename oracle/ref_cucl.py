@@ -53,6 +53,10 @@ def workloads():
     for b in (2, 256):
         for i in (4, 7):
             res.append((f"nin_b{b}_l{i}_simd", bench.nin_ops(b)[i], st))
+    ct = OpTune(use_local_mem=2, vw=4, Kb=1)      # conv_simd: the general vector variant (stride 4 / 11x11, 5x5 pad 2, 3x3 pad 1)
+    for b in (2, 64):
+        for i in (0, 1, 2):
+            res.append((f"alexnet_b{b}_l{i}_simd", bench.alexnet_b256_ops(b)[i], ct))
     it = OpTune(k1conv=1, tconv=1, ipconv=1)
     for b in (64, 256):
         for i in (5, 6):

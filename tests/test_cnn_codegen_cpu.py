@@ -43,8 +43,11 @@ def test_annotations_reproduce_the_reference_geometries():
         cc.annotate_ref(sg[64], OpTune())
     with pytest.raises(UnsupErr):
         cc.annotate_ref(nin[1], OpTune(k1conv=1, use_local_mem=2))     # vw defaults to 8: an OpenCL vector type, HIP has float2 / float4
-    with pytest.raises(UnsupErr):
-        cc.annotate_ref(bench.alexnet_b256_ops()[1], OpTune(use_local_mem=2, vw=4))     # conv_simd is not restated
+    with pytest.raises(RtErr):
+        cc.annotate_ref(bench.alexnet_b256_ops()[1], OpTune(use_local_mem=2, vw=4))     # conv_simd: Kb must be 1 (the reference asserts it, src/cnn_op.cc:246)
+    cs = cc.annotate_ref(bench.alexnet_b256_ops(4)[0], OpTune(use_local_mem=2, vw=4, Kb=1))     # conv1 11x11 / 4: planes padded 227 -> 228, outputs on the 57x57 grid
+    assert cs.get_func_name() == "conv_simd" and cs.get_dims("in_pels").sizes == (4, 228, 228) and cs.get_dims("out_pels").sizes == (4, 57, 57)
+    assert cs.get_dims("in").names == ("chan", "pel") and cs.get_dims("in").dsz("pel") >= 4 * 228 * 228 + 7 * 228 + 7 and cs.get_dims("in").dsz("pel") % 4 == 0
     ks = cc.annotate_ref(nin[4], OpTune(k1conv=1, tconv=1, use_local_mem=2, vw=4))      # k1conv_simd: in / filts / out as (chan, pel) matrices padded to the blocking
     w = ks.get_dims("work")
     assert ks.get_func_name() == "k1conv_simd" and ks.get_dims("in").names == ("chan", "pel") and ks.get_dims("out").names == ("chan", "pel")
@@ -60,12 +63,12 @@ def test_annotations_reproduce_the_reference_geometries():
 
 
 @have_ref
-@pytest.mark.parametrize("which", ["sgemm", "sgemm_no_local", "sgemm_simd", "sgemm_simd_local", "conv", "k1conv", "k1conv_simd", "tconv", "ipconv"])
+@pytest.mark.parametrize("which", ["sgemm", "sgemm_no_local", "sgemm_simd", "sgemm_simd_local", "conv", "conv_simd", "k1conv", "k1conv_simd", "tconv", "ipconv"])
 def test_reference_templates_instantiate_and_compile(which):
     sg2048 = [o for o in bench.sgemm_full_ops() if o.sgemm_geom()["M"] == 2048][0]
     op, tune = {"sgemm": (sg2048, OpTune()), "sgemm_no_local": (sg2048, OpTune(use_local_mem=0)), "sgemm_simd": (sg2048, OpTune(use_local_mem=2, vw=4)),
                 "sgemm_simd_local": (sg2048, OpTune(use_local_mem=3, vw=4)),
-                "conv": (bench.alexnet_b256_ops(4)[5], KT), "k1conv": (bench.nin_ops(4)[4], KT), "tconv": (bench.alexnet_b256_ops(4)[1], KT), "k1conv_simd": (bench.nin_ops(4)[4], OpTune(k1conv=1, tconv=1, use_local_mem=2, vw=4)),
+                "conv": (bench.alexnet_b256_ops(4)[5], KT), "k1conv": (bench.nin_ops(4)[4], KT), "tconv": (bench.alexnet_b256_ops(4)[1], KT), "conv_simd": (bench.alexnet_b256_ops(4)[1], OpTune(use_local_mem=2, vw=4, Kb=1)), "k1conv_simd": (bench.nin_ops(4)[4], OpTune(k1conv=1, tconv=1, use_local_mem=2, vw=4)),
                 "ipconv": (bench.alexnet_b256_ops(4)[6], OpTune(k1conv=1, tconv=1, ipconv=1))}[which]
     anno = cc.annotate_ref(op, tune)
     assert anno.get_func_name() == which

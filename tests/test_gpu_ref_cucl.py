@@ -145,6 +145,20 @@ def test_reference_kernel_matches_oracle(rtc, e):
             TIMES[e["tag"]] = {"variant": e["variant"], "tpb": e["main"]["tpb"], "blks": e["main"]["blks"], "ms": round(ms, 5), "tflops": round(op.flops() / ms / 1e9, 2),
                                "bit_exact_vs_oracle": False, "max_abs_err_vs_exact": err_ip, "oracle_chain_max_abs_err_vs_exact": err_chain}
             return
+        if e["variant"] in ("conv_simd", "k1conv_simd") and not (SsdsDiff.of(want, got).mrd < MRD):
+            # the vector variants have no barrier in their reduction loop: compiled with fast-math (as the reference compiles them) their sum may be
+            # re-associated.  Same criterion as for ipconv: as close to the exact fp64 convolution as the oracle's own chain, and 2e-3 to the oracle
+            import torch
+            y = torch.nn.functional.conv2d(torch.from_numpy(i[:nb]).double(), torch.from_numpy(f).double(), torch.from_numpy(res["biases"]).double(),
+                                           stride=(g["SY"], g["SX"]), padding=(g["PY"], g["PX"]))
+            exact = torch.relu(y).numpy()
+            err_v, err_chain = float(np.abs(got - exact).max()), float(np.abs(want - exact).max())
+            assert err_v <= 1.5 * err_chain, (e["tag"], err_v, err_chain)
+            sd = SsdsDiff.of(want, got)
+            assert not sd.has_nan() and sd.mrd < 2e-3, (e["tag"], sd.basic_str())
+            TIMES[e["tag"]] = {"variant": e["variant"], "tpb": e["main"]["tpb"], "blks": e["main"]["blks"], "ms": round(ms, 5), "tflops": round(op.flops() / ms / 1e9, 2),
+                               "bit_exact_vs_oracle": False, "max_abs_err_vs_exact": err_v, "oracle_chain_max_abs_err_vs_exact": err_chain}
+            return
         last = res["out"][-1]
         assert np.isfinite(last).all() and last.max() > 0
     sd = SsdsDiff.of(want, got)
