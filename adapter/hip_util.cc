@@ -22,10 +22,12 @@ namespace boda {
   {
     virtual cinfo_t const * get_cinfo( void ) const; // required declaration for NESI support
     uint32_t device; //NESI(default=0,help="HIP device ordinal (one process per GPU)")
+    vect_uint32_t devices; //NESI(help="if non-empty: HIP device ordinals of ONE backend over several GPUs (vars with a leading img / M dim sharded, weights replicated)")
     bodahip_ctx * ctx;
     hip_compute_t( void ) : ctx(0) {}
     ~hip_compute_t( void ) { bodahip_destroy( ctx ); }
-    void init( void ) { hchk( bodahip_create( &ctx, device ) ); hchk( bodahip_set_gen_src( ctx, gen_src, gen_src_output_dir.exp.c_str() ) ); hchk( bodahip_init( ctx ) ); }
+    void init( void ) { vector< int > ords( devices.begin(), devices.end() );
+      hchk( ords.empty() ? bodahip_create( &ctx, device ) : bodahip_create_multi( &ctx, ords.size(), &ords[0] ) ); hchk( bodahip_set_gen_src( ctx, gen_src, gen_src_output_dir.exp.c_str() ) ); hchk( bodahip_init( ctx ) ); }
     string get_plat_tag( void ) { char b[512]; hchk( bodahip_get_plat_tag( ctx, b, sizeof(b) ) ); return b; }
     void create_var_with_dims( string const & vn, dims_t const & dims ) { hdims_t d(dims); hchk( bodahip_create_var( ctx, vn.c_str(), &d.d ) ); }
     void create_var_with_dims_as_reshaped_view_of_var( string const & vn, dims_t const & dims, string const & src_vn ) {

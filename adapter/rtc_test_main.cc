@@ -7,12 +7,14 @@
 #include <cstdio>
 namespace boda {
 p_rtc_compute_t make_rtc_compute_by_type_id( string const & be, uint32_t const device );
+p_rtc_compute_t make_rtc_compute_by_type_id_devices( string const & be, vect_uint32_t const & devices );
 static char const * const dot_src =
   "CUCL_GLOBAL_KERNEL void my_dot( GASQ float const * const a, GASQ float const * const b, GASQ float * const c, uint32_t const n ) {\n"
   "  uint32_t const ix = GLOB_ID_1D;\n  if( ix < n ) { c[ix] = a[ix] + b[ix]; }\n}\n";
 int rtc_test_main( int argc, char ** argv ) {
   try {
-    p_rtc_compute_t rtc = make_rtc_compute_by_type_id( "hip", 0 );
+    // "run": one device; "run-multi": the NESI field `devices` set to 0:0 -- ONE backend over two shards of GPU 0 (bodahip_create_multi)
+    p_rtc_compute_t rtc = ( argc >= 2 && string( argv[1] ) == "run-multi" ) ? make_rtc_compute_by_type_id_devices( "hip", vect_uint32_t{ 0, 0 } ) : make_rtc_compute_by_type_id( "hip", 0 );
     if( argc < 2 ) { printf( "adapter linked: be=%s\n", rtc->be.c_str() ); return 0; }
     uint32_t const data_sz = 10000;
     rtc->init();

@@ -6,3 +6,6 @@ p_rtc_compute_t make_rtc_compute_by_type_id( string const & be, uint32_t const d
   shared_ptr< hip_compute_t > r = make_shared< hip_compute_t >(); r->be = be; r->device = device; r->gen_src = 0; r->gen_src_output_dir.exp = "rtc-gen-src";
   return r;
 }
+p_rtc_compute_t make_rtc_compute_by_type_id_devices( string const & be, vect_uint32_t const & devices ) {   // (be=hip,devices=0:1:...) as NESI would fill it
+  p_rtc_compute_t r = make_rtc_compute_by_type_id( be, 0 ); dynamic_cast< hip_compute_t & >( *r ).devices = devices; return r;
+}

@@ -1,0 +1,53 @@
+"""-m gpu: bench.py as the driver runs it.  (1) `python bench.py --gpus 2` launches ITSELF under torch.distributed.run (one process per GPU) and
+prints one JSON line from rank 0; on the one-GPU test box BENCH_SAME_GPU=1 puts both ranks on GPU 0 over gloo, which exercises the whole N>1
+branch -- sharded data generation, the one-time weight broadcast (no silent fallback), barrier / max-over-ranks timing -- with the HIP kernels
+doing the arithmetic.  (2) the default N=1 line carries the AlexNet / NiN conv-ops legs under `conv_ops`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env_extra=None, timeout=600):
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+@pytest.mark.parametrize("workload", ["nin-net", "nin", "sgemm-ops-full"])
+def test_bench_launches_itself_for_two_ranks(workload):
+    args = ["--gpus", "2", "--workload", workload, "--steps", "1", "--warmup", "0", "--settle-ms", "0"] + ([] if workload == "sgemm-ops-full" else ["--batch", "8"])
+    r, lines = _bench(args, {"BENCH_SAME_GPU": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])          # exactly one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert "broadcast once" in out["config"]["weights"] and "failed" not in out["config"]["weights"]
+    assert out["config"]["rccl_ranks"] == 2
+    assert "cpu_baseline" not in out                                        # rank 0 at N=1 only
+
+
+def test_world_size_mismatch_is_an_error():
+    r, lines = _bench(["--gpus", "2", "--steps", "1"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode == 2 and not lines
+
+
+def test_default_line_carries_conv_ops():
+    r, lines = _bench(["--steps", "2", "--warmup", "1", "--settle-ms", "100"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["workload"].startswith("test/sgemm-ops-full.txt") and out["dtype"] == "f32"
+    assert out["roofline"]["bound"] == "mfma" and out["cpu_baseline"]["value"] > 0
+    co = out["conv_ops"]
+    for nm, n_layers in (("alexnet", 8), ("nin", 12)):
+        assert len(co[nm]["per_op"]) == n_layers and co[nm]["value"] > 0 and 0 < co[nm]["roofline"]["frac"] <= 1
+    h = co["nin"]["roofline"]["hbm_frac_1x1"]                             # cccp1 / cccp2 (AI 24): priced against HBM as well
+    assert h["layers"] == [1, 2] and 0 < h["frac"] <= 1
