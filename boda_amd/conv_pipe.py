@@ -209,12 +209,14 @@ FWD_SRC = """
 // Concat: copy one input into its channel range of the output (semantics of test/rtc/copy.cucl; src/rtc_fwd.cc:267-280)
 CUCL_GLOBAL_KERNEL void fwd_copy( GASQ float const * const in, GASQ float * const out, uint32_t const n_in, uint32_t const chw_in,
                                   uint32_t const chw_out, uint32_t const off_out ) {
+  // CUCL IX GLOB_ID_1D in
   if( GLOB_ID_1D >= n_in ) { return; }
   uint32_t const img = GLOB_ID_1D / chw_in;
   out[img*chw_out + off_out + ( GLOB_ID_1D - img*chw_in )] = in[GLOB_ID_1D];
 }
 // stand-alone ReLU (one that could not be fused into its conv): non-positive values, -0.0 included, become +0.0; NaN passes through
 CUCL_GLOBAL_KERNEL void fwd_relu( GASQ float * const inout, uint32_t const n ) {
+  // CUCL IX GLOB_ID_1D inout
   uint32_t const i = GLOB_ID_1D;
   if( i < n ) {
     float const v = inout[i];
@@ -448,6 +450,8 @@ class ConvPipeFwd:
             elif self.nhwc and op.type == "Pooling":
                 self.fwd_calls.append(FwdCall(op.tag, _nhwc.pool_call(vn(op.bot), op.top, vd(op.bot), vd(op.top), op.kern_sz, op.stride, op.in_pad, int(op.avg_pool)), "nhwc_pool"))
             elif self.nhwc and op.type == "LRN":
+                if op.in_place:   # the channels-last kernel reloads halo chunks of its INPUT at wave edges: in == out would read what neighbouring waves already stored
+                    raise UnsupErr(f"channels-last LRN {op.tag} in place is not supported (the kernel reads neighbouring chunks of its input)")
                 self.fwd_calls.append(FwdCall(op.tag, _nhwc.lrn_call(vn(op.bot), op.top, vd(op.bot), *op.lrn), "nhwc_lrn"))
             elif self.nhwc and op.type == "ReLU":
                 self.fwd_calls.append(FwdCall(op.tag, _nhwc.relu_call(vn(op.bot), vd(op.top)), "nhwc_relu"))
@@ -610,7 +614,8 @@ class ConvPipeFwd:
             wr = [am[a].n for a in ("out", "inout") if a in am and am[a].is_var()]
             if c.func == "nhwc_xpose_in":     # (the layout pass of the net's input: reads <in>_ref, writes <in>)
                 rd, wr = [am["in_ref"].n], [am["in"].n]
-            partial = c.func in ("fwd_copy", "nhwc_copy") or ("out_chan_off" in am and c.tag in getattr(self, "slices", {}))   # writers of disjoint channel ranges of one var: unordered among themselves
+            slice_outs = {t for t, _, _ in getattr(self, "slices", {}).values()}   # (Concat outputs that convs write channel ranges of)
+            partial = c.func in ("fwd_copy", "nhwc_copy") or ("out_chan_off" in am and am["out"].n in slice_outs)   # writers of disjoint channel ranges of one var: unordered among themselves
             d = set()
             for v in rd:
                 d.update(writers.get(v, []))

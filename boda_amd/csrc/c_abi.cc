@@ -85,6 +85,7 @@ int bodahip_get_var_dims(bodahip_ctx *ctx, const char *vn, char *tn_buf, size_t 
 int bodahip_set_var_to_zero(bodahip_ctx *ctx, const char *vn) { ABI_TRY R(ctx).set_var_to_zero(S(vn, "vn")); ABI_CATCH }
 int bodahip_compile(bodahip_ctx *ctx, uint32_t n, const bodahip_func_info *funcs, const bodahip_compile_opts *opts) {
   ABI_TRY
+  if (n && !funcs) rt_err("compile: null func_infos with n > 0");
   vect_rtc_func_info_t fis;
   for (uint32_t i = 0; i < n; ++i) {
     rtc_func_info_t fi; fi.func_name = S(funcs[i].func_name, "func_name"); fi.func_src = funcs[i].func_src ? funcs[i].func_src : "";
@@ -97,6 +98,7 @@ int bodahip_compile(bodahip_ctx *ctx, uint32_t n, const bodahip_func_info *funcs
   ABI_CATCH }
 int bodahip_compile_code_object(bodahip_ctx *ctx, const void *code, size_t code_sz, uint32_t n, const bodahip_func_info *funcs) {
   ABI_TRY
+  if (n && !funcs) rt_err("compile_code_object: null func_infos with n > 0");
   vect_rtc_func_info_t fis;
   for (uint32_t i = 0; i < n; ++i) {
     rtc_func_info_t fi; fi.func_name = S(funcs[i].func_name, "func_name");

@@ -11,9 +11,16 @@
 //     hipMemcpyPeerAsync, one copy per link; devices without peer access get their own H2D); copy_var_to_nda gathers shards into the slices
 //     of the caller's buffer (replicated vars are read from device 0);
 //   * run(): native functions (hip_sgemm / hip_conv / hip_conv_nhwc and aliases: shapes come from the vars at run time) are enqueued on every
-//     device's stream in turn from the one host thread -- the devices then work concurrently -- and get ONE call id; generated CUCL functions
-//     have their sizes baked in or passed by value for the whole tensor, so they run (on every device, keeping replicas equal) only when all
-//     their var arguments are replicated, and are refused with unsup_err otherwise;
+//     device's stream in turn from the one host thread -- the devices then work concurrently -- and get ONE call id.  Generated CUCL functions
+//     have their sizes baked in or passed by value for the WHOLE tensor.  On replicated vars they run as they are, on every device (replicas
+//     stay equal).  On vars sharded along their leading dim they run too, when they are per-element functions: the function's own index
+//     declaration -- the `// CUCL IX GLOB_ID_1D <arg> [use_dims=...]` line every reference template carries into its generated source
+//     (src/rtc_func_gen.cc:227-246; test/rtc/{pool,lrn,relu,copy,gen_data_*}.cucl) -- says that its 1-D ids enumerate the elements of <arg>,
+//     leading dim first.  Device i then launches only the ids of its own images, [b_i, e_i) x ids-per-image: GLOB_ID_1D starts at b_i x
+//     ids-per-image (threads past the shard's last id see U32_MAX and leave through the function's own range test), every sharded var is passed as (shard pointer - b_i x bytes-per-image), and all
+//     sizes stay those of the whole tensor -- each thread computes exactly what it computes on one device (incl. the flat-index hash of
+//     gen_data), on memory its device owns.  Functions that use the workgroup (LOC_ID_1D, GRP_ID_1D, LOCSHAR_MEM, BARRIER_SYNC), that declare
+//     no GLOB_ID_1D index, or that take a var sharded along its second dim (sgemm `a`) are refused with unsup_err on sharded vars;
 //   * get_dur(b, e) = the longest of the devices' durations; finish_and_sync() waits for all.
 // The per-GPU process model of bench.py / boda_amd/shard.py (torch.distributed, RCCL weight broadcast) stays: this class is for callers that
 // want one process -- an unmodified Boda with --rtc='(be=hip,devices=...)'.  Devices may repeat (e.g. {0, 0}): the same GPU then holds several
@@ -22,18 +29,66 @@
 #include "native_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <sstream>
 
 namespace bodahip {
 
 void *hip_compute_stream(rtc_compute_t *rtc);
+void hip_compute_set_shard_aware(rtc_compute_t *rtc);
+uint32_t hip_compute_run_shard(rtc_compute_t *rtc, rtc_func_call_t const &rfc, uint32_t blks, uint32_t gid_off, uint32_t gid_last, std::map<string, int64_t> const &var_bias);
 
 struct multi_var_t { dims_t dims; int shard_dim = -1; };   // logical dims; index of the sharded dim (-1: replicated)
+
+// what a generated function's source says about its index space
+struct gen_func_t {
+  bool has_ix = false, uses_group = false;
+  string ix_arg; vect_string use_dims;
+};
+static bool ident_char(char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_'; }
+static bool has_token(string const &s, char const *tok) {
+  size_t const n = strlen(tok);
+  for (size_t p = s.find(tok); p != string::npos; p = s.find(tok, p + 1))
+    if ((p == 0 || !ident_char(s[p - 1])) && (p + n >= s.size() || !ident_char(s[p + n]))) return true;
+  return false;
+}
+static gen_func_t scan_gen_func(string const &all_src, string const &func_name) {
+  gen_func_t g;
+  // the text of this kernel: from its name (followed by an argument list) to the next kernel of the batch
+  size_t at = string::npos;
+  for (size_t p = all_src.find(func_name); p != string::npos; p = all_src.find(func_name, p + 1)) {
+    size_t q = p + func_name.size();
+    if (p && ident_char(all_src[p - 1])) continue;
+    while (q < all_src.size() && (all_src[q] == ' ' || all_src[q] == '\t' || all_src[q] == '\n')) ++q;
+    if (q < all_src.size() && all_src[q] == '(') { at = p; break; }
+  }
+  if (at == string::npos) return g;
+  size_t const end = all_src.find("CUCL_GLOBAL_KERNEL", at);
+  string const body = all_src.substr(at, (end == string::npos) ? string::npos : end - at);
+  for (char const *t : {"LOC_ID_1D", "GRP_ID_1D", "LOC_SZ_1D", "LOCSHAR_MEM", "BARRIER_SYNC"}) if (has_token(body, t)) g.uses_group = true;
+  char const *const key = "// CUCL IX ";
+  for (size_t p = body.find(key); p != string::npos; p = body.find(key, p + 1)) {
+    size_t const eol = body.find('\n', p);
+    std::istringstream is(body.substr(p + strlen(key), (eol == string::npos) ? string::npos : eol - p - strlen(key)));
+    string ix, arg, opt; is >> ix >> arg;
+    if (ix != "GLOB_ID_1D") { g.uses_group = true; continue; }
+    if (g.has_ix) { g.has_ix = false; g.uses_group = true; return g; }   // (two declarations of the same index: not a form we know)
+    g.has_ix = !arg.empty(); g.ix_arg = arg;
+    while (is >> opt) if (startswith(opt, "use_dims=")) {
+      string cur; for (char c : opt.substr(9)) { if (c == ':') { if (!cur.empty()) g.use_dims.push_back(cur); cur.clear(); } else cur.push_back(c); }
+      if (!cur.empty()) g.use_dims.push_back(cur);
+    }
+  }
+  return g;
+}
 
 struct hip_multi_compute_t : public rtc_compute_t {
   std::vector<int> devs;
   std::vector<p_rtc_compute_t> subs;
   std::map<string, multi_var_t> vis;
   std::map<string, bool> func_native;
+  std::map<string, gen_func_t> func_gen;       // generated functions: their index declaration
+  std::vector<hipEvent_t> peer_evs;            // per device: marks the end of its last peer copy out of device 0
+  static constexpr uint32_t kNoCall = 0xffffffffu;   // per-device call id of a call that launched nothing there (an empty shard)
   std::vector<std::vector<uint32_t>> calls;   // multi call id -> per-device call ids
   std::vector<char> peer_ok;                   // device i reachable from device 0 by hipMemcpyPeerAsync
   bool init_done = false;
@@ -43,14 +98,16 @@ struct hip_multi_compute_t : public rtc_compute_t {
     if (devs.empty()) rt_err("hip multi-device backend: empty device list");
     for (int d : devs) subs.push_back(make_hip_compute(d));
   }
+  ~hip_multi_compute_t() override { for (hipEvent_t e : peer_evs) if (e) (void)hipEventDestroy(e); }
   size_t n() const { return subs.size(); }
 
   void init() override {
     assert_st(!init_done);
-    for (auto &s : subs) { s->gen_src = gen_src; s->gen_src_output_dir = gen_src_output_dir; s->init(); }
-    peer_ok.assign(n(), 0);
+    for (auto &s : subs) { s->gen_src = gen_src; s->gen_src_output_dir = gen_src_output_dir; s->init(); hip_compute_set_shard_aware(s.get()); }
+    peer_ok.assign(n(), 0); peer_evs.assign(n(), nullptr);
+    bool const force_peer = getenv("BODAHIP_FORCE_PEER") != nullptr;   // (tests: take the device-to-device fan-out between shards of ONE GPU too)
     for (size_t i = 1; i < n(); ++i) {
-      if (devs[i] == devs[0]) continue;
+      if (devs[i] == devs[0]) { peer_ok[i] = force_peer ? 1 : 0; continue; }
       int can = 0;
       if (hipDeviceCanAccessPeer(&can, devs[i], devs[0]) == hipSuccess && can) {
         (void)hipSetDevice(devs[i]);
@@ -112,12 +169,24 @@ struct hip_multi_compute_t : public rtc_compute_t {
       bool any_peer = false; for (size_t i = 1; i < n(); ++i) any_peer = any_peer || peer_ok[i];
       if (any_peer) subs[0]->finish_and_sync();
       void *const src = subs[0]->get_var_raw_native_pointer(vn)->rp_elems();
+      bool copied = false;
       for (size_t i = 1; i < n(); ++i) {
         if (peer_ok[i] && v.dims.bytes_sz()) {
           void *const dst = subs[i]->get_var_raw_native_pointer(vn)->rp_elems();
+          hipStream_t const si = (hipStream_t)hip_compute_stream(subs[i].get());
           hip_err_chk(hipSetDevice(devs[i]), "hipSetDevice");
-          hip_err_chk(hipMemcpyPeerAsync(dst, devs[i], src, devs[0], v.dims.bytes_sz(), (hipStream_t)hip_compute_stream(subs[i].get())), "hipMemcpyPeerAsync");
+          hip_err_chk(hipMemcpyPeerAsync(dst, devs[i], src, devs[0], v.dims.bytes_sz(), si), "hipMemcpyPeerAsync");
+          // the copy READS device 0's buffer on device i's stream: device 0's stream must not overwrite that buffer (an in-place function,
+          // set_var_to_zero, the next upload) before the copy has read it
+          if (!peer_evs[i]) hip_err_chk(hipEventCreateWithFlags(&peer_evs[i], hipEventDisableTiming), "hipEventCreateWithFlags");
+          hip_err_chk(hipEventRecord(peer_evs[i], si), "hipEventRecord(peer copy)");
+          copied = true;
         } else subs[i]->copy_nda_to_var(vn, nda);
+      }
+      if (copied) {
+        hip_err_chk(hipSetDevice(devs[0]), "hipSetDevice");
+        for (size_t i = 1; i < n(); ++i) if (peer_ok[i] && v.dims.bytes_sz())
+          hip_err_chk(hipStreamWaitEvent((hipStream_t)hip_compute_stream(subs[0].get()), peer_evs[i], 0), "hipStreamWaitEvent(peer copy)");
       }
       return;
     }
@@ -178,22 +247,73 @@ struct hip_multi_compute_t : public rtc_compute_t {
     assert_st(init_done);
     for (auto const &fi : func_infos) if (func_native.count(fi.func_name)) rt_err("compile: function '" + fi.func_name + "' already exists");
     for (auto &s : subs) s->compile(func_infos, opts);
-    for (auto const &fi : func_infos) func_native[fi.func_name] = native_kernels_t::is_native_func_name(fi.op.has_func_name() ? fi.op.get_func_name() : string());
+    string all_src; for (auto const &fi : func_infos) all_src += fi.func_src;
+    for (auto const &fi : func_infos) {
+      bool const nat = native_kernels_t::is_native_func_name(fi.op.has_func_name() ? fi.op.get_func_name() : string());
+      func_native[fi.func_name] = nat;
+      if (!nat) func_gen[fi.func_name] = scan_gen_func(all_src, fi.func_name);
+    }
   }
-  void release_func(string const &fn) override { must_find(func_native, fn); for (auto &s : subs) s->release_func(fn); func_native.erase(fn); }
-  void release_all_funcs() override { for (auto &s : subs) s->release_all_funcs(); func_native.clear(); }
+  void release_func(string const &fn) override { must_find(func_native, fn); for (auto &s : subs) s->release_func(fn); func_native.erase(fn); func_gen.erase(fn); }
+  void release_all_funcs() override { for (auto &s : subs) s->release_all_funcs(); func_native.clear(); func_gen.clear(); }
 
   uint32_t run(rtc_func_call_t const &rfc) override {
     assert_st(init_done);
     auto fit = func_native.find(rfc.rtc_func_name);
     if (fit == func_native.end()) rt_err("run: unknown function '" + rfc.rtc_func_name + "' (not compiled, or released)");
-    if (!fit->second) {   // generated CUCL source: sizes are baked in / passed for the whole tensor -> only on replicated vars
-      for (auto const &kv : rfc.arg_map) if (kv.second.is_valid() && kv.second.is_var() && must_find(vis, kv.second.n).shard_dim >= 0)
-        unsup_err("multi-device backend: generated function '" + rfc.rtc_func_name + "' takes the sharded var '" + kv.second.n +
-                  "'; only the native functions (hip_sgemm / hip_conv ...) run on sharded vars");
+    if (!fit->second) {
+      bool sharded = false;
+      for (auto const &kv : rfc.arg_map) if (kv.second.is_valid() && kv.second.is_var() && must_find(vis, kv.second.n).shard_dim >= 0) sharded = true;
+      if (sharded) return run_generated_on_shards(rfc);
     }
     std::vector<uint32_t> ids;
     for (auto &s : subs) ids.push_back(s->run(rfc));   // enqueue on every device's stream in turn; the devices then run concurrently
+    calls.push_back(ids);
+    return (uint32_t)calls.size() - 1;
+  }
+  // a per-element generated function over vars sharded along their leading dim: see the header of this file
+  uint32_t run_generated_on_shards(rtc_func_call_t const &rfc) {
+    string const &fn = rfc.rtc_func_name;
+    gen_func_t const &g = must_find(func_gen, fn);
+    string const why = "multi-device backend: generated function '" + fn + "' takes sharded vars but ";
+    if (g.uses_group) unsup_err(why + "uses the workgroup (LOC_ID_1D / GRP_ID_1D / LOCSHAR_MEM / BARRIER_SYNC): only per-element functions run on shards");
+    if (!g.has_ix) unsup_err(why + "its source declares no `// CUCL IX GLOB_ID_1D <arg>` index: the backend cannot tell which ids belong to which image");
+    uint32_t T = 0;
+    for (auto const &kv : rfc.arg_map) {
+      if (!kv.second.is_valid() || !kv.second.is_var()) continue;
+      multi_var_t const &v = must_find(vis, kv.second.n);
+      if (v.shard_dim < 0) continue;
+      if (v.shard_dim != 0) unsup_err(why + "var '" + kv.second.n + "' is sharded along its second dim (sgemm a, K:M)");
+      if (T && v.dims.dims(0) != T) unsup_err(why + "with different batch sizes (" + std::to_string(T) + " and " + std::to_string(v.dims.dims(0)) + ")");
+      T = v.dims.dims(0);
+    }
+    auto ai = rfc.arg_map.find(g.ix_arg);
+    if (ai == rfc.arg_map.end() || !ai->second.is_valid()) rt_err(why + "binds no argument named '" + g.ix_arg + "', the one its index is declared over");
+    dims_t const ixd = ai->second.is_var() ? must_find(vis, ai->second.n).dims : ai->second.v->dims;
+    uint64_t W = 1; bool lead_ok = false;
+    {
+      vect_string names; std::vector<uint32_t> sizes;
+      if (g.use_dims.empty()) for (uint32_t k = 0; k < ixd.sz(); ++k) { names.push_back(ixd.names(k)); sizes.push_back(ixd.dims(k)); }
+      else for (auto const &u : g.use_dims) { names.push_back(u); sizes.push_back(ixd.dsz(u)); }
+      lead_ok = !names.empty() && names[0] == "img" && sizes[0] == T;
+      for (size_t k = 1; k < sizes.size(); ++k) W *= sizes[k];
+    }
+    if (!lead_ok) unsup_err(why + "its index over '" + g.ix_arg + "' " + ixd.pretty_str() + " does not lead with the sharded batch dim img=" + std::to_string(T));
+    if (W * T >= 0xffffffffull || !W) unsup_err(why + "its index space does not fit 32 bits");
+    if (!rfc.tpb) rt_err("boda/rtc: can't launch kernel; tpb is zero: rtc_func_name=" + fn);
+    std::vector<uint32_t> ids;
+    for (size_t i = 0; i < n(); ++i) {
+      uint32_t const b = chunk_begin(T, i), e = chunk_begin(T, i + 1);
+      if (e == b) { ids.push_back(kNoCall); continue; }
+      std::map<string, int64_t> bias;
+      for (auto const &kv : rfc.arg_map) {
+        if (!kv.second.is_valid() || !kv.second.is_var()) continue;
+        multi_var_t const &v = must_find(vis, kv.second.n);
+        if (v.shard_dim == 0) bias[kv.second.n] = -(int64_t)((uint64_t)b * (v.dims.dims_prod() / T) * v.dims.tsz());
+      }
+      uint64_t const work = (uint64_t)(e - b) * W;
+      ids.push_back(hip_compute_run_shard(subs[i].get(), rfc, (uint32_t)((work + rfc.tpb - 1) / rfc.tpb), (uint32_t)(b * W), (uint32_t)(e * W - 1), bias));
+    }
     calls.push_back(ids);
     return (uint32_t)calls.size() - 1;
   }
@@ -202,7 +322,7 @@ struct hip_multi_compute_t : public rtc_compute_t {
   float get_dur(uint32_t const &b, uint32_t const &e) override {
     if (b >= calls.size() || e >= calls.size()) rt_err("invalid call_id");
     float ms = 0.f;
-    for (size_t i = 0; i < n(); ++i) ms = std::max(ms, subs[i]->get_dur(calls[b][i], calls[e][i]));
+    for (size_t i = 0; i < n(); ++i) if (calls[b][i] != kNoCall && calls[e][i] != kNoCall) ms = std::max(ms, subs[i]->get_dur(calls[b][i], calls[e][i]));
     return ms;
   }
   void profile_start() override { subs[0]->profile_start(); }

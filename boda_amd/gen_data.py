@@ -57,8 +57,10 @@ CUCL_GLOBAL_KERNEL void gen_data_sgemm_b( GASQ float * const b, uint32_t const m
 }
 // 4-D tensors ?:?:y:x (Convolution in / filts) and the 1-D biases; hc = per-tensor hash constant
 // ix_off: flat-index offset of this var inside the global tensor (img-axis shard of `in`: img0*chan*y*x); unsharded: 0
+// (the index declaration is what lets a multi-device backend run the function on a var sharded along img: csrc/hip_multi.cc)
 CUCL_GLOBAL_KERNEL void gen_data_Convolution_4d( GASQ float * const t, uint32_t const mode, float const vi, uint32_t const sz,
                                                  uint32_t const Y, uint32_t const X, uint32_t const hc, uint32_t const ix_off ) {
+  // CUCL IX GLOB_ID_1D t
   if( GLOB_ID_1D >= sz ) { return; }
   uint32_t const x = GLOB_ID_1D % X; uint32_t const y = ( GLOB_ID_1D / X ) % Y;
   float val = vi;

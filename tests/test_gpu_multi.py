@@ -2,6 +2,7 @@
 sharded, weights replicated, copy_nda_to_var scatters, run() enqueues on every device, copy_var_to_nda gathers.  The device list repeats GPU 0
 ({0,0}, {0,0,0}), so the sharding logic runs with the HIP kernels doing the arithmetic on a one-GPU box: gathered results must equal the
 oracle -- and the single-device backend -- bit for bit, for even, uneven and empty shards."""
+import os
 import numpy as np
 import pytest
 
@@ -107,3 +108,186 @@ def test_multi_device_contract(multi):
         assert not rtc.copy_var_to_nda("s").any()
     finally:
         rtc.release_var("r"); rtc.release_var("s"); rtc.release_func("add1"); rtc.release_per_call_id_data()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# generated (CUCL-source) functions on sharded vars: per-element functions that declare `// CUCL IX GLOB_ID_1D <arg>` run on each device over
+# the ids of its own images (whole-tensor indices, shard pointers moved back by the shard's offset) -- csrc/hip_multi.cc
+# ---------------------------------------------------------------------------------------------------------------
+def test_generated_per_element_function_on_sharded_vars(multi):
+    rtc, n = multi
+    decl = "CUCL_GLOBAL_KERNEL void {name}( GASQ float * const a, GASQ float const * const b, uint32_t const n ) {{\n{ix}  if( GLOB_ID_1D >= n ) {{ return; }}\n{body}}}\n"
+    src = (decl.format(name="addix", ix="  // CUCL IX GLOB_ID_1D a\n", body="  a[GLOB_ID_1D] += b[GLOB_ID_1D / 100] + (float)GLOB_ID_1D;\n")          # NOT idempotent: every id exactly once
+           + decl.format(name="noix", ix="", body="  a[GLOB_ID_1D] += 1.0f;\n")
+           + decl.format(name="grp", ix="  // CUCL IX GLOB_ID_1D a\n", body="  a[GLOB_ID_1D] += (float)LOC_ID_1D;\n"))
+    op = lambda f: Op({"type": "x", "func_name": f}, {})
+    rtc.compile([RtcFuncInfo("addix", src, ["a", "b", "n"], op("addix")), RtcFuncInfo("noix", "", ["a", "b", "n"], op("noix")), RtcFuncInfo("grp", "", ["a", "b", "n"], op("grp"))])
+    for B in (10, 1, n - 1 if n > 1 else 1):       # incl. batches smaller than the device count (empty shards)
+        rtc.create_var_with_dims("s", Dims(("img", "chan"), (B, 100), "float")); rtc.create_var_with_dims("t", Dims(("img",), (B,), "float"))
+        try:
+            x = np.arange(B * 100, dtype=np.float32).reshape(B, 100) * np.float32(0.5); y = np.arange(B, dtype=np.float32) * np.float32(1000.0)
+            rtc.copy_nda_to_var("s", x); rtc.copy_nda_to_var("t", y)
+            am = {"a": RtcArg.var("s"), "b": RtcArg.var("t"), "n": RtcArg.scalar(B * 100, "uint32_t")}
+            cid = rtc.run(RtcFuncCall("addix", am, tpb=64, blks=(B * 100 + 63) // 64)); rtc.finish_and_sync()
+            assert rtc.get_dur(cid, cid) >= 0
+            assert np.array_equal(rtc.copy_var_to_nda("s"), x + y[:, None] + np.arange(B * 100, dtype=np.float32).reshape(B, 100))
+            for bad in ("noix", "grp"):            # no index declaration / workgroup-level function: refused on sharded vars, as before
+                with pytest.raises(UnsupErr):
+                    rtc.run(RtcFuncCall(bad, am, tpb=64, blks=(B * 100 + 63) // 64))
+        finally:
+            rtc.release_var("s"); rtc.release_var("t"); rtc.release_per_call_id_data()
+    for f in ("addix", "noix", "grp"):
+        rtc.release_func(f)
+
+
+def test_gen_data_on_a_sharded_var_gives_the_global_pattern(multi):
+    """The reference's flat-index hash pattern (test/rtc/gen_data_Convolution_in.cucl: det_hash_rand( GLOB_ID_1D + c )) generated ON the devices,
+    each over the ids of its own images: the gathered tensor is the whole-tensor pattern."""
+    from boda_amd import gen_data as gd
+    rtc, n = multi
+    if not getattr(rtc, "_gen_data_compiled", False):
+        rtc.compile(gd.func_infos()); rtc._gen_data_compiled = True
+    d = Dims(("img", "chan", "y", "x"), (7, 5, 9, 11), "float")
+    rtc.create_var_with_dims("gin", d)
+    try:
+        rtc.run(gd.gen_call("Convolution", "in", "gin", d, 5, 0.0)); rtc.finish_and_sync()
+        assert np.array_equal(rtc.copy_var_to_nda("gin"), bo.gen_conv_in(7, 5, 9, 11))
+    finally:
+        rtc.release_var("gin"); rtc.release_per_call_id_data()
+
+
+@pytest.mark.parametrize("net,batch,ndev", [("nin", 16, 4), ("alexnet", 5, 3)])
+def test_full_net_forward_on_a_multi_device_backend_equals_single_device(single, net, batch, ndev):
+    """BASELINE config 4 behind the boundary: the whole net through ConvPipeFwd on (be=hip,devices=0:0:..) -- inputs and weights generated on the
+    devices, hip_conv on every shard, the templated pool / LRN kernels over each shard's ids -- node for node bit-identical to one device."""
+    from boda_amd import gen_data as gd
+    from boda_amd.conv_pipe import ConvPipeFwd, alexnet_ng_conv, nin_imagenet
+    cp_of = {"nin": nin_imagenet, "alexnet": alexnet_ng_conv}[net]
+    res = []
+    for be in ("(be=hip,devices=" + ":".join(["0"] * ndev) + ")", None):
+        rtc = make_rtc(be) if be else single
+        if be:
+            rtc.init()
+        cp = cp_of(batch)
+        fwd = ConvPipeFwd(rtc); fwd.init(cp)
+        try:
+            rtc.run(gd.gen_call("Convolution", "in", fwd.in_var, cp.nodes["data"], 5, 0.0)); rtc.finish_and_sync()
+            nodes = [nn for nn in cp.nodes if nn in {o.top for o in cp.ops if o.type != "Dropout"}]
+            for c in fwd.fwd_calls:
+                c.call_id = rtc.run(c.rfc)
+            rtc.finish_and_sync()
+            assert rtc.get_dur(fwd.fwd_calls[0].call_id, fwd.fwd_calls[-1].call_id) > 0
+            res.append({nn: rtc.copy_var_to_nda(fwd.var_of(nn)) for nn in ["data"] + nodes})
+        finally:
+            fwd.release(); rtc.release_per_call_id_data()
+            if be:
+                for k in ("_pool_funcs",):
+                    rtc.__dict__.pop(k, None)
+                rtc.close()
+    assert np.array_equal(res[0]["data"], bo.gen_conv_in(*cp.nodes["data"].sizes))
+    for nn in res[1]:
+        assert np.array_equal(res[0][nn], res[1][nn]), nn
+    assert np.abs(res[1][cp.out_node()]).max() > 0
+
+
+def test_ops_prof_end_to_end_on_a_sharded_backend(golden_dir):
+    """The ops-prof protocol (src/rtc_prof.cc:44-126,194-371: vars, inputs generated ON DEVICE, run, read back, digests vs the reference's wisdom
+    file) through ONE backend over three shards: the reference-held digests of test/good_tr/conv-debug are met by the gathered outputs."""
+    import io
+    from boda_amd.ops_prof import ops_prof
+    from boda_amd.op import read_ops
+    from boda_amd.digest import read_wisdoms
+    rtc = make_rtc("(be=hip,devices=0:0:0)"); rtc.init()
+    try:
+        ops = read_ops(os.path.join(golden_dir, "ops", "conv-ops-debug-tmp.txt"))
+        win = read_wisdoms(os.path.join(golden_dir, "wisdom", "conv-debug.wis"))
+        buf = io.StringIO()
+        wout, nfail, rows = ops_prof(rtc, ops, {"def": OpTune(), "t64": OpTune(hip_tile="64x64x16x1x1")}, "def", 5, wisdom_in=win, write_runs=True, out=buf)
+        assert nfail == 0 and "***ALL IS WELL***" in buf.getvalue(), buf.getvalue()
+        for w, wi in zip(wout, win):
+            assert w.kgs[0][1].mrd_comp(wi.kgs[0][1], 2e-4) == ""
+    finally:
+        rtc.close()
+
+
+def test_uneven_eight_way_split_at_config4_size(single):
+    """BASELINE config 4's first layer at (nearly) its full batch: NiN conv1 on 1021 images (in 631 MB, out 1.18 GB: over 2 GiB / 2 as ONE tensor, every
+    shard far below the 2 GiB-per-launch limit) split 8 ways unevenly (127 / 128 images), data generated on the devices.  Gathered result ==
+    the single-device result bit for bit; first two and last image == the oracle (batch-prefix invariance)."""
+    from boda_amd import gen_data as gd
+    B = 1021
+    op = _conv_op(B, 3, 227, 227, 96, 11, 11, 4, 0)
+    anno = add_codegen_annotations(op, OpTune()); fn = anno.get_func_name()
+    outs = []
+    for be in ("(be=hip,devices=0:0:0:0:0:0:0:0)", None):
+        rtc = make_rtc(be) if be else single
+        if be:
+            rtc.init()
+        if not getattr(rtc, "_gen_data_compiled", False):
+            rtc.compile(gd.func_infos()); rtc._gen_data_compiled = True
+        rtc.compile([RtcFuncInfo("big", "", [a for a, _ in NATIVE_ARGS[fn]], anno)])
+        am, made = {}, []
+        try:
+            for an, io_ in NATIVE_ARGS[fn]:
+                if io_ == "REF":
+                    am[an] = RtcArg.ref(anno.get_dims(an)); continue
+                rtc.create_var_with_dims("big_" + an, anno.get_dims(an)); made.append("big_" + an); am[an] = RtcArg.var("big_" + an)
+                if io_ == "IN":
+                    rtc.run(gd.gen_call("Convolution", an, "big_" + an, anno.get_dims(an), 5, 0.0))
+            rtc.run(RtcFuncCall("big", am)); rtc.finish_and_sync()
+            outs.append(rtc.copy_var_to_nda("big_out"))
+        finally:
+            for vn in made:
+                rtc.release_var(vn)
+            rtc.release_func("big"); rtc.release_per_call_id_data()
+            if be:
+                rtc.close()
+    assert np.array_equal(outs[0], outs[1])
+    f = bo.gen_conv_filts(96, 3, 11, 11); bi = bo.gen_conv_biases(96)
+    full_in_head = bo.gen_conv_in(B, 3, 227, 227)[[0, 1, B - 1]]
+    want = bo.conv_fwd(full_in_head, f, bi, (4, 4), (0, 0), True)
+    assert np.array_equal(outs[0][[0, 1, B - 1]], want)
+
+
+def test_peer_fan_out_of_replicated_vars_is_ordered(monkeypatch):
+    """copy_nda_to_var of a replicated var = one H2D to device 0 + device-to-device copies to the others, read on THEIR streams: device 0's stream
+    must wait for those reads before it overwrites the buffer.  BODAHIP_FORCE_PEER=1 takes the device-to-device path between shards of one GPU
+    (two distinct GPUs take it by themselves); back-to-back uploads into the same var must leave every replica holding the LAST upload --
+    checked through a convolution, which reads each device's own replica."""
+    monkeypatch.setenv("BODAHIP_FORCE_PEER", "1")
+    rtc = make_rtc("(be=hip,devices=0:0:0)"); rtc.init()
+    try:
+        shape = (6, 64, 28, 28, 512, 3, 3, 1, 1)
+        B, C, H, W, OC, KH, KW, S, P = shape
+        ins = {"in": bo.gen_conv_in(B, C, H, W), "filts": bo.gen_conv_filts(OC, C, KH, KW), "biases": bo.gen_conv_biases(OC)}
+        op = _conv_op(*shape); anno = add_codegen_annotations(op, OpTune()); fn = anno.get_func_name()
+        rtc.compile([RtcFuncInfo("f", "", [a for a, _ in NATIVE_ARGS[fn]], anno)])
+        am = {}
+        for an, io_ in NATIVE_ARGS[fn]:
+            if io_ == "REF":
+                am[an] = RtcArg.ref(anno.get_dims(an)); continue
+            rtc.create_var_with_dims(an, anno.get_dims(an)); am[an] = RtcArg.var(an)
+        rtc.copy_nda_to_var("in", ins["in"]); rtc.copy_nda_to_var("biases", ins["biases"])
+        for k in range(4):     # uploads chase each other: junk, junk, junk, the real filters
+            rtc.copy_nda_to_var("filts", ins["filts"] if k == 3 else np.full_like(ins["filts"], float(k + 1)))
+        rtc.run(RtcFuncCall("f", am)); rtc.finish_and_sync()
+        assert np.array_equal(rtc.copy_var_to_nda("out"), bo.conv_fwd(ins["in"], ins["filts"], ins["biases"], (S, S), (P, P), True))
+        rtc.set_var_to_zero("filts"); rtc.run(RtcFuncCall("f", am)); rtc.finish_and_sync()      # every replica zeroed: out = relu(bias)
+        assert np.array_equal(rtc.copy_var_to_nda("out"), np.broadcast_to(np.maximum(ins["biases"], 0)[None, :, None, None], (B, OC, H, W)))
+    finally:
+        rtc.close()
+
+
+def test_peer_fan_out_between_two_distinct_gpus():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the one-GPU box covers the same code path with BODAHIP_FORCE_PEER)")
+    rtc = make_rtc("(be=hip,devices=0:1)"); rtc.init()
+    try:
+        shape = (6, 64, 28, 28, 512, 3, 3, 1, 1)
+        B, C, H, W, OC, KH, KW, S, P = shape
+        ins = {"in": bo.gen_conv_in(B, C, H, W), "filts": bo.gen_conv_filts(OC, C, KH, KW), "biases": bo.gen_conv_biases(OC)}
+        got = _run(rtc, _conv_op(*shape), ins)
+        assert np.array_equal(got["out"], bo.conv_fwd(ins["in"], ins["filts"], ins["biases"], (S, S), (P, P), True))
+    finally:
+        rtc.close()
