@@ -36,6 +36,8 @@ class OpTune:
     # the originals kept as <arg>_ref and filled / read back by xpose functions outside the timed call -- the reference's own k1conv / tconv protocol (boda_amd/nhwc.py)
     hip_s2d: int = 1  # extension (with hip_layout=nhwc): 1 = conv1-type layers (stride >= 2 on <= 8 channels) run space-to-depth, the regrouping done by the layout pass of `in` (boda_amd/nhwc.py)
     hip_out: str = ""  # extension (with hip_layout=nhwc): "f32" = the kernel writes float instead of bfloat16
+    hip_exact: int = 1  # extension: 1 = fp32 results bit-identical to the reference's per-thread fma chain (default); 0 = tolerance mode: within the reference's bound for re-associating
+    # kernels (mrd < 2e-3, src/rtc_prof.cc:317-319,436; its 2e-4 default, :161, is not met by ANY second association of a K = 9216 sum on its U(-5,5) data) -- deterministic K slices on tile-starved long-K layers, Winograd where it is faster
     hip_tile: str = ""  # extension: workgroup tile of the native kernels "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF]]]]" ("" = heuristic)
 
     _ALWAYS = ("MNt", "MNb", "tconv_max_ksz")  # u32_pt_t fields print as "8 8" != default text "8:8": always dumped
@@ -125,6 +127,8 @@ def add_codegen_annotations(op: Op, tune: OpTune) -> Op:
             raise UnsupErr(f"sgemm variants of use_be={tune.use_be!r} are generated by the reference's CUCL code generator")
     else:
         raise UnsupErr(f"op type {t!r} is not on the conv_fwd / sgemm hot path")
+    if not tune.hip_exact and native and not tune.use_culibs and tune.hip_dtype != "bf16":
+        a.str_vals["hip_exact"] = "0"   # travels with the function, like hip_tile
     if tune.hip_tile and native and not tune.use_culibs:
         a.str_vals["hip_tile"] = tune.hip_tile   # travels with the function: the backend applies it to this function's calls only
     return a

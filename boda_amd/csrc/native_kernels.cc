@@ -41,6 +41,7 @@ native_kernels_t::native_kernels_t(native_host_t *host_) : impl(new impl_t), hos
   if (char const *e = getenv("BODAHIP_CONV_TILE")) impl->tune["conv_tile"] = e;
   if (char const *e = getenv("BODAHIP_K1_STREAM")) impl->tune["k1_stream"] = e;
   if (char const *e = getenv("BODAHIP_CONV_ALGO")) impl->tune["conv_algo"] = e;
+  if (char const *e = getenv("BODAHIP_EXACT")) impl->tune["exact"] = e;
 }
 native_kernels_t::~native_kernels_t() {
   for (auto &kv : impl->kernels) { if (kv.second.mod) (void)hipModuleUnload(kv.second.mod); }
@@ -63,7 +64,8 @@ void native_kernels_t::check_compile_time(rtc_func_info_t const &fi) {
   rt_err("unknown/unhandled native hip function: " + fn);
 }
 void native_kernels_t::set_tune(string const &key, string const &val) {
-  if (key != "sgemm_tile" && key != "conv_tile" && key != "k1_stream" && key != "conv_algo") rt_err("set_tune: unknown key '" + key + "'");
+  if (key != "sgemm_tile" && key != "conv_tile" && key != "k1_stream" && key != "conv_algo" && key != "exact") rt_err("set_tune: unknown key '" + key + "'");
+  if (key == "exact" && !val.empty() && val != "0" && val != "1") rt_err("set_tune: exact must be 0 | 1");
   if (key == "conv_algo" && !val.empty() && val != "direct" && val != "winograd" && val != "winograd_all") rt_err("set_tune: conv_algo must be direct | winograd | winograd_all");
   if (val.empty()) impl->tune.erase(key); else { impl->tune[key] = val; }
 }
@@ -387,7 +389,31 @@ static bool plan_ipconv_dma(conv_geom_t const &g, int num_cus, plan_t &p) {
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
   return true;
 }
-static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false, string const &k1s = string(), bool allow_splitk = true) {
+// Tolerance mode (tune `exact` = 0, op_tune hip_exact=0): the default fp32 plan keeps every output ONE ascending-k fma chain -- bit-identical to the
+// reference's per-thread loop -- which leaves tile-starved layers with a long K (AlexNet fc6 / fc7 / fc8: 256 / 256 / 64 tiles of 64x64 for 256
+// CUs, 128-288 barrier-separated K steps each) on one workgroup per CU.  The reference's own bar is a tolerance, not bit equality; with exact = 0
+// the planner may cut K into slices (deterministic: slice s owns K-tiles [s*kt_per, (s+1)*kt_per), the slabs are summed in ascending slice
+// order by bodahip_splitk_reduce) when the tiles do not fill the chip and K >= 2048.  That re-associates the sum: on the reference's U(-5,5)
+// data fc6 (K = 9216) then differs from the single chain by mrd 8.6e-4 -- inside the reference's bound for re-associating kernels (2e-3,
+// src/rtc_prof.cc:317-319,436), outside its 2e-4 default (:161), and no farther from the exact fp64 product than the chain itself (tested).
+// Measured (MI355X, AlexNet at 256 images, TF/s): fc6 75 -> 94 alone, 80 -> 106 in the layer sequence (64x64, 4 slices of 72 K steps),
+// fc7 78 -> 94, fc8 33 -> 57.
+static void tolerance_splitk(plan_t &p, conv_geom_t const &g, int num_cus, long Nj, long Kt) {
+  if (p.bf16 || p.stream || p.patch16 || p.patch || p.nhwc || p.rows || p.cfg.SPLITK != 1 || Kt < 2048) return;
+  tile_cfg_t c = p.cfg;
+  long tiles = (long)((g.OC + c.BI - 1) / c.BI) * ((Nj + c.BJ - 1) / c.BJ);
+  if (tiles > num_cus) return;
+  if (c.MT != 32 || c.BI < 64 || c.BJ < 64) {   // the thin tiles tile starvation chose: with K slices the common 64x64 tile fills the chip
+    c.BI = 64; c.BJ = 64; c.BK = 32; c.WI = 2; c.WJ = 2; c.MINW = 2; c.MT = 32; c.PF = 2;
+    tiles = (long)((g.OC + 63) / 64) * ((Nj + 63) / 64);
+  }
+  long const nkt = (Kt + c.BK - 1) / c.BK;
+  int sk = 1;
+  while (sk < 16 && nkt / (sk * 2) >= 32 && tiles * sk * 2 <= 4l * num_cus) sk *= 2;
+  if (sk < 2) return;
+  c.SPLITK = sk; p.cfg = c;
+}
+static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false, string const &k1s = string(), bool allow_splitk = true, bool exact = true) {
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   plan_t p;
   if (!bf16 && tile.empty() && plan_ipconv_dma(g, num_cus, p)) return p;
@@ -455,6 +481,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
     }
   }
   if (p.patch && tile.empty()) p.cfg.PF = pf_for(p.cfg);
+  if (!bf16 && !exact && tile.empty() && allow_splitk) tolerance_splitk(p, g, num_cus, Nj, Kt);
   if (bf16) bf16_cfg(p.cfg, !p.ipconv, g.OC, Nj, Kt, allow_splitk ? num_cus : 0, !tile.empty());
   else check_cfg(p.cfg, !p.ipconv && !p.patch);
   p.defs = cfg_defs(p.cfg);
@@ -793,7 +820,11 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   if (!Nj || !g.OC) return;
   if (Nj > 0x7fffffffl || Kt > 0x7fffffffl) unsup_err("hip_conv: dims exceed int32");
-  if (!bf16 && winograd_applies(g, algo ? string(algo) : tune_of(impl, "conv_algo")) && tune_of(impl, "conv_tile").empty()) {
+  bool const exact = tune_of(impl, "exact") != "0";
+  // tolerance mode: 3x3 / stride-1 layers take the F(2x2,3x3) path where it measured ahead of the direct kernel unless conv_algo says otherwise
+  // (the reference holds Winograd results to mrd < 2e-3, src/rtc_prof.cc:317-319,436)
+  string const conv_algo = algo ? string(algo) : (tune_of(impl, "conv_algo").empty() && !exact ? string("winograd") : tune_of(impl, "conv_algo"));
+  if (!bf16 && winograd_applies(g, conv_algo) && tune_of(impl, "conv_tile").empty()) {
     conv_winograd(filts, biases, in, out, g, out_ctot, out_coff); return;
   }
   if (bf16 && tune_of(impl, "conv_tile").empty()) {
@@ -837,7 +868,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
       return;
     }
   }
-  plan_t const p = plan_conv(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), bf16, tune_of(impl, "k1_stream"), out_ctot == g.OC);
+  plan_t const p = plan_conv(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), bf16, tune_of(impl, "k1_stream"), out_ctot == g.OC, exact);
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
   if (p.nhwc) {   // (fp32 here: the k-contiguous shapes through the LDS-DMA kernel, plan_ipconv_dma)
@@ -969,7 +1000,7 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
     else if (bf16 && tile.empty() && s2d_geom(g, g2, pry, prx) && plan_patch_bf16(g2, num_cus, p)) { // conv1-type layers: space-to-depth front end (see conv())
       s2d = "s2d(" + std::to_string(g2.C) + "x" + std::to_string(g2.H) + "x" + std::to_string(g2.W) + ",k" + std::to_string(g2.KH) + "x" + std::to_string(g2.KW) + ")+";
       if (!arch.empty()) { plan_t sp; sp.patch16 = true; sp.bf16 = true; sp.kname = "bodahip_s2d"; sp.defs = {"-DS2D_ONLY=1"}; compile_plan(sp, arch, &log); }
-    } else p = plan_conv(g, num_cus, tile, bf16);
+    } else { auto xe = op.str_vals.find("hip_exact"); p = plan_conv(g, num_cus, tile, bf16, string(), true, !(xe != op.str_vals.end() && xe->second == "0")); }
   } else rt_err("prebuild: op type '" + t + "' has no native kernel");
   if (plan_out) { *plan_out = s2d + p.kname + " " + p.cfg.str(); for (auto const &d : p.defs) *plan_out += " " + d; }
   if (arch.empty()) return 0;
@@ -1025,8 +1056,22 @@ struct tile_override_t {
   ~tile_override_t() { if (!active) return; if (had) impl->tune[key] = old; else impl->tune.erase(key); }
 };
 
+// str_val hip_exact of the annotated op (op_tune hip_exact=0): tolerance mode for this function's calls only
+struct exact_override_t {
+  native_kernels_t::impl_t *impl; bool active = false, had = false; string old;
+  exact_override_t(native_kernels_t::impl_t *impl_, op_base_t const &op) : impl(impl_) {
+    auto it = op.str_vals.find("hip_exact");
+    if (it == op.str_vals.end() || it->second.empty()) return;
+    if (it->second != "0" && it->second != "1") rt_err("hip_exact must be 0 | 1, got '" + it->second + "'");
+    active = true; auto t = impl->tune.find("exact"); had = (t != impl->tune.end()); if (had) old = t->second;
+    impl->tune["exact"] = it->second;
+  }
+  ~exact_override_t() { if (!active) return; if (had) impl->tune["exact"] = old; else impl->tune.erase("exact"); }
+};
+
 void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &am) {
   string const &fn = fi.op.get_func_name();
+  exact_override_t const xov(impl, fi.op);
   bool const bf16 = (fn == "hip_sgemm_bf16" || fn == "hip_conv_bf16");
   if (fn == "hip_sgemm" || fn == "cublas_sgemm" || fn == "hip_sgemm_bf16") {
     string const an = var_of(am, "a"), bn = var_of(am, "b"), cn = var_of(am, "c");

@@ -69,6 +69,8 @@ struct native_kernels_t {
 
   // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"; key "k1_stream" -> "off" | "WIxWJxOCBxCB[xMINW]";
   // key "conv_algo" -> "winograd": 3x3 / stride-1 convs go through the F(2x2,3x3) path (kernels/winograd_f32.hip; not bit-exact)
+  // key "exact" -> "0": tolerance mode -- fp32 results within the reference's bound for re-associating kernels (mrd < 2e-3, src/rtc_prof.cc:317-319) instead of bit-identical to
+  // its fma chain: deterministic K slices on tile-starved long-K layers, Winograd where it is faster.  Default ("" / "1"): bit-exact plans only
   void set_tune(string const &key, string const &val);
   static size_t prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile, string *plan_out = nullptr);
   launch_info_t last_launch;

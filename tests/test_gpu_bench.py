@@ -51,3 +51,5 @@ def test_default_line_carries_conv_ops():
         assert len(co[nm]["per_op"]) == n_layers and co[nm]["value"] > 0 and 0 < co[nm]["roofline"]["frac"] <= 1
     h = co["nin"]["roofline"]["hbm_frac_1x1"]                             # cccp1 / cccp2 (AI 24): priced against HBM as well
     assert h["layers"] == [1, 2] and 0 < h["frac"] <= 1
+    tol = co["tolerance_mode"]                                              # op_tune hip_exact=0 beside the bit-exact default
+    assert set(tol) == {"alexnet", "nin"} and all(0 < v["frac"] <= 1 and v["value"] > 0 for v in tol.values())

@@ -869,6 +869,39 @@ def test_config5_layers_at_bench_batch_prefix_invariance(be, net, batch):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# tolerance mode (op_tune hip_exact=0): deterministic K slices on tile-starved long-K layers, Winograd on 3x3 / stride-1 layers.  Both re-associate
+# the fp32 sum, so they are held to the reference's bound for re-associating kernels (mrd < 2e-3, src/rtc_prof.cc:317-319,436) against the
+# bit-exact chain -- NOT to its 2e-4 default (:161): on the reference's own U(-5,5) data a K = 9216 dot product carries ~1e-2 of absolute
+# rounding error in ANY association (the single chain included), which is 8.6e-4 of the smaller outputs (measured, fc6) -- and, for the K
+# slices, to the exact fp64 result: no farther from it than the reference's chain is.  At the benched batch.
+# ---------------------------------------------------------------------------------------------------------------
+def test_tolerance_mode_at_bench_batch(be):
+    import bench
+    big, small = bench.alexnet_b256_ops(256), bench.alexnet_b256_ops(2)
+    seen = set()
+    for i in (2, 5, 6, 7):    # conv3 (3x3: Winograd), fc6 / fc7 / fc8 (K = 9216 / 4096 / 4096 on 256 / 256 / 64 tiles: K slices)
+        outs, prc = _run(be, big[i], 5, tune=OpTune(hip_exact=0))
+        assert prc.op.str_vals.get("hip_exact") == "0"
+        want = bo.run_op(small[i], 5)["out"]
+        sd = SsdsDiff.of(want, outs["out"][:2])
+        assert not sd.has_nan() and sd.mrd < MRD_REASSOC, (prc.launch, sd.basic_str())
+        if i == 2:
+            assert "winograd" in prc.launch["kernel"], prc.launch
+        else:
+            assert "_s" in prc.launch["cfg"], prc.launch
+            g = small[i].conv_geom(); K = g["C"] * g["KH"] * g["KW"]
+            x = bo.gen_conv_in(2, g["C"], g["H"], g["W"]).reshape(2, K).astype(np.float64)
+            f = bo.gen_conv_filts(g["OC"], g["C"], g["KH"], g["KW"]).reshape(g["OC"], K).astype(np.float64)
+            exact64 = np.maximum(x @ f.T + bo.gen_conv_biases(g["OC"]).astype(np.float64), 0.0).reshape(want.shape)
+            err_slices = np.abs(outs["out"][:2].astype(np.float64) - exact64).max(); err_chain = np.abs(want.astype(np.float64) - exact64).max()
+            assert err_slices <= 1.25 * err_chain + 1e-6, (i, err_slices, err_chain)
+        seen.add(prc.launch["kernel"])
+        exact, prc_e = _run(be, big[i], 5)                                  # the default stays the bit-exact plan
+        assert "_s" not in prc_e.launch["cfg"] and "winograd" not in prc_e.launch["kernel"] and np.array_equal(want, exact["out"][:2])
+    assert len(seen) == 2
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # bf16 kernels at the BENCHED sizes (BASELINE config 5: 64 images per GPU; config 3's fc layers at 256; sgemm-ops-full >= 2048).
 # Parity is unpinned for bf16 by construction (the reference has none): the stated bound is  mrd < 1e-3 * max(1, sqrt(K/2400))
 # against the oracle fed the same bf16-rounded operands, enforced here where the bench runs.
