@@ -19,7 +19,7 @@ trailing `int32_t cai__<arg>_<dim>_{dim,stride}` / `cai__<arg>_dims_prod` by-val
 (`Instance.call_args`; `add_dyn_nda_dims_sz`, `src/rtc_func_gen.cc:429-469`, `rcg_func_call_t::run`, `:496-584`).  `_multi`
 arguments (`float_multi const * const ins`: a pack of op[`ins_num`] arguments `ins_0` .. declared through `%(ins_decl)`, `src/rtc_func_gen.cc:24-41,
 143-151,388-391`) expand per op; custom code generation is a hook (`custom`), restated for the reference's sgemm / conv variants and `reduce` in
-`boda_amd/cnn_codegen.py`.
+`oracle/cnn_codegen.py`.
 """
 from __future__ import annotations
 import os

@@ -11,7 +11,9 @@ Two layers of the reference are restated here (behaviour, not code):
 The templates themselves are NOT part of this repository: `instantiate_ref` reads them from a Boda checkout's test/rtc directory.  Where a
 checkout exists (the build container), oracle/ref_cucl.py instantiates them for a list of ops and compiles them for gfx950 into
 oracle/_ref/ (code objects + a manifest of launch geometries) -- the reference's real kernels, timed and checked on the GPU box beside the
-native ones (tests/test_gpu_ref_cucl.py, bench.py's `ref_cucl_gpu` object).
+native ones (tests/test_gpu_ref_cucl.py; their times: DESIGN.md section 5).
+This module is TEST INFRASTRUCTURE (it lives under oracle/ with its only users, oracle/ref_cucl.py and the tests): the product's own annotation
+layer is boda_amd/cnn_op.py, which routes ops to the native kernels.
 
 Covered: all four sgemm variants (use_local_mem 0..3; vector width 2 / 4), conv / conv_simd / k1conv / k1conv_simd / tconv / ipconv, reduce; sgemm_prof and the
 backward ops raise UnsupErr.
@@ -20,9 +22,9 @@ from __future__ import annotations
 import os
 from typing import Callable, Dict, List, Optional, Tuple
 
-from .cnn_op import OpTune
-from .cucl_template import CallGen, Instance, instantiate, load_template
-from .op import Dims, Nda, Op, RtErr, UnsupErr
+from boda_amd.cnn_op import OpTune
+from boda_amd.cucl_template import CallGen, Instance, instantiate, load_template
+from boda_amd.op import Dims, Nda, Op, RtErr, UnsupErr
 
 
 def _cdiv(a: int, b: int) -> int:
@@ -93,7 +95,7 @@ def annotate_ref(op: Op, tune: OpTune) -> Op:
             raise UnsupErr("CUCL compatibility mode: the sgemm_prof variant is not generated")
         variants = {0: "sgemm_no_local", 1: "sgemm", 2: "sgemm_simd", 3: "sgemm_simd_local"}      # src/cnn_op.cc:368-374
         if tune.use_local_mem not in variants:
-            raise RtErr(f"unknonw value for op_tune.use_local_mem of {tune.use_local_mem}")
+            raise RtErr(f"op_tune.use_local_mem must be 0..3, got {tune.use_local_mem}")
         mb, nb = tune.MNb[0] * tune.MNt[0], tune.MNb[1] * tune.MNt[1]
         for what, v, blk in (("M", g["M"], mb), ("N", g["N"], nb), ("K", g["K"], tune.Kb)):
             if v % blk:   # (the reference's own restriction, src/cnn_op.cc:349-360: its default tune cannot run sgemm 64^3)
@@ -388,12 +390,12 @@ def gen_conv(cg: CallGen) -> None:
     cg.line("stores", "int32_t tpix[%(work_pels_dim)];")
     cg.line("stores", "int32_t tcix[%(work_out_chan_dim)];")
     for ty in range(P):
-        cg.line("stores", f"tpix[{ty}] = %(pel_ix_{ty}_img)*%(out_img_stride) + ( %(pel_ix_{ty}_x_nomod) %% (%(out_y_dim)*%(out_x_dim)) ); // cache out pel ixs ")
+        cg.line("stores", f"tpix[{ty}] = %(pel_ix_{ty}_img)*%(out_img_stride) + ( %(pel_ix_{ty}_x_nomod) %% (%(out_y_dim)*%(out_x_dim)) );")
     for tx in range(OC):
-        cg.line("stores", f"  tcix[{tx}] = (%(out_chan_ix)+{tx})*%(out_chan_stride); // cache out chan ixs")
+        cg.line("stores", f"  tcix[{tx}] = (%(out_chan_ix)+{tx})*%(out_chan_stride);")
     _fma_tile(cg, "fmas", work, lambda ty: ty)
     for ty in range(P):
-        cg.line("stores", f"if( %(pel_ix_{ty}_x_nomod) >= %(pel_ix_0_dims_prod) ) {{ return; }} // this pel and the following are off-the-end pels, so don't store them.")
+        cg.line("stores", f"if( %(pel_ix_{ty}_x_nomod) >= %(pel_ix_0_dims_prod) ) {{ return; }}")
         for tx in range(OC):
             cg.line("stores", f"if( tcix[{tx}] < (%(out_chan_dim)*%(out_chan_stride)) ) {{ out[ tpix[{ty}] + tcix[{tx}] ] = {_bias_relu(cg, work, tx, ty)}; }}")
 
@@ -420,11 +422,11 @@ def gen_k1conv(cg: CallGen) -> None:
     for ty in range(P):
         cg.insert_nda_ix_exprs(f"out_pel_{ty}", cg.all_ix_dims["out_ref_pel"],
                                f"( (%(GRP_ID_1D_pels_blk)*%(work_pels_tile_dim) + %(LOC_ID_1D_pels_tile))*%(work_pels_dim) + {ty} )")
-        cg.line("stores", f"  tpix[{ty}] = %(out_pel_{ty}_img)*%(out_img_stride) +  %(out_pel_{ty}_x)*%(out_x_stride) + %(out_pel_{ty}_y)*%(out_y_stride)   ; // cache out pel ixs")
+        cg.line("stores", f"  tpix[{ty}] = %(out_pel_{ty}_img)*%(out_img_stride) +  %(out_pel_{ty}_x)*%(out_x_stride) + %(out_pel_{ty}_y)*%(out_y_stride);")
     for tx in range(OC):
-        cg.line("stores", f"  tcix[{tx}] = (%(out_chan_ix)+{tx})*%(out_chan_stride); // cache out chan ixs")
+        cg.line("stores", f"  tcix[{tx}] = (%(out_chan_ix)+{tx})*%(out_chan_stride);")
     for ty in range(P):
-        cg.line("stores", f"  if( %(out_pel_{ty}_img) >= %(out_img_dim) ) {{ return; }} // this pel and the following are off-the-end pels, so don't store them.")
+        cg.line("stores", f"  if( %(out_pel_{ty}_img) >= %(out_img_dim) ) {{ return; }}")
         for tx in range(OC):
             cg.line("stores", f"if( tcix[{tx}] < (%(out_chan_dim)*%(out_chan_stride)) ) {{ out[ tpix[{ty}] + tcix[{tx}] ] = {_bias_relu(cg, work, tx, ty)}; }}")
     for ty in range(P):
@@ -493,7 +495,7 @@ def gen_ipconv(cg: CallGen) -> None:
         cg.line("loads", f"in_strip[{ty}] = in_smem_off[{ty}*%(work_fioc_tile_dim)];")
     _fma_tile(cg, "fmas", work, lambda ty: ty)
     # the store loop runs over the thread's pels at run time: row work_pel of the register tile is copied into filts_strip first
-    cg.line("outs_to_filts_strip", "if( (in_pel+work_pel) >= %(in_img_dim) ) { return; } // this pel and the following are off-the-end pels, so don't store them.")
+    cg.line("outs_to_filts_strip", "if( (in_pel+work_pel) >= %(in_img_dim) ) { return; }")
     cg.line("outs_to_filts_strip", "switch(work_pel) { ")
     for ty in range(P):
         cg.line("outs_to_filts_strip", f"case {ty}:")

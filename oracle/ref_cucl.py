@@ -3,7 +3,7 @@
 The reference's arithmetic exists only as CUCL templates (test/rtc/{sgemm,conv,k1conv,tconv,xpose_filts,k1conv_xpose_in,tconv_xpose_in}.cucl
 of a Boda checkout) that its code generator instantiates per op and hands to NVRTC / OpenCL.  Where a checkout is present (the build
 container: /root/reference), this recipe instantiates them with this repository's restatement of that generator
-(boda_amd/cucl_template.py + boda_amd/cnn_codegen.py), compiles each generated function with hiprtc for gfx950, and writes
+(boda_amd/cucl_template.py + oracle/cnn_codegen.py), compiles each generated function with hiprtc for gfx950, and writes
     oracle/_ref/cucl/<function>.hsaco      code objects (git-ignored; they travel to the GPU box like any built .so)
     oracle/_ref/cucl/manifest.json         per op: the op line, the tune, per function its name, argument list and kinds, tpb, blks
 Nothing of the reference's text is kept: the generated sources exist only in memory.  On the GPU box tests/test_gpu_ref_cucl.py loads the
@@ -72,7 +72,8 @@ def build(rtc_dir: str = REF_RTC_DIR, verbose: bool = False) -> int:
         return 0
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
-    from boda_amd import cnn_codegen as cc, rtc
+    from boda_amd import rtc
+    from oracle import cnn_codegen as cc
     from boda_amd.cucl_template import load_template
     os.makedirs(OUT, exist_ok=True)
     manifest, n = [], 0

@@ -5,7 +5,8 @@ import os
 import pytest
 
 import bench
-from boda_amd import cnn_codegen as cc, rtc
+from boda_amd import rtc
+from oracle import cnn_codegen as cc
 from boda_amd.cnn_op import OpTune
 from boda_amd.op import RtErr, UnsupErr
 

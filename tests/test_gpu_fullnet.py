@@ -332,3 +332,61 @@ def test_full_net_forward_channels_last_bf16(rtc, net, batch):
         assert np.array_equal(fwd._fetch(out), want)
     finally:
         fwd.release()
+
+
+@pytest.mark.parametrize("net,batch", [("nin", 128), ("alexnet", 256)])
+@pytest.mark.parametrize("mode", ["f32", "nhwc_bf16"])
+def test_full_net_forward_at_bench_batch(rtc, net, batch, mode):
+    """The whole net at the BENCHED per-GPU batch (BASELINE config 4: NiN at 128 images per GPU; AlexNet at config 3's 256) -- where the planner
+    picks other tiles and kernels than at batch 2 and the templated pool / LRN kernels run over 10^7-10^8 elements -- checked through batch-prefix
+    invariance: inputs are a hash of the flat index, so the first two images of the big input ARE the batch-2 input, and every op of the path
+    works per image: node[:2] of the big run against the oracle's batch-2 forward (pools and LRN included).  fp32: bit-exact up to the first
+    LRN / average pool, the reference's full-net tolerance 5e-4 (src/test_compute.cc:45) after it; channels-last bf16: the bounds of
+    test_full_net_forward_channels_last_bf16.  The last image must be finite and not all zero."""
+    from boda_amd.cnn_op import OpTune
+    mk = {"nin": nin_imagenet, "alexnet": alexnet_ng_conv}[net]
+    cp, cp2 = mk(batch), mk(2)
+    params = _params(cp2)
+    data = bo.gen_conv_in(*cp.nodes["data"].sizes)
+    assert np.array_equal(data[:2], bo.gen_conv_in(*cp2.nodes["data"].sizes))
+    fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc") if mode == "nhwc_bf16" else None)
+    fwd.init(cp, op_params=params)
+    try:
+        nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
+        io = {"data": data}
+        fwd.run_fwd(["data"], io, nodes)
+        head = {n: np.ascontiguousarray(io[n][:2]) for n in nodes}
+        last = io[cp.out_node()][-1]
+        assert np.isfinite(last).all() and np.abs(last).max() > 0
+        del io
+        depth = {cp2.in_node: 0}
+        for op in cp2.ops:
+            depth[op.top] = max(depth[b] for b in (op.bots or (op.bot,))) + (1 if op.type == "Convolution" else 0)
+        if mode == "f32":
+            want = oracle_forward(cp2, data[:2], params)
+            exact = True
+            for op in cp2.ops:
+                if op.type in ("ReLU", "Dropout"):
+                    continue
+                if op.type == "LRN" or (op.type == "Pooling" and op.avg_pool):
+                    exact = False      # (powf / fast-math division: ulp-level differences from here on)
+                sd = SsdsDiff.of(want[op.top], head[op.top])
+                assert not sd.has_nan() and sd.mrd < FULLNET_MRD, (op.top, sd.basic_str())
+                if exact:
+                    assert np.array_equal(want[op.top], head[op.top]), (op.top, sd.basic_str())
+        else:
+            want_b = oracle_forward(cp2, data[:2], params, store_bf16=True)
+            want_x = oracle_forward(cp2, data[:2], params)
+            def nrms(w, g):
+                w = w.astype(np.float64); g = g.astype(np.float64)
+                return float(np.sqrt(np.mean((w - g) ** 2)) / max(1e-30, np.sqrt(np.mean(w ** 2))))
+            for op in cp2.ops:
+                if op.type in ("ReLU", "Dropout"):
+                    continue
+                g = head[op.top]
+                assert np.isfinite(g).all() and np.array_equal(bo.to_bf16(g), g), op.top
+                eb, ex = nrms(want_b[op.top], g), nrms(want_x[op.top], g)
+                assert eb < 1.5e-2, (op.top, "vs the oracle forward with the device's roundings", eb)
+                assert ex < 4.5e-3 * np.sqrt(max(1, depth[op.top])), (op.top, depth[op.top], "vs exact fp32 forward", ex)
+    finally:
+        fwd.release()

@@ -13,7 +13,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from boda_amd import cnn_codegen as cc, gen_data as gd
+from boda_amd import gen_data as gd
+from oracle import cnn_codegen as cc
 from boda_amd.cnn_op import OpTune
 from boda_amd.digest import SsdsDiff
 from boda_amd.op import Dims, parse_op
