@@ -37,10 +37,10 @@ int rtc_test_main( int argc, char ** argv ) {
     // an unsupported request must come back as unsup_err through the adapter (rc 1 of the C ABI)
     bool unsup = false;
     try { op_base_t bad; bad.set_func_name( "hip_sgemm" ); rtc->compile( vect_rtc_func_info_t{ rtc_func_info_t{ "sg", "", {"a","b","c"}, bad } }, rtc_compile_opts_t() );
-      rtc->create_var_with_dims( "ha", dims_t( {4, 4}, {"K", "M"}, "half" ) ); rtc->create_var_with_dims( "hb", dims_t( {4, 4}, {"K", "N"}, "half" ) ); rtc->create_var_with_dims( "hc", dims_t( {4, 4}, {"M", "N"}, "half" ) );
+      rtc->create_var_with_dims( "ha", dims_t( {4, 4}, {"K", "M"}, "double" ) ); rtc->create_var_with_dims( "hb", dims_t( {4, 4}, {"K", "N"}, "double" ) ); rtc->create_var_with_dims( "hc", dims_t( {4, 4}, {"M", "N"}, "double" ) );
       rtc_func_call_t r2; r2.rtc_func_name = "sg"; r2.arg_map["a"] = rtc_arg_t( "ha" ); r2.arg_map["b"] = rtc_arg_t( "hb" ); r2.arg_map["c"] = rtc_arg_t( "hc" ); rtc->run( r2 );
     } catch( unsup_exception const & ) { unsup = true; }
-    if( !unsup ) { printf( "half-typed hip_sgemm did not raise unsup_err through the adapter\n" ); return 1; }
+    if( !unsup ) { printf( "double-typed hip_sgemm did not raise unsup_err through the adapter\n" ); return 1; }
     printf( "All is Well. plat_tag=%s my_dot %.4f ms\n", rtc->get_plat_tag().c_str(), ms );
     return 0;
   } catch( std::exception const & e ) { printf( "error: %s\n", e.what() ); return 2; }

@@ -80,8 +80,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef ABLATE
 #define ABLATE 0 // experiment hook (tools/tile_sweep.py via BODAHIP_EXTRA_DEFS): 1 no epilogue stores | 2 no J loads | 4 no in-loop LDS stores | 8 no I loads
 #endif
+#ifndef HALF
+#define HALF 0 // 1 (sgemm, I_MODE / J_MODE 0 | 1, EPI 0): a / b / c are STORED as IEEE half (2-byte elements; ld* and the element offsets unchanged), converted to
+#endif         // float on the way into LDS, accumulated by the same fp32 MFMA chain, rounded to half (RNE) when stored -- the reference's 16-bit-storage /
+               // fp32-math sgemm (vload_half / vstore_half, src/cnn_codegen.cc:440-449, test/sgemm-ops-debug-half.txt).  half -> float is exact, so the
+               // result is bit-identical to the reference's per-thread fmaf loop over the converted values.
 #ifndef SWAPST
-#define SWAPST ((BJ / (WJ * 32)) % 2 == 0) // paired 256-byte row stores in the epilogue (see there); 0 forces the plain per-block stores
+#define SWAPST (((BJ / (WJ * 32)) % 2 == 0) && !HALF) // paired 256-byte row stores in the epilogue (see there); 0 forces the plain per-block stores
 #endif
 #ifndef PF
 #define PF 1 // K-tiles prefetched ahead in registers: 1 | 2 (two register sets; for workgroups that run alone on their CU)
@@ -178,8 +183,34 @@ __device__ __forceinline__ f32x2 bload2(rsrc_t r, int byte_off) { return __built
 __device__ __forceinline__ f32x3 bload3(rsrc_t r, int byte_off) { return __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, byte_off, 0, 0)); }
 __device__ __forceinline__ float bload1(rsrc_t r, int byte_off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0)); }
 
+#if HALF
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+static_assert((I_MODE == 0 || I_MODE == 1) && (J_MODE == 0 || J_MODE == 1) && EPI == 0 && !SPLITK, "half storage: plain k-major sgemm operands only");
+#endif
 template <int MODE, int BX, int NR>
 __device__ __forceinline__ void load_tile(float (&r)[NR], rsrc_t P, int ld, int x0, int X, int k0, int K, int tid) {
+#if HALF
+  if constexpr (MODE == 0) {   // four consecutive halves = one 8-byte load (rows start 8-byte aligned: ld % 4 == 0)
+    constexpr int VPR = BX / 4, TOT = BK * VPR;
+#pragma unroll
+    for (int p = 0; p < NR / 4; ++p) {
+      int const v = tid + p * kNT, row = v / VPR, c4 = v % VPR;
+      int const k = k0 + row, x = x0 + 4 * c4;
+      bool const in_tile = ((p + 1) * kNT <= TOT) || (v < TOT);
+      h16x4 const val = __builtin_bit_cast(h16x4, __builtin_amdgcn_raw_buffer_load_b64(P, (in_tile && (k < K) && (x < X)) ? ((k * ld + x) * 2) : kOOB, 0, 0));
+      r[4 * p + 0] = (float)val[0]; r[4 * p + 1] = (float)val[1]; r[4 * p + 2] = (float)val[2]; r[4 * p + 3] = (float)val[3];
+    }
+  } else {
+    constexpr int TOT = BK * BX;
+#pragma unroll
+    for (int p = 0; p < NR; ++p) {
+      int const e = tid + p * kNT, row = e / BX, c = e % BX;
+      int const k = k0 + row, x = x0 + c;
+      bool const in_tile = ((p + 1) * kNT <= TOT) || (e < TOT);
+      r[p] = (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(P, (in_tile && (k < K) && (x < X)) ? ((k * ld + x) * 2) : kOOB, 0, 0));
+    }
+  }
+#else
   if constexpr (MODE == 0) {
     constexpr int VPR = BX / 4, TOT = BK * VPR;
 #pragma unroll
@@ -229,6 +260,7 @@ __device__ __forceinline__ void load_tile(float (&r)[NR], rsrc_t P, int ld, int 
       r[p] = bload1(P, (in_tile && (x < X) && (k < K)) ? ((x * ld + k) * 4) : kOOB);
     }
   }
+#endif
 }
 
 // registers -> LDS image [BK][LD] (k-major)
@@ -644,6 +676,8 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #if EPI == 1
     rsrc_t const rB = make_rsrc(p.bias, (unsigned)p.Mi * 4u);
     unsigned const S4 = (unsigned)(p.OH * p.OW) * 4u;
+#elif HALF
+    unsigned const S4 = (unsigned)p.ldD * 2u;   // (row pitch in bytes of the half-typed c)
 #else
     unsigned const S4 = (unsigned)p.ldD * 4u;
 #endif
@@ -708,6 +742,8 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
         int const OHW = p.OH * p.OW;
         int const img = jg / OHW, pel = jg - img * OHW;
         unsigned const jpart = (((unsigned)img * (unsigned)p.out_ctot + (unsigned)p.out_coff) * (unsigned)OHW + (unsigned)pel) * 4u;
+#elif HALF
+        unsigned const jpart = (unsigned)jg * 2u;
 #else
         unsigned const jpart = (unsigned)jg * 4u;
 #endif
@@ -726,7 +762,11 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #if ABLATE & 1
             if (v == 123.456f)
 #endif
+#if HALF
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)v), rD, (int)(jpart + ipart), (int)((unsigned)rowc(ta, r) * S4), 0);   // (RNE, as vstore_half)
+#else
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rD, (int)(jpart + ipart), (int)((unsigned)rowc(ta, r) * S4), 0);
+#endif
           }
       }
     };

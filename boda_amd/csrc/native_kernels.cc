@@ -629,11 +629,13 @@ static sgemm_split_t plan_sgemm_split(uint32_t M, uint32_t N, uint32_t K, int nu
   return sp;
 }
 
-void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16) {
+void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16, bool half) {
   if (!M || !N) return;
-  if (!K) { hip_err_chk(hipMemsetAsync(c, 0, (size_t)M * N * 4, host->nh_stream()), "hipMemsetAsync"); return; }
+  size_t const esz = half ? 2 : 4;   // half: a / b / c stored as IEEE half, fp32 math (the reference's 16-bit-storage sgemm, src/cnn_codegen.cc:440-449)
+  if (half && bf16) unsup_err("hip_sgemm_bf16: half-typed tensors are not supported (bf16 OPERANDS are made from float tensors)");
+  if (!K) { hip_err_chk(hipMemsetAsync(c, 0, (size_t)M * N * esz, host->nh_stream()), "hipMemsetAsync"); return; }
   if (M > 0x7fffffffu || N > 0x7fffffffu || K > 0x7fffffffu) unsup_err("hip_sgemm: dims exceed int32");
-  if (!bf16 && tune_of(impl, "sgemm_tile").empty()) {
+  if (!bf16 && !half && tune_of(impl, "sgemm_tile").empty()) {
     sgemm_split_t const sp = plan_sgemm_split(M, N, K, host->nh_num_cus());
     if (sp.m_main) {
       if ((uint64_t)K * M * 4 > 0x80000000ull || (uint64_t)K * N * 4 > 0x80000000ull || (uint64_t)M * N * 4 >= 0x7ffffff0ull) unsup_err("hip_sgemm: operands / c of 2 GiB or more are not supported (32-bit buffer offsets)");
@@ -655,24 +657,28 @@ void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t 
       return;
     }
   }
-  plan_t const p = plan_sgemm(M, N, K, host->nh_num_cus(), tune_of(impl, "sgemm_tile"), bf16);
+  plan_t p = plan_sgemm(M, N, K, host->nh_num_cus(), tune_of(impl, "sgemm_tile"), bf16);
+  if (half) {
+    if (p.cfg.SPLITK > 1) unsup_err("hip_sgemm: split-K tiles are not supported for half-typed tensors");
+    p.kname = "bodahip_sgemm_f16s"; p.defs.push_back("-DHALF=1");
+  }
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
   gemm_args_t ga; memset(&ga, 0, sizeof(ga));
   ga.I = a; ga.J = b; ga.D = c; ga.bias = nullptr;
   ga.Mi = (int)M; ga.Nj = (int)N; ga.K = (int)K; ga.ldI = (int)M; ga.ldJ = (int)N; ga.ldD = (int)N;
   if ((uint64_t)K * M * 4 > 0x80000000ull || (uint64_t)K * N * 4 > 0x80000000ull) unsup_err("hip_sgemm: operands larger than 2 GiB are not supported (32-bit buffer offsets)");
-  ga.I_bytes = (unsigned)((uint64_t)K * M * 4); ga.J_bytes = (unsigned)((uint64_t)K * N * 4);
+  ga.I_bytes = (unsigned)((uint64_t)K * M * esz); ga.J_bytes = (unsigned)((uint64_t)K * N * esz);
   // (outputs share the operands' 2 GiB limit: the epilogue masks lanes past the last column with byte offset 0x80000000, which the
   //  buffer range check only drops while the output itself ends below that offset)
   if ((uint64_t)M * N * 4 >= 0x7ffffff0ull) unsup_err("hip_sgemm: c of 2 GiB or more is not supported (32-bit store offsets, masked lanes use offset 2^31)");
-  ga.D_bytes = (unsigned)((uint64_t)M * N * 4);
+  ga.D_bytes = (unsigned)((uint64_t)M * N * esz);
   ga.tiles_i = (int)((M + cfg.BI - 1) / cfg.BI); ga.tiles_j = (int)((N + cfg.BJ - 1) / cfg.BJ);
   setup_splitk(impl, host, ga, cfg, (size_t)M * N);
   launch(host, k, ga, cfg);
   if (cfg.SPLITK > 1) reduce_splitk(impl, host, ga, (long)M * N, false, false, 1, 1);
   last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)ga.tiles_i * ga.tiles_j * cfg.SPLITK; last_launch.block = cfg.threads();
-  last_launch.flops = 2.0 * M * N * K; last_launch.algo_bytes = 4.0 * ((double)K * M + (double)K * N + (double)M * N);
+  last_launch.flops = 2.0 * M * N * K; last_launch.algo_bytes = (double)esz * ((double)K * M + (double)K * N + (double)M * N);
 }
 
 // patch16 launch: filters re-laid-out once per call into F'[group][tap][out_chan][8] bf16 (scratch at ws_off), then the patch kernel
@@ -983,7 +989,7 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
   bool const bf16 = op.has_func_name() && (op.get_func_name() == "hip_sgemm_bf16" || op.get_func_name() == "hip_conv_bf16");
   if (t == "sgemm") {
     dims_t const &a = op.get_dims("a"), &b = op.get_dims("b");
-    sgemm_split_t sp; if (!bf16 && tile.empty()) sp = plan_sgemm_split(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus);
+    sgemm_split_t sp; if (!bf16 && tile.empty() && a.tn != "half") sp = plan_sgemm_split(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus);
     if (sp.m_main) {   // two-level tiling: the large tile over the first m_main rows (reported), small tiles over the rest
       plan_t const tp = plan_sgemm(a.dsz("M") - sp.m_main, b.dsz("N"), a.dsz("K"), num_cus, sp.tail_tile, false);
       p = plan_sgemm(sp.m_main, b.dsz("N"), a.dsz("K"), num_cus, kBigTile, false);
@@ -991,6 +997,7 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
       if (!arch.empty()) compile_plan(p, arch, &log);
       p = tp;
     } else p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, tile, bf16);
+    if (a.tn == "half") { s2d.clear(); p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, tile, false); p.kname = "bodahip_sgemm_f16s"; p.defs.push_back("-DHALF=1"); }
   }
   else if (t == "Convolution") {
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
@@ -1076,14 +1083,16 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
   if (fn == "hip_sgemm" || fn == "cublas_sgemm" || fn == "hip_sgemm_bf16") {
     string const an = var_of(am, "a"), bn = var_of(am, "b"), cn = var_of(am, "c");
     dims_t const a = host->nh_var_dims(an), b = host->nh_var_dims(bn), c = host->nh_var_dims(cn);
-    need_float(a, "a"); need_float(b, "b"); need_float(c, "c");
+    // storage type: float, or all three `half` (16-bit storage, fp32 math: the reference's sgemm with __tn__=half dims, test/sgemm-ops-debug-half.txt)
+    bool const half = (a.tn == "half" && b.tn == "half" && c.tn == "half");
+    if (!half) { need_float(a, "a"); need_float(b, "b"); need_float(c, "c"); }
     uint32_t const M = a.dsz("M"), K = a.dsz("K"), N = b.dsz("N");
     // same consistency checks as culibs_wrap_t::sgemm (src/culibs-wrap.cc:218-225); a is K:M, b is K:N, c is M:N
     assert_st(a.sz() == 2 && b.sz() == 2 && c.sz() == 2);
     assert_st(a.names(0) == "K" && a.names(1) == "M" && b.names(0) == "K" && b.names(1) == "N" && c.names(0) == "M" && c.names(1) == "N");
     assert_st(b.dsz("K") == K); assert_st(c.dsz("M") == M); assert_st(c.dsz("N") == N);
     tile_override_t const tov(impl, "sgemm_tile", fi.op);
-    sgemm((float const *)host->nh_var_ptr(an), (float const *)host->nh_var_ptr(bn), (float *)host->nh_var_ptr(cn), M, N, K, bf16);
+    sgemm((float const *)host->nh_var_ptr(an), (float const *)host->nh_var_ptr(bn), (float *)host->nh_var_ptr(cn), M, N, K, bf16, half);
     return;
   }
   if (fn == "hip_conv_nhwc") {

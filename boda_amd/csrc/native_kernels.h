@@ -59,7 +59,7 @@ struct native_kernels_t {
   void run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &arg_map);
 
   // direct entry points on raw device pointers (used by run() and by the C ABI's fast paths)
-  void sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16 = false);
+  void sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16 = false, bool half = false);   // half: 2-byte IEEE half elements, fp32 math
   void conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16 = false, int out_ctot = 0, int out_coff = 0,
             char const *algo = nullptr);
 

@@ -26,10 +26,10 @@ CUCL_DEVICE float det_hash_rand( uint32_t const rv ) {
 }
 """
 
-SRC = _UTIL + """
+_SGEMM_T = """
 // a: K:M
 // m_off / M_glob: this var holds columns [m_off, m_off+M) of a global K:M_glob tensor (batch-axis shard); unsharded: 0 / M
-CUCL_GLOBAL_KERNEL void gen_data_sgemm_a( GASQ float * const a, uint32_t const mode, float const vi, uint32_t const K, uint32_t const M,
+CUCL_GLOBAL_KERNEL void gen_data_sgemm_a%(SFX)( GASQ %(TN) * const a, uint32_t const mode, float const vi, uint32_t const K, uint32_t const M,
                                           uint32_t const m_off, uint32_t const M_glob ) {
   uint32_t fin_mode = mode; if( fin_mode >= 100 ) { fin_mode = fin_mode / 100; }
   if( GLOB_ID_1D >= K*M ) { return; }
@@ -41,10 +41,10 @@ CUCL_GLOBAL_KERNEL void gen_data_sgemm_a( GASQ float * const a, uint32_t const m
   else if( fin_mode == 4 ) { if( (m==M_glob/2) && (k==K/2) ) { val += 1.0f; } }
   else if( fin_mode == 5 ) { val += det_hash_rand( gix + 12738732 ); }
   else if( fin_mode == 6 ) { val += m*1000 + k; }
-  a[GLOB_ID_1D] = val;
+  store_float_to_rp_%(RPTN)( val, GLOB_ID_1D, a );
 }
 // b: K:N
-CUCL_GLOBAL_KERNEL void gen_data_sgemm_b( GASQ float * const b, uint32_t const mode, float const vi, uint32_t const K, uint32_t const N ) {
+CUCL_GLOBAL_KERNEL void gen_data_sgemm_b%(SFX)( GASQ %(TN) * const b, uint32_t const mode, float const vi, uint32_t const K, uint32_t const N ) {
   if( GLOB_ID_1D >= K*N ) { return; }
   uint32_t const k = GLOB_ID_1D / N; uint32_t const n = GLOB_ID_1D % N;
   float val = vi;
@@ -53,8 +53,16 @@ CUCL_GLOBAL_KERNEL void gen_data_sgemm_b( GASQ float * const b, uint32_t const m
   else if( mode == 4 ) { if( (n==N/2) && (k==K/2) ) { val += 1.0f; } }
   else if( mode == 5 ) { val += det_hash_rand( GLOB_ID_1D + 12738732 ); }
   else if( mode >= 100 ) { if( n==k ) { val += 1.0f; } }
-  b[GLOB_ID_1D] = val;
+  store_float_to_rp_%(RPTN)( val, GLOB_ID_1D, b );
 }
+"""
+# the sgemm generators exist per storage type, as the reference's templates do (`GASQ %(a_tn) * const a` + store_float_to_rp_%(a_tn),
+# test/rtc/gen_data_sgemm_a.cucl:2,20): float, and half for 16-bit-storage sgemms (test/sgemm-ops-debug-half.txt)
+def _sgemm_src(sfx: str, tn: str, rptn: str) -> str:
+    return _SGEMM_T.replace("%(SFX)", sfx).replace("%(TN)", tn).replace("%(RPTN)", rptn)
+
+
+SRC = _UTIL + _sgemm_src("", "float", "float") + _sgemm_src("_half", "_Float16", "half") + """
 // 4-D tensors ?:?:y:x (Convolution in / filts) and the 1-D biases; hc = per-tensor hash constant
 // ix_off: flat-index offset of this var inside the global tensor (img-axis shard of `in`: img0*chan*y*x); unsharded: 0
 // (the index declaration is what lets a multi-device backend run the function on a var sharded along img: csrc/hip_multi.cc)
@@ -81,6 +89,8 @@ CUCL_GLOBAL_KERNEL void gen_data_Convolution_biases( GASQ float * const biases, 
 FUNCS: Dict[str, List[str]] = {
     "gen_data_sgemm_a": ["a", "mode", "vi", "K", "M", "m_off", "M_glob"],
     "gen_data_sgemm_b": ["b", "mode", "vi", "K", "N"],
+    "gen_data_sgemm_a_half": ["a", "mode", "vi", "K", "M", "m_off", "M_glob"],
+    "gen_data_sgemm_b_half": ["b", "mode", "vi", "K", "N"],
     "gen_data_Convolution_4d": ["t", "mode", "vi", "sz", "Y", "X", "hc", "ix_off"],
     "gen_data_Convolution_biases": ["biases", "mode", "vi", "sz"],
 }
@@ -108,7 +118,7 @@ def gen_call(op_type: str, arg: str, vn: str, dims: Dims, mode: int, vi: float, 
         am = {arg: RtcArg.var(vn), **base, "K": u32(dims.dsz("K")), other: u32(dims.dsz(other))}
         if arg == "a":
             am["m_off"] = u32(shard_off); am["M_glob"] = u32(shard_glob or dims.dsz("M"))
-        fn = "gen_data_sgemm_" + arg
+        fn = "gen_data_sgemm_" + arg + ("_half" if dims.tn == "half" else "")
     elif op_type == "Convolution" and arg in ("in", "filts"):
         am = {"t": RtcArg.var(vn), **base, "sz": u32(n), "Y": u32(dims.dsz("y")), "X": u32(dims.dsz("x")),
               "hc": u32(HASH_CONSTS[(op_type, arg)]),

@@ -13,7 +13,7 @@ import os, shutil, sys
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 WIS = ["sgemm-gen5", "sgemm-gen600", "conv-gen5", "conv-debug", "conv-full-gen5", "ops-prof-conv-3x3-cudnn-boda"]
-OPS = ["sgemm-ops-micro.txt", "sgemm-ops-tiny.txt", "sgemm-ops-small.txt", "sgemm-ops-full.txt", "sgemm-ops-debug.txt",
+OPS = ["sgemm-ops-micro.txt", "sgemm-ops-tiny.txt", "sgemm-ops-small.txt", "sgemm-ops-full.txt", "sgemm-ops-debug.txt", "sgemm-ops-debug-half.txt",
        "conv-ops-debug.txt", "conv-ops-debug-tmp.txt", "conv-ops-tiny.txt", "conv-ops-small.txt",
        "conv-ops-1-5-20-nin-alex-gn.txt", "ops/conv/conv-ops-kern-3x3-batch-1-5-20-nin-alex-gn.txt"]
 os.makedirs(os.path.join(HERE, "wisdom"), exist_ok=True)

@@ -216,15 +216,42 @@ def test_sgemm_bad_tile_is_unsupported(be):
         _run(be, _sgemm_op(64, 64, 64), 5, tune=OpTune(hip_tile="48x128x16x1x2"))
 
 
-def test_sgemm_alias_cublas_and_half_unsupported(be):
+def test_sgemm_alias_cublas_and_mixed_types_unsupported(be):
     op = _sgemm_op(128, 256, 64)
     a, _ = _run(be, op, 5)
     b, prc = _run(be, op, 5, tune=OpTune(use_culibs=1))
     assert prc.op.get_func_name() == "cublas_sgemm" and np.array_equal(a["c"], b["c"])
-    hop = parse_op("(str_vals=(type=sgemm),nda_vals=(a=(tn=half,dims=(K=64,M=64)),b=(tn=half,dims=(K=64,N=64)),c=(tn=half,dims=(M=64,N=64))))")
+    hop = parse_op("(str_vals=(type=sgemm),nda_vals=(a=(tn=half,dims=(K=64,M=64)),b=(dims=(K=64,N=64)),c=(tn=half,dims=(M=64,N=64))))")   # half a, float b
     with pytest.raises(UnsupErr):
         anno = add_codegen_annotations(hop, OpTune())
         profile_rcg_call(be, anno, None)
+    dop = parse_op("(str_vals=(type=sgemm),nda_vals=(a=(tn=double,dims=(K=64,M=64)),b=(tn=double,dims=(K=64,N=64)),c=(tn=double,dims=(M=64,N=64))))")
+    with pytest.raises(UnsupErr):
+        profile_rcg_call(be, add_codegen_annotations(dop, OpTune()), None)
+
+
+def test_sgemm_half_storage_fp32_math(be, golden_dir):
+    """16-bit storage, fp32 math: the reference's reduced-precision precedent (sgemm with __tn__=half dims: vload_half -> float, fp32 fma chain,
+    vstore_half; src/cnn_codegen.cc:440-449, gen_data through store_float_to_rp_half, test/rtc/gen_data_sgemm_a.cucl:20).  half -> float is exact and
+    the fp32 MFMA chain is the reference's per-thread fmaf loop, so c is BIT-identical to the oracle run on the half-rounded operands and rounded
+    to half (RNE) once.  The reference's own op (test/sgemm-ops-debug-half.txt: 2048^3) and ragged shapes (scalar 16-bit loads, tile edges)."""
+    ops = read_ops(os.path.join(golden_dir, "ops", "sgemm-ops-debug-half.txt"))
+    assert len(ops) == 1 and all(ops[0].get_dims(an).tn == "half" for an in "abc") and ops[0].sgemm_geom() == {"M": 2048, "N": 2048, "K": 2048}
+    for op in ops + [parse_op(f"(str_vals=(type=sgemm),nda_vals=(a=(tn=half,dims=(K={K},M={M})),b=(tn=half,dims=(K={K},N={N})),c=(tn=half,dims=(M={M},N={N}))))")
+                     for M, N, K in ((100, 36, 50), (33, 257, 19), (260, 130, 70), (1, 64, 64), (64, 3, 7))]:
+        g = op.sgemm_geom()
+        outs, prc = _run(be, op, 5, include_ins=True)
+        assert prc.op.get_func_name() == "hip_sgemm" and prc.launch["kernel"] == "bodahip_sgemm_f16s" and outs["c"].dtype == np.float16
+        a16 = bo.gen_sgemm_a(g["K"], g["M"]).astype(np.float16); b16 = bo.gen_sgemm_b(g["K"], g["N"]).astype(np.float16)
+        assert np.array_equal(outs["a"], a16) and np.array_equal(outs["b"], b16)                      # the device generator rounds like numpy (RNE)
+        want = bo.sgemm(a16.astype(np.float32), b16.astype(np.float32)).astype(np.float16)
+        assert np.isfinite(want.astype(np.float32)).all()
+        assert np.array_equal(outs["c"], want), (g, prc.launch["cfg"], SsdsDiff.of(want.astype(np.float32), outs["c"].astype(np.float32)).basic_str())
+        assert prc.launch["algo_bytes"] == 2.0 * (g["K"] * g["M"] + g["K"] * g["N"] + g["M"] * g["N"])
+    # mode 600 (a = 1000 m + k as half: exact below 2048, b = identity): c == a^T
+    op = parse_op("(str_vals=(type=sgemm),nda_vals=(a=(tn=half,dims=(K=64,M=2)),b=(tn=half,dims=(K=64,N=64)),c=(tn=half,dims=(M=2,N=64))))")
+    outs, _ = _run(be, op, 600, include_ins=True)
+    assert np.array_equal(outs["c"], outs["a"].T)
 
 
 def test_sgemm_full_sizes_exact_answer(be, golden_dir):
