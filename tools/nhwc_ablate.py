@@ -8,7 +8,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from boda_amd.rtc import make_rtc
     rtc = make_rtc("(be=hip)", 0); rtc.init(); be = OpsBackend(rtc)
     seen = {}
-    for op in bench.net_conv_ops("resnet-50", 64): seen.setdefault(op.to_str(), op)
+    for op in bench.net_conv_ops(os.environ.get("NET", "resnet-50"), 64): seen.setdefault(op.to_str(), op)
     ops = list(seen.values())
     out = []
     for i in [int(x) for x in os.environ.get("SEL", "3,7,8,12,14,17").split(",")]:
