@@ -326,8 +326,12 @@ class ConvPipeFwd:
     """`has_conv_fwd_t` with mode=rtc over an rtc backend (src/has_conv_fwd.H:16-25, src/rtc_fwd.cc:43-577)."""
     mode = "rtc"
 
-    def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False):
+    def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False, fuse_siblings: bool = True):
         self.rtc, self.op_tune = rtc, op_tune or OpTune()
+        # channels-last bf16 nets: convolutions that read the SAME node with the same kernel geometry (an inception module's 1x1 / 3x3-reduce / 5x5-reduce
+        # convs) run as one hip_conv_nhwc_grp launch -- input read once, the members' tiles in one grid, two launches fewer per module; same bits
+        self.fuse_siblings = fuse_siblings
+        self.groups: List[Tuple[str, ...]] = []      # tags of the members of each fused call
         self.per_call_fn, self.enable_double_run = per_call_fn, enable_double_run
         self.fwd_calls: List[FwdCall] = []
         self.op_param_names: List[str] = []
@@ -405,6 +409,21 @@ class ConvPipeFwd:
                 s2d_ok = self.nhwc and len(in_readers) == 1 and in_readers[0] is o
                 annos[o.tag] = add_codegen_annotations(cp.conv_op(o), dataclasses.replace(self.op_tune, hip_s2d=int(s2d_ok)) if self.nhwc else self.op_tune)
         in_anno = annos[in_readers[0].tag] if (self.nhwc and len(in_readers) == 1 and in_readers[0].type == "Convolution") else None
+        # sibling convolutions (channels-last nets): same bottom node, same kernel / stride / padding / fused ReLU, plain hip_conv_nhwc members
+        group_of: Dict[str, List[PipeOp]] = {}     # tag of a member -> its group (list of ops, definition order)
+        if self.nhwc and self.fuse_siblings:
+            by_key: Dict[tuple, List[PipeOp]] = {}
+            for o in cp.ops:
+                if o.type == "Convolution" and not annos[o.tag].has("nhwc_s2d"):
+                    by_key.setdefault((o.bot, tuple(o.kern_sz), tuple(o.stride), tuple(o.in_pad), has_relu[o.tag]), []).append(o)
+            for members in by_key.values():
+                for k in range(0, len(members), 4):
+                    grp = members[k:k + 4]
+                    if len(grp) >= 2:
+                        for o in grp:
+                            group_of[o.tag] = grp
+                        self.groups.append(tuple(o.tag for o in grp))
+        grp_done = set()
         def vd(node: str) -> Dims:   # dims a node's var is created with
             if not self.nhwc:
                 return cp.nodes[node]
@@ -432,7 +451,34 @@ class ConvPipeFwd:
                     alias[op.top] = vn(op.bot)
                 continue
             if not op.in_place and op.top not in made and op.top not in self.slices:
-                rtc.create_var_with_dims(op.top, vd(op.top)); self._vars.append(op.top)
+                rtc.create_var_with_dims(op.top, vd(op.top)); self._vars.append(op.top); made.add(op.top)
+            if op.type == "Convolution" and op.tag in group_of:
+                grp = group_of[op.tag]
+                if grp[0].tag in grp_done:
+                    continue                 # (emitted with the group's first member)
+                grp_done.add(grp[0].tag)
+                for o in grp:                # every member's output var exists before the fused call
+                    annos[o.tag].nda_vals["conv_has_relu"].v = (has_relu[o.tag],)
+                    if o.top not in made and o.top not in self.slices and o.top not in self._vars:
+                        rtc.create_var_with_dims(o.top, vd(o.top)); self._vars.append(o.top); made.add(o.top)
+                ganno = _nhwc.annotate_group([annos[o.tag] for o in grp])
+                gname = "+".join(o.tag for o in grp); gen_fn = f"{_nhwc.GRP_FUNC}__{cp.name}_{grp[0].tag}"
+                rtc.compile([RtcFuncInfo(gen_fn, "", _nhwc.group_arg_names(len(grp)), ganno)]); self._funcs.append(gen_fn)
+                fv, bv = f"{gen_fn}_filts", f"{gen_fn}_biases"
+                rtc.create_var_with_dims(fv, ganno.get_dims("filts")); rtc.create_var_with_dims(bv, ganno.get_dims("biases")); self._vars += [fv, bv]
+                self._grp_params = getattr(self, "_grp_params", []) + [(fv, bv, ganno.get_dims("grp"), [o.tag for o in grp])]
+                am = {"filts": RtcArg.var(fv), "biases": RtcArg.var(bv), "in": RtcArg.var(vn(op.bot)), "stride": RtcArg.ref(ganno.get_dims("stride")),
+                      "in_pad": RtcArg.ref(ganno.get_dims("in_pad")), "grp": RtcArg.ref(ganno.get_dims("grp"))}
+                for m, o in enumerate(grp):
+                    if o.top in self.slices:
+                        cat, c_off, _ = self.slices[o.top]
+                        am[f"out_{m}"] = RtcArg.var(cat); am[f"out_chan_off_{m}"] = _u32(c_off)
+                    else:
+                        am[f"out_{m}"] = RtcArg.var(o.top)
+                        if vd(o.top).dsz("chan") != o.out_chans:
+                            am[f"out_chan_off_{m}"] = _u32(0)
+                self.fwd_calls.append(FwdCall(gname, RtcFuncCall(gen_fn, am), _nhwc.GRP_FUNC, sum(cp.conv_op(o).flops() for o in grp)))
+                continue
             if op.type == "Convolution":
                 cop = cp.conv_op(op)
                 anno = annos[op.tag]
@@ -521,7 +567,23 @@ class ConvPipeFwd:
             if dst != pn:
                 rtc.run(_nhwc.xpose_call("filts", dst, pn, cp.params[pn], pdims(pn), annos[pn[:-len("_filts")]])); rtc.finish_and_sync(); rtc.release_var(dst)
         rtc.finish_and_sync()
+        self.refresh_group_params()
         rtc.release_per_call_id_data()
+
+    def refresh_group_params(self) -> None:
+        """Stacked filters / biases of the fused sibling convolutions, from the members' own (already transposed) params: init time only (and again after a
+        caller overwrote params, e.g. a weight broadcast)."""
+        rtc = self.rtc
+        for fv, bv, grp, tags in getattr(self, "_grp_params", []):
+            from . import nhwc as _nhwc
+            offs = _nhwc.group_row_offsets(grp)
+            fd, bd = rtc.get_var_dims(fv), rtc.get_var_dims(bv)
+            F = np.zeros(fd.sizes, dtype=np.uint16); Bv = np.zeros(bd.sizes, dtype=np.float32)
+            for off, tag in zip(offs, tags):
+                f = rtc.copy_var_to_nda(tag + "_filts"); b = rtc.copy_var_to_nda(tag + "_biases")
+                F[off:off + f.shape[0]] = f; Bv[off:off + b.shape[0]] = b
+            rtc.copy_nda_to_var(fv, F); rtc.copy_nda_to_var(bv, Bv)
+        rtc.finish_and_sync()
 
     def var_of(self, node: str) -> str:
         return self._alias.get(node, node)
@@ -595,7 +657,11 @@ class ConvPipeFwd:
         for c in self.fwd_calls:
             rtc.run(c.rfc)
         if parallel:
-            self.call_deps = self._call_deps()
+            try:
+                self.call_deps = self._call_deps()
+            except Exception:
+                rtc.graph_destroy(rtc.graph_end()[0])      # (leave no capture open behind a host-side error)
+                raise
             self._graph = rtc.graph_end_deps(self.call_deps); n = len(self.fwd_calls)
         else:
             self._graph, n = rtc.graph_end()
@@ -611,23 +677,24 @@ class ConvPipeFwd:
         for i, c in enumerate(self.fwd_calls):
             am = c.rfc.arg_map
             rd = [am[a].n for a in ("in", "inout") if a in am and am[a].is_var()]
-            wr = [am[a].n for a in ("out", "inout") if a in am and am[a].is_var()]
+            outs = [a for a in am if (a in ("out", "inout") or (a.startswith("out_") and not a.startswith("out_chan_off"))) and am[a].is_var()]
+            wr = [am[a].n for a in outs]
             if c.func == "nhwc_xpose_in":     # (the layout pass of the net's input: reads <in>_ref, writes <in>)
                 rd, wr = [am["in_ref"].n], [am["in"].n]
             slice_outs = {t for t, _, _ in getattr(self, "slices", {}).values()}   # (Concat outputs that convs write channel ranges of)
-            partial = c.func in ("fwd_copy", "nhwc_copy") or ("out_chan_off" in am and am["out"].n in slice_outs)   # writers of disjoint channel ranges of one var: unordered among themselves
+            part_of = {am[a].n: (c.func in ("fwd_copy", "nhwc_copy") or am[a].n in slice_outs) for a in outs}   # writers of disjoint channel ranges of one var: unordered among themselves
             d = set()
             for v in rd:
                 d.update(writers.get(v, []))
             for v in wr:
-                if not (partial and not readers.get(v)):
+                if not (part_of.get(v, False) and not readers.get(v)):
                     d.update(writers.get(v, []))
                 d.update(readers.get(v, []))
             d.discard(i)
             for v in rd:
                 readers.setdefault(v, []).append(i)
             for v in wr:
-                if partial and not readers.get(v):
+                if part_of.get(v, False) and not readers.get(v):
                     writers.setdefault(v, []).append(i)
                 else:
                     writers[v] = [i]; readers[v] = []
@@ -655,4 +722,4 @@ class ConvPipeFwd:
             rtc.release_func(f)
         for v in self._vars:
             rtc.release_var(v)
-        self._funcs, self._vars, self.fwd_calls = [], [], []
+        self._funcs, self._vars, self.fwd_calls, self._grp_params, self.groups = [], [], [], [], []

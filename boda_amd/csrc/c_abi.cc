@@ -8,6 +8,7 @@
 using namespace bodahip;
 namespace bodahip {
 void *hip_compute_stream(rtc_compute_t *rtc);
+void hip_compute_set_timing(rtc_compute_t *rtc, bool stream);
 void hip_compute_graph_begin(rtc_compute_t *rtc);
 uint32_t hip_compute_graph_end(rtc_compute_t *rtc);
 uint32_t hip_compute_graph_launch(rtc_compute_t *rtc, uint32_t id);
@@ -162,7 +163,14 @@ int bodahip_get_device_info(bodahip_ctx *ctx, char *arch_buf, size_t n, int *num
   if (clock_khz) { int khz = 0; (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, h->nh_device()); *clock_khz = khz; } // (the ctx's device, not the thread's current one)
   ABI_CATCH }
 int bodahip_set_tune(bodahip_ctx *ctx, const char *key, const char *value) {
-  ABI_TRY for (uint32_t i = 0; i < hip_multi_num_devices(&R(ctx)); ++i) hip_compute_native(hip_multi_sub(&R(ctx), i))->set_tune(S(key, "key"), value ? value : ""); ABI_CATCH }
+  ABI_TRY
+  if (S(key, "key") == "timing") {   // how get_dur attributes stream time to calls (hip_compute.cc: timing_stream)
+    string const v = value ? value : "";
+    if (!v.empty() && v != "call" && v != "stream") rt_err("set_tune: timing must be call | stream");
+    for (uint32_t i = 0; i < hip_multi_num_devices(&R(ctx)); ++i) hip_compute_set_timing(hip_multi_sub(&R(ctx), i), v == "stream");
+    return 0;
+  }
+  for (uint32_t i = 0; i < hip_multi_num_devices(&R(ctx)); ++i) hip_compute_native(hip_multi_sub(&R(ctx), i))->set_tune(S(key, "key"), value ? value : ""); ABI_CATCH }
 int bodahip_last_launch(bodahip_ctx *ctx, char *kbuf, size_t kn, char *cbuf, size_t cn, uint32_t *grid, uint32_t *block, double *flops, double *algo_bytes) {
   ABI_TRY
   launch_info_t const &li = hip_compute_native(hip_multi_sub(&R(ctx), 0))->last_launch;   // (a multi-device backend: device 0's)

@@ -161,6 +161,13 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
   std::unique_ptr<native_kernels_t> native;
   uint32_t compile_call_ix = 0;
   void *null_ptr = nullptr;
+  // get_dur() attribution.  Default ("call"): every call is bracketed by its own pair of events, get_dur(b, e) = begin of b .. end of e -- the reference's
+  // semantics (src/nvrtc_util.cc:373-380).  On this runtime an event record is a marker packet of its own: two per launch put ~3 us between back-to-back
+  // kernels and an EMPTY kernel measures 6.1 us this way (rocprofv3's kernel trace of the same launches: 2-3 us less each).  "stream" (tune key `timing`):
+  // a call records only its END event; its duration is the stream time since the previous call's end event (its own begin event only when it is the
+  // first call after release_per_call_id_data).  Per-call durations then add up EXACTLY to first-begin .. last-end of the call list, kernels are
+  // queued back to back as in production, and a call's figure contains its own dispatch gap, no marker.  What bench.py's per-op roofline uses.
+  bool timing_stream = false;
   bool shard_aware = false;   // device of a multi-device backend: generated functions are compiled so that a launch can cover a shard of the id space
 
   explicit hip_compute_t(int dev) : device_ordinal(dev) { be = "hip"; }
@@ -299,17 +306,26 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
   uint32_t new_call_events() {
     ev_pair_t ce;
     if (!ev_pool.empty()) { ce = ev_pool.back(); ev_pool.pop_back(); }
-    else { hip_err_chk(hipEventCreate(&ce.b), "hipEventCreate"); hip_err_chk(hipEventCreate(&ce.e), "hipEventCreate"); }
+    else {
+      static unsigned const flags = getenv("BODAHIP_EVENT_FLAGS") ? (unsigned)strtoul(getenv("BODAHIP_EVENT_FLAGS"), nullptr, 0) : 0u;   // (experiments)
+      hip_err_chk(hipEventCreateWithFlags(&ce.b, flags), "hipEventCreate"); hip_err_chk(hipEventCreateWithFlags(&ce.e, flags), "hipEventCreate"); }
     call_evs.push_back(ce);
+    begin_recorded.push_back(1);
     return (uint32_t)call_evs.size() - 1;
   }
+  std::vector<char> begin_recorded;   // per call: its own begin event was recorded (always in "call" timing; in "stream" timing only for the first call of a batch)
+  void record_begin(uint32_t call_id) {
+    if (timing_stream && call_id > 0) { begin_recorded[call_id] = 0; return; }   // begins where the previous call ended
+    hip_err_chk(hipEventRecord(call_events(call_id).b, stream), "hipEventRecord");
+  }
+  hipEvent_t begin_event(uint32_t id) { ev_pair_t &ce = call_events(id); return begin_recorded[id] ? ce.b : call_events(id - 1).e; }
   static constexpr uint32_t kCapturedCallId = 0xfffffffeu; // what run() returns while a graph is being captured: the call has no events of its own
   ev_pair_t &call_events(uint32_t id) { if (id == kCapturedCallId) rt_err("this call was captured into a graph: time the graph launch instead"); if (id >= call_evs.size()) rt_err("invalid call_id " + std::to_string(id)); return call_evs[id]; }
-  void release_per_call_id_data() override { for (auto &ce : call_evs) ev_pool.push_back(ce); call_evs.clear(); }
+  void release_per_call_id_data() override { for (auto &ce : call_evs) ev_pool.push_back(ce); call_evs.clear(); begin_recorded.clear(); }
   float get_dur(uint32_t const &b, uint32_t const &e) override {
     use_dev();
     float ms = 0.f;
-    hip_err_chk(hipEventElapsedTime(&ms, call_events(b).b, call_events(e).e), "hipEventElapsedTime");
+    hip_err_chk(hipEventElapsedTime(&ms, begin_event(b), call_events(e).e), "hipEventElapsedTime");
     return ms;
   }
 
@@ -321,7 +337,7 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
     if (hf.native) {
       if (capturing) { try { native->run(hf.info, rfc.arg_map); } catch (...) { graph_abort(); throw; } note_captured_call(); return kCapturedCallId; }
       uint32_t const call_id = new_call_events();
-      hip_err_chk(hipEventRecord(call_events(call_id).b, stream), "hipEventRecord");
+      record_begin(call_id);
       native->run(hf.info, rfc.arg_map);
       hip_err_chk(hipEventRecord(call_events(call_id).e, stream), "hipEventRecord");
       return call_id;
@@ -360,7 +376,7 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
       note_captured_call(); return kCapturedCallId;
     }
     uint32_t const call_id = new_call_events();
-    hip_err_chk(hipEventRecord(call_events(call_id).b, stream), "hipEventRecord");
+    record_begin(call_id);
     hip_err_chk(hipModuleLaunchKernel(hf.func, blks, 1, 1, rfc.tpb, 1, 1, 0, stream, kargs.empty() ? nullptr : kargs.data(), nullptr),
                 ("hipModuleLaunchKernel(" + rfc.rtc_func_name + ")").c_str());
     hip_err_chk(hipEventRecord(call_events(call_id).e, stream), "hipEventRecord");
@@ -487,7 +503,7 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
     if (capturing) rt_err("graph_launch during capture");
     graph_t &gr = get_graph(id);
     uint32_t const call_id = new_call_events();
-    hip_err_chk(hipEventRecord(call_events(call_id).b, stream), "hipEventRecord");
+    record_begin(call_id);
     hip_err_chk(hipGraphLaunch(gr.exec, stream), "hipGraphLaunch");
     hip_err_chk(hipEventRecord(call_events(call_id).e, stream), "hipEventRecord");
     return call_id;
@@ -522,6 +538,7 @@ uint32_t hip_compute_run_shard(rtc_compute_t *rtc, rtc_func_call_t const &rfc, u
   if (fit->second.native) rt_err("run_shard: '" + rfc.rtc_func_name + "' is a native function");
   return h.run_generated(fit->second, rfc, blks, gid_off, gid_last, &var_bias);
 }
+void hip_compute_set_timing(rtc_compute_t *rtc, bool stream_mode) { hip_compute_t &h = as_hip(rtc); h.finish_and_sync(); h.release_per_call_id_data(); h.timing_stream = stream_mode; }
 void *hip_compute_stream(rtc_compute_t *rtc) { hip_compute_t *h = dynamic_cast<hip_compute_t *>(rtc); if (!h) rt_err("not a hip_compute_t"); return (void *)h->stream; }
 native_kernels_t *hip_compute_native(rtc_compute_t *rtc) { hip_compute_t *h = dynamic_cast<hip_compute_t *>(rtc); if (!h || !h->native) rt_err("hip backend not initialised"); return h->native.get(); }
 

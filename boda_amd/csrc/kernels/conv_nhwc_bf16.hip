@@ -69,6 +69,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define INTERLEAVE 0  // 1: spread the next step's LDS-DMA pieces between the MFMA groups of the current step instead of issuing them back to back at the top of
 #endif                // the step.  Measured on MI355X (ResNet-50 / GoogLeNet lists at 64 images): 35 % SLOWER (kernel time 1.51 -> 2.06 ms, res4 3x3 41 -> 64 us):
                       // an LDS-DMA issued among MFMAs and ds_reads costs far more than one issued in a run of its own.  Kept for the record, off.
+#ifndef GROUPS
+#define GROUPS 0 // 1: HORIZONTALLY FUSED convolutions -- up to four convolutions that read the same `in` with the same kernel geometry (an inception module's 1x1 /
+#endif           // 3x3-reduce / 5x5-reduce convs; a ResNet stage's branch1 + branch2a) run as ONE launch: `filts` / `bias` are the members' filters / biases
+                 // stacked along out_chan, every member padded with zero rows to a multiple of GP out_chans (GP a multiple of BI, so a tile row belongs to
+                 // exactly one member), and each member's tile rows are stored to that member's own destination (tensor, channel count, channel offset) --
+                 // second kernel argument grp_args_t.  The input is read once and the launch has the members' tiles together (they are tile-starved and
+                 // launch-bound one by one).  Same MFMA chain per output as the separate launches: bit-identical results.  No split-K.
 #ifndef NBUF
 #define NBUF 2   // LDS ring depth: the loads of K step s + NBUF - 1 are issued before the MFMAs of step s (NBUF - 2 steps of loads stay in flight across a barrier)
 #endif
@@ -86,6 +93,11 @@ struct gemm_args_t { // identical to gemm_conv_f32.hip (one host-side struct); I
   int out_ctot, out_coff;
   int const *ktab; int ktab_n;
   long bsI, bsJ, bsD;
+};
+
+struct grp_args_t { // GROUPS: member m owns fused out_chans [oc0[m], oc0[m] + noc[m]) (oc0[m] multiples of the pad granularity; rows up to oc0[m+1] are zero padding)
+  int n; int oc0[4]; int noc[4];
+  void *D[4]; unsigned D_bytes[4]; int ctot[4]; int coff[4];
 };
 
 #ifdef REDUCE_ONLY
@@ -159,7 +171,12 @@ __device__ __forceinline__ rsrc_t make_rsrc(void const *p, unsigned bytes) { ret
 __device__ __forceinline__ constexpr int swz(int row) { return (row / kRP) & (kCPR - 1); }
 } // namespace
 
+#if GROUPS
+static_assert(!SPLITK && !IN_F32, "fused convolutions: no K slices, bf16 tensors");
+extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p, grp_args_t const q) {
+#else
 extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p) {
+#endif
   __shared__ __attribute__((aligned(1024))) char smem[kSmem];
   int const tid = threadIdx.x, lane = tid & 63;
   int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -365,9 +382,21 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #if SPLITK
   rsrc_t const rD = make_rsrc(p.ws + (long)(blockIdx.x % p.splitk) * p.ws_slab, (unsigned)p.Nj * (unsigned)p.Mi * 4u), rB = make_rsrc(p.bias, 0u);  // (no bias here: every load reads 0)
   int const o_ctot = p.Mi, o_coff = 0;
+#elif GROUPS
+  // the member this tile row belongs to (workgroup-uniform); from here on `e_i0` / `e_Mi` are the tile's first out_chan and the out_chan count INSIDE the member
+  int gm = 0;
+#pragma unroll
+  for (int m = 1; m < 4; ++m) if (m < q.n && i0 >= q.oc0[m]) gm = m;
+  rsrc_t const rD = make_rsrc(q.D[gm], q.D_bytes[gm]), rB = make_rsrc(p.bias + q.oc0[gm], (unsigned)q.noc[gm] * 4u);
+  int const o_ctot = q.ctot[gm], o_coff = q.coff[gm];
 #else
   rsrc_t const rD = make_rsrc(p.D, p.D_bytes), rB = make_rsrc(p.bias, (unsigned)p.Mi * 4u);
   int const o_ctot = p.out_ctot, o_coff = p.out_coff;
+#endif
+#if GROUPS
+  int const e_i0 = i0 - q.oc0[gm], e_Mi = q.noc[gm];
+#else
+  int const e_i0 = i0, e_Mi = p.Mi;
 #endif
   constexpr bool kRelu = RELU && !SPLITK;
   f32x4 bv[kTI][4];
@@ -375,11 +404,11 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   for (int ta = 0; ta < kTI; ++ta)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      int const oc = i0 + wi * (kTI * 32) + ta * 32 + 8 * g + 4 * h;
-      if (oc + 4 <= p.Mi) bv[ta][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, oc * 4, 0, 0));
+      int const oc = e_i0 + wi * (kTI * 32) + ta * 32 + 8 * g + 4 * h;
+      if (oc + 4 <= e_Mi) bv[ta][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, oc * 4, 0, 0));
       else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[ta][g][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, (oc + e < p.Mi) ? (oc + e) * 4 : kOOB, 0, 0));
+        for (int e = 0; e < 4; ++e) bv[ta][g][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, (oc + e < e_Mi) ? (oc + e) * 4 : kOOB, 0, 0));
       }
     }
 #if OUT_F32 || SPLITK
@@ -392,17 +421,17 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     for (int ta = 0; ta < kTI; ++ta)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        int const oc = i0 + wi * (kTI * 32) + ta * 32 + 8 * g + 4 * h;
+        int const oc = e_i0 + wi * (kTI * 32) + ta * 32 + 8 * g + 4 * h;
         float x[4];   // (scalars, not elements of a vector: this hipcc mis-compiles element-wise bit-casts of a vector's lanes -- DESIGN.md section 3.1)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { x[e] = acc[ta][tb][4 * g + e] + bv[ta][g][e]; if (kRelu) x[e] = (x[e] > 0.f) ? x[e] : 0.f; }
         if (pel < p.Nj) {
-          if (oc + 4 <= p.Mi && ((o_ctot | o_coff) & 3) == 0) {
+          if (oc + 4 <= e_Mi && ((o_ctot | o_coff) & 3) == 0) {
             f32x4 v; v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rD, (int)(rowoff + (unsigned)oc * 4u), 0, 0);
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (oc + e < p.Mi) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, x[e]), rD, (int)(rowoff + (unsigned)(oc + e) * 4u), 0, 0);
+            for (int e = 0; e < 4; ++e) if (oc + e < e_Mi) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, x[e]), rD, (int)(rowoff + (unsigned)(oc + e) * 4u), 0, 0);
           }
         }
       }
@@ -432,15 +461,15 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
       int const idx = tid + n * kNT;
       if (kChunks % kNT != 0 && idx >= kChunks) break;
       int const prow = idx / kRowChunks, cc = idx - prow * kRowChunks;
-      int const pel = j0 + prow, oc = i0 + cc * 8;
-      if (pel >= p.Nj || oc >= p.Mi) continue;
+      int const pel = j0 + prow, oc = e_i0 + cc * 8;
+      if (pel >= p.Nj || oc >= e_Mi) continue;
       u32x4 const v = *reinterpret_cast<u32x4 const *>(E + prow * kEPitch + cc * 16);
       unsigned const off = ((unsigned)pel * (unsigned)o_ctot + (unsigned)o_coff + (unsigned)oc) * 2u;
-      if (vec_ok && oc + 8 <= p.Mi) __builtin_amdgcn_raw_buffer_store_b128(v, rD, (int)off, 0, 0);
+      if (vec_ok && oc + 8 <= e_Mi) __builtin_amdgcn_raw_buffer_store_b128(v, rD, (int)off, 0, 0);
       else {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (oc + e < p.Mi) __builtin_amdgcn_raw_buffer_store_b16((short)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu), rD, (int)(off + 2u * e), 0, 0);
+          if (oc + e < e_Mi) __builtin_amdgcn_raw_buffer_store_b16((short)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu), rD, (int)(off + 2u * e), 0, 0);
       }
     }
   }

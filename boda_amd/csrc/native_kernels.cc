@@ -60,7 +60,7 @@ bool native_kernels_t::is_native_func_name(string const &fn) {
 void native_kernels_t::check_compile_time(rtc_func_info_t const &fi) {
   string const &fn = fi.op.get_func_name();
   if (fn == "hip_sgemm" || fn == "cublas_sgemm" || fn == "hip_sgemm_bf16") return;
-  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd" || fn == "hip_conv_nhwc") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
+  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd" || fn == "hip_conv_nhwc" || fn == "hip_conv_nhwc_grp") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
   rt_err("unknown/unhandled native hip function: " + fn);
 }
 void native_kernels_t::set_tune(string const &key, string const &val) {
@@ -293,7 +293,9 @@ static bool plan_patch_bf16(conv_geom_t const &g, int num_cus, plan_t &p) {
 
 // Channels-last bf16 convolution (kernels/conv_nhwc_bf16.hip): implicit GEMM D[oc][pel], operands straight from HBM into LDS
 // (buffer_load ... lds), 32x32x16 bf16 MFMA.  g.C is the STORED channel count (a multiple of 8).  tile: "BIxBJxBKxWIxWJ[xMINW]" or "".
-static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &tile, bool out_f32) {
+// grp_pad > 0: horizontally fused convolutions (-DGROUPS=1): g.OC is the stacked, padded out_chan count, every member starts at a multiple of grp_pad -> tiles
+// may not be taller than grp_pad and must divide it; no K slices.
+static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &tile, bool out_f32, int grp_pad = 0) {
   if (g.C % 8) unsup_err("hip_conv_nhwc: in_chan of a channels-last bf16 tensor must be a multiple of 8 (the layout pass pads)");
   if (g.H >= 32768 || g.W >= 32768) unsup_err("hip_conv_nhwc: planes of 32768 rows / columns or more are not supported");
   long const Nj = (long)g.B * g.OH * g.OW;
@@ -312,6 +314,7 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
     { int nf = 1; for (char ch : tile) if (ch == 'x' || ch == ':') ++nf; if (nf >= 9) nbuf = c.PF; }
     c.MT = 32; c.PF = 1;
     if (c.SPLITK < 1 || c.SPLITK > 64) unsup_err("hip_conv_nhwc: unsupported K split " + std::to_string(c.SPLITK));
+    if (grp_pad && (c.SPLITK != 1 || c.BI > grp_pad || grp_pad % c.BI)) unsup_err("hip_conv_nhwc_grp: tile " + c.str() + " does not fit the members' padding of " + std::to_string(grp_pad) + " out_chans");
   } else {
     // score = base rate of the tile x fraction of the padded tile grid that is real work x how evenly the tiles deal out over the CUs
     // (the rule of choose_cfg); base rates are first MI355X measurements of this kernel relative to 128x128
@@ -326,9 +329,10 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
     //     ~45 % of the CU's bf16 MFMA rate (AlexNet / NiN conv2, 5x5 96->256 at 256 images: 128x128 305, 128x256 254, 256x256 243 us).
     static cand_t const cands[] = {{128, 128, 2, 2, 2}, {64, 128, 1, 4, 2}, {64, 64, 2, 2, 2}, {32, 128, 1, 4, 2}, {32, 64, 1, 2, 2}, {128, 256, 2, 4, 1}, {256, 256, 4, 4, 1}};
     long const nk = (kc + c.BK / 8 - 1) / (c.BK / 8);
-    bool const may_split = getenv("BODAHIP_NO_NHWC_SPLITK") == nullptr;
+    bool const may_split = getenv("BODAHIP_NO_NHWC_SPLITK") == nullptr && !grp_pad;
     double best = 1e30;
     for (cand_t const &cd : cands) {
+      if (grp_pad && (cd.bi > grp_pad || grp_pad % cd.bi)) continue;
       long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
       if (cd.bi * cd.bj > 128 * 128 && ((long)(cd.bi + cd.bj) * c.BK * 2 * 2 > 140 * 1024 || !getenv("BODAHIP_NHWC_BIG_TILES"))) continue;   // 128x256 / 256x256 at one workgroup per CU:
       // opt-in.  Measured (MI355X, same box, A/B): NiN whole net +2 %, ResNet-50 / GoogLeNet lists and AlexNet net within noise, single layers both ways --
@@ -365,6 +369,7 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
             "-DCH=" + std::to_string(g.H), "-DCW=" + std::to_string(g.W), "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW),
             string("-DRELU=") + (g.relu ? "1" : "0"), string("-DOUT_F32=") + (out_f32 ? "1" : "0"), "-DNBUF=" + std::to_string(nbuf)};
   if (c.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
+  if (grp_pad) p.defs.push_back("-DGROUPS=1");
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
   return p;
 }
@@ -934,6 +939,45 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
 }
 
 
+struct grp_args_t { // must match kernels/conv_nhwc_bf16.hip
+  int n; int oc0[4]; int noc[4];
+  void *D[4]; unsigned D_bytes[4]; int ctot[4]; int coff[4];
+};
+// Horizontally fused channels-last convolutions (hip_conv_nhwc_grp): n <= 4 members that read the same `in` with the same kernel geometry; filts / biases hold
+// the members stacked along out_chan, member m at rows [m_oc0, m_oc0 + noc[m]) with m_oc0 = sum of the earlier members' out_chans each rounded up to `pad`.
+void native_kernels_t::conv_nhwc_grp(void const *filts, float const *biases, void const *in, conv_geom_t const &g, bool out_f32, int n, int const *noc, void *const *outs,
+                                     int const *ctot, int const *coff, int pad) {
+  if (n < 1 || n > 4 || pad < 32 || pad % 32) unsup_err("hip_conv_nhwc_grp: 1..4 members, padding a multiple of 32 out_chans");
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  if (!Nj) return;
+  if (Nj > 0x7fffffffl || Kt > 0x7fffffffl) unsup_err("hip_conv_nhwc_grp: dims exceed int32");
+  grp_args_t q; memset(&q, 0, sizeof(q)); q.n = n;
+  int tot = 0; double real_oc = 0;
+  for (int m = 0; m < n; ++m) {
+    if (noc[m] < 1) rt_err("hip_conv_nhwc_grp: empty member");
+    q.oc0[m] = tot; q.noc[m] = noc[m]; tot += (noc[m] + pad - 1) / pad * pad; real_oc += noc[m];
+    uint64_t const ob = (uint64_t)Nj * ctot[m] * (out_f32 ? 4 : 2);
+    if (ob >= 0x7ffffff0ull) unsup_err("hip_conv_nhwc_grp: out of 2 GiB or more");
+    q.D[m] = outs[m]; q.D_bytes[m] = (unsigned)ob; q.ctot[m] = ctot[m]; q.coff[m] = coff[m];
+  }
+  if (tot != g.OC) rt_err("hip_conv_nhwc_grp: filts hold " + std::to_string(g.OC) + " out_chans, the members (padded to " + std::to_string(pad) + ") need " + std::to_string(tot));
+  plan_t const p = plan_conv_nhwc(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), out_f32, pad);
+  tile_cfg_t const &cfg = p.cfg;
+  kernel_t &k = get_kernel(impl, host, p);
+  gemm_args_t ga; memset(&ga, 0, sizeof(ga));
+  uint64_t const in_bytes = (uint64_t)g.B * g.C * g.H * g.W * 2, f_bytes = (uint64_t)g.OC * Kt * 2;
+  if (in_bytes >= 0x7ffffff0ull || f_bytes >= 0x7ffffff0ull) unsup_err("hip_conv_nhwc_grp: tensors of 2 GiB or more are not supported (32-bit buffer offsets)");
+  ga.I = (float const *)filts; ga.J = (float const *)in; ga.D = nullptr; ga.bias = biases;
+  ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
+  ga.I_bytes = (unsigned)f_bytes; ga.J_bytes = (unsigned)in_bytes; ga.splitk = 1;
+  ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
+  void *params[] = {&ga, &q};
+  hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j), 1, 1, (uint32_t)cfg.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(conv_nhwc_bf16, fused)");
+  last_launch.kernel = p.kname + "(x" + std::to_string(n) + ")"; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(ga.tiles_i * ga.tiles_j); last_launch.block = cfg.threads();
+  last_launch.flops = 2.0 * Nj * real_oc * Kt;   // (the members' own out_chans: zero padding rows are work done, not credit)
+  last_launch.algo_bytes = 2.0 * ((double)g.B * g.C * g.H * g.W + real_oc * Kt) + (out_f32 ? 4.0 : 2.0) * (double)Nj * real_oc + 4.0 * real_oc;
+}
+
 void native_kernels_t::conv_nhwc(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, bool out_f32, int out_ctot, int out_coff) {
   if (out_ctot <= 0) { out_ctot = g.OC; out_coff = 0; }
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
@@ -1001,9 +1045,10 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
   }
   else if (t == "Convolution") {
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
-    conv_geom_t const g = geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims("out"), op.get_dims("stride"), op.get_dims("in_pad"), relu);
+    conv_geom_t const g = geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims(op.has("out") ? "out" : "out_0"), op.get_dims("stride"), op.get_dims("in_pad"), relu);
     conv_geom_t g2; int pry = 0, prx = 0;
     if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc") p = plan_conv_nhwc(g, num_cus, tile, op.get_dims("out").tn == "float");
+    else if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc_grp") { dims_t const &grp = op.get_dims("grp"); p = plan_conv_nhwc(g, num_cus, tile, op.get_dims("out_0").tn == "float", (int)grp.dims(grp.sz() - 1)); }
     else if (bf16 && tile.empty() && s2d_geom(g, g2, pry, prx) && plan_patch_bf16(g2, num_cus, p)) { // conv1-type layers: space-to-depth front end (see conv())
       s2d = "s2d(" + std::to_string(g2.C) + "x" + std::to_string(g2.H) + "x" + std::to_string(g2.W) + ",k" + std::to_string(g2.KH) + "x" + std::to_string(g2.KW) + ")+";
       if (!arch.empty()) { plan_t sp; sp.patch16 = true; sp.bf16 = true; sp.kname = "bodahip_s2d"; sp.defs = {"-DS2D_ONLY=1"}; compile_plan(sp, arch, &log); }
@@ -1093,6 +1138,44 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     assert_st(b.dsz("K") == K); assert_st(c.dsz("M") == M); assert_st(c.dsz("N") == N);
     tile_override_t const tov(impl, "sgemm_tile", fi.op);
     sgemm((float const *)host->nh_var_ptr(an), (float const *)host->nh_var_ptr(bn), (float *)host->nh_var_ptr(cn), M, N, K, bf16, half);
+    return;
+  }
+  if (fn == "hip_conv_nhwc_grp") {
+    // horizontally fused channels-last convolutions: filts / biases stacked and padded (REF `grp`: dims m0..m{n-1} = the members' out_chans, pad = padding granularity),
+    // outputs out_0 .. out_{n-1} (vars), optional by-value out_chan_off_<m> (member m writes a channel slice of a wider tensor)
+    string const fnm = var_of(am, "filts"), bnm = var_of(am, "biases"), inm = var_of(am, "in");
+    dims_t const f = host->nh_var_dims(fnm), bi = host->nh_var_dims(bnm), in = host->nh_var_dims(inm);
+    need_float(bi, "biases");
+    if (f.tn != "bfloat16" || in.tn != "bfloat16") unsup_err("hip_conv_nhwc_grp: filts / in must have type bfloat16");
+    assert_st(f.sz() == 4 && in.sz() == 4 && bi.sz() == 1);
+    if (!(f.names(0) == "out_chan" && f.names(1) == "y" && f.names(2) == "x" && f.names(3) == "in_chan")) rt_err("hip_conv_nhwc_grp: filts must be out_chan:y:x:in_chan, got " + f.pretty_str());
+    auto si = am.find("stride"), pi = am.find("in_pad"), gi = am.find("grp");
+    if (si == am.end() || pi == am.end() || gi == am.end()) rt_err("hip_conv_nhwc_grp: 'stride', 'in_pad' and 'grp' REF args are required");
+    dims_t const stride = si->second.get_dims(host->nh_rtc()), in_pad = pi->second.get_dims(host->nh_rtc()), grp = gi->second.get_dims(host->nh_rtc());
+    int const n = (int)grp.sz() - 1;
+    if (n < 1 || n > 4 || grp.names(n) != "pad") rt_err("hip_conv_nhwc_grp: grp must be (m0=..,..,pad=..) with 1..4 members");
+    int noc[4], ctot[4], coff[4]; void *outs[4]; bool out_f32 = false; dims_t out0;
+    for (int m = 0; m < n; ++m) {
+      string const onm = var_of(am, "out_" + std::to_string(m));
+      dims_t const out = host->nh_var_dims(onm);
+      if (out.tn != "bfloat16" && out.tn != "float") unsup_err("hip_conv_nhwc_grp: outputs must have type bfloat16 or float");
+      if (!(out.sz() == 4 && out.names(0) == "img" && out.names(1) == "y" && out.names(2) == "x" && out.names(3) == "chan")) rt_err("hip_conv_nhwc_grp: outputs must be img:y:x:chan, got " + out.pretty_str());
+      if (m == 0) { out0 = out; out_f32 = (out.tn == "float"); }
+      else if (out.tn != out0.tn || out.dsz("img") != out0.dsz("img") || out.dsz("y") != out0.dsz("y") || out.dsz("x") != out0.dsz("x")) rt_err("hip_conv_nhwc_grp: the members' outputs must agree in type and map size");
+      noc[m] = (int)grp.dims(m); ctot[m] = (int)out.dsz("chan"); coff[m] = 0; outs[m] = host->nh_var_ptr(onm);
+      auto oi = am.find("out_chan_off_" + std::to_string(m));
+      if (oi != am.end()) {
+        if (oi->second.is_var() || !oi->second.v || !oi->second.v->rp_elems()) rt_err("hip_conv_nhwc_grp: out_chan_off_<m> must be a by-value uint32");
+        coff[m] = (int)*(uint32_t const *)oi->second.v->rp_elems();
+      } else if (ctot[m] != noc[m]) rt_err("hip_conv_nhwc_grp: member " + std::to_string(m) + " writes a wider tensor: out_chan_off_" + std::to_string(m) + " is required");
+      if (coff[m] < 0 || coff[m] + noc[m] > ctot[m]) rt_err("hip_conv_nhwc_grp: out_chan_off + out_chans exceeds the channels of out_" + std::to_string(m));
+    }
+    conv_geom_t g = geom_from_dims(f, in, out0, stride, in_pad, fi.op.get_u32("conv_has_relu") != 0);
+    if (f.dsz("in_chan") != (uint32_t)g.C || bi.dsz("out_chan") != (uint32_t)g.OC) rt_err("hip_conv_nhwc_grp: inconsistent filts / biases / in dims");
+    if (!g.SY || !g.SX) rt_err("hip_conv_nhwc_grp: zero stride");
+    if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW || out0.dsz("img") != (uint32_t)g.B) rt_err("hip_conv_nhwc_grp: out dims do not match in/filts/stride/in_pad");
+    tile_override_t const tov(impl, "conv_tile", fi.op);
+    conv_nhwc_grp(host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), host->nh_var_ptr(inm), g, out_f32, n, noc, outs, ctot, coff, (int)grp.dims(n));
     return;
   }
   if (fn == "hip_conv_nhwc") {

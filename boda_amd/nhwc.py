@@ -82,6 +82,56 @@ def annotate(a: Op, out_tn: str = "bfloat16", allow_s2d: bool = True) -> None:
     a.set_func_name(FUNC)
 
 
+GRP_FUNC = "hip_conv_nhwc_grp"
+
+
+def group_pad(ocs) -> int:
+    """Padding granularity of the members of a horizontally fused convolution: the largest of 128 / 64 / 32 out_chans that adds at most a quarter of zero
+    rows (a tile row must belong to one member, so tiles are no taller than this)."""
+    for gp in (128, 64, 32):
+        if sum(-(-o // gp) * gp for o in ocs) <= 1.25 * sum(ocs):
+            return gp
+    return 32
+
+
+def annotate_group(annos: List[Op]) -> Op:
+    """`hip_conv_nhwc_grp`: up to four annotated hip_conv_nhwc ops that read the same `in` with the same kernel geometry, as ONE function -- filts / biases
+    stacked along out_chan (member m at rows [oc0_m, oc0_m + out_chans_m), oc0_m = the earlier members' out_chans each rounded up to grp.pad), outputs
+    out_0 .. out_{n-1}.  The horizontal counterpart of what the reference does vertically when it fuses a ReLU into its conv (src/rtc_fwd.cc:486-493)."""
+    a0 = annos[0]
+    if not (2 <= len(annos) <= 4):
+        raise UnsupErr("hip_conv_nhwc_grp: 2..4 members")
+    for a in annos:
+        if a.get_func_name() != FUNC or a.has("nhwc_s2d"):
+            raise UnsupErr("hip_conv_nhwc_grp: members must be plain hip_conv_nhwc functions")
+        for an in ("in", "stride", "in_pad", "kern_sz"):
+            if a.get_dims(an) != a0.get_dims(an):
+                raise UnsupErr(f"hip_conv_nhwc_grp: members differ in {an}")
+        if a.get_u32("conv_has_relu") != a0.get_u32("conv_has_relu") or a.get_dims("out").tn != a0.get_dims("out").tn:
+            raise UnsupErr("hip_conv_nhwc_grp: members differ in ReLU / output type")
+    ocs = [a.get_dims("filts").dsz("out_chan") for a in annos]
+    gp = group_pad(ocs); tot = sum(-(-o // gp) * gp for o in ocs)
+    f0 = a0.get_dims("filts")
+    nv = {"in": a0.nda_vals["in"], "stride": a0.nda_vals["stride"], "in_pad": a0.nda_vals["in_pad"], "kern_sz": a0.nda_vals["kern_sz"],
+          "filts": Nda(dims=Dims(f0.names, (tot,) + tuple(f0.sizes[1:]), "bfloat16"), tn="bfloat16"), "biases": Nda(dims=Dims(("out_chan",), (tot,), "float"), tn="float"),
+          "grp": Nda(dims=Dims(tuple(f"m{m}" for m in range(len(ocs))) + ("pad",), tuple(ocs) + (gp,), "none"), tn="none"),
+          "conv_has_relu": a0.nda_vals["conv_has_relu"]}
+    for m, a in enumerate(annos):
+        nv[f"out_{m}"] = a.nda_vals["out"]
+    return Op({"type": "Convolution", "func_name": GRP_FUNC}, nv)
+
+
+def group_arg_names(n: int) -> List[str]:
+    return ["filts", "biases", "in", "stride", "in_pad", "grp"] + [f"out_{m}" for m in range(n)]
+
+
+def group_row_offsets(grp: Dims) -> List[int]:
+    gp = grp.dsz("pad"); offs, t = [], 0
+    for m in range(len(grp.sizes) - 1):
+        offs.append(t); t += -(-grp.sizes[m] // gp) * gp
+    return offs
+
+
 # layout passes (one thread per element of the destination; sizes by value).  `__bf16` conversions round to nearest even.
 XPOSE_SRC = """
 typedef __bf16 xp_bf16x8_t __attribute__((ext_vector_type(8)));

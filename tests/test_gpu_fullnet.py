@@ -278,7 +278,8 @@ def test_full_net_forward_channels_last_bf16(rtc, net, batch):
     fwd.init(cp, op_params=params)
     try:
         funcs = [c.func for c in fwd.fwd_calls]
-        assert funcs[0] == "nhwc_xpose_in" and funcs.count("hip_conv_nhwc") == sum(o.type == "Convolution" for o in cp.ops)
+        assert funcs[0] == "nhwc_xpose_in" and funcs.count("hip_conv_nhwc") + sum(len(g) for g in fwd.groups) == sum(o.type == "Convolution" for o in cp.ops)
+        assert funcs.count("hip_conv_nhwc_grp") == len(fwd.groups) == (9 if net == "googlenet" else 0)   # an inception module's 1x1 / 3x3-reduce / 5x5-reduce convs: one launch
         assert not any(f.startswith("fwd_") or f == "hip_conv" for f in funcs)
         nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
         io = {"data": data}
@@ -390,3 +391,32 @@ def test_full_net_forward_at_bench_batch(rtc, net, batch, mode):
                 assert ex < 4.5e-3 * np.sqrt(max(1, depth[op.top])), (op.top, depth[op.top], "vs exact fp32 forward", ex)
     finally:
         fwd.release()
+
+
+def test_sibling_fusion_is_bit_identical(rtc):
+    """Channels-last GoogLeNet with the same-input convolutions of every inception module fused into one hip_conv_nhwc_grp launch (stacked, padded filters;
+    members writing their own tensor or their channel range of the module's Concat output) against the same net run conv by conv: every node equal bit for bit
+    (same MFMA chain per output), 18 launches fewer."""
+    from boda_amd.cnn_op import OpTune
+    cp = googlenet_conv(3)
+    params = _params(cp)
+    data = bo.gen_conv_in(*cp.nodes["data"].sizes)
+    nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
+    res, ncalls = [], []
+    for fuse in (True, False):
+        fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc"), fuse_siblings=fuse)
+        fwd.init(cp, op_params=params)
+        try:
+            io = {"data": data}
+            fwd.run_fwd(["data"], io, nodes)
+            res.append(io); ncalls.append(len(fwd.fwd_calls))
+            if fuse:
+                assert len(fwd.groups) == 9 and all(len(g) == 3 for g in fwd.groups)
+                n = fwd.capture_graph(parallel=True); out = cp.out_node()     # the dependency-wired graph handles calls with several outputs
+                rtc.set_var_to_zero(fwd.var_of(out)); fwd.run_graph()
+                assert np.array_equal(fwd._fetch(out), io[out])
+        finally:
+            fwd.release()
+    assert ncalls[1] - ncalls[0] == 18
+    for n in nodes:
+        assert np.array_equal(res[0][n], res[1][n]), n

@@ -132,5 +132,12 @@ def test_config5_every_layer_nhwc_at_bench_batch(be, net):
         last = outs["out"][-1]
         assert np.isfinite(last).all() and last.max() > 0
         cfgs.add(prc.launch["cfg"])
+        # ... and with bf16 OUTPUTS, which is what bench.py --dtype bf16 --layout nhwc times (the LDS-transposed 16-byte-store epilogue at the benched
+        # tiles): the float result rounded once more -- |got - want| <= 2^-8 |want| + the float bound
+        outs_b, prc_b = profile_rcg_call(be, add_codegen_annotations(ob, OpTune(**NHWC)), 5, 0.0, 1)
+        got = outs_b["out"][:2]; w64 = want.astype(np.float64)
+        assert prc_b.launch["cfg"] == prc.launch["cfg"] and np.array_equal(bo.to_bf16(got), got)
+        err = np.abs(got.astype(np.float64) - w64); lim = 2.0 ** -8 * np.abs(w64) + _bound(K) * np.maximum(1.0, np.abs(w64))
+        assert np.isfinite(outs_b["out"]).all() and (err <= lim).all(), (ob.to_str(), prc_b.launch["cfg"], float((err / lim).max()))
     print(f"{net}: hip_conv_nhwc tiles taken at B=64: {sorted(cfgs)}; worst mrd / bound = {worst:.3f}")
     assert len(cfgs) >= 2
