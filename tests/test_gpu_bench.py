@@ -53,3 +53,6 @@ def test_default_line_carries_conv_ops():
     assert h["layers"] == [1, 2] and 0 < h["frac"] <= 1
     tol = co["tolerance_mode"]                                              # op_tune hip_exact=0 beside the bit-exact default
     assert set(tol) == {"alexnet", "nin"} and all(0 < v["frac"] <= 1 and v["value"] > 0 for v in tol.values())
+    cf = out["configs"]                                                     # BASELINE configs[3] / [4] as legs of the same line
+    assert set(cf) >= {"config4_nin-net_b128_f32", "config5_googlenet_b64_bf16_nhwc", "config5_resnet50_b64_bf16_nhwc"}
+    assert all("error" not in v and v["value"] > 0 and 0 < v["roofline"]["frac"] <= 1 for v in cf.values()), cf
