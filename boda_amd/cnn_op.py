@@ -35,6 +35,7 @@ class OpTune:
     hip_layout: str = ""  # extension (with hip_dtype=bf16): "nhwc" = channels-last bf16 STORAGE for in / filts / out: func hip_conv_nhwc on transposed operands,
     # the originals kept as <arg>_ref and filled / read back by xpose functions outside the timed call -- the reference's own k1conv / tconv protocol (boda_amd/nhwc.py)
     hip_s2d: int = 1  # extension (with hip_layout=nhwc): 1 = conv1-type layers (stride >= 2 on <= 8 channels) run space-to-depth, the regrouping done by the layout pass of `in` (boda_amd/nhwc.py)
+    hip_patch: int = 1  # extension (with hip_layout=nhwc): 1 = layers with more than one tap and stride 1 in x take the LDS input-patch kernel (filts in the in_grp:y:x:out_chan:in_chan8 form); 0 = implicit GEMM for every layer
     hip_out: str = ""  # extension (with hip_layout=nhwc): "f32" = the kernel writes float instead of bfloat16
     hip_exact: int = 1  # extension: 1 = fp32 results bit-identical to the reference's per-thread fma chain (default); 0 = tolerance mode: within the reference's bound for re-associating
     # kernels (mrd < 2e-3, src/rtc_prof.cc:317-319,436; its 2e-4 default, :161, is not met by ANY second association of a K = 9216 sum on its U(-5,5) data) -- deterministic K slices on tile-starved long-K layers, Winograd where it is faster
@@ -111,7 +112,7 @@ def add_codegen_annotations(op: Op, tune: OpTune) -> Op:
             a.set_func_name("cudnn_conv")
         elif native and not (tune.k1conv or tune.tconv or tune.ipconv) and tune.hip_dtype == "bf16" and tune.hip_layout == "nhwc":
             from . import nhwc
-            nhwc.annotate(a, "float" if tune.hip_out == "f32" else "bfloat16", allow_s2d=bool(tune.hip_s2d))
+            nhwc.annotate(a, "float" if tune.hip_out == "f32" else "bfloat16", allow_s2d=bool(tune.hip_s2d), allow_patch=bool(tune.hip_patch))
         elif native and not (tune.k1conv or tune.tconv or tune.ipconv):
             a.set_func_name("hip_conv_bf16" if tune.hip_dtype == "bf16" else ("hip_conv_winograd" if tune.hip_algo == "winograd" else "hip_conv"))
         else:

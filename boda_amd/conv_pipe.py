@@ -414,7 +414,7 @@ class ConvPipeFwd:
         if self.nhwc and self.fuse_siblings:
             by_key: Dict[tuple, List[PipeOp]] = {}
             for o in cp.ops:
-                if o.type == "Convolution" and not annos[o.tag].has("nhwc_s2d"):
+                if o.type == "Convolution" and not annos[o.tag].has("nhwc_s2d") and not annos[o.tag].get_dims("filts").has("in_grp"):
                     by_key.setdefault((o.bot, tuple(o.kern_sz), tuple(o.stride), tuple(o.in_pad), has_relu[o.tag]), []).append(o)
             for members in by_key.values():
                 for k in range(0, len(members), 4):

@@ -1,0 +1,264 @@
+// conv_nhwc_patch_bf16.hip -- KH x KW (stride 1 in x) convolution on channels-last bf16 tensors from an LDS INPUT PATCH, for gfx950 (BASELINE config 5).
+// Same contract as bodahip_conv_nhwc_bf16 (kernels/conv_nhwc_bf16.hip: in / out img:y:x:chan bf16, biases float, bias + ReLU epilogue, optional channel slice
+// of a wider output, float output) except for the filters, which arrive as
+//       filts  in_grp : y : x : out_chan : in_chan8     bf16      F'[g][ky][kx][oc][8] = filts[oc][ky][kx][8g .. 8g+8)
+// (the layout pass writes that form for the layers that take this kernel: `hip_conv_nhwc` binds by the dims of its `filts`).
+//
+// Why: the implicit-GEMM kernel re-reads every input position once per tap -- for a 3x3 layer the pel-side operand stream is 9x the tensor, and on the
+// 3x3 layers of ResNet-50 / GoogLeNet at 64 images that L2 -> LDS stream (measured ~22 TB/s chip-wide) takes as long as the MFMAs and overlaps poorly with
+// them.  Here a K step is CG groups of 8 channels x ALL taps: the LDS holds, per group, the zero-padded input rows the tile's output positions touch
+// ("slots" of W + 2 PX chunks; consecutive output rows of an image share slots; a tile that crosses into the next image starts a new slot group -- the
+// geometry of gemm_conv_f32.hip's patch mode and of conv_patch_bf16.hip), each input chunk is loaded ONCE per K step with a 16-byte load, and a lane's MFMA B
+// fragment for tap (ky, kx) is one ds_read_b128 at   patch[g][(slot(j) + ky) * Wp + ox(j) + kx].   The contraction index is ordered (group, ky, kx, channel
+// in group) in both operands.  Operands are register-staged (global loads of step s+1 fly under the MFMAs of step s) into a single LDS image.
+// Lanes of a staging load are laid out position-major (CG consecutive lanes = the CG x 16 contiguous bytes of one position), the LDS image group-major with a
+// group pitch that is 2 (mod 16) chunks, so the transposing ds_write_b128s are conflict-free.
+//
+// Numerics: as conv_nhwc_bf16.hip (fp32 accumulate in the MFMA's own order; parity stated against the oracle on bf16-rounded operands).
+//
+// -D parameters: KNAME BI BJ WI WJ MINW CG CIN KH KW SY PY PX CH CW COH COW RELU OUT_F32        (SX == 1)
+
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#endif
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef GROUP_I
+#define GROUP_I 8
+#endif
+#ifndef RELU
+#define RELU 0
+#endif
+#ifndef OUT_F32
+#define OUT_F32 0
+#endif
+
+struct gemm_args_t { // identical to gemm_conv_f32.hip (one host-side struct); I = F', J = in
+  float const *I; float const *J; float *D; float const *bias;
+  int Mi, Nj, K;
+  int ldI, ldJ, ldD;
+  int C, H, W, OH, OW;
+  int tiles_i, tiles_j;
+  int splitk, kt_per;
+  float *ws; long ws_slab;
+  unsigned I_bytes, J_bytes;
+  unsigned D_bytes;
+  int out_ctot, out_coff;
+  int const *ktab; int ktab_n;
+  long bsI, bsJ, bsD;
+};
+
+namespace {
+constexpr int kNT = WI * WJ * 64;
+constexpr int kTI = BI / (WI * 32);
+constexpr int kTJ = BJ / (WJ * 32);
+static_assert(BI % (WI * 32) == 0 && BJ % (WJ * 32) == 0, "tile must be a multiple of the MFMA tile per wave");
+static_assert(CIN % 8 == 0, "channels-last tensors carry whole 16-byte chunks per position");
+constexpr int kTaps = KH * KW, kWp = CW + 2 * PX;
+constexpr int kNCG = CIN / 8;                                      // channel groups of the tensor
+constexpr int kNKT = (kNCG + CG - 1) / CG;                         // K steps
+constexpr int kNPr = CG * kTaps;                                   // k-slots (of 8 channels) per K step ...
+constexpr int kNP = kNPr + (kNPr & 1);                             // ... padded to whole MFMAs (two slots each): an odd count gets one all-zero filter slot
+static_assert(KH >= SY, "patch slots assume overlapping or abutting windows in y");
+constexpr int kRowsMax = (BJ - 2) / COW + 2;                       // output rows a BJ-pel tile can touch
+constexpr int kSegFull = (COH - 1) * SY + KH;                      // slots of a whole image
+constexpr int kSegMax0 = (COH - 1 + kRowsMax - 1) / COH + 1;       // images a tile can touch
+constexpr int kSegMax = kSegMax0 < kRowsMax ? kSegMax0 : kRowsMax;
+constexpr int kSlots = (kRowsMax - kSegMax) * SY + kSegMax * KH;   // slots per channel group (upper bound over tile positions)
+constexpr int kCS = kSlots * kWp;                                  // input positions (16-byte chunks) per channel group
+constexpr int kCSp = kCS + ((2 - kCS % 16) + 16) % 16;             // group pitch in chunks: 2 (mod 16) -> the CG chunks of a position land 8 banks apart
+constexpr int kPE = (kCS * CG + kNT - 1) / kNT;                    // patch chunks per thread per K step
+constexpr int kIE = (kNP * BI + kNT - 1) / kNT;                    // filter chunks per thread per K step
+constexpr int kEPitch = BI * 2 + 16;                               // epilogue tile [pel][oc] bf16, rows de-phased by 4 banks
+constexpr int kOpB = 16 * (kNP * BI + CG * kCSp), kEpiB = OUT_F32 ? 0 : BJ * kEPitch;
+constexpr int kSmem = kOpB > kEpiB ? kOpB : kEpiB;
+constexpr int kOOB = (int)0x80000000;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(void const *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)bytes, 0x00020000); }
+__device__ __forceinline__ u32x4 bload4(rsrc_t r, int voff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0); }
+// chunk offset of k-slot q = (g, ky, kx) inside the patch, relative to a lane's output position
+constexpr int slot_off(int q) { return (q >= kNPr) ? 0 : ((q / kTaps) * kCSp + ((q % kTaps) / KW) * kWp + (q % KW)); } // (the pad slot reads tap 0: its filter row is zero)
+} // namespace
+
+extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p) {
+  __shared__ __attribute__((aligned(16))) char smem[kSmem];
+  u32x4 *const Is = reinterpret_cast<u32x4 *>(smem);               // A operand: [k-slot][out_chan] chunks
+  u32x4 *const Js = Is + kNP * BI;                                 // input patch: [group][slot][padded column] chunks, group pitch kCSp
+  int const tid = threadIdx.x, lane = tid & 63;
+  int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int const wi = wave / WJ, wj = wave % WJ;
+
+  int tile_i, tile_j; // XCD-aware workgroup -> tile map (as gemm_conv_f32.hip)
+  {
+    int const bid = blockIdx.x, nb = p.tiles_i * p.tiles_j;
+    int const q = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    int const nid = ((xcd < rr) ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    int const group_sz = GROUP_I * p.tiles_j, gid = nid / group_sz, first_i = gid * GROUP_I;
+    int const gsz = min(p.tiles_i - first_i, GROUP_I), in_g = nid - gid * group_sz;
+    tile_i = first_i + in_g % gsz; tile_j = in_g / gsz;
+  }
+  int const i0 = tile_i * BI, j0 = tile_j * BJ;
+
+  // ---- this thread's patch chunks: element el = (position, group within the K step), position-major (CG consecutive lanes read CG x 16 contiguous bytes)
+  int const R0 = j0 / COW, img0 = R0 / COH, oy0 = R0 - img0 * COH;   // first output row of the tile (workgroup-uniform)
+  int const seg0 = (COH - 1 - oy0) * SY + KH;                        // slots of the first image's part
+  int const n_img = p.Nj / (COH * COW);
+  int pgoff[kPE], pdst[kPE];
+#pragma unroll
+  for (int e = 0; e < kPE; ++e) {
+    int const el = tid + e * kNT, pos = el / CG, g = el - pos * CG, s = pos / kWp, ix = pos - s * kWp - PX;
+    int const s2 = s - seg0, im2 = s2 / kSegFull;
+    int const img = (s < seg0) ? img0 : (img0 + 1 + im2);
+    int const iy = (s < seg0) ? (oy0 * SY - PY + s) : (s2 - im2 * kSegFull - PY);
+    bool const ok = (el < kCS * CG) && (img < n_img) && ((unsigned)iy < (unsigned)CH) && ((unsigned)ix < (unsigned)CW);
+    pgoff[e] = ok ? (((img * CH + iy) * CW + ix) * (CIN * 2) + g * 16) : kOOB;
+    pdst[e] = g * kCSp + pos;
+  }
+  int bj[kTJ]; // MFMA B operand: chunk index of this lane's output position (tap (0,0), group 0)
+#pragma unroll
+  for (int t = 0; t < kTJ; ++t) {
+    int const jg = min(j0 + wj * (kTJ * 32) + t * 32 + (lane & 31), p.Nj - 1);
+    int const R = jg / COW, ox = jg - R * COW, img = R / COH, oy = R - img * COH;
+    int const slot = (img == img0) ? ((oy - oy0) * SY) : (seg0 + (img - img0 - 1) * kSegFull + oy * SY);
+    bj[t] = slot * kWp + ox;
+  }
+  bool const hi = (lane >> 5) != 0; // lanes 32-63 supply the odd k-slot of an MFMA
+
+  f32x16 acc[kTI][kTJ];
+#pragma unroll
+  for (int a = 0; a < kTI; ++a)
+#pragma unroll
+    for (int b = 0; b < kTJ; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  rsrc_t const rI = make_rsrc(p.I, p.I_bytes), rJ = make_rsrc(p.J, p.J_bytes);
+  u32x4 rp[kPE], rf[kIE];
+  auto load_step = [&](int kt) {
+    int const cg0 = kt * CG;
+#pragma unroll
+    for (int e = 0; e < kPE; ++e) {
+      int const el = tid + e * kNT, g = el % CG;
+      bool const ok = (pgoff[e] != kOOB) && (kNCG % CG == 0 || cg0 + g < kNCG);
+      rp[e] = bload4(rJ, ok ? (pgoff[e] + cg0 * 16) : kOOB);
+    }
+#pragma unroll
+    for (int e = 0; e < kIE; ++e) {
+      int const el = tid + e * kNT, q = el / BI, i = el - q * BI;             // k-slot q = (g, tap) of this step, out_chan i0 + i
+      int const g = q / kTaps, tap = q - g * kTaps, cg = cg0 + g;
+      bool const ok = (el < kNP * BI) && (q < kNPr) && (cg < kNCG) && (i0 + i < p.Mi);
+      rf[e] = bload4(rI, ok ? (int)((((unsigned)cg * kTaps + tap) * (unsigned)p.Mi + (unsigned)(i0 + i)) * 16u) : kOOB);
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int e = 0; e < kPE; ++e) if (((e + 1) * kNT <= kCS * CG) || (tid + e * kNT < kCS * CG)) Js[pdst[e]] = rp[e];
+#pragma unroll
+    for (int e = 0; e < kIE; ++e) { int const el = tid + e * kNT; if (((e + 1) * kNT <= kNP * BI) || (el < kNP * BI)) Is[el] = rf[e]; }
+  };
+
+  load_step(0);
+  for (int kt = 0; kt < kNKT; ++kt) {
+    store_step();
+    __syncthreads();
+    if (kt + 1 < kNKT) load_step(kt + 1);      // next step's loads fly under this step's MFMAs
+    u32x4 const *const Ic = Is + wi * (kTI * 32) + (lane & 31);
+#pragma unroll
+    for (int s = 0; s < kNP / 2; ++s) {
+      int const jo = hi ? slot_off(2 * s + 1) : slot_off(2 * s);
+      bf16x8 a[kTI], b[kTJ];
+#pragma unroll
+      for (int t = 0; t < kTI; ++t) a[t] = __builtin_bit_cast(bf16x8, Ic[(2 * s + (hi ? 1 : 0)) * BI + t * 32]);
+#pragma unroll
+      for (int t = 0; t < kTJ; ++t) b[t] = __builtin_bit_cast(bf16x8, Js[bj[t] + jo]);
+#pragma unroll
+      for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < kTJ; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+    }
+    __syncthreads();                           // every wave is done reading before the next step overwrites the images
+  }
+
+  // ---- epilogue (as conv_nhwc_bf16.hip).  C/D layout of the 32x32 MFMA family: column j = lane & 31, rows i = 8*g + 4*(lane >> 5) + e for register 4*g + e
+  int const h = lane >> 5;
+  rsrc_t const rD = make_rsrc(p.D, p.D_bytes), rB = make_rsrc(p.bias, (unsigned)p.Mi * 4u);
+  int const o_ctot = p.out_ctot, o_coff = p.out_coff;
+  f32x4 bv[kTI][4];
+#pragma unroll
+  for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      int const oc = i0 + wi * (kTI * 32) + ta * 32 + 8 * g + 4 * h;
+      if (oc + 4 <= p.Mi) bv[ta][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, oc * 4, 0, 0));
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[ta][g][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rB, (oc + e < p.Mi) ? (oc + e) * 4 : kOOB, 0, 0));
+      }
+    }
+#if OUT_F32
+#pragma unroll
+  for (int tb = 0; tb < kTJ; ++tb) {
+    int const pel = j0 + wj * (kTJ * 32) + tb * 32 + (lane & 31);
+    unsigned const rowoff = ((unsigned)pel * (unsigned)o_ctot + (unsigned)o_coff) * 4u;
+#pragma unroll
+    for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int const oc = i0 + wi * (kTI * 32) + ta * 32 + 8 * g + 4 * h;
+        float x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] = acc[ta][tb][4 * g + e] + bv[ta][g][e]; if (RELU) x[e] = (x[e] > 0.f) ? x[e] : 0.f; }
+        if (pel < p.Nj) {
+          if (oc + 4 <= p.Mi && ((o_ctot | o_coff) & 3) == 0) {
+            f32x4 v; v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rD, (int)(rowoff + (unsigned)oc * 4u), 0, 0);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (oc + e < p.Mi) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, x[e]), rD, (int)(rowoff + (unsigned)(oc + e) * 4u), 0, 0);
+          }
+        }
+      }
+  }
+#else
+  {
+    char *const E = smem;   // (every wave is past the last barrier of the K loop: the operand images are dead)
+#pragma unroll
+    for (int tb = 0; tb < kTJ; ++tb) {
+      int const prow = wj * (kTJ * 32) + tb * 32 + (lane & 31);
+#pragma unroll
+      for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { float x = acc[ta][tb][4 * g + e] + bv[ta][g][e]; if (RELU) x = (x > 0.f) ? x : 0.f; v[e] = (__bf16)x; }
+          *reinterpret_cast<bf16x4 *>(E + prow * kEPitch + (wi * (kTI * 32) + ta * 32 + 8 * g + 4 * h) * 2) = v;
+        }
+    }
+    __syncthreads();
+    constexpr int kRowChunks = BI / 8, kChunks = BJ * kRowChunks;
+    bool const vec_ok = ((o_ctot | o_coff) & 7) == 0;   // 16-byte aligned rows and slices
+#pragma unroll
+    for (int n = 0; n < (kChunks + kNT - 1) / kNT; ++n) {
+      int const idx = tid + n * kNT;
+      if (kChunks % kNT != 0 && idx >= kChunks) break;
+      int const prow = idx / kRowChunks, cc = idx - prow * kRowChunks;
+      int const pel = j0 + prow, oc = i0 + cc * 8;
+      if (pel >= p.Nj || oc >= p.Mi) continue;
+      u32x4 const v = *reinterpret_cast<u32x4 const *>(E + prow * kEPitch + cc * 16);
+      unsigned const off = ((unsigned)pel * (unsigned)o_ctot + (unsigned)o_coff + (unsigned)oc) * 2u;
+      if (vec_ok && oc + 8 <= p.Mi) __builtin_amdgcn_raw_buffer_store_b128(v, rD, (int)off, 0, 0);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (oc + e < p.Mi) __builtin_amdgcn_raw_buffer_store_b16((short)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu), rD, (int)(off + 2u * e), 0, 0);
+      }
+    }
+  }
+#endif
+}

@@ -160,7 +160,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(hipModuleLaunchKernel(k.func, grid, 1, 1, (uint32_t)c.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, patch16 = false, nhwc = false; int rows = 0, cg = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, patch16 = false, nhwc = false, nhwc_patch = false; int rows = 0, cg = 0; };
 
 // Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
 //   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
@@ -373,6 +373,65 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
   return p;
 }
+// Channels-last bf16 convolution from an LDS input patch (kernels/conv_nhwc_patch_bf16.hip): KH x KW kernels with more than one tap, stride 1 in x; filters in the
+// F'[in_grp][ky][kx][out_chan][8] form.  A K step is CG groups of 8 channels x all taps.  tile: "BIxBJx0xWIxWJ[xMINW]" or "".
+static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string const &tile, bool out_f32) {
+  if (g.C % 8) unsup_err("hip_conv_nhwc: in_chan of a channels-last bf16 tensor must be a multiple of 8");
+  int const taps = g.KH * g.KW, ncg = g.C / 8;
+  if (!(g.SX == 1 && taps >= 2 && g.KH >= g.SY)) unsup_err("hip_conv_nhwc (patch form of filts): needs stride 1 in x and more than one tap");
+  long const Nj = (long)g.B * g.OH * g.OW;
+  int cg = std::min(ncg, 4); while (cg > 1 && cg * taps > 40) --cg;     // K step of <= 40 k-slots: 3x3 -> 4 groups (36), 5x5 -> 1 group (25 + a zero slot)
+  if (char const *e = getenv("BODAHIP_NHWC_PATCH_CG")) { if (atoi(e) > 0) cg = std::min(ncg, atoi(e)); }   // (experiments)
+  int const wp = g.W + 2 * g.PX;
+  auto lds_cg = [&](int bi, int bj, int cgx) {
+    int const npx = cgx * taps + ((cgx * taps) & 1);
+    int const rows_max = (bj - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
+    long const cs = (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp, csp = cs + ((2 - cs % 16) + 16) % 16;
+    return std::max<long>(16l * ((long)npx * bi + cgx * csp), out_f32 ? 0 : (long)bj * (bi * 2 + 16));
+  };
+  auto lds = [&](int bi, int bj) { return lds_cg(bi, bj, cg); };
+  struct cand_t { int bi, bj, wi, wj, minw; };
+  static cand_t const cands[] = {{64, 256, 1, 4, 2}, {64, 128, 1, 4, 2}, {32, 256, 1, 4, 2}, {128, 128, 2, 2, 2}, {32, 128, 1, 4, 2}, {64, 64, 2, 2, 2}};
+  plan_t p; p.nhwc = true; p.nhwc_patch = true; p.bf16 = true; p.kname = "bodahip_conv_nhwc_patch_bf16";
+  tile_cfg_t c; c.MT = 32; c.SPLITK = 1; c.PF = 1;
+  if (!tile.empty()) {
+    if (!parse_tile(tile, c)) rt_err("bad conv_tile '" + tile + "'");
+    c.MT = 32; c.SPLITK = 1; c.PF = 1;
+  } else {
+    // Narrow in out_chan, wide in pels: the filter tile -- the larger operand stream here -- is staged once per BJ pels.  score = padding efficiency x share of
+    // the CUs that get a workgroup / operand bytes per flop (filter stream ~ 1/BJ, patch stream ~ 1/(4 BI)).  Measured on MI355X (tools/patch_sweep.sh, 64
+    // images, us incl. the ~6 us launch floor): ResNet-50 3x3 at 56^2 / 28^2 / 14^2 / 7^2: 64x256 30 / 26 / 27 / 45, 64x128 34 / 29 / 27 / 32.5, 32x128 35 / 29 /
+    // 30 / 34; GoogLeNet 3x3 64->192 at 56^2: 64x256 63-66, 32x128 91.  Two workgroups per CU must fit the LDS (80 KB each): wide planes take 2 channel groups
+    // per K step instead of 4 (level with each other where both fit; 8 groups measured 10-50 % slower).
+    int pick = -1, pick_cg = cg; double best = -1;
+    for (int ci = 0; ci < (int)(sizeof(cands) / sizeof(cand_t)); ++ci) {
+      cand_t const &cd = cands[ci];
+      int cgx = cg; while (cgx > 1 && lds_cg(cd.bi, cd.bj, cgx) > 80 * 1024) cgx = (cgx + 1) / 2;
+      if (lds_cg(cd.bi, cd.bj, cgx) > 80 * 1024) continue;
+      if (cd.bi > 64 && g.OC <= 64) continue;
+      long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
+      double const pad = ((double)g.OC / (double)(ti * cd.bi)) * ((double)Nj / (double)(tj * cd.bj));
+      double const fill = std::min(1.0, (double)tiles / (double)num_cus);
+      double const bytes_per_flop = 1.0 / cd.bj + 0.25 / cd.bi;
+      double const score = pad * fill / bytes_per_flop;
+      if (score > best) { best = score; pick = ci; pick_cg = cgx; }
+    }
+    if (pick < 0) unsup_err("hip_conv_nhwc (patch form of filts): no tile fits the LDS for this plane width");
+    c.BI = cands[pick].bi; c.BJ = cands[pick].bj; c.WI = cands[pick].wi; c.WJ = cands[pick].wj; c.MINW = cands[pick].minw; cg = pick_cg;
+  }
+  while (cg > 1 && lds(c.BI, c.BJ) > 160 * 1024) cg = (cg + 1) / 2;
+  p.cg = cg; c.BK = cg * 8 * taps;
+  bool ok = c.BI > 0 && c.BJ > 0 && c.WI > 0 && c.WJ > 0 && c.threads() <= 1024 && (c.BI % (c.WI * 32) == 0) && (c.BJ % (c.WJ * 32) == 0) &&
+            (c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) * 16 <= 256 && c.MINW >= 1 && lds(c.BI, c.BJ) <= 160 * 1024;
+  if (!ok) unsup_err("hip_conv_nhwc (patch form of filts): unsupported tile configuration " + c.str());
+  p.cfg = c;
+  p.defs = {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DWI=" + std::to_string(c.WI), "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW),
+            "-DCG=" + std::to_string(cg), "-DCIN=" + std::to_string(g.C), "-DKH=" + std::to_string(g.KH), "-DKW=" + std::to_string(g.KW), "-DSY=" + std::to_string(g.SY),
+            "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX), "-DCH=" + std::to_string(g.H), "-DCW=" + std::to_string(g.W),
+            "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW), string("-DRELU=") + (g.relu ? "1" : "0"), string("-DOUT_F32=") + (out_f32 ? "1" : "0")};
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return p;
+}
 // Exact fp32 convolutions whose operands are k-contiguous in the REFERENCE layout -- output 1x1, no padding, kernel == whole input (AlexNet
 // fc6-fc8: in[img][K], filts[out_chan][K]) -- through the LDS-DMA kernel's IN_F32 variant (kernels/conv_nhwc_bf16.hip): 64x64 tiles of four
 // waves, 32-deep K steps, an 8-slot LDS ring (six K steps of loads in flight).  Same ascending-k fma chain: bit-exact (tested).  MEASURED SLOWER
@@ -505,7 +564,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
 }
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
-  return hiprtc_compile(p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.stream ? k_src_k1_stream_f32 : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
+  return hiprtc_compile(p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.stream ? k_src_k1_stream_f32 : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
 }
 
 // grow-only scratch shared by the split-K slabs and the Winograd-domain tensors (like the reference's cudnn scratch var)
@@ -978,12 +1037,12 @@ void native_kernels_t::conv_nhwc_grp(void const *filts, float const *biases, voi
   last_launch.algo_bytes = 2.0 * ((double)g.B * g.C * g.H * g.W + real_oc * Kt) + (out_f32 ? 4.0 : 2.0) * (double)Nj * real_oc + 4.0 * real_oc;
 }
 
-void native_kernels_t::conv_nhwc(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, bool out_f32, int out_ctot, int out_coff) {
+void native_kernels_t::conv_nhwc(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, bool out_f32, int out_ctot, int out_coff, bool patch_filts) {
   if (out_ctot <= 0) { out_ctot = g.OC; out_coff = 0; }
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   if (!Nj || !g.OC) return;
   if (Nj > 0x7fffffffl || Kt > 0x7fffffffl) unsup_err("hip_conv_nhwc: dims exceed int32");
-  plan_t const p = plan_conv_nhwc(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), out_f32);
+  plan_t const p = patch_filts ? plan_conv_nhwc_patch(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), out_f32) : plan_conv_nhwc(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), out_f32);
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
   gemm_args_t ga; memset(&ga, 0, sizeof(ga));
@@ -1047,7 +1106,8 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
     conv_geom_t const g = geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims(op.has("out") ? "out" : "out_0"), op.get_dims("stride"), op.get_dims("in_pad"), relu);
     conv_geom_t g2; int pry = 0, prx = 0;
-    if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc") p = plan_conv_nhwc(g, num_cus, tile, op.get_dims("out").tn == "float");
+    if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc" && op.get_dims("filts").sz() == 5) p = plan_conv_nhwc_patch(g, num_cus, tile, op.get_dims("out").tn == "float");
+    else if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc") p = plan_conv_nhwc(g, num_cus, tile, op.get_dims("out").tn == "float");
     else if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc_grp") { dims_t const &grp = op.get_dims("grp"); p = plan_conv_nhwc(g, num_cus, tile, op.get_dims("out_0").tn == "float", (int)grp.dims(grp.sz() - 1)); }
     else if (bf16 && tile.empty() && s2d_geom(g, g2, pry, prx) && plan_patch_bf16(g2, num_cus, p)) { // conv1-type layers: space-to-depth front end (see conv())
       s2d = "s2d(" + std::to_string(g2.C) + "x" + std::to_string(g2.H) + "x" + std::to_string(g2.W) + ",k" + std::to_string(g2.KH) + "x" + std::to_string(g2.KW) + ")+";
@@ -1181,11 +1241,18 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
   if (fn == "hip_conv_nhwc") {
     // channels-last bf16 tensors: filts out_chan:y:x:in_chan, in / out img:y:x:chan (out bf16 or float), biases float
     string const fnm = var_of(am, "filts"), bnm = var_of(am, "biases"), inm = var_of(am, "in"), onm = var_of(am, "out");
-    dims_t const f = host->nh_var_dims(fnm), bi = host->nh_var_dims(bnm), in = host->nh_var_dims(inm), out = host->nh_var_dims(onm);
+    dims_t f = host->nh_var_dims(fnm); dims_t const bi = host->nh_var_dims(bnm), in = host->nh_var_dims(inm), out = host->nh_var_dims(onm);
     need_float(bi, "biases");
     if (f.tn != "bfloat16" || in.tn != "bfloat16") unsup_err("hip_conv_nhwc: filts / in must have type bfloat16 (got " + f.tn + " / " + in.tn + ")");
     if (out.tn != "bfloat16" && out.tn != "float") unsup_err("hip_conv_nhwc: out must have type bfloat16 or float (got " + out.tn + ")");
-    assert_st(f.sz() == 4 && in.sz() == 4 && out.sz() == 4 && bi.sz() == 1);
+    assert_st((f.sz() == 4 || f.sz() == 5) && in.sz() == 4 && out.sz() == 4 && bi.sz() == 1);
+    // filts: out_chan:y:x:in_chan (implicit-GEMM kernel) or in_grp:y:x:out_chan:in_chan8 (LDS input-patch kernel; in_chan8 = 8): the layout the function was
+    // annotated with decides the kernel
+    bool const patch_filts = (f.sz() == 5);
+    if (patch_filts) {
+      if (!(f.names(0) == "in_grp" && f.names(1) == "y" && f.names(2) == "x" && f.names(3) == "out_chan" && f.names(4) == "in_chan8" && f.dims(4) == 8)) rt_err("hip_conv_nhwc: 5-d filts must be in_grp:y:x:out_chan:in_chan8(=8), got " + f.pretty_str());
+      f = dims_t({f.dims(3), f.dims(1), f.dims(2), f.dims(0) * 8}, {"out_chan", "y", "x", "in_chan"}, f.tn);   // (the logical filter dims)
+    }
     if (!(f.names(0) == "out_chan" && f.names(1) == "y" && f.names(2) == "x" && f.names(3) == "in_chan")) rt_err("hip_conv_nhwc: filts must be out_chan:y:x:in_chan, got " + f.pretty_str());
     for (dims_t const *d : {&in, &out}) if (!(d->names(0) == "img" && d->names(1) == "y" && d->names(2) == "x" && d->names(3) == "chan")) rt_err("hip_conv_nhwc: in / out must be img:y:x:chan, got " + d->pretty_str());
     auto si = am.find("stride"), pi = am.find("in_pad");
@@ -1205,7 +1272,7 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     if (!g.SY || !g.SX) rt_err("hip_conv_nhwc: zero stride");
     if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW) rt_err("hip_conv_nhwc: out dims do not match in/filts/stride/in_pad");
     tile_override_t const tov(impl, "conv_tile", fi.op);
-    conv_nhwc(host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), host->nh_var_ptr(inm), host->nh_var_ptr(onm), g, out.tn == "float", out_ctot, out_coff);
+    conv_nhwc(host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), host->nh_var_ptr(inm), host->nh_var_ptr(onm), g, out.tn == "float", out_ctot, out_coff, patch_filts);
     return;
   }
   if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd") {

@@ -66,7 +66,7 @@ struct native_kernels_t {
             char const *algo = nullptr);
 
   // channels-last bf16 tensors (kernels/conv_nhwc_bf16.hip): filts out_chan:y:x:in_chan, in / out img:y:x:chan; g.C = stored channels (multiple of 8)
-  void conv_nhwc(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, bool out_f32, int out_ctot = 0, int out_coff = 0);
+  void conv_nhwc(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, bool out_f32, int out_ctot = 0, int out_coff = 0, bool patch_filts = false);   // patch_filts: filts are F'[in_grp][ky][kx][out_chan][8] -> the LDS input-patch kernel
   // horizontally fused channels-last convolutions (same `in`, same kernel geometry; filts / biases stacked along out_chan, members padded to `pad` rows)
   void conv_nhwc_grp(void const *filts, float const *biases, void const *in, conv_geom_t const &g, bool out_f32, int n, int const *noc, void *const *outs,
                      int const *ctot, int const *coff, int pad);

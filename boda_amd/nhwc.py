@@ -55,7 +55,18 @@ def s2d_geom(g: dict):
     return dict(S=s, PRY=pry, PRX=prx, KH2=kh2, KW2=kw2, C2=g["C"] * s * s, H2=g["OH"] + kh2 - 1, W2=g["OW"] + kw2 - 1)
 
 
-def annotate(a: Op, out_tn: str = "bfloat16", allow_s2d: bool = True) -> None:
+def patch_eligible(g: dict) -> bool:
+    """Layers that run from an LDS input patch (kernels/conv_nhwc_patch_bf16.hip): more than one tap, stride 1 in x, windows that overlap or abut in y, an output
+    map (not the whole-input kernels of fully-connected layers, which stay implicit GEMMs with K slices)."""
+    return g["KH"] * g["KW"] >= 2 and g["SX"] == 1 and g["KH"] >= g["SY"] and g["OH"] * g["OW"] > 1
+
+
+def patch_filts_dims(f: Dims) -> Dims:
+    """out_chan:in_chan:y:x -> in_grp:y:x:out_chan:in_chan8: F'[g][ky][kx][oc][8] = filts[oc][8g .. 8g+8)[ky][kx] (zero past in_chan)."""
+    return Dims(("in_grp", "y", "x", "out_chan", "in_chan8"), (pad8(f.dsz("in_chan")) // 8, f.dsz("y"), f.dsz("x"), f.dsz("out_chan"), 8), "bfloat16")
+
+
+def annotate(a: Op, out_tn: str = "bfloat16", allow_s2d: bool = True, allow_patch: bool = True) -> None:
     """In place: the `hip_conv_nhwc` form of an annotated Convolution -- kernel dims for in / filts / out, the originals as <arg>_ref.
     conv1-type layers additionally go space-to-depth (s2d_geom): the kernel then sees a stride-1, unpadded convolution; the original
     stride / in_pad / kern_sz stay as <arg>_ref and the scalars nhwc_s2d{,_pry,_prx} tell the layout passes how `in` / `filts` are filled."""
@@ -67,7 +78,8 @@ def annotate(a: Op, out_tn: str = "bfloat16", allow_s2d: bool = True) -> None:
     i, f, o = a.get_dims("in_ref"), a.get_dims("filts_ref"), a.get_dims("out_ref")
     if sd is None:
         a.nda_vals["in"] = Nda(dims=nhwc_dims(i), tn="bfloat16")
-        a.nda_vals["filts"] = Nda(dims=ohwi_dims(f), tn="bfloat16")
+        # the filters' layout selects the kernel: F' for the input-patch kernel (3x3 / 5x5 ... stride-1-in-x layers), out_chan:y:x:in_chan for the implicit GEMM
+        a.nda_vals["filts"] = Nda(dims=patch_filts_dims(f) if (allow_patch and patch_eligible(g)) else ohwi_dims(f), tn="bfloat16")
     else:
         c2p = pad8(sd["C2"])
         a.nda_vals["in"] = Nda(dims=Dims(("img", "y", "x", "chan"), (g["B"], sd["H2"], sd["W2"], c2p), "bfloat16"), tn="bfloat16")
@@ -102,7 +114,7 @@ def annotate_group(annos: List[Op]) -> Op:
     if not (2 <= len(annos) <= 4):
         raise UnsupErr("hip_conv_nhwc_grp: 2..4 members")
     for a in annos:
-        if a.get_func_name() != FUNC or a.has("nhwc_s2d"):
+        if a.get_func_name() != FUNC or a.has("nhwc_s2d") or a.get_dims("filts").has("in_grp"):
             raise UnsupErr("hip_conv_nhwc_grp: members must be plain hip_conv_nhwc functions")
         for an in ("in", "stride", "in_pad", "kern_sz"):
             if a.get_dims(an) != a0.get_dims(an):
@@ -170,6 +182,19 @@ CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_filts( GASQ float const * const filt
   }
   filts[i] = r;
 }
+// filts_ref out_chan:in_chan:y:x float -> F' in_grp:y:x:out_chan:in_chan8 bf16 (the input-patch kernel's filters): one thread per 16-byte chunk (g, ky, kx, oc)
+CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_filts_patch( GASQ float const * const filts_ref, GASQ xp_bf16x8_t * const filts, uint32_t const n, uint32_t const C,
+                                                          uint32_t const KH, uint32_t const KW, uint32_t const OC ) {
+  uint32_t const i = GLOB_ID_1D;
+  if( i >= n ) { return; }
+  uint32_t const oc = i % OC, kx = ( i / OC ) % KW, ky = ( i / ( OC*KW ) ) % KH, g = i / ( OC*KW*KH );
+  xp_bf16x8_t r;
+  for( uint32_t e = 0; e != 8; ++e ) {
+    uint32_t const c = 8*g + e;
+    r[e] = (__bf16)( ( c < C ) ? filts_ref[( ( oc*C + c )*KH + ky )*KW + kx] : 0.0f );
+  }
+  filts[i] = r;
+}
 // out img:y:x:chan (bf16 / float) -> out_ref img:chan:y:x float
 CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_out_bf16( GASQ __bf16 const * const out, GASQ float * const out_ref, uint32_t const n, uint32_t const C, uint32_t const HW ) {
   uint32_t const i = GLOB_ID_1D;
@@ -187,6 +212,7 @@ CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_out_f32( GASQ float const * const ou
 XPOSE_FUNCS: Dict[str, List[str]] = {
     "hip_conv_nhwc_xpose_in": ["in_ref", "in", "n", "C", "H", "W", "C2", "C8", "H2", "W2", "S", "PRY", "PRX"],
     "hip_conv_nhwc_xpose_filts": ["filts_ref", "filts", "n", "C", "KH", "KW", "C2", "C8", "KH2", "KW2", "S", "OFY", "OFX"],
+    "hip_conv_nhwc_xpose_filts_patch": ["filts_ref", "filts", "n", "C", "KH", "KW", "OC"],
     "hip_conv_nhwc_xpose_out_bf16": ["out", "out_ref", "n", "C", "HW"],
     "hip_conv_nhwc_xpose_out_f32": ["out", "out_ref", "n", "C", "HW"],
 }
@@ -216,6 +242,11 @@ def xpose_call(arg: str, ref_vn: str, vn: str, ref_dims: Dims, dims: Dims, anno:
               "C2": _u32(C * (s * s if s else 1)), "C8": _u32(dims.dsz("chan") // 8), "H2": _u32(dims.dsz("y")), "W2": _u32(dims.dsz("x")), "S": _u32(s or 1),
               "PRY": _u32(pry), "PRX": _u32(prx)}
         return RtcFuncCall("hip_conv_nhwc_xpose_in", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
+    if arg == "filts" and dims.has("in_grp"):     # F' for the input-patch kernel
+        n = dims.dims_prod() // 8
+        am = {"filts_ref": RtcArg.var(ref_vn), "filts": RtcArg.var(vn), "n": _u32(n), "C": _u32(ref_dims.dsz("in_chan")), "KH": _u32(ref_dims.dsz("y")),
+              "KW": _u32(ref_dims.dsz("x")), "OC": _u32(ref_dims.dsz("out_chan"))}
+        return RtcFuncCall("hip_conv_nhwc_xpose_filts_patch", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
     if arg == "filts":
         n = dims.dims_prod() // 8
         C = ref_dims.dsz("in_chan")

@@ -82,8 +82,14 @@ EDGE = [  # B, C, H, W, OC, KH, KW, S, P : 1x1 (stride 1 / 2, padded), 3x3, 5x5 
 def test_nhwc_conv_float_out_vs_oracle(be, shape):
     op = _conv_op(*shape)
     outs, prc = _run(be, op, OpTune(**NHWC_F32))
-    assert prc.launch["kernel"] == "bodahip_conv_nhwc_bf16"
+    from boda_amd import nhwc
+    g = op.conv_geom(); patch = nhwc.patch_eligible(g) and nhwc.s2d_geom(g) is None      # more than one tap, stride 1 in x: the LDS input-patch kernel
+    assert prc.launch["kernel"] == ("bodahip_conv_nhwc_patch_bf16" if patch else "bodahip_conv_nhwc_bf16"), prc.launch
     _check_f32(op, outs, prc)
+    if patch:                                          # ... and the implicit-GEMM kernel on the same layer (op_tune hip_patch=0)
+        outs, prc = _run(be, op, OpTune(hip_patch=0, **NHWC_F32))
+        assert prc.launch["kernel"] == "bodahip_conv_nhwc_bf16"
+        _check_f32(op, outs, prc)
 
 
 @pytest.mark.parametrize("shape", EDGE[::2], ids=lambda s: "x".join(str(v) for v in s))
@@ -98,10 +104,23 @@ def test_nhwc_conv_bf16_out_vs_oracle(be, shape):
 def test_nhwc_conv_tiles_agree_with_oracle(be, tile):
     for shape in [(3, 40, 15, 15, 100, 3, 3, 1, 1), (2, 64, 9, 9, 200, 1, 1, 1, 0), (2, 3, 33, 33, 48, 7, 7, 2, 3)]:
         op = _conv_op(*shape)
-        outs, prc = _run(be, op, OpTune(hip_tile=tile, **NHWC_F32))
+        outs, prc = _run(be, op, OpTune(hip_tile=tile, hip_patch=0, **NHWC_F32))
         assert prc.launch["cfg"].startswith(tile.split("x")[0] + "x" + tile.split("x")[1] + "x" + tile.split("x")[2]), prc.launch
         if len(tile.split("x")) >= 7 and int(tile.split("x")[6]) > 1:
             assert f"_s{tile.split('x')[6]}" in prc.launch["cfg"], prc.launch     # K slices + the reduce pass
+        _check_f32(op, outs, prc)
+        outs, prc = _run(be, op, OpTune(hip_tile=tile, hip_patch=0, **NHWC))
+        _check_bf16(op, outs, prc)
+
+
+@pytest.mark.parametrize("tile", ["64x256x0x1x4", "64x128x0x1x4", "128x128x0x2x2", "32x128x0x1x4", "64x64x0x2x2", "32x64x0x1x2", "128x256x0x2x4x1", "64x128x0x2x2x1"])
+def test_nhwc_patch_kernel_tiles_agree_with_oracle(be, tile):
+    """kernels/conv_nhwc_patch_bf16.hip under forced tiles: 3x3 / 5x5 / 2x2 / 7x1-ish windows, padding 0..3, ragged channel counts (K tail of the channel groups),
+    tiles that straddle image boundaries (maps of 15x15, 9x9, 5x5 pels against 64..256-pel tiles), ragged out_chans; float and bf16 outputs."""
+    for shape in [(3, 40, 15, 15, 100, 3, 3, 1, 1), (5, 24, 9, 9, 70, 5, 5, 1, 2), (2, 8, 12, 12, 33, 2, 2, 1, 0), (7, 72, 5, 5, 64, 3, 3, 1, 1), (2, 16, 20, 11, 48, 7, 7, 1, 3), (40, 32, 3, 3, 64, 3, 3, 1, 1)]:
+        op = _conv_op(*shape)
+        outs, prc = _run(be, op, OpTune(hip_tile=tile, **NHWC_F32))
+        assert prc.launch["kernel"] == "bodahip_conv_nhwc_patch_bf16" and prc.launch["cfg"].startswith(tile.split("x")[0] + "x" + tile.split("x")[1] + "x"), prc.launch
         _check_f32(op, outs, prc)
         outs, prc = _run(be, op, OpTune(hip_tile=tile, **NHWC))
         _check_bf16(op, outs, prc)
