@@ -83,7 +83,9 @@ def annotate(a: Op, out_tn: str = "bfloat16", allow_s2d: bool = True, allow_patc
     else:
         c2p = pad8(sd["C2"])
         a.nda_vals["in"] = Nda(dims=Dims(("img", "y", "x", "chan"), (g["B"], sd["H2"], sd["W2"], c2p), "bfloat16"), tn="bfloat16")
-        a.nda_vals["filts"] = Nda(dims=Dims(("out_chan", "y", "x", "in_chan"), (g["OC"], sd["KH2"], sd["KW2"], c2p), "bfloat16"), tn="bfloat16")
+        # (the space-to-depth form is a stride-1 KH2 x KW2 convolution: the input-patch kernel's case)
+        a.nda_vals["filts"] = Nda(dims=Dims(("in_grp", "y", "x", "out_chan", "in_chan8"), (c2p // 8, sd["KH2"], sd["KW2"], g["OC"], 8), "bfloat16") if allow_patch else
+                                  Dims(("out_chan", "y", "x", "in_chan"), (g["OC"], sd["KH2"], sd["KW2"], c2p), "bfloat16"), tn="bfloat16")
         none = lambda y, x: Nda(Dims(("y", "x"), (y, x), "none"), "none")
         for an, v in (("stride", none(1, 1)), ("in_pad", none(0, 0)), ("kern_sz", none(sd["KH2"], sd["KW2"]))):
             if a.has(an):
@@ -183,15 +185,19 @@ CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_filts( GASQ float const * const filt
   filts[i] = r;
 }
 // filts_ref out_chan:in_chan:y:x float -> F' in_grp:y:x:out_chan:in_chan8 bf16 (the input-patch kernel's filters): one thread per 16-byte chunk (g, ky, kx, oc)
+// (S > 1: the space-to-depth filters, as hip_conv_nhwc_xpose_filts: tap (a, b), channel c2 = c*S*S + dy*S + dx is tap (S*a + dy - OFY, S*b + dx - OFX) of channel c)
 CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_filts_patch( GASQ float const * const filts_ref, GASQ xp_bf16x8_t * const filts, uint32_t const n, uint32_t const C,
-                                                          uint32_t const KH, uint32_t const KW, uint32_t const OC ) {
+                                                          uint32_t const KH, uint32_t const KW, uint32_t const OC, uint32_t const C2, uint32_t const KH2,
+                                                          uint32_t const KW2, uint32_t const S, uint32_t const OFY, uint32_t const OFX ) {
   uint32_t const i = GLOB_ID_1D;
   if( i >= n ) { return; }
-  uint32_t const oc = i % OC, kx = ( i / OC ) % KW, ky = ( i / ( OC*KW ) ) % KH, g = i / ( OC*KW*KH );
+  uint32_t const oc = i % OC, b = ( i / OC ) % KW2, a = ( i / ( OC*KW2 ) ) % KH2, g = i / ( OC*KW2*KH2 );
   xp_bf16x8_t r;
   for( uint32_t e = 0; e != 8; ++e ) {
-    uint32_t const c = 8*g + e;
-    r[e] = (__bf16)( ( c < C ) ? filts_ref[( ( oc*C + c )*KH + ky )*KW + kx] : 0.0f );
+    uint32_t const c2 = 8*g + e, c = c2 / ( S*S ), dy = ( c2 / S ) % S, dx = c2 % S;
+    int32_t const y = (int32_t)( S*a + dy ) - (int32_t)OFY, x = (int32_t)( S*b + dx ) - (int32_t)OFX;
+    bool const ok = ( c2 < C2 ) && ( y >= 0 ) && ( y < (int32_t)KH ) && ( x >= 0 ) && ( x < (int32_t)KW );
+    r[e] = (__bf16)( ok ? filts_ref[( ( oc*C + c )*KH + y )*KW + x] : 0.0f );
   }
   filts[i] = r;
 }
@@ -212,7 +218,7 @@ CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_out_f32( GASQ float const * const ou
 XPOSE_FUNCS: Dict[str, List[str]] = {
     "hip_conv_nhwc_xpose_in": ["in_ref", "in", "n", "C", "H", "W", "C2", "C8", "H2", "W2", "S", "PRY", "PRX"],
     "hip_conv_nhwc_xpose_filts": ["filts_ref", "filts", "n", "C", "KH", "KW", "C2", "C8", "KH2", "KW2", "S", "OFY", "OFX"],
-    "hip_conv_nhwc_xpose_filts_patch": ["filts_ref", "filts", "n", "C", "KH", "KW", "OC"],
+    "hip_conv_nhwc_xpose_filts_patch": ["filts_ref", "filts", "n", "C", "KH", "KW", "OC", "C2", "KH2", "KW2", "S", "OFY", "OFX"],
     "hip_conv_nhwc_xpose_out_bf16": ["out", "out_ref", "n", "C", "HW"],
     "hip_conv_nhwc_xpose_out_f32": ["out", "out_ref", "n", "C", "HW"],
 }
@@ -244,8 +250,10 @@ def xpose_call(arg: str, ref_vn: str, vn: str, ref_dims: Dims, dims: Dims, anno:
         return RtcFuncCall("hip_conv_nhwc_xpose_in", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
     if arg == "filts" and dims.has("in_grp"):     # F' for the input-patch kernel
         n = dims.dims_prod() // 8
-        am = {"filts_ref": RtcArg.var(ref_vn), "filts": RtcArg.var(vn), "n": _u32(n), "C": _u32(ref_dims.dsz("in_chan")), "KH": _u32(ref_dims.dsz("y")),
-              "KW": _u32(ref_dims.dsz("x")), "OC": _u32(ref_dims.dsz("out_chan"))}
+        C = ref_dims.dsz("in_chan")
+        am = {"filts_ref": RtcArg.var(ref_vn), "filts": RtcArg.var(vn), "n": _u32(n), "C": _u32(C), "KH": _u32(ref_dims.dsz("y")),
+              "KW": _u32(ref_dims.dsz("x")), "OC": _u32(ref_dims.dsz("out_chan")), "C2": _u32(C * (s * s if s else 1)), "KH2": _u32(dims.dsz("y")), "KW2": _u32(dims.dsz("x")),
+              "S": _u32(s or 1), "OFY": _u32(ofy), "OFX": _u32(ofx)}
         return RtcFuncCall("hip_conv_nhwc_xpose_filts_patch", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
     if arg == "filts":
         n = dims.dims_prod() // 8

@@ -83,7 +83,7 @@ def test_nhwc_conv_float_out_vs_oracle(be, shape):
     op = _conv_op(*shape)
     outs, prc = _run(be, op, OpTune(**NHWC_F32))
     from boda_amd import nhwc
-    g = op.conv_geom(); patch = nhwc.patch_eligible(g) and nhwc.s2d_geom(g) is None      # more than one tap, stride 1 in x: the LDS input-patch kernel
+    g = op.conv_geom(); patch = nhwc.patch_eligible(g) or nhwc.s2d_geom(g) is not None   # more than one tap, stride 1 in x (also: the stride-1 space-to-depth form of a conv1-type layer): the LDS input-patch kernel
     assert prc.launch["kernel"] == ("bodahip_conv_nhwc_patch_bf16" if patch else "bodahip_conv_nhwc_bf16"), prc.launch
     _check_f32(op, outs, prc)
     if patch:                                          # ... and the implicit-GEMM kernel on the same layer (op_tune hip_patch=0)
