@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh final'
-# then, back here:  python tools/make_profile_summaries.py gpurun_out/final r02
+# then, back here:  python tools/make_profile_summaries.py gpurun_out/final r03
 # Kernel-trace stats and the PMC passes are separate runs (one --pmc set per run, never combined with other trace domains).
 D=${1:-final}
 R=$PWD
@@ -17,30 +17,30 @@ prof() {   # key, bench args
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_$k -o p -- python $R/bench.py "$@" --steps 1 --warmup 0 --settle-ms 0 --no-cpu-baseline > $O/write_$k.log 2>&1
   rocprofv3 --kernel-trace --pmc $SQ -d $O/sq_$k -o p -- python $R/bench.py "$@" --steps 1 --warmup 0 --settle-ms 0 --no-cpu-baseline > $O/sq_$k.log 2>&1
 }
-prof sgemm-ops-full --workload sgemm-ops-full
+prof sgemm-ops-full --workload sgemm-ops-full --no-conv-ops
 prof alexnet --workload alexnet
 prof nin --workload nin
 prof googlenet-bf16-nhwc --workload googlenet --dtype bf16 --layout nhwc
 prof resnet50-bf16-nhwc --workload resnet50 --dtype bf16 --layout nhwc
 cd $R
 python -c "import bench; print(bench.kernel_src_hash())" > $O/kernel_src_hash.txt
-python bench.py > $O/bench_sgemm-ops-full.json 2>$O/bench_sgemm-ops-full.err
+python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2>$O/bench_default.err      # the driver's command: headline + conv_ops + configs legs
 for w in alexnet nin; do python bench.py --workload $w > $O/bench_$w.json 2>$O/bench_$w.err; done
 for w in googlenet resnet50; do
   python bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null
-  python bench.py --workload $w --dtype bf16 --no-cpu-baseline > $O/bench_${w}_bf16.json 2>/dev/null
   python bench.py --workload $w --dtype bf16 --layout nhwc --no-cpu-baseline > $O/bench_${w}_bf16_nhwc.json 2>/dev/null
-  python bench.py --workload $w --dtype bf16 --layout nhwc --graph --steps 10 --no-cpu-baseline > $O/bench_${w}_bf16_nhwc_graph.json 2>/dev/null
+  python bench.py --workload $w --dtype bf16 --layout nhwc --graph --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_${w}_bf16_nhwc_graph.json 2>/dev/null
+  python bench.py --workload $w --dtype bf16 --layout nhwc --graph --steps 20 --warmup 5 --no-patch --no-cpu-baseline > $O/bench_${w}_bf16_nhwc_graph_nopatch.json 2>/dev/null
 done
+python bench.py --workload googlenet --dtype bf16 --layout nhwc --graph --steps 20 --warmup 5 --group-siblings --no-cpu-baseline > $O/bench_googlenet_bf16_nhwc_graph_grouped.json 2>/dev/null
 for w in nin-net alexnet-net googlenet-net; do
   python bench.py --workload $w --no-cpu-baseline --graph --parallel-branches > $O/bench_${w}_graph.json 2>/dev/null
-  python bench.py --workload $w --dtype bf16 --no-cpu-baseline --graph --parallel-branches > $O/bench_${w}_bf16_graph.json 2>/dev/null
-  python bench.py --workload $w --dtype bf16 --layout nhwc --no-cpu-baseline --graph --parallel-branches > $O/bench_${w}_bf16_nhwc_graph.json 2>/dev/null
+  python bench.py --workload $w --dtype bf16 --layout nhwc --no-cpu-baseline --graph --parallel-branches --steps 20 --warmup 5 > $O/bench_${w}_bf16_nhwc_graph.json 2>/dev/null
+  python bench.py --workload $w --dtype bf16 --layout nhwc --no-cpu-baseline --graph --parallel-branches --steps 20 --warmup 5 --no-patch --no-fuse-siblings > $O/bench_${w}_bf16_nhwc_graph_r02kernels.json 2>/dev/null
 done
-python bench.py --workload alexnet --conv-algo winograd --no-cpu-baseline > $O/bench_alexnet_winograd.json 2>/dev/null
-BODAHIP_WINO_FUSED=1 python bench.py --workload alexnet --conv-algo winograd --no-cpu-baseline > $O/bench_alexnet_winograd_fused.json 2>/dev/null
-BODAHIP_NO_SGEMM_SPLIT=1 python bench.py --no-cpu-baseline > $O/bench_sgemm-ops-full_nosplit.json 2>/dev/null
+python bench.py --workload alexnet --exact 0 --no-cpu-baseline > $O/bench_alexnet_tolerance.json 2>/dev/null
 python bench.py --workload nin-net --batch 128 --no-cpu-baseline > $O/bench_nin-net_b128.json 2>/dev/null
+python bench.py --workload nin-net --batch 128 --exact 0 --no-cpu-baseline > $O/bench_nin-net_b128_tolerance.json 2>/dev/null
 python bench.py --workload nin --batch 128 --no-cpu-baseline > $O/bench_nin_b128.json 2>/dev/null
 find $O -name "*.db" -size +30M -delete   # keep the merge-back under the 64 MiB cap
 ls $O | head -80
