@@ -311,7 +311,8 @@ class Op:
                  OC=f.dsz("out_chan"), KH=f.dsz("y"), KW=f.dsz("x"),
                  SY=st.dsz("y"), SX=st.dsz("x"), PY=pad.dsz("y"), PX=pad.dsz("x"),
                  OH=o.dsz("y"), OW=o.dsz("x"))
-        if f.dsz("in_chan") != g["C"]:
+        f_in = f.dsz("in_grp") * f.dsz("in_chan8") if f.has("in_grp") else f.dsz("in_chan")   # (filts in the input-patch kernel's in_grp:y:x:out_chan:in_chan8 form, boda_amd/nhwc.py)
+        if f_in != g["C"]:
             raise RtErr("conv: filts.in_chan != in.chan (groups are not on this path)")
         if o.dsz("img") != g["B"] or o.dsz("chan") != g["OC"]:
             raise RtErr("conv: out dims inconsistent with in/filts")

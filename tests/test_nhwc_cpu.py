@@ -33,7 +33,8 @@ def test_annotation_gives_kernel_dims_and_keeps_reference_dims():
     # layer becomes a 4x4 / 1 / pad 0 one on a 115 x 115 map (pad 3 rounded up to 4: 224 + 4 + ... -> (112 + 4 - 1)); originals kept as <arg>_ref
     s = add_codegen_annotations(op, OpTune(hip_dtype="bf16", hip_layout="nhwc"))
     assert s.get_dims("in") == Dims(("img", "y", "x", "chan"), (64, 115, 115, 16), "bfloat16")
-    assert s.get_dims("filts") == Dims(("out_chan", "y", "x", "in_chan"), (64, 4, 4, 16), "bfloat16")
+    assert s.get_dims("filts") == Dims(("in_grp", "y", "x", "out_chan", "in_chan8"), (2, 4, 4, 64, 8), "bfloat16")    # (stride 1 now: the input-patch kernel's filter form)
+    assert add_codegen_annotations(op, OpTune(hip_dtype="bf16", hip_layout="nhwc", hip_patch=0)).get_dims("filts") == Dims(("out_chan", "y", "x", "in_chan"), (64, 4, 4, 16), "bfloat16")
     assert s.get_dims("stride").sizes == (1, 1) and s.get_dims("in_pad").sizes == (0, 0) and s.get_dims("kern_sz").sizes == (4, 4)
     assert s.get_dims("stride_ref").sizes == (2, 2) and s.get_dims("in_pad_ref").sizes == (3, 3) and s.get_dims("kern_sz_ref").sizes == (7, 7)
     assert (s.get_u32("nhwc_s2d"), s.get_u32("nhwc_s2d_pry"), s.get_u32("nhwc_s2d_prx")) == (2, 4, 4)
@@ -49,17 +50,46 @@ def test_planner_choices():
     p = plan((64, 256, 56, 56, 64, 1, 1, 1, 0))
     assert p[0] == "bodahip_conv_nhwc_bf16" and "-DCIN=256" in p and "-DOUT_F32=0" in p
     assert "-DBK=32" in plan((64, 64, 56, 56, 256, 1, 1, 1, 0))                 # short K: 32-deep steps, deeper ring
-    assert "-DBK=64" in plan((64, 512, 7, 7, 512, 3, 3, 1, 1))
+    assert "-DBK=64" in plan((64, 512, 7, 7, 512, 3, 3, 1, 1), hip_patch=0)
+    # more than one tap, stride 1 in x: the annotation asks for the F' filter form and the function binds the LDS input-patch kernel; tiles narrow in out_chan, wide in pels
+    pk = plan((64, 512, 7, 7, 512, 3, 3, 1, 1))
+    assert pk[0] == "bodahip_conv_nhwc_patch_bf16" and pk[1].startswith("64x128x288_w1x4") and "-DCG=4" in pk and "-DCIN=512" in pk
+    assert plan((64, 64, 56, 56, 192, 3, 3, 1, 1))[1].startswith("64x256x288_w1x4")        # 2352 tiles: the widest pel tile
+    assert "-DCG=1" in plan((64, 32, 28, 28, 96, 5, 5, 1, 2))                                # 5x5: one channel group per K step (25 k-slots + a zero slot)
+    assert plan((64, 256, 56, 56, 64, 1, 1, 1, 0))[0] == plan((64, 128, 28, 28, 128, 3, 3, 2, 1))[0] == "bodahip_conv_nhwc_bf16"   # 1x1, and stride 2 in x: implicit GEMM
+    assert plan((64, 128, 4, 4, 1024, 4, 4, 1, 0))[0] == "bodahip_conv_nhwc_bf16"            # whole-input kernel (an fc layer): implicit GEMM + K slices
     fc = plan((64, 2048, 1, 1, 1000, 1, 1, 1, 0))                                # 64 output rows, K = 2048: K slices + reduce pass
     assert "-DSPLITK=1" in fc and "_s" in fc[1]
     assert "-DSPLITK=1" not in plan((64, 1024, 14, 14, 256, 1, 1, 1, 0))        # 3.2 M outputs: the fp32 partial tiles would cost more than they save
     assert "-DOUT_F32=1" in plan((2, 64, 8, 8, 64, 3, 3, 1, 1), hip_out="f32")
-    t = plan((2, 64, 8, 8, 64, 3, 3, 1, 1), hip_tile="64x64x32x2x2x2x2x32x3")
+    t = plan((2, 64, 8, 8, 64, 3, 3, 1, 1), hip_tile="64x64x32x2x2x2x2x32x3", hip_patch=0)
     assert t[1].startswith("64x64x32_w2x2_s2") and "-DNBUF=3" in t
+    for kw in (dict(hip_patch=0), {}):
+        with pytest.raises(UnsupErr):
+            plan((2, 64, 8, 8, 64, 3, 3, 1, 1), hip_tile="48x64x32x1x2", **kw)           # not a multiple of the MFMA tile
     with pytest.raises(UnsupErr):
-        plan((2, 64, 8, 8, 64, 3, 3, 1, 1), hip_tile="48x64x32x1x2")           # not a multiple of the MFMA tile
+        plan((2, 64, 8, 8, 64, 3, 3, 1, 1), hip_tile="32x64x32x1x4x2x1x32x3", hip_patch=0)  # uneven loads per wave: no deep ring
+
+
+def test_sibling_group_annotation():
+    """hip_conv_nhwc_grp: the members' filters / biases stacked along out_chan, each member padded to grp.pad rows; tiles no taller than the padding."""
+    t = OpTune(hip_dtype="bf16", hip_layout="nhwc")
+    mem = [add_codegen_annotations(_conv_op(64, 192, 28, 28, oc, 1, 1, 1, 0), t) for oc in (96, 16, 64)]
+    ga = nhwc.annotate_group(mem)
+    assert ga.get_func_name() == "hip_conv_nhwc_grp" and ga.get_dims("grp") == Dims(("m0", "m1", "m2", "pad"), (96, 16, 64, 32), "none")
+    assert ga.get_dims("filts") == Dims(("out_chan", "y", "x", "in_chan"), (192, 1, 1, 192), "bfloat16") and ga.get_dims("biases").sizes == (192,)
+    assert nhwc.group_row_offsets(ga.get_dims("grp")) == [0, 96, 128] and nhwc.group_arg_names(3)[-3:] == ["out_0", "out_1", "out_2"]
+    assert [ga.get_dims(f"out_{m}").dsz("chan") for m in range(3)] == [96, 16, 64]
+    assert nhwc.group_pad([192, 48, 384]) == 128 and nhwc.group_pad([128, 32, 128]) == 64 and nhwc.group_pad([16, 16]) == 32
+    p = rtc.explain_plan(ga).split()
+    assert p[0] == "bodahip_conv_nhwc_bf16" and "-DGROUPS=1" in p and p[1].startswith("32x") and "-DSPLITK=1" not in p
+    assert rtc.parse_op_native(ga.to_str()) == ga.to_str() and rtc.prebuild(ga) > 0
     with pytest.raises(UnsupErr):
-        plan((2, 64, 8, 8, 64, 3, 3, 1, 1), hip_tile="32x64x32x1x4x2x1x32x3")  # uneven loads per wave: no deep ring
+        nhwc.annotate_group(mem[:1])                                                                        # a group has 2..4 members
+    with pytest.raises(UnsupErr):
+        nhwc.annotate_group([mem[0], add_codegen_annotations(_conv_op(64, 192, 28, 28, 32, 1, 1, 2, 0), t)])   # another stride: not siblings
+    with pytest.raises(UnsupErr):
+        nhwc.annotate_group([add_codegen_annotations(_conv_op(64, 96, 28, 28, oc, 3, 3, 1, 1), t) for oc in (64, 64)])   # patch-form filters are not stacked
 
 
 def test_kernel_and_layout_passes_compile_for_gfx950_without_a_device():
