@@ -287,6 +287,7 @@ struct hip_multi_compute_t : public rtc_compute_t {
       if (T && v.dims.dims(0) != T) unsup_err(why + "with different batch sizes (" + std::to_string(T) + " and " + std::to_string(v.dims.dims(0)) + ")");
       T = v.dims.dims(0);
     }
+    if (!T) { calls.push_back(std::vector<uint32_t>(n(), kNoCall)); return (uint32_t)calls.size() - 1; }   // (an empty batch: nothing to run anywhere)
     auto ai = rfc.arg_map.find(g.ix_arg);
     if (ai == rfc.arg_map.end() || !ai->second.is_valid()) rt_err(why + "binds no argument named '" + g.ix_arg + "', the one its index is declared over");
     dims_t const ixd = ai->second.is_var() ? must_find(vis, ai->second.n).dims : ai->second.v->dims;
