@@ -115,6 +115,17 @@ def conv_ops(text: str, batch: int, in_chw: Tuple[int, int, int] = (3, 224, 224)
     return out
 
 
+def conv_bottoms(text: str) -> List[Tuple[str, str]]:
+    """-> [(layer name, bottom blob)] of the TEST-phase Convolution / InnerProduct layers in definition order (the order of conv_ops): which convolutions read the
+    same blob -- sibling convolutions that can run as one fused launch -- is a fact of the net graph, not of the layer shapes."""
+    root = parse(text)
+    out: List[Tuple[str, str]] = []
+    for L in root.get("layer", []) or root.get("layers", []):
+        if _is_test_phase(L) and str(_one(L, "type")).upper().replace("_", "") in ("CONVOLUTION", "INNERPRODUCT"):
+            out.append((str(_one(L, "name")), str(L.get("bottom", [""])[0])))
+    return out
+
+
 def pipe_spec(text: str, in_chw: Tuple[int, int, int] = (3, 224, 224)) -> List[str]:
     """-> the TEST-phase forward ops of a net definition as compact one-line records (boda_amd.conv_pipe.pipe_from_spec reads
     them back): what the reference's reader keeps of each layer for conv_pipe_t (src/caffepb.cc:166-326).

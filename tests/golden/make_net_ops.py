@@ -5,7 +5,7 @@ build container only.  The outputs are data: one op line per Convolution layer, 
 layer order and multiplicity preserved (64 GoogLeNet convs incl. the auxiliary heads, 53 ResNet-50 convs + its fc)."""
 import os, sys
 HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(os.path.dirname(HERE)); sys.path.insert(0, ROOT)
-from boda_amd.prototxt import conv_ops, pipe_spec
+from boda_amd.prototxt import conv_bottoms, conv_ops, pipe_spec
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 for net in ("googlenet_conv", "resnet-50"):
     ops = conv_ops(open(os.path.join(REF, "nets", net, "train_val.prototxt")).read(), 1)
@@ -13,6 +13,12 @@ for net in ("googlenet_conv", "resnet-50"):
         for name, op in ops:
             f.write(op.to_str() + "\n")
     print(net, len(ops), "convs", sum(o.flops() for _, o in ops) / 1e9, "GF at batch 1")
+    # which blob every conv of that list reads (name + bottom, same order): sibling convolutions = same bottom (bench.py --group-siblings)
+    os.makedirs(os.path.join(HERE, "nets"), exist_ok=True)
+    cb = conv_bottoms(open(os.path.join(REF, "nets", net, "train_val.prototxt")).read())
+    assert [n for n, _ in cb] == [n for n, _ in ops]
+    with open(os.path.join(HERE, "nets", f"{net}-conv-bottoms.txt"), "w") as f:
+        f.write("".join(f"{n} {b}\n" for n, b in cb))
 
 # full-net op records (TEST phase) for the nets whose every layer type has a forward kernel here (GoogLeNet: conv, ReLU, max/avg
 # pool, LRN, Concat, Dropout) -- read back by boda_amd.conv_pipe.pipe_from_spec

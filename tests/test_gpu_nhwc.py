@@ -160,3 +160,67 @@ def test_config5_every_layer_nhwc_at_bench_batch(be, net):
         assert np.isfinite(outs_b["out"]).all() and (err <= lim).all(), (ob.to_str(), prc_b.launch["cfg"], float((err / lim).max()))
     print(f"{net}: hip_conv_nhwc tiles taken at B=64: {sorted(cfgs)}; worst mrd / bound = {worst:.3f}")
     assert len(cfgs) >= 2
+
+
+@pytest.mark.parametrize("case", [dict(B=5, C=64, H=15, S=2, ocs=(96, 24, 130, 8), out="bf16"), dict(B=3, C=40, H=9, S=1, ocs=(64, 64), out="f32"),
+                                   dict(B=2, C=256, H=14, S=2, ocs=(512, 128), out="bf16"), dict(B=4, C=24, H=7, S=1, ocs=(16, 200, 33), out="bf16", k=3)])
+def test_fused_sibling_convs_equal_the_separate_calls(be, case):
+    """hip_conv_nhwc_grp against its members run one by one on the same device tensors: bit-identical outputs (stride 1 / 2, ragged member sizes -- padded to 32 /
+    64 / 128 rows --, float and bf16 outputs, a member writing a channel slice of a wider tensor; a 3x3 group through the implicit-GEMM form)."""
+    from boda_amd import gen_data as gd, nhwc
+    from boda_amd.rtc import RtcArg, RtcFuncCall, RtcFuncInfo
+    rtc = be.rtc
+    nhwc.ensure_compiled(rtc)
+    B, C, H, S, k = case["B"], case["C"], case["H"], case["S"], case.get("k", 1)
+    tune = OpTune(hip_patch=0, **(NHWC_F32 if case["out"] == "f32" else NHWC))
+    annos = [add_codegen_annotations(_conv_op(B, C, H, H, oc, k, k, S, k // 2), tune) for oc in case["ocs"]]
+    ga = nhwc.annotate_group(annos)
+    made, funcs = [], []
+    def mk(vn, dims):
+        rtc.create_var_with_dims(vn, dims); made.append(vn)
+    try:
+        a0 = annos[0]
+        mk("g_in_ref", a0.get_dims("in_ref")); mk("g_in", a0.get_dims("in"))
+        rtc.run(gd.gen_call("Convolution", "in", "g_in_ref", a0.get_dims("in_ref"), 5, 0.0)); rtc.run(nhwc.xpose_call("in", "g_in_ref", "g_in", a0.get_dims("in_ref"), a0.get_dims("in"), a0))
+        wide = a0.get_dims("out").sizes[:3] + (a0.get_dims("out").dsz("chan") + 24,)      # member 0 also writes channels [16, 16 + oc) of a wider tensor
+        sep, F, Bv = [], np.zeros(ga.get_dims("filts").sizes, np.uint16), np.zeros(ga.get_dims("biases").sizes, np.float32)
+        for m, (an, off) in enumerate(zip(annos, nhwc.group_row_offsets(ga.get_dims("grp")))):
+            for arg in ("filts", "biases"):
+                mk(f"g{m}_{arg}", an.get_dims(arg))
+            mk(f"g{m}_filts_ref", an.get_dims("filts_ref"))
+            rtc.run(gd.gen_call("Convolution", "filts", f"g{m}_filts_ref", an.get_dims("filts_ref"), 5, float(m))); rtc.run(gd.gen_call("Convolution", "biases", f"g{m}_biases", an.get_dims("biases"), 5, float(m)))
+            rtc.run(nhwc.xpose_call("filts", f"g{m}_filts_ref", f"g{m}_filts", an.get_dims("filts_ref"), an.get_dims("filts"), an))
+            odims = an.get_dims("out") if m else type(an.get_dims("out"))(an.get_dims("out").names, wide, an.get_dims("out").tn)
+            mk(f"g{m}_out_sep", odims); mk(f"g{m}_out_grp", odims)
+            rtc.finish_and_sync()
+            f = rtc.copy_var_to_nda(f"g{m}_filts"); b = rtc.copy_var_to_nda(f"g{m}_biases")
+            F[off:off + f.shape[0]] = f; Bv[off:off + b.shape[0]] = b
+            fn = f"sep{m}"; rtc.compile([RtcFuncInfo(fn, "", ["filts", "biases", "in", "stride", "in_pad", "out"], an)]); funcs.append(fn)
+            am = {"filts": RtcArg.var(f"g{m}_filts"), "biases": RtcArg.var(f"g{m}_biases"), "in": RtcArg.var("g_in"), "stride": RtcArg.ref(an.get_dims("stride")),
+                  "in_pad": RtcArg.ref(an.get_dims("in_pad")), "out": RtcArg.var(f"g{m}_out_sep")}
+            if m == 0:
+                am["out_chan_off"] = RtcArg.scalar(16, "uint32_t")
+            sep.append(RtcFuncCall(fn, am))
+        mk("g_filts", ga.get_dims("filts")); mk("g_biases", ga.get_dims("biases"))
+        rtc.copy_nda_to_var("g_filts", F); rtc.copy_nda_to_var("g_biases", Bv)
+        rtc.compile([RtcFuncInfo("grp", "", nhwc.group_arg_names(len(annos)), ga)]); funcs.append("grp")
+        gam = {"filts": RtcArg.var("g_filts"), "biases": RtcArg.var("g_biases"), "in": RtcArg.var("g_in"), "stride": RtcArg.ref(ga.get_dims("stride")),
+               "in_pad": RtcArg.ref(ga.get_dims("in_pad")), "grp": RtcArg.ref(ga.get_dims("grp")), "out_chan_off_0": RtcArg.scalar(16, "uint32_t")}
+        for m in range(len(annos)):
+            gam[f"out_{m}"] = RtcArg.var(f"g{m}_out_grp")
+        for c in sep:
+            rtc.run(c)
+        rtc.run(RtcFuncCall("grp", gam)); rtc.finish_and_sync()
+        assert rtc.last_launch()["kernel"].startswith("bodahip_conv_nhwc_bf16(x")
+        for m in range(len(annos)):
+            a, b = rtc.copy_var_to_nda(f"g{m}_out_sep"), rtc.copy_var_to_nda(f"g{m}_out_grp")
+            assert np.array_equal(a, b) and np.abs(a.astype(np.float64)).max() > 0, m
+        w0 = rtc.copy_var_to_nda("g0_out_grp")
+        assert not w0[..., :16].any() and not w0[..., 16 + case["ocs"][0]:].any()          # the guard channels of the wider tensor are untouched
+    finally:
+        rtc.finish_and_sync()
+        for fn in funcs:
+            rtc.release_func(fn)
+        for vn in made:
+            rtc.release_var(vn)
+        rtc.release_per_call_id_data()

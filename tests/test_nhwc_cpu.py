@@ -96,3 +96,24 @@ def test_kernel_and_layout_passes_compile_for_gfx950_without_a_device():
     assert rtc.compile_offline(nhwc.XPOSE_SRC, use_cache=True) > 0
     for shape, kw in [((2, 24, 28, 28, 64, 5, 5, 1, 2), {}), ((2, 3, 64, 64, 24, 11, 11, 4, 5), dict(hip_out="f32")), ((4, 2048, 1, 1, 1000, 1, 1, 1, 0), {})]:
         assert rtc.prebuild(add_codegen_annotations(_conv_op(*shape), OpTune(hip_dtype="bf16", hip_layout="nhwc", **kw))) > 0
+
+
+def test_sibling_fixtures_agree_with_the_net_graphs():
+    """tests/golden/nets/<net>-conv-bottoms.txt (bench.py --group-siblings): the convolutions that share a bottom blob.  GoogLeNet: exactly the groups ConvPipeFwd
+    finds in the pipe (nine inception modules x {1x1, 3x3-reduce, 5x5-reduce}); ResNet-50: the four stage-start pairs branch1 + branch2a."""
+    import os
+    from boda_amd.conv_pipe import googlenet_conv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def groups(net):
+        nb = [l.split() for l in open(os.path.join(root, "tests", "golden", "nets", f"{net}-conv-bottoms.txt")).read().splitlines() if l.strip()]
+        by = {}
+        for n, b in nb:
+            by.setdefault(b, []).append(n)
+        return nb, sorted(tuple(v) for v in by.values() if len(v) > 1)
+    nb, gg = groups("googlenet_conv")
+    cp = googlenet_conv(2)
+    convs = [o for o in cp.ops if o.type == "Convolution"]
+    assert [n for n, _ in nb] == [o.tag for o in convs] and [b for _, b in nb] == [o.bot for o in convs]
+    assert len(gg) == 9 and all(len(g) == 3 for g in gg)
+    nb, gr = groups("resnet-50")
+    assert len(nb) == 54 and gr == sorted((f"res{s}a_branch1", f"res{s}a_branch2a") for s in (2, 3, 4, 5))
