@@ -37,6 +37,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef OUT_F32
 #define OUT_F32 0
 #endif
+#ifndef DBUF
+#define DBUF 0     // 1: two LDS images -- step s+1 is stored into the other image right after the MFMAs of step s were issued (one barrier per K step instead of two,
+#endif             // a wave's staging stores overlap the other waves' MFMAs); costs twice the LDS
+#ifndef ABLATE
+#define ABLATE 0   // measurement only (wrong results): 1 = no operand loads, 2 = no fragment reads / MFMAs, 3 = no LDS stores of the staged operands, 4 = no K loop at all
+#endif
 
 struct gemm_args_t { // identical to gemm_conv_f32.hip (one host-side struct); I = F', J = in
   float const *I; float const *J; float *D; float const *bias;
@@ -75,7 +81,8 @@ constexpr int kCSp = kCS + ((2 - kCS % 16) + 16) % 16;             // group pitc
 constexpr int kPE = (kCS * CG + kNT - 1) / kNT;                    // patch chunks per thread per K step
 constexpr int kIE = (kNP * BI + kNT - 1) / kNT;                    // filter chunks per thread per K step
 constexpr int kEPitch = BI * 2 + 16;                               // epilogue tile [pel][oc] bf16, rows de-phased by 4 banks
-constexpr int kOpB = 16 * (kNP * BI + CG * kCSp), kEpiB = OUT_F32 ? 0 : BJ * kEPitch;
+constexpr int kImgC = kNP * BI + CG * kCSp;                         // chunks of one operand image pair
+constexpr int kOpB = 16 * kImgC * (DBUF ? 2 : 1), kEpiB = OUT_F32 ? 0 : BJ * kEPitch;
 constexpr int kSmem = kOpB > kEpiB ? kOpB : kEpiB;
 constexpr int kOOB = (int)0x80000000;
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -87,8 +94,8 @@ constexpr int slot_off(int q) { return (q >= kNPr) ? 0 : ((q / kTaps) * kCSp + (
 
 extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p) {
   __shared__ __attribute__((aligned(16))) char smem[kSmem];
-  u32x4 *const Is = reinterpret_cast<u32x4 *>(smem);               // A operand: [k-slot][out_chan] chunks
-  u32x4 *const Js = Is + kNP * BI;                                 // input patch: [group][slot][padded column] chunks, group pitch kCSp
+  u32x4 *const Is0 = reinterpret_cast<u32x4 *>(smem);              // A operand: [k-slot][out_chan] chunks
+  u32x4 *const Js0 = Is0 + kNP * BI;                               // input patch: [group][slot][padded column] chunks, group pitch kCSp
   int const tid = threadIdx.x, lane = tid & 63;
   int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int const wi = wave / WJ, wj = wave % WJ;
@@ -140,6 +147,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   rsrc_t const rI = make_rsrc(p.I, p.I_bytes), rJ = make_rsrc(p.J, p.J_bytes);
   u32x4 rp[kPE], rf[kIE];
   auto load_step = [&](int kt) {
+    if (ABLATE == 1) { for (int e = 0; e < kPE; ++e) rp[e] = u32x4{0u, 0u, 0u, 0u}; for (int e = 0; e < kIE; ++e) rf[e] = u32x4{0u, 0u, 0u, 0u}; return; }
     int const cg0 = kt * CG;
 #pragma unroll
     for (int e = 0; e < kPE; ++e) {
@@ -155,7 +163,9 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
       rf[e] = bload4(rI, ok ? (int)((((unsigned)cg * kTaps + tap) * (unsigned)p.Mi + (unsigned)(i0 + i)) * 16u) : kOOB);
     }
   };
-  auto store_step = [&]() {
+  auto store_step = [&](int buf) {
+    if (ABLATE == 3) { asm volatile("" ::"v"(rp[0]), "v"(rf[0])); return; }
+    u32x4 *const Is = Is0 + buf * kImgC, *const Js = Js0 + buf * kImgC;
 #pragma unroll
     for (int e = 0; e < kPE; ++e) if (((e + 1) * kNT <= kCS * CG) || (tid + e * kNT < kCS * CG)) Js[pdst[e]] = rp[e];
 #pragma unroll
@@ -163,13 +173,23 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   };
 
   load_step(0);
-  for (int kt = 0; kt < kNKT; ++kt) {
-    store_step();
+#if DBUF
+  store_step(0);
+  __syncthreads();
+#endif
+  for (int kt = 0; kt < ((ABLATE == 4) ? 0 : kNKT); ++kt) {
+#if DBUF
+    int const cur = kt & 1;
+#else
+    int const cur = 0;
+    store_step(0);
     __syncthreads();
+#endif
     if (kt + 1 < kNKT) load_step(kt + 1);      // next step's loads fly under this step's MFMAs
+    u32x4 const *const Is = Is0 + cur * kImgC, *const Js = Js0 + cur * kImgC;
     u32x4 const *const Ic = Is + wi * (kTI * 32) + (lane & 31);
 #pragma unroll
-    for (int s = 0; s < kNP / 2; ++s) {
+    for (int s = 0; s < ((ABLATE == 2) ? 0 : kNP / 2); ++s) {
       int const jo = hi ? slot_off(2 * s + 1) : slot_off(2 * s);
       bf16x8 a[kTI], b[kTJ];
 #pragma unroll
@@ -181,7 +201,10 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #pragma unroll
         for (int tb = 0; tb < kTJ; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
     }
-    __syncthreads();                           // every wave is done reading before the next step overwrites the images
+#if DBUF
+    if (kt + 1 < kNKT) store_step(cur ^ 1);    // (the other image: its last readers passed the previous barrier)
+#endif
+    __syncthreads();                           // every wave is done reading before the next step overwrites the images (DBUF: and the next image is complete)
   }
 
   // ---- epilogue (as conv_nhwc_bf16.hip).  C/D layout of the 32x32 MFMA family: column j = lane & 31, rows i = 8*g + 4*(lane >> 5) + e for register 4*g + e

@@ -15,8 +15,8 @@ native ones (tests/test_gpu_ref_cucl.py; their times: DESIGN.md section 5).
 This module is TEST INFRASTRUCTURE (it lives under oracle/ with its only users, oracle/ref_cucl.py and the tests): the product's own annotation
 layer is boda_amd/cnn_op.py, which routes ops to the native kernels.
 
-Covered: all four sgemm variants (use_local_mem 0..3; vector width 2 / 4), conv / conv_simd / k1conv / k1conv_simd / tconv / ipconv, reduce; sgemm_prof and the
-backward ops raise UnsupErr.
+Covered: all four sgemm variants (use_local_mem 0..3; vector width 2 / 4), conv / conv_simd / k1conv (incl. write-xposed
+chaining into the next k1conv) / k1conv_simd / tconv / ipconv, reduce; sgemm_prof (not instantiable in the reference either) and the backward ops raise UnsupErr.
 """
 from __future__ import annotations
 import os
@@ -91,8 +91,6 @@ def annotate_ref(op: Op, tune: OpTune) -> Op:
     t = a.get_type()
     if t == "sgemm":
         g = a.sgemm_geom()
-        if tune.prof_variant:
-            raise UnsupErr("CUCL compatibility mode: the sgemm_prof variant is not generated")
         variants = {0: "sgemm_no_local", 1: "sgemm", 2: "sgemm_simd", 3: "sgemm_simd_local"}      # src/cnn_op.cc:368-374
         if tune.use_local_mem not in variants:
             raise RtErr(f"op_tune.use_local_mem must be 0..3, got {tune.use_local_mem}")
@@ -102,6 +100,11 @@ def annotate_ref(op: Op, tune: OpTune) -> Op:
                 raise RtErr(f"FIXME: currently, {what}={v} must be a multiple of {what}_blk={blk}")
         a.set_dims("work", _none_dims(Mg=g["M"] // mb, Ng=g["N"] // nb, Mb=tune.MNb[0], Nb=tune.MNb[1], Kb=tune.Kb, Mt=tune.MNt[0], Nt=tune.MNt[1]))
         a.set_u32("use_local_mem", tune.use_local_mem); a.set_u32("prof_variant", tune.prof_variant); a.set_u32("vw", tune.vw)
+        if tune.prof_variant:
+            # (src/cnn_op.cc:365-367 would name the function sgemm_prof -- a memory-access probe, c = a + b -- but test/rtc/sgemm_prof.cucl reads %(prof_variant), which
+            # the reference's template layer only defines for DECLARED by-value arguments (src/rtc_func_gen.cc:160-176): the template declares none, so the reference
+            # itself stops with "unknown template variable" there.  Nothing to be compatible with.)
+            raise UnsupErr("CUCL compatibility mode: sgemm_prof cannot be instantiated (its template reads %(prof_variant) without declaring it, in the reference too)")
         a.set_func_name(variants[tune.use_local_mem])
         return a
     if t != "Convolution":
@@ -401,13 +404,12 @@ def gen_conv(cg: CallGen) -> None:
 
 
 def gen_k1conv(cg: CallGen) -> None:
-    """src/cnn_codegen.cc:625-761 (reference-layout output only): 1x1 / stride 1 / no padding; in is blk:blk_iter:blk_iter_chan:blk_pel."""
+    """src/cnn_codegen.cc:625-761: 1x1 / stride 1 / no padding; in is blk:blk_iter:blk_iter_chan:blk_pel; out in the reference layout, or -- write-xposed -- in the
+    next k1conv's input layout."""
     work, filts, inp, out = (cg.get_arg_dims_by_name(n) for n in ("work", "filts", "in", "out"))
     st, pad = cg.get_arg_dims_by_name("stride"), cg.get_arg_dims_by_name("in_pad")
     if pad.sizes != (0, 0) or st.sizes != (1, 1) or filts.dsz("x") != 1 or filts.dsz("y") != 1:
         raise RtErr("k1conv needs a 1x1 kernel, stride 1 and no padding")
-    if out.has("blk"):
-        raise UnsupErr("CUCL compatibility mode: k1conv writes the reference output layout only (no write-xposed chaining)")
     P, OC = work.dsz("pels"), work.dsz("out_chan")
     filts_smem_sz = filts.dstride("in_chan") * inp.dsz("blk_iter_chan")
     out_smem_sz = work.dsz("pels_tile") * work.dsz("out_chan_tile") * P
@@ -417,18 +419,29 @@ def gen_k1conv(cg: CallGen) -> None:
     _guarded(cg, "smem_loads", inp.dstride("blk_iter"), lambda i, ix: f"    in_smem[{ix}] = in[ blk_in_ix_base + (%(tpb)*{i}) ];", "%(in_blk_iter_stride)")
     cg.set("out_chan_tile", "(%(GRP_ID_1D_out_chan_blk)*%(work_out_chan_tile_dim)+%(LOC_ID_1D_out_chan_tile))")
     cg.set("out_chan_ix", "(%(out_chan_tile)*%(work_out_chan_dim))")
-    cg.line("stores", "  int32_t tpix[%(work_pels_dim)];")
-    cg.line("stores", "  int32_t tcix[%(work_out_chan_dim)];")
-    for ty in range(P):
-        cg.insert_nda_ix_exprs(f"out_pel_{ty}", cg.all_ix_dims["out_ref_pel"],
-                               f"( (%(GRP_ID_1D_pels_blk)*%(work_pels_tile_dim) + %(LOC_ID_1D_pels_tile))*%(work_pels_dim) + {ty} )")
-        cg.line("stores", f"  tpix[{ty}] = %(out_pel_{ty}_img)*%(out_img_stride) +  %(out_pel_{ty}_x)*%(out_x_stride) + %(out_pel_{ty}_y)*%(out_y_stride);")
-    for tx in range(OC):
-        cg.line("stores", f"  tcix[{tx}] = (%(out_chan_ix)+{tx})*%(out_chan_stride);")
-    for ty in range(P):
-        cg.line("stores", f"  if( %(out_pel_{ty}_img) >= %(out_img_dim) ) {{ return; }}")
+    if out.has("blk"):
+        # write-xposed chaining (src/cnn_codegen.cc:656-707, src/rtc_fwd.cc:495-503): `out` has the NEXT k1conv's input dims (blk:blk_iter:blk_iter_chan:blk_pel), so
+        # that layer needs no k1conv_xpose_in pass.  Per per-thread out_chan the block's values go through local memory and leave as (mostly) sequential runs of pels.
+        if work.dsz("out_chan_blk") * work.dsz("out_chan_tile") * OC != out.dsz("blk_iter") * out.dsz("blk_iter_chan"):
+            raise RtErr("k1conv write-xposed: padded out_chans of this layer != padded in_chans of the next")
+        if work.dsz("pels_blk") * work.dsz("pels_tile") * P != out.dsz("blk") * out.dsz("blk_pel") or out.dsz("blk_pel") != inp.dsz("blk_pel"):
+            raise RtErr("k1conv write-xposed: the two layers' pel blockings differ")
+        cg.line("stores", "int32_t const out_ix = (%(GRP_ID_1D_out_chan_blk)*%(work_out_chan_tile_dim)*%(work_out_chan_dim))*%(out_blk_iter_chan_stride) + %(GRP_ID_1D_pels_blk)*%(out_blk_stride);")
+        cg.line("stores", "int32_t xpbuf_rd_pel;")
+        cg.line("stores", "int32_t xpbuf_rd_chan;")
         for tx in range(OC):
-            cg.line("stores", f"if( tcix[{tx}] < (%(out_chan_dim)*%(out_chan_stride)) ) {{ out[ tpix[{ty}] + tcix[{tx}] ] = {_bias_relu(cg, work, tx, ty)}; }}")
+            cg.line("stores", "  BARRIER_SYNC;")
+            for ty in range(P):
+                cg.line("stores", f"out_smem_off[%(tpb)*{ty}] = {_bias_relu(cg, work, tx, ty)};")
+            cg.line("stores", "  BARRIER_SYNC;")
+            for ty in range(P):
+                obe = f"(LOC_ID_1D + %(tpb)*{ty})"
+                cg.line("stores", f"  xpbuf_rd_pel = {obe} %% %(out_blk_pel_dim) ;")
+                cg.line("stores", f"  xpbuf_rd_chan = {obe} / %(out_blk_pel_dim) ;")
+                cg.line("stores", f"out[out_ix + xpbuf_rd_pel + (xpbuf_rd_chan*%(work_out_chan_dim)+{tx})*%(out_blk_iter_chan_stride)] = "
+                                  "all_smem[xpbuf_rd_chan+(xpbuf_rd_pel %% %(work_pels_dim))*%(tpb)+ (xpbuf_rd_pel / %(work_pels_dim))*%(work_out_chan_tile_dim) ];")
+    else:
+        _k1conv_ref_stores(cg, work, P, OC)
     for ty in range(P):
         for tx in range(OC):
             cg.line("dummy_stores", f"out_off[{(ty * OC + tx) * cg.tpb}] = {_bias_relu(cg, work, tx, ty)};")
@@ -442,6 +455,22 @@ def gen_k1conv(cg: CallGen) -> None:
         for ty in range(P):
             cg.line("inner_loop_body", f"in_strip[{ty}] = in_smem_off[({ic}*%(in_blk_pel_dim)+{ty})];")
         _fma_tile(cg, "inner_loop_body", work, lambda ty: ty)
+
+
+def _k1conv_ref_stores(cg: CallGen, work: Dims, P: int, OC: int) -> None:
+    """k1conv's stores into the reference output layout (src/cnn_codegen.cc:708-731)."""
+    cg.line("stores", "  int32_t tpix[%(work_pels_dim)];")
+    cg.line("stores", "  int32_t tcix[%(work_out_chan_dim)];")
+    for ty in range(P):
+        cg.insert_nda_ix_exprs(f"out_pel_{ty}", cg.all_ix_dims["out_ref_pel"],
+                               f"( (%(GRP_ID_1D_pels_blk)*%(work_pels_tile_dim) + %(LOC_ID_1D_pels_tile))*%(work_pels_dim) + {ty} )")
+        cg.line("stores", f"  tpix[{ty}] = %(out_pel_{ty}_img)*%(out_img_stride) +  %(out_pel_{ty}_x)*%(out_x_stride) + %(out_pel_{ty}_y)*%(out_y_stride);")
+    for tx in range(OC):
+        cg.line("stores", f"  tcix[{tx}] = (%(out_chan_ix)+{tx})*%(out_chan_stride);")
+    for ty in range(P):
+        cg.line("stores", f"  if( %(out_pel_{ty}_img) >= %(out_img_dim) ) {{ return; }}")
+        for tx in range(OC):
+            cg.line("stores", f"if( tcix[{tx}] < (%(out_chan_dim)*%(out_chan_stride)) ) {{ out[ tpix[{ty}] + tcix[{tx}] ] = {_bias_relu(cg, work, tx, ty)}; }}")
 
 
 def gen_tconv(cg: CallGen) -> None:
@@ -593,6 +622,16 @@ def custom_codegen(cg: CallGen, template_name: str) -> None:
             cg.line("ins_ops", f"v += {vn}[GLOB_ID_1D];")
     elif template_name in ("bconv", "bconv_fb"):
         raise UnsupErr(f"CUCL compatibility mode: the custom code generation of '{template_name}' is not restated")
+
+
+def chain_k1conv(first: Op, second: Op) -> None:
+    """In place: `first` (an annotated k1conv whose output feeds only `second`, another annotated k1conv) writes its output in `second`'s input layout
+    (conv_pipe_fwd_t::init with enable_write_xpose, src/rtc_fwd.cc:495-503): second then runs without its k1conv_xpose_in pass."""
+    if first.get_func_name() != "k1conv" or second.get_func_name() != "k1conv":
+        raise UnsupErr("write-xposed chaining needs two k1conv functions")
+    if first.get_dims("out_ref") != second.get_dims("in_ref"):
+        raise RtErr("write-xposed chaining: the second layer does not read the first one's output")
+    first.reset_dims("out", second.get_dims("in"))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------

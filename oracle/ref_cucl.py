@@ -104,6 +104,18 @@ def build(rtc_dir: str = REF_RTC_DIR, verbose: bool = False) -> int:
         manifest.append(entry)
         if verbose:
             print(tag, entry["variant"], entry["main"]["tpb"], entry["main"]["blks"])
+    # write-xposed chaining (src/rtc_fwd.cc:495-503): NiN cccp1 -> cccp2 as two k1conv functions, the first writing the second's input layout (no
+    # k1conv_xpose_in between them)
+    import bench
+    from boda_amd.cnn_op import OpTune
+    for b in (2, 256):
+        ops2 = bench.nin_ops(b)[1:3]; kt = OpTune(k1conv=1, tconv=1)
+        a1, a2 = cc.annotate_ref(ops2[0], kt), cc.annotate_ref(ops2[1], kt)
+        cc.chain_k1conv(a1, a2)
+        tag = f"nin_b{b}_chain_l1l2"
+        l1 = {"xposes": [dict(emit(f"{tag}__1_{t}", t, x), src=sa, dst=da) for t, sa, da, x in cc.xpose_ops(a1)], "main": emit(f"{tag}__1_k1conv_wx", "k1conv", a1)}
+        l2 = {"xposes": [dict(emit(f"{tag}__2_{t}", t, x), src=sa, dst=da) for t, sa, da, x in cc.xpose_ops(a2) if da != "in"], "main": emit(f"{tag}__2_k1conv", "k1conv", a2)}
+        manifest.append({"tag": tag, "variant": "k1conv_chain", "ops": [o.to_str() for o in ops2], "tune": kt.to_str(), "l1": l1, "l2": l2})
     # the one template of the reference with a `_multi` argument pack (test/rtc/reduce.cucl: out = sum of ins_num tensors; custom code generation
     # src/cnn_codegen.cc:28-34): exercises the pack expansion of the template layer on the GPU
     from boda_amd.op import Dims, Nda, Op

@@ -88,8 +88,22 @@ def test_build_recipe_writes_code_objects_and_manifest():
     if not os.path.exists(os.path.join(ref_cucl.OUT, "manifest.json")):
         assert ref_cucl.build() > 0
     man = json.load(open(os.path.join(ref_cucl.OUT, "manifest.json")))
-    assert len(man) >= 30 and all(os.path.getsize(os.path.join(ref_cucl.OUT, e["main"]["file"])) > 1000 for e in man)
-    assert {e["variant"] for e in man} >= {"sgemm", "conv", "k1conv", "tconv"}
+    assert len(man) >= 30 and all(os.path.getsize(os.path.join(ref_cucl.OUT, (e.get("main") or e["l1"]["main"])["file"])) > 1000 for e in man)
+    assert {e["variant"] for e in man} >= {"sgemm", "conv", "k1conv", "tconv", "k1conv_chain"}
+
+
+def test_k1conv_write_xposed_chain_annotation():
+    """enable_write_xpose (src/rtc_fwd.cc:495-503): the first k1conv's `out` takes the second's `in` dims; the padded out_chans / pel blocks of the two layers agree."""
+    ops = bench.nin_ops(20)[1:3]
+    a1, a2 = cc.annotate_ref(ops[0], KT), cc.annotate_ref(ops[1], KT)
+    cc.chain_k1conv(a1, a2)
+    o = a1.get_dims("out")
+    assert o == a2.get_dims("in") and o.names == ("blk", "blk_iter", "blk_iter_chan", "blk_pel") and o.sizes == (757, 12, 8, 80)      # (cccp1 at 20 images: blk=757, blk_pel=80, SURVEY appendix C)
+    assert a1.get_dims("out_ref") == ops[0].get_dims("out")
+    with pytest.raises(UnsupErr):
+        cc.chain_k1conv(cc.annotate_ref(bench.nin_ops(20)[0], KT), a2)           # conv1 is a tconv, not a k1conv
+    with pytest.raises(UnsupErr):
+        cc.annotate_ref(bench.sgemm_full_ops()[5], OpTune(prof_variant=1))        # sgemm_prof: not instantiable (in the reference either)
 
 
 @have_ref

@@ -45,7 +45,7 @@ def rtc():
 def test_manifest_present_and_geometries_match_the_reference_fixtures():
     if not MAN:
         pytest.skip("oracle/_ref/cucl not built (no Boda checkout on the build machine)")
-    geo = {e["tag"]: (e["variant"], e["main"]["tpb"], e["main"]["blks"]) for e in MAN}
+    geo = {e["tag"]: (e["variant"], e["main"]["tpb"], e["main"]["blks"]) for e in MAN if "main" in e}
     # SURVEY.md section 8 a5 (probed from test/rtc_func_sigs.txt and good_tr/nin of the reference) and a4 (sgemm 8192^3 -> 8192 blocks)
     assert geo["alexnet_b256_l0"] == ("tconv", 120, 9856) and geo["alexnet_b256_l1"] == ("tconv", 128, 6912)
     assert geo["alexnet_b256_l2"][2] == geo["alexnet_b256_l3"][2] == 2496 and geo["alexnet_b256_l4"][2] == 1664
@@ -106,7 +106,7 @@ def _run_entry(rtc, e, iters=3):
 TIMES = {}
 
 
-CONV_SGEMM = [e for e in MAN if e["variant"] != "reduce"]
+CONV_SGEMM = [e for e in MAN if e["variant"] not in ("reduce", "k1conv_chain")]
 
 
 @pytest.mark.parametrize("e", CONV_SGEMM, ids=[e["tag"] for e in CONV_SGEMM])
@@ -168,6 +168,57 @@ def test_reference_kernel_matches_oracle(rtc, e):
                        "bit_exact_vs_oracle": bool(np.array_equal(want, got))}
 
 
+@pytest.mark.parametrize("e", [e for e in MAN if e["variant"] == "k1conv_chain"], ids=[e["tag"] for e in MAN if e["variant"] == "k1conv_chain"])
+def test_reference_k1conv_write_xposed_chain(rtc, e):
+    """conv_pipe_fwd_t's enable_write_xpose (src/rtc_fwd.cc:495-503, src/cnn_codegen.cc:656-707): NiN cccp1 -> cccp2 as two of the reference's k1conv functions, the first
+    writing its output in the second's input layout (blk:blk_iter:blk_iter_chan:blk_pel) so that no k1conv_xpose_in pass runs between them; the second layer's output
+    against the oracle applied twice."""
+    kt = OpTune.parse(e["tune"]); ops = [parse_op(o) for o in e["ops"]]
+    a1, a2 = cc.annotate_ref(ops[0], kt), cc.annotate_ref(ops[1], kt)
+    cc.chain_k1conv(a1, a2)
+    assert a1.get_dims("out") == a2.get_dims("in") and a1.get_dims("out").has("blk")
+    funcs = [(f, a1, "l1") for f in e["l1"]["xposes"] + [e["l1"]["main"]]] + [(f, a2, "l2") for f in e["l2"]["xposes"] + [e["l2"]["main"]]]
+    assert not any(f["template"].endswith("xpose_in") for f in e["l2"]["xposes"])
+    # var of (layer, arg): layer 1's out IS layer 2's in
+    def vname(layer, an):
+        return "mid" if (layer, an) in (("l1", "out"), ("l2", "in")) else f"{layer}_{an}"
+    made, loaded = [], []
+    try:
+        for f, anno, layer in funcs:
+            rtc.compile_code_object(open(os.path.join(CUCL, f["file"]), "rb").read(), [RtcFuncInfo(f["func"], "", f["arg_names"], anno)]); loaded.append(f["func"])
+            for an, kind in zip(f["arg_names"], f["arg_kinds"]):
+                if kind in ("IN", "OUT", "INOUT") and vname(layer, an) not in made:
+                    rtc.create_var_with_dims(vname(layer, an), anno.get_dims(an)); made.append(vname(layer, an))
+        for layer, anno, vi in (("l1", a1, 0.0), ("l2", a2, 0.25)):
+            for an in (("in", "filts", "biases") if layer == "l1" else ("filts", "biases")):
+                tgt = an + "_ref" if anno.has(an + "_ref") and vname(layer, an + "_ref") in made else an
+                rtc.run(gd.gen_call("Convolution", an, vname(layer, tgt), anno.get_dims(tgt), 5, vi))
+        ids = []
+        for f, anno, layer in funcs:
+            am = {}
+            for an, kind in zip(f["arg_names"], f["arg_kinds"]):
+                am[an] = RtcArg.var(vname(layer, an)) if kind in ("IN", "OUT", "INOUT") else (RtcArg.scalar(0, "uint32_t") if kind == "SCALAR" else RtcArg.ref(anno.get_dims(an)))
+            ids.append(rtc.run(RtcFuncCall(f["func"], am, tpb=f["tpb"], blks=f["blks"])))
+        rtc.finish_and_sync()
+        x = rtc.copy_var_to_nda("l1_in_ref"); g = ops[0].conv_geom(); nb = min(2, g["B"])
+        f1, b1, f2, b2 = (rtc.copy_var_to_nda(v) for v in ("l1_filts_ref", "l1_biases", "l2_filts_ref", "l2_biases"))
+        mid = bo.conv_fwd(x[:nb], f1, b1, (1, 1), (0, 0), True)
+        want = bo.conv_fwd(mid, f2, b2, (1, 1), (0, 0), True)
+        got = rtc.copy_var_to_nda("l2_out")
+        sd = SsdsDiff.of(want, got[:nb])
+        assert not sd.has_nan() and sd.mrd < MRD and np.abs(want).max() > 0, (e["tag"], sd.basic_str())
+        assert np.isfinite(got[-1]).all() and got[-1].max() > 0
+        TIMES[e["tag"]] = {"variant": "k1conv (write-xposed) -> k1conv", "ms_l1": round(rtc.get_dur(ids[len(e["l1"]["xposes"])], ids[len(e["l1"]["xposes"])]), 5), "ms_l2": round(rtc.get_dur(ids[-1], ids[-1]), 5),
+                           "bit_exact_vs_oracle": bool(np.array_equal(want, got[:nb]))}
+    finally:
+        rtc.finish_and_sync()
+        for vn in made:
+            rtc.release_var(vn)
+        for fn in loaded:
+            rtc.release_func(fn)
+        rtc.release_per_call_id_data()
+
+
 def test_reference_reduce_template_with_multi_argument_pack(rtc):
     """test/rtc/reduce.cucl -- the reference's one template with a `_multi` argument pack (ins_num arguments ins_0 ..): generated by the restated template
     layer + gen_op_reduce, compiled for gfx950 on the build machine, run here under be=hip; the sum in the generated order is exact in fp32."""
@@ -201,4 +252,4 @@ def test_zz_write_reference_kernel_times():
     out = os.path.join(ROOT, "gpurun_out"); os.makedirs(out, exist_ok=True)
     json.dump(TIMES, open(os.path.join(out, "ref_cucl_times.json"), "w"), indent=1)
     big = {k: v for k, v in TIMES.items() if "b256" in k or k.startswith("sgemm")}
-    print("reference CUCL kernels on this GPU (TF/s):", {k: v["tflops"] for k, v in big.items()})
+    print("reference CUCL kernels on this GPU (TF/s):", {k: v["tflops"] for k, v in big.items() if "tflops" in v})
