@@ -8,7 +8,7 @@
 using namespace bodahip;
 namespace bodahip {
 void *hip_compute_stream(rtc_compute_t *rtc);
-void hip_compute_set_timing(rtc_compute_t *rtc, bool stream);
+void hip_compute_set_timing(rtc_compute_t *rtc, int mode);
 void hip_compute_graph_begin(rtc_compute_t *rtc);
 uint32_t hip_compute_graph_end(rtc_compute_t *rtc);
 uint32_t hip_compute_graph_launch(rtc_compute_t *rtc, uint32_t id);
@@ -166,8 +166,8 @@ int bodahip_set_tune(bodahip_ctx *ctx, const char *key, const char *value) {
   ABI_TRY
   if (S(key, "key") == "timing") {   // how get_dur attributes stream time to calls (hip_compute.cc: timing_stream)
     string const v = value ? value : "";
-    if (!v.empty() && v != "call" && v != "stream") rt_err("set_tune: timing must be call | stream");
-    for (uint32_t i = 0; i < hip_multi_num_devices(&R(ctx)); ++i) hip_compute_set_timing(hip_multi_sub(&R(ctx), i), v == "stream");
+    if (!v.empty() && v != "call" && v != "stream" && v != "kernel") rt_err("set_tune: timing must be call | stream | kernel");
+    for (uint32_t i = 0; i < hip_multi_num_devices(&R(ctx)); ++i) hip_compute_set_timing(hip_multi_sub(&R(ctx), i), v == "stream" ? 1 : (v == "kernel" ? 2 : 0));
     return 0;
   }
   for (uint32_t i = 0; i < hip_multi_num_devices(&R(ctx)); ++i) hip_compute_native(hip_multi_sub(&R(ctx), i))->set_tune(S(key, "key"), value ? value : ""); ABI_CATCH }

@@ -14,6 +14,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <hip/hip_ext.h>
 
 #include <map>
 #include <set>
@@ -168,6 +169,11 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
   // first call after release_per_call_id_data).  Per-call durations then add up EXACTLY to first-begin .. last-end of the call list, kernels are
   // queued back to back as in production, and a call's figure contains its own dispatch gap, no marker.  What bench.py's per-op roofline uses.
   bool timing_stream = false;
+  // "kernel" (tune key `timing`): no marker packets at all -- the call's begin / end events are bound to its own kernel DISPATCHES (hipExtModuleLaunchKernel's
+  // startEvent of the call's first kernel, stopEvent of its last): get_dur is the kernels' execution time as the command processor stamps it, which is what
+  // rocprofv3's kernel trace reports, and back-to-back launches are not separated by markers.  What bench.py's per-op numbers use.
+  bool timing_kernel = false;
+  int cur_call = -1; bool cur_first = true;     // the call whose kernels are being launched (kernel timing)
   bool shard_aware = false;   // device of a multi-device backend: generated functions are compiled so that a launch can cover a shard of the id space
 
   explicit hip_compute_t(int dev) : device_ordinal(dev) { be = "hip"; }
@@ -337,9 +343,9 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
     if (hf.native) {
       if (capturing) { try { native->run(hf.info, rfc.arg_map); } catch (...) { graph_abort(); throw; } note_captured_call(); return kCapturedCallId; }
       uint32_t const call_id = new_call_events();
-      record_begin(call_id);
-      native->run(hf.info, rfc.arg_map);
-      hip_err_chk(hipEventRecord(call_events(call_id).e, stream), "hipEventRecord");
+      call_begin(call_id);
+      try { native->run(hf.info, rfc.arg_map); } catch (...) { cur_call = -1; throw; }
+      call_end(call_id);
       return call_id;
     }
     return run_generated(hf, rfc, rfc.blks, 0u, 0xffffffffu, nullptr);
@@ -376,10 +382,10 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
       note_captured_call(); return kCapturedCallId;
     }
     uint32_t const call_id = new_call_events();
-    record_begin(call_id);
-    hip_err_chk(hipModuleLaunchKernel(hf.func, blks, 1, 1, rfc.tpb, 1, 1, 0, stream, kargs.empty() ? nullptr : kargs.data(), nullptr),
-                ("hipModuleLaunchKernel(" + rfc.rtc_func_name + ")").c_str());
-    hip_err_chk(hipEventRecord(call_events(call_id).e, stream), "hipEventRecord");
+    call_begin(call_id);
+    hipError_t const le = launch_kernel(hf.func, blks, 1, rfc.tpb, kargs.empty() ? nullptr : kargs.data());
+    if (le != hipSuccess) { cur_call = -1; hip_err_chk(le, ("hipModuleLaunchKernel(" + rfc.rtc_func_name + ")").c_str()); }
+    call_end(call_id);
     return call_id;
   }
   void finish_and_sync() override { use_dev(); if (capturing) { graph_abort(); rt_err("finish_and_sync during graph capture"); } hip_err_chk(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
@@ -388,6 +394,30 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
 
   // ---- native_host_t: what the native kernels need from the backend
   hipStream_t nh_stream() override { return stream; }
+  hipError_t launch_kernel(hipFunction_t f, uint32_t gx, uint32_t gy, uint32_t block, void **params) {
+    if (timing_kernel && cur_call >= 0 && !capturing && (uint64_t)gx * block <= 0xffffffffull) {
+      ev_pair_t &ce = call_evs[cur_call];
+      hipError_t const e = hipExtModuleLaunchKernel(f, gx * block, gy, 1, block, 1, 1, 0, stream, params, nullptr, cur_first ? ce.b : nullptr, ce.e, 0);
+      cur_first = false;
+      return e;
+    }
+    if (timing_kernel && cur_call >= 0 && !capturing && cur_first) {   // (a grid too large for the work-item form: markers for this call)
+      hipError_t const e0 = hipEventRecord(call_evs[cur_call].b, stream); if (e0 != hipSuccess) return e0;
+      cur_first = false; cur_marker_end = true;
+    }
+    return hipModuleLaunchKernel(f, gx, gy, 1, block, 1, 1, 0, stream, params, nullptr);
+  }
+  bool cur_marker_end = false;
+  hipError_t nh_launch(hipFunction_t f, uint32_t gx, uint32_t gy, uint32_t block, void **params) override { return launch_kernel(f, gx, gy, block, params); }
+  // kernel timing: bracket of one call
+  void call_begin(uint32_t call_id) { if (timing_kernel) { cur_call = (int)call_id; cur_first = true; cur_marker_end = false; begin_recorded[call_id] = 1; } else record_begin(call_id); }
+  void call_end(uint32_t call_id) {
+    if (timing_kernel) {
+      if (cur_first) { hip_err_chk(hipEventRecord(call_events(call_id).b, stream), "hipEventRecord"); cur_marker_end = true; }   // (the call launched nothing: empty interval)
+      if (cur_marker_end) hip_err_chk(hipEventRecord(call_events(call_id).e, stream), "hipEventRecord");
+      cur_call = -1;
+    } else hip_err_chk(hipEventRecord(call_events(call_id).e, stream), "hipEventRecord");
+  }
   bool nh_capturing() override { return capturing; }
   int nh_live_graphs() override { int n = 0; for (auto const &gr : graphs) if (gr.exec) ++n; return n; }
 
@@ -538,7 +568,8 @@ uint32_t hip_compute_run_shard(rtc_compute_t *rtc, rtc_func_call_t const &rfc, u
   if (fit->second.native) rt_err("run_shard: '" + rfc.rtc_func_name + "' is a native function");
   return h.run_generated(fit->second, rfc, blks, gid_off, gid_last, &var_bias);
 }
-void hip_compute_set_timing(rtc_compute_t *rtc, bool stream_mode) { hip_compute_t &h = as_hip(rtc); h.finish_and_sync(); h.release_per_call_id_data(); h.timing_stream = stream_mode; }
+void hip_compute_set_timing(rtc_compute_t *rtc, int mode) {   // 0 call (markers around every call) | 1 stream (end markers only) | 2 kernel (events bound to the dispatches)
+  hip_compute_t &h = as_hip(rtc); h.finish_and_sync(); h.release_per_call_id_data(); h.timing_stream = (mode == 1); h.timing_kernel = (mode == 2); }
 void *hip_compute_stream(rtc_compute_t *rtc) { hip_compute_t *h = dynamic_cast<hip_compute_t *>(rtc); if (!h) rt_err("not a hip_compute_t"); return (void *)h->stream; }
 native_kernels_t *hip_compute_native(rtc_compute_t *rtc) { hip_compute_t *h = dynamic_cast<hip_compute_t *>(rtc); if (!h || !h->native) rt_err("hip backend not initialised"); return h->native.get(); }
 

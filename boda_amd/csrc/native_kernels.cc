@@ -157,7 +157,7 @@ static kernel_t &get_kernel(native_kernels_t::impl_t *impl, native_host_t *host,
 static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t const &c) {
   void *params[] = {&a};
   uint32_t const grid = (uint32_t)a.tiles_i * (uint32_t)a.tiles_j * (uint32_t)std::max(1, a.splitk);
-  hip_err_chk(hipModuleLaunchKernel(k.func, grid, 1, 1, (uint32_t)c.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(native)");
+  hip_err_chk(host->nh_launch(k.func, grid, 1, (uint32_t)c.threads(), params), "hipModuleLaunchKernel(native)");
 }
 
 struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, patch16 = false, nhwc = false, nhwc_patch = false; int rows = 0, cg = 0; };
@@ -606,7 +606,7 @@ static void reduce_splitk(native_kernels_t::impl_t *impl, native_host_t *host, g
   void *params[] = {&ws, &ws_slab, &splitk, &D, &n, &bias, &chan_stride, &n_chan};
   long const groups = (n / 4 + 255) / 256;
   uint32_t const grid = (uint32_t)std::max<long>(1, std::min<long>(groups, 2048));
-  hip_err_chk(hipModuleLaunchKernel(k.func, grid, 1, 1, 256, 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(splitk_reduce)");
+  hip_err_chk(host->nh_launch(k.func, grid, 1, 256, params), "hipModuleLaunchKernel(splitk_reduce)");
 }
 
 // per-k tables of the im2col gather (three arrays of n ints): offset of (in_chan,ky,kx) inside one image | ky | kx.
@@ -761,10 +761,10 @@ static void launch_patch16(native_kernels_t::impl_t *impl, native_host_t *host, 
   fa.I = filts; fa.D = (float *)((char *)impl->ws + ws_off); fa.Mi = g.OC; fa.C = g.C; fa.K = taps;
   void *fparams[] = {&fa};
   long const nchunks = (long)ncg * taps * g.OC;
-  hip_err_chk(hipModuleLaunchKernel(fk.func, (uint32_t)((nchunks + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), fparams, nullptr), "hipModuleLaunchKernel(filt_bf16)");
+  hip_err_chk(host->nh_launch(fk.func, (uint32_t)((nchunks + 255) / 256), 1, 256, fparams), "hipModuleLaunchKernel(filt_bf16)");
   ga.I = (float const *)((char *)impl->ws + ws_off); ga.I_bytes = (unsigned)fbytes;
   void *params[] = {&ga};
-  hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j), 1, 1, (uint32_t)p.cfg.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(conv_patch_bf16)");
+  hip_err_chk(host->nh_launch(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j), 1, (uint32_t)p.cfg.threads(), params), "hipModuleLaunchKernel(conv_patch_bf16)");
 }
 
 // bf16 conv1-type layers (stride s in both axes, few input channels): space-to-depth front end + the patch kernel (kernels/conv_patch_bf16.hip)
@@ -828,9 +828,9 @@ void native_kernels_t::conv_winograd(float const *filts, float const *biases, fl
     wa.C = g.C; wa.H = g.H; wa.W = g.W; wa.OC = g.OC; wa.OH = g.OH; wa.OW = g.OW; wa.TH = TH; wa.TW = TW; wa.PY = g.PY; wa.PX = g.PX; wa.relu = g.relu ? 1 : 0;
     wa.out_ctot = out_ctot; wa.out_coff = out_coff; wa.B0 = 0; wa.Bc = g.B; wa.Tc = (int)((long)g.B * tpi);
     void *wparams[] = {&wa};
-    hip_err_chk(hipModuleLaunchKernel(impl->wino_filt_t, (uint32_t)(((long)g.C * g.OC + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), wparams, nullptr), "hipModuleLaunchKernel(wino_filt_t)");
+    hip_err_chk(host->nh_launch(impl->wino_filt_t, (uint32_t)(((long)g.C * g.OC + 255) / 256), 1, 256, wparams), "hipModuleLaunchKernel(wino_filt_t)");
     uint32_t const grid = (uint32_t)((g.OC + 63) / 64) * (uint32_t)((wa.Tc + 63) / 64);
-    hip_err_chk(hipModuleLaunchKernel(impl->wino_fused, grid, 1, 1, 512, 1, 1, 0, host->nh_stream(), wparams, nullptr), "hipModuleLaunchKernel(wino_fused)");
+    hip_err_chk(host->nh_launch(impl->wino_fused, grid, 1, 512, wparams), "hipModuleLaunchKernel(wino_fused)");
     tile_cfg_t fc; fc.BI = 64; fc.BJ = 64; fc.BK = 8; fc.WI = 2; fc.WJ = 4; fc.MINW = 1; fc.MT = 32; fc.PF = 1; fc.SPLITK = 1;
     long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * 9;
     last_launch.kernel = "bodahip_conv_winograd_fused_f32"; last_launch.cfg = fc; last_launch.grid = grid; last_launch.block = 512;
@@ -858,7 +858,7 @@ void native_kernels_t::conv_winograd(float const *filts, float const *biases, fl
   wa.out_ctot = out_ctot; wa.out_coff = out_coff;
   void *wparams[] = {&wa};
   auto launch1 = [&](hipFunction_t f, long n, char const *what) {
-    hip_err_chk(hipModuleLaunchKernel(f, (uint32_t)((n + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), wparams, nullptr), what);
+    hip_err_chk(host->nh_launch(f, (uint32_t)((n + 255) / 256), 1, 256, wparams), what);
   };
   launch1(impl->wino_filt, (long)g.C * g.OC, "hipModuleLaunchKernel(wino_filt)");
   string const tile = tune_of(impl, "sgemm_tile");
@@ -877,7 +877,7 @@ void native_kernels_t::conv_winograd(float const *filts, float const *biases, fl
     ga.bsI = (long)g.C * g.OC; ga.bsJ = (long)g.C * Tc; ga.bsD = (long)g.OC * Tc;
     ga.tiles_i = (g.OC + p.cfg.BI - 1) / p.cfg.BI; ga.tiles_j = (int)((Tc + p.cfg.BJ - 1) / p.cfg.BJ); ga.splitk = 1;
     void *gparams[] = {&ga};
-    hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j), 16, 1, (uint32_t)p.cfg.threads(), 1, 1, 0, host->nh_stream(), gparams, nullptr),
+    hip_err_chk(host->nh_launch(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j), 16, (uint32_t)p.cfg.threads(), gparams),
                 "hipModuleLaunchKernel(winograd sgemm)");
     launch1(impl->wino_out, (long)g.OC * Tc, "hipModuleLaunchKernel(wino_out)");
     last_cfg = p.cfg; last_grid = (uint32_t)(ga.tiles_i * ga.tiles_j * 16);
@@ -916,15 +916,15 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
       sa.src = in; sa.dst = (float *)((char *)impl->ws + off_in2); sa.H2 = g2.H; sa.W2 = g2.W; sa.oy = pry; sa.ox = prx; sa.filt = 0;
       sa.mode = 1; sa.c2_lo = 0;
       long const n1 = (long)g.B * g.C * g2.H * g.SY * g2.W;
-      hip_err_chk(hipModuleLaunchKernel(sk.func, (uint32_t)((n1 + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), sparams, nullptr), "hipModuleLaunchKernel(s2d in)");
+      hip_err_chk(host->nh_launch(sk.func, (uint32_t)((n1 + 255) / 256), 1, 256, sparams), "hipModuleLaunchKernel(s2d in)");
       sa.mode = 0; sa.c2_lo = g.C * g.SY * g.SY;
       if (sa.c2_lo < g2.C) { // zero pad channels up to a multiple of 8
         long const n0 = (long)g.B * (g2.C - sa.c2_lo) * g2.H * g2.W;
-        hip_err_chk(hipModuleLaunchKernel(sk.func, (uint32_t)((n0 + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), sparams, nullptr), "hipModuleLaunchKernel(s2d pad)");
+        hip_err_chk(host->nh_launch(sk.func, (uint32_t)((n0 + 255) / 256), 1, 256, sparams), "hipModuleLaunchKernel(s2d pad)");
       }
       sa.c2_lo = 0;
       sa.src = filts; sa.dst = (float *)((char *)impl->ws + off_f2); sa.H2 = g2.KH; sa.W2 = g2.KW; sa.oy = pry - g.PY; sa.ox = prx - g.PX; sa.filt = 1;
-      hip_err_chk(hipModuleLaunchKernel(sk.func, (uint32_t)((f2 + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), sparams, nullptr), "hipModuleLaunchKernel(s2d filts)");
+      hip_err_chk(host->nh_launch(sk.func, (uint32_t)((f2 + 255) / 256), 1, 256, sparams), "hipModuleLaunchKernel(s2d filts)");
       kernel_t &k2 = get_kernel(impl, host, p2);
       gemm_args_t ga; memset(&ga, 0, sizeof(ga));
       ga.J = (float const *)((char *)impl->ws + off_in2); ga.D = out; ga.bias = biases;
@@ -952,7 +952,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
     na.I_bytes = (unsigned)fb; na.J_bytes = (unsigned)ib; na.D_bytes = (unsigned)ob; na.out_ctot = out_ctot; na.out_coff = out_coff; na.splitk = 1;
     na.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; na.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
     void *nparams[] = {&na};
-    hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(na.tiles_i * na.tiles_j), 1, 1, (uint32_t)cfg.threads(), 1, 1, 0, host->nh_stream(), nparams, nullptr), "hipModuleLaunchKernel(conv_nhwc_f32)");
+    hip_err_chk(host->nh_launch(k.func, (uint32_t)(na.tiles_i * na.tiles_j), 1, (uint32_t)cfg.threads(), nparams), "hipModuleLaunchKernel(conv_nhwc_f32)");
     last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(na.tiles_i * na.tiles_j); last_launch.block = cfg.threads();
     last_launch.flops = 2.0 * Nj * g.OC * Kt;
     last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
@@ -986,7 +986,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
     long const per = (ga.tiles_j + slots - 1) / slots;
     ga.kt_per = (int)((ga.tiles_j + per - 1) / per); ga.splitk = 1;
     void *params[] = {&ga};
-    hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(ga.kt_per * ga.tiles_i), 1, 1, (uint32_t)cfg.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(k1_stream)");
+    hip_err_chk(host->nh_launch(k.func, (uint32_t)(ga.kt_per * ga.tiles_i), 1, (uint32_t)cfg.threads(), params), "hipModuleLaunchKernel(k1_stream)");
     last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(ga.kt_per * ga.tiles_i); last_launch.block = cfg.threads();
     last_launch.flops = 2.0 * Nj * g.OC * Kt;
     last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
@@ -1034,7 +1034,7 @@ void native_kernels_t::conv_nhwc_grp(void const *filts, float const *biases, voi
   ga.I_bytes = (unsigned)f_bytes; ga.J_bytes = (unsigned)in_bytes; ga.splitk = 1;
   ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
   void *params[] = {&ga, &q};
-  hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j), 1, 1, (uint32_t)cfg.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(conv_nhwc_bf16, fused)");
+  hip_err_chk(host->nh_launch(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j), 1, (uint32_t)cfg.threads(), params), "hipModuleLaunchKernel(conv_nhwc_bf16, fused)");
   last_launch.kernel = p.kname + "(x" + std::to_string(n) + ")"; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(ga.tiles_i * ga.tiles_j); last_launch.block = cfg.threads();
   last_launch.flops = 2.0 * Nj * real_oc * Kt;   // (the members' own out_chans: zero padding rows are work done, not credit)
   last_launch.algo_bytes = 2.0 * ((double)g.B * g.C * g.H * g.W + real_oc * Kt) + (out_f32 ? 4.0 : 2.0) * (double)Nj * real_oc + 4.0 * real_oc;
@@ -1064,14 +1064,14 @@ void native_kernels_t::conv_nhwc(void const *filts, float const *biases, void co
     ga.splitk = cfg.SPLITK; ga.kt_per = (int)((nk + cfg.SPLITK - 1) / cfg.SPLITK); ga.ws = (float *)impl->ws; ga.ws_slab = (long)slab;
   }
   void *params[] = {&ga};
-  hip_err_chk(hipModuleLaunchKernel(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j * ga.splitk), 1, 1, (uint32_t)cfg.threads(), 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(conv_nhwc_bf16)");
+  hip_err_chk(host->nh_launch(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j * ga.splitk), 1, (uint32_t)cfg.threads(), params), "hipModuleLaunchKernel(conv_nhwc_bf16)");
   if (cfg.SPLITK > 1) {
     plan_t rp; rp.nhwc = true; rp.bf16 = true; rp.kname = "bodahip_nhwc_splitk_reduce";
     rp.defs = {"-DREDUCE_ONLY=1", string("-DRELU=") + (g.relu ? "1" : "0"), string("-DOUT_F32=") + (out_f32 ? "1" : "0")};
     kernel_t &rk = get_kernel(impl, host, rp);
     bool const v4 = (g.OC % 4 == 0) && (((out_ctot | out_coff) & 3) == 0);
     long const n = v4 ? Nj * g.OC / 4 : Nj * g.OC;
-    hip_err_chk(hipModuleLaunchKernel(rk.func, (uint32_t)((n + 255) / 256), 1, 1, 256, 1, 1, 0, host->nh_stream(), params, nullptr), "hipModuleLaunchKernel(nhwc_splitk_reduce)");
+    hip_err_chk(host->nh_launch(rk.func, (uint32_t)((n + 255) / 256), 1, 256, params), "hipModuleLaunchKernel(nhwc_splitk_reduce)");
   }
   last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(ga.tiles_i * ga.tiles_j * ga.splitk); last_launch.block = cfg.threads();
   last_launch.flops = 2.0 * Nj * g.OC * Kt;   // (as stored: zero pad channels of a conv1-type layer count as work done, not as credit -- bench.py credits the op's own 2MNK)

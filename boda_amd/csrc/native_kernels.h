@@ -29,6 +29,9 @@ string default_cache_dir();
 struct native_host_t {
   virtual ~native_host_t() {}
   virtual hipStream_t nh_stream() = 0;
+  // launch a kernel of the current call on the backend's stream (grid gx x gy workgroups of `block` threads).  The backend decides how the call is TIMED: with marker
+  // events around the call, or -- timing mode "kernel" -- with start / stop events bound to the call's own dispatches (hipExtModuleLaunchKernel)
+  virtual hipError_t nh_launch(hipFunction_t f, uint32_t gx, uint32_t gy, uint32_t block, void **params) = 0;
   virtual bool nh_capturing() = 0; // stream capture (hipGraph) in progress: nothing may be compiled / allocated / synchronised
   virtual int nh_live_graphs() = 0; // captured graphs not yet destroyed (their kernel arguments may point into the kernel scratch)
   virtual string const &nh_arch() = 0;
