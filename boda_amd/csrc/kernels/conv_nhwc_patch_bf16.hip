@@ -16,7 +16,7 @@
 //
 // Numerics: as conv_nhwc_bf16.hip (fp32 accumulate in the MFMA's own order; parity stated against the oracle on bf16-rounded operands).
 //
-// -D parameters: KNAME BI BJ WI WJ MINW CG CIN KH KW SY PY PX CH CW COH COW RELU OUT_F32        (SX == 1)
+// -D parameters: KNAME BI BJ WI WJ MINW CG CIN KH KW SY PY PX CH CW COH COW RELU OUT_F32 [ADIRECT PF]       (SX == 1)
 
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
@@ -40,6 +40,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef DBUF
 #define DBUF 0     // 1: two LDS images -- step s+1 is stored into the other image right after the MFMAs of step s were issued (one barrier per K step instead of two,
 #endif             // a wave's staging stores overlap the other waves' MFMAs); costs twice the LDS
+#ifndef ADIRECT
+#define ADIRECT 0  // 1: the FILTER operand does not pass through the LDS at all.  A filter chunk has no reuse across taps (the patch has KH*KW-fold reuse): staging it only
+#endif             // shares it between the WJ waves of a tile row, at the price of most of the ds_write traffic of a K step (a 128 x 36-slot filter image is 18 of the 23
+                   // 16-byte stores per thread) and of the LDS space that limits the workgroups per CU.  Here every wave loads its own MFMA A fragments straight from
+                   // global memory -- in F'[g][ky][kx][oc][8] the fragment of k-iteration s is 2 x 512 contiguous bytes, rows (s, s+1) of a [k-slot][out_chan] matrix
+                   // -- PF k-iterations ahead through a register ring (counted vmcnt, loads return in order), waves of the same tile row meet in the L1.  The LDS
+                   // holds only the patch, double-buffered: one barrier per K step.  Wants wave tiles wide in pels (kTJ = 4: one 1-KB A load per four MFMAs).
+#ifndef PF
+#define PF 8       // ADIRECT: k-iterations of filter fragments in flight
+#endif
 #ifndef ABLATE
 #define ABLATE 0   // measurement only (wrong results): 1 = no operand loads, 2 = no fragment reads / MFMAs, 3 = no LDS stores of the staged operands, 4 = no K loop at all
 #endif
@@ -81,8 +91,9 @@ constexpr int kCSp = kCS + ((2 - kCS % 16) + 16) % 16;             // group pitc
 constexpr int kPE = (kCS * CG + kNT - 1) / kNT;                    // patch chunks per thread per K step
 constexpr int kIE = (kNP * BI + kNT - 1) / kNT;                    // filter chunks per thread per K step
 constexpr int kEPitch = BI * 2 + 16;                               // epilogue tile [pel][oc] bf16, rows de-phased by 4 banks
-constexpr int kImgC = kNP * BI + CG * kCSp;                         // chunks of one operand image pair
-constexpr int kOpB = 16 * kImgC * (DBUF ? 2 : 1), kEpiB = OUT_F32 ? 0 : BJ * kEPitch;
+constexpr int kAImg = ADIRECT ? 0 : kNP * BI;                      // chunks of the filter image
+constexpr int kImgC = kAImg + CG * kCSp;                            // chunks of one operand image pair
+constexpr int kOpB = 16 * kImgC * ((DBUF || ADIRECT) ? 2 : 1), kEpiB = OUT_F32 ? 0 : BJ * kEPitch;
 constexpr int kSmem = kOpB > kEpiB ? kOpB : kEpiB;
 constexpr int kOOB = (int)0x80000000;
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -95,7 +106,7 @@ constexpr int slot_off(int q) { return (q >= kNPr) ? 0 : ((q / kTaps) * kCSp + (
 extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p) {
   __shared__ __attribute__((aligned(16))) char smem[kSmem];
   u32x4 *const Is0 = reinterpret_cast<u32x4 *>(smem);              // A operand: [k-slot][out_chan] chunks
-  u32x4 *const Js0 = Is0 + kNP * BI;                               // input patch: [group][slot][padded column] chunks, group pitch kCSp
+  u32x4 *const Js0 = Is0 + kAImg;                                 // input patch: [group][slot][padded column] chunks, group pitch kCSp
   int const tid = threadIdx.x, lane = tid & 63;
   int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int const wi = wave / WJ, wj = wave % WJ;
@@ -172,6 +183,75 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     for (int e = 0; e < kIE; ++e) { int const el = tid + e * kNT; if (((e + 1) * kNT <= kNP * BI) || (el < kNP * BI)) Is[el] = rf[e]; }
   };
 
+#if ADIRECT
+  {
+    constexpr int kN = kNP / 2, kPF = (PF < kN) ? PF : kN;          // MFMA k-iterations per K step; fragments in flight
+    int aoff[kTI];                                                   // byte offset of this lane's chunk in k-slot row (hi) of a k-iteration
+#pragma unroll
+    for (int t = 0; t < kTI; ++t) { int const oc = i0 + wi * (kTI * 32) + t * 32 + (lane & 31); aoff[t] = (oc < p.Mi) ? ((hi ? p.Mi : 0) + oc) * 16 : kOOB; }
+    int const rowB = p.Mi * 16;
+    // k-slot q of K step kt is row kt * kNPr + q of the [k-slot][out_chan] filter matrix; rows past its end (the ragged last step, the step after the last) are past
+    // the buffer and read as zero.  (The offset goes through the VGPR: an SGPR offset is not range-checked.)
+    auto load_a = [&](int kt, int s, u32x4 *dst) {
+      int const ro = (kt * kNPr + 2 * s) * rowB;
+#pragma unroll
+      for (int t = 0; t < kTI; ++t) {
+        int const vo = ((kNPr & 1) && s == kN - 1 && hi) ? kOOB : aoff[t];   // (the zero pad slot of an odd step)
+        dst[t] = (ABLATE == 1) ? u32x4{0u, 0u, 0u, 0u} : bload4(rI, vo + ro);
+      }
+    };
+    auto load_patch = [&](int kt) {
+      int const cg0 = kt * CG;
+#pragma unroll
+      for (int e = 0; e < kPE; ++e) {
+        int const el = tid + e * kNT, g = el % CG;
+        bool const ok = (pgoff[e] != kOOB) && (kNCG % CG == 0 || cg0 + g < kNCG);
+        rp[e] = (ABLATE == 1) ? u32x4{0u, 0u, 0u, 0u} : bload4(rJ, ok ? (pgoff[e] + cg0 * 16) : kOOB);
+      }
+    };
+    auto store_patch = [&](int buf) {
+      u32x4 *const Js = Js0 + buf * kImgC;
+#pragma unroll
+      for (int e = 0; e < kPE; ++e) if (((e + 1) * kNT <= kCS * CG) || (tid + e * kNT < kCS * CG)) Js[pdst[e]] = rp[e];
+    };
+    u32x4 cur[kN][kTI], nxt[kPF][kTI];
+    load_patch(0);
+#pragma unroll
+    for (int s = 0; s < kPF; ++s) load_a(0, s, cur[s]);
+    store_patch(0);
+    __syncthreads();
+    for (int kt = 0; kt < ((ABLATE == 4) ? 0 : kNKT); ++kt) {
+      u32x4 const *const Js = Js0 + (kt & 1) * kImgC;
+      if (kt + 1 < kNKT) load_patch(kt + 1);
+      bf16x8 b[2][kTJ];
+#pragma unroll
+      for (int t = 0; t < kTJ; ++t) b[0][t] = __builtin_bit_cast(bf16x8, Js[bj[t] + (hi ? slot_off(1) : slot_off(0))]);
+#pragma unroll
+      for (int s = 0; s < kN; ++s) {
+        if (s + kPF < kN) load_a(kt, s + kPF, cur[s + kPF]); else load_a(kt + 1, s + kPF - kN, nxt[s + kPF - kN]);
+        if (s + 1 < kN) {
+          int const jo = hi ? slot_off(2 * s + 3) : slot_off(2 * s + 2);
+#pragma unroll
+          for (int t = 0; t < kTJ; ++t) b[(s + 1) & 1][t] = __builtin_bit_cast(bf16x8, Js[bj[t] + jo]);
+        }
+        if (ABLATE != 2) {
+#pragma unroll
+          for (int ta = 0; ta < kTI; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < kTJ; ++tb)
+              acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[s][ta]), b[s & 1][tb], acc[ta][tb], 0, 0, 0);
+        } else asm volatile("" ::"v"(cur[s][0]), "v"(b[s & 1][0]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kt + 1 < kNKT) store_patch((kt & 1) ^ 1);
+#pragma unroll
+      for (int s = 0; s < kPF; ++s)
+#pragma unroll
+        for (int t = 0; t < kTI; ++t) cur[s][t] = nxt[s][t];
+      __syncthreads();
+    }
+  }
+#else
   load_step(0);
 #if DBUF
   store_step(0);
@@ -206,6 +286,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #endif
     __syncthreads();                           // every wave is done reading before the next step overwrites the images (DBUF: and the next image is complete)
   }
+#endif // ADIRECT
 
   // ---- epilogue (as conv_nhwc_bf16.hip).  C/D layout of the 32x32 MFMA family: column j = lane & 31, rows i = 8*g + 4*(lane >> 5) + e for register 4*g + e
   int const h = lane >> 5;

@@ -380,6 +380,8 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
   int const taps = g.KH * g.KW, ncg = g.C / 8;
   if (!(g.SX == 1 && taps >= 2 && g.KH >= g.SY)) unsup_err("hip_conv_nhwc (patch form of filts): needs stride 1 in x and more than one tap");
   long const Nj = (long)g.B * g.OH * g.OW;
+  // ADIRECT (default): filter fragments straight from global memory, the LDS holds the (double-buffered) patch only.  BODAHIP_NHWC_ADIRECT=0: both operands staged.
+  bool adirect = true; if (char const *e = getenv("BODAHIP_NHWC_ADIRECT")) adirect = atoi(e) != 0;
   int cg = std::min(ncg, 4); while (cg > 1 && cg * taps > 40) --cg;     // K step of <= 40 k-slots: 3x3 -> 4 groups (36), 5x5 -> 1 group (25 + a zero slot)
   if (char const *e = getenv("BODAHIP_NHWC_PATCH_CG")) { if (atoi(e) > 0) cg = std::min(ncg, atoi(e)); }   // (experiments)
   int const wp = g.W + 2 * g.PX;
@@ -387,24 +389,29 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
     int const npx = cgx * taps + ((cgx * taps) & 1);
     int const rows_max = (bj - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
     long const cs = (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp, csp = cs + ((2 - cs % 16) + 16) % 16;
-    return std::max<long>(16l * ((long)npx * bi + cgx * csp), out_f32 ? 0 : (long)bj * (bi * 2 + 16));
+    long const ops = adirect ? 2l * 16l * cgx * csp : 16l * ((long)npx * bi + cgx * csp);
+    return std::max<long>(ops, out_f32 ? 0 : (long)bj * (bi * 2 + 16));
   };
   auto lds = [&](int bi, int bj) { return lds_cg(bi, bj, cg); };
   struct cand_t { int bi, bj, wi, wj, minw; };
-  static cand_t const cands[] = {{64, 256, 1, 4, 2}, {64, 128, 1, 4, 2}, {32, 256, 1, 4, 2}, {128, 128, 2, 2, 2}, {32, 128, 1, 4, 2}, {64, 64, 2, 2, 2}};
+  static cand_t const cands_staged[] = {{64, 256, 1, 4, 2}, {64, 128, 1, 4, 2}, {32, 256, 1, 4, 2}, {128, 128, 2, 2, 2}, {32, 128, 1, 4, 2}, {64, 64, 2, 2, 2}};
+  // ADIRECT: wave tiles wide in pels first (32 x 128: one 1-KB filter fragment load per four MFMAs), in order of preference on equal cost
+  static cand_t const cands_direct[] = {{128, 128, 4, 1, 2}, {64, 256, 2, 2, 2}, {64, 128, 2, 2, 2}, {128, 64, 4, 1, 2}, {32, 128, 1, 4, 2}};
+  cand_t const *const cands = adirect ? cands_direct : cands_staged;
+  int const n_cands = adirect ? (int)(sizeof(cands_direct) / sizeof(cand_t)) : (int)(sizeof(cands_staged) / sizeof(cand_t));
   plan_t p; p.nhwc = true; p.nhwc_patch = true; p.bf16 = true; p.kname = "bodahip_conv_nhwc_patch_bf16";
   tile_cfg_t c; c.MT = 32; c.SPLITK = 1; c.PF = 1;
   if (!tile.empty()) {
     if (!parse_tile(tile, c)) rt_err("bad conv_tile '" + tile + "'");
     c.MT = 32; c.SPLITK = 1; c.PF = 1;
-  } else {
+  } else if (!adirect) {
     // Narrow in out_chan, wide in pels: the filter tile -- the larger operand stream here -- is staged once per BJ pels.  score = padding efficiency x share of
     // the CUs that get a workgroup / operand bytes per flop (filter stream ~ 1/BJ, patch stream ~ 1/(4 BI)).  Measured on MI355X (tools/patch_sweep.sh, 64
     // images, us incl. the ~6 us launch floor): ResNet-50 3x3 at 56^2 / 28^2 / 14^2 / 7^2: 64x256 30 / 26 / 27 / 45, 64x128 34 / 29 / 27 / 32.5, 32x128 35 / 29 /
     // 30 / 34; GoogLeNet 3x3 64->192 at 56^2: 64x256 63-66, 32x128 91.  Two workgroups per CU must fit the LDS (80 KB each): wide planes take 2 channel groups
     // per K step instead of 4 (level with each other where both fit; 8 groups measured 10-50 % slower).
     int pick = -1, pick_cg = cg; double best = -1;
-    for (int ci = 0; ci < (int)(sizeof(cands) / sizeof(cand_t)); ++ci) {
+    for (int ci = 0; ci < n_cands; ++ci) {
       cand_t const &cd = cands[ci];
       int cgx = cg; while (cgx > 1 && lds_cg(cd.bi, cd.bj, cgx) > 80 * 1024) cgx = (cgx + 1) / 2;
       if (lds_cg(cd.bi, cd.bj, cgx) > 80 * 1024) continue;
@@ -415,6 +422,27 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
       double const bytes_per_flop = 1.0 / cd.bj + 0.25 / cd.bi;
       double const score = pad * fill / bytes_per_flop;
       if (score > best) { best = score; pick = ci; pick_cg = cgx; }
+    }
+    if (pick < 0) unsup_err("hip_conv_nhwc (patch form of filts): no tile fits the LDS for this plane width");
+    c.BI = cands[pick].bi; c.BJ = cands[pick].bj; c.WI = cands[pick].wi; c.WJ = cands[pick].wj; c.MINW = cands[pick].minw; cg = pick_cg;
+  } else {
+    // What a launch costs here (tools/adirect_ablate.sh, ResNet-50 256 -> 256 at 14^2, 64 images, 128 x 128 tiles: 20.6 us = 7.3 without the K loop + 7.7 of MFMA
+    // issue + 5.3 of operand loads, 1.5 us of which overlap): the MFMA work of the busiest SIMD -- rounds of workgroups over the CUs x the wave tile -- inflated by
+    // the filter fragments its waves pull through the CU's 64 B/clk L1 path per MFMA (1 / pel blocks of the wave tile).  tiles <= CUs: one round; <= 2 CUs: the CUs
+    // that hold two workgroups set the pace (1.7: two waves per SIMD overlap better than one); beyond that workgroups are handed out as CUs free up.  Measured on
+    // MI355X (tools/adirect_sweep2.sh, 64 images, us incl. the ~6 us launch floor, staged -> direct): ResNet-50 3x3 at 28^2 / 14^2 / 7^2 25.4 -> 21.3 / 26.8 -> 21.2 /
+    // 32.3 -> 24.4-25.1; GoogLeNet 96->208 / 128->256 / 160->320 at 14^2 14.7 -> 11.8 / 17.1 -> 13.8 / 20.7 -> 16.7, 64->192 at 56^2 64.6 -> 60.5; 4 channel groups
+    // per K step (8: 5-100 % slower, 2: level or 10 % slower); 4 / 8 / 12 fragments in flight: level.
+    int pick = -1, pick_cg = cg; double best = 1e30;
+    for (int ci = 0; ci < n_cands; ++ci) {
+      cand_t const &cd = cands[ci];
+      int cgx = cg; while (cgx > 1 && lds_cg(cd.bi, cd.bj, cgx) > 80 * 1024) cgx = (cgx + 1) / 2;
+      if (lds_cg(cd.bi, cd.bj, cgx) > 80 * 1024) continue;
+      long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
+      double const rounds = (tiles <= num_cus) ? 1.0 : (tiles <= 2l * num_cus) ? 1.7 : ((double)tiles / (double)num_cus + 0.25);
+      int const ktj = cd.bj / (cd.wj * 32);
+      double const cost = rounds * (double)(cd.bi * cd.bj) / (double)(cd.wi * cd.wj) * ((ktj >= 4) ? 1.1 : (ktj >= 2) ? 1.3 : 2.0);   // (fitted to the sweep)
+      if (cost < best * 0.97) { best = cost; pick = ci; pick_cg = cgx; }   // (a later candidate must be clearly cheaper)
     }
     if (pick < 0) unsup_err("hip_conv_nhwc (patch form of filts): no tile fits the LDS for this plane width");
     c.BI = cands[pick].bi; c.BJ = cands[pick].bj; c.WI = cands[pick].wi; c.WJ = cands[pick].wj; c.MINW = cands[pick].minw; cg = pick_cg;
@@ -429,6 +457,7 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
             "-DCG=" + std::to_string(cg), "-DCIN=" + std::to_string(g.C), "-DKH=" + std::to_string(g.KH), "-DKW=" + std::to_string(g.KW), "-DSY=" + std::to_string(g.SY),
             "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX), "-DCH=" + std::to_string(g.H), "-DCW=" + std::to_string(g.W),
             "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW), string("-DRELU=") + (g.relu ? "1" : "0"), string("-DOUT_F32=") + (out_f32 ? "1" : "0")};
+  if (adirect) p.defs.push_back("-DADIRECT=1");
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
   return p;
 }

@@ -51,10 +51,13 @@ def test_planner_choices():
     assert p[0] == "bodahip_conv_nhwc_bf16" and "-DCIN=256" in p and "-DOUT_F32=0" in p
     assert "-DBK=32" in plan((64, 64, 56, 56, 256, 1, 1, 1, 0))                 # short K: 32-deep steps, deeper ring
     assert "-DBK=64" in plan((64, 512, 7, 7, 512, 3, 3, 1, 1), hip_patch=0)
-    # more than one tap, stride 1 in x: the annotation asks for the F' filter form and the function binds the LDS input-patch kernel; tiles narrow in out_chan, wide in pels
+    # more than one tap, stride 1 in x: the annotation asks for the F' filter form and the function binds the LDS input-patch kernel; filter fragments straight from
+    # global memory (ADIRECT), wave tiles of 32 out_chans x 64 or 128 pels, tile by the MFMA work of the busiest SIMD
     pk = plan((64, 512, 7, 7, 512, 3, 3, 1, 1))
-    assert pk[0] == "bodahip_conv_nhwc_patch_bf16" and pk[1].startswith("64x128x288_w1x4") and "-DCG=4" in pk and "-DCIN=512" in pk
-    assert plan((64, 64, 56, 56, 192, 3, 3, 1, 1))[1].startswith("64x256x288_w1x4")        # 2352 tiles: the widest pel tile
+    assert pk[0] == "bodahip_conv_nhwc_patch_bf16" and pk[1].startswith("64x128x288_w2x2") and "-DCG=4" in pk and "-DCIN=512" in pk and "-DADIRECT=1" in pk
+    assert plan((64, 64, 56, 56, 192, 3, 3, 1, 1))[1].startswith("64x256x288_w2x2")        # 2352 tiles: the widest pel tile
+    assert plan((64, 256, 14, 14, 256, 3, 3, 1, 1))[1].startswith("128x128x288_w4x1")      # 196 tiles of four 32 x 128 wave tiles: one round
+    assert plan((64, 160, 7, 7, 320, 3, 3, 1, 1))[1].startswith("32x128x288_w1x4")         # 3136 pels: 250 small tiles rather than 125 on half the CUs
     assert "-DCG=1" in plan((64, 32, 28, 28, 96, 5, 5, 1, 2))                                # 5x5: one channel group per K step (25 k-slots + a zero slot)
     assert plan((64, 256, 56, 56, 64, 1, 1, 1, 0))[0] == plan((64, 128, 28, 28, 128, 3, 3, 2, 1))[0] == "bodahip_conv_nhwc_bf16"   # 1x1, and stride 2 in x: implicit GEMM
     assert plan((64, 128, 4, 4, 1024, 4, 4, 1, 0))[0] == "bodahip_conv_nhwc_bf16"            # whole-input kernel (an fc layer): implicit GEMM + K slices
