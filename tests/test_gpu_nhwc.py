@@ -122,8 +122,8 @@ def test_nhwc_patch_kernel_tiles_agree_with_oracle(be, tile, direct, monkeypatch
     filter fragments straight from global memory (the default; an odd count of k-slots per step, K steps past the end, out_chans past the end all read as zero
     through the buffer's range check) and both operands staged through the LDS."""
     monkeypatch.setenv("BODAHIP_NHWC_ADIRECT", str(direct))
-    if not direct and tile in ("128x64x0x4x1", "256x128x0x4x1x1", "128x128x0x4x1", "64x256x0x2x2"):
-        pytest.skip("tiles of the direct path")
+    if not direct and tile not in ("64x256x0x1x4", "128x128x0x2x2", "32x64x0x1x2", "64x128x0x2x2x1"):
+        pytest.skip("the staged form keeps four tiles under test")
     for shape in [(3, 40, 15, 15, 100, 3, 3, 1, 1), (5, 24, 9, 9, 70, 5, 5, 1, 2), (2, 8, 12, 12, 33, 2, 2, 1, 0), (7, 72, 5, 5, 64, 3, 3, 1, 1), (2, 16, 20, 11, 48, 7, 7, 1, 3), (40, 32, 3, 3, 64, 3, 3, 1, 1)]:
         op = _conv_op(*shape)
         outs, prc = _run(be, op, OpTune(hip_tile=tile, **NHWC_F32))
