@@ -326,8 +326,10 @@ class ConvPipeFwd:
     """`has_conv_fwd_t` with mode=rtc over an rtc backend (src/has_conv_fwd.H:16-25, src/rtc_fwd.cc:43-577)."""
     mode = "rtc"
 
-    def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False, fuse_siblings: bool = True):
+    def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False, fuse_siblings: bool = True,
+                 spec_fwd: bool = True):
         self.rtc, self.op_tune = rtc, op_tune or OpTune()
+        self.spec_fwd = spec_fwd     # channels-last nets: pool / LRN kernels specialised per geometry (False: the generic kernels with run-time geometry)
         # channels-last bf16 nets: convolutions that read the SAME node with the same kernel geometry (an inception module's 1x1 / 3x3-reduce / 5x5-reduce
         # convs) run as one hip_conv_nhwc_grp launch -- input read once, the members' tiles in one grid, two launches fewer per module; same bits
         self.fuse_siblings = fuse_siblings
@@ -494,11 +496,12 @@ class ConvPipeFwd:
                     am["out_chan_off"] = _u32(0)     # (the var carries zero pad channels: the conv writes the first out_chans of each row)
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(gen_fn, am), fn, cop.flops()))
             elif self.nhwc and op.type == "Pooling":
-                self.fwd_calls.append(FwdCall(op.tag, _nhwc.pool_call(vn(op.bot), op.top, vd(op.bot), vd(op.top), op.kern_sz, op.stride, op.in_pad, int(op.avg_pool)), "nhwc_pool"))
+                self.fwd_calls.append(FwdCall(op.tag, _nhwc.pool_call(vn(op.bot), op.top, vd(op.bot), vd(op.top), op.kern_sz, op.stride, op.in_pad, int(op.avg_pool),
+                                                                      rtc if self.spec_fwd else None), "nhwc_pool"))
             elif self.nhwc and op.type == "LRN":
                 if op.in_place:   # the channels-last kernel reloads halo chunks of its INPUT at wave edges: in == out would read what neighbouring waves already stored
                     raise UnsupErr(f"channels-last LRN {op.tag} in place is not supported (the kernel reads neighbouring chunks of its input)")
-                self.fwd_calls.append(FwdCall(op.tag, _nhwc.lrn_call(vn(op.bot), op.top, vd(op.bot), *op.lrn), "nhwc_lrn"))
+                self.fwd_calls.append(FwdCall(op.tag, _nhwc.lrn_call(vn(op.bot), op.top, vd(op.bot), *op.lrn, rtc=rtc if self.spec_fwd else None), "nhwc_lrn"))
             elif self.nhwc and op.type == "ReLU":
                 self.fwd_calls.append(FwdCall(op.tag, _nhwc.relu_call(vn(op.bot), vd(op.top)), "nhwc_relu"))
             elif self.nhwc and op.type == "Concat":

@@ -363,19 +363,131 @@ def ensure_fwd_compiled(rtc) -> None:
     rtc._nhwc_fwd_compiled = True
 
 
-def pool_call(in_vn: str, out_vn: str, i: Dims, o: Dims, kern, stride, pad, avg: int) -> RtcFuncCall:
-    """i / o: the channels-last dims of the vars (img:y:x:chan, chan a multiple of 8)."""
+# Geometry-specialised forms of nhwc_pool / nhwc_lrn (the backend compiles at run time anyway -- the reference instantiates pool.cucl / lrn.cucl per
+# geometry the same way, src/rtc_func_gen.cc): window, stride, padding and plane sizes are literals, so the taps unroll into independent 16-byte loads
+# issued back to back (a tap outside the plane is loaded from the nearest position INSIDE the clipped window -- a duplicate does not change a maximum;
+# an average adds it as zero), index arithmetic is multiply-shift, LRN shuffles only the `half` squares it needs from each neighbour lane and takes
+# x^-beta as exp2(-beta * log2 x) (v_log_f32 / v_exp_f32, relative error ~3e-7 against a result stored with 8 bits of mantissa).  Same values as the
+# generic kernels for max pooling (exact) and the same order of additions for averages; LRN within one bf16 rounding (tests/test_gpu_fullnet.py).
+POOL_SPEC_SRC = """
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// one thread: XT consecutive outputs along x of one (img, oy, 8 channels); the (XT-1)*SX + KW input columns they touch are loaded once ( x KH rows)
+CUCL_GLOBAL_KERNEL void @NAME@( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n ) {
+  uint32_t const i = GLOB_ID_1D;
+  if( i >= n ) { return; }
+  uint32_t const c = i % @C8@u, p = i / @C8@u, xg = p % @OWG@u, q = p / @OWG@u, oy = q % @OH@u, img = q / @OH@u;
+  int32_t const y0 = (int32_t)( oy*@SY@u ) - @PY@, xs = (int32_t)( xg*( @XT@u*@SX@u ) ) - @PX@;
+  int32_t const ya = ( y0 < 0 ) ? 0 : y0, yb = ( y0 + @KH@ > @H@ ) ? @H@ : y0 + @KH@;
+  GASQ bf16x8_t const * const base = in + (size_t)img*( @H@u*@W@u*@C8@u ) + c;
+  bf16x8_t v[@NCOL@][@KH@];
+#pragma unroll
+  for( int32_t j = 0; j != @NCOL@; ++j ) {
+#pragma unroll
+    for( int32_t ky = 0; ky != @KH@; ++ky ) {
+      int32_t const y = y0 + ky, x = xs + j;
+      int32_t const yc = ( y < ya ) ? ya : ( ( y >= yb ) ? yb - 1 : y ), xc = ( x < 0 ) ? 0 : ( ( x >= @W@ ) ? @W@ - 1 : x );
+      v[j][ky] = base[( yc*@W@ + xc )*@C8@];
+    }
+  }
+#pragma unroll
+  for( int32_t t = 0; t != @XT@; ++t ) {
+    uint32_t const ox = xg*@XT@u + t;
+    int32_t const x0 = xs + t*@SX@;
+    int32_t const xa = ( x0 < 0 ) ? 0 : x0, xb = ( x0 + @KW@ > @W@ ) ? @W@ : x0 + @KW@;
+    float acc[8];
+    for( int32_t e = 0; e != 8; ++e ) { acc[e] = @AVG@ ? 0.0f : -FLT_MAX; }
+#pragma unroll
+    for( int32_t kx = 0; kx != @KW@; ++kx ) {
+#pragma unroll
+      for( int32_t ky = 0; ky != @KH@; ++ky ) {
+        bool const ok = ( y0 + ky >= ya ) && ( y0 + ky < yb ) && ( x0 + kx >= xa ) && ( x0 + kx < xb );
+        for( int32_t e = 0; e != 8; ++e ) {
+          float const f = (float)v[t*@SX@ + kx][ky][e];
+          if( @AVG@ ) { if( ok ) { acc[e] = acc[e] + f; } } else { acc[e] = ( f > acc[e] ) ? f : acc[e]; }
+        }
+      }
+    }
+    float const area = (float)( ( yb - ya ) * ( xb - xa ) );
+    bf16x8_t r;
+    for( int32_t e = 0; e != 8; ++e ) { r[e] = (__bf16)( @AVG@ ? acc[e] / area : acc[e] ); }
+    if( ( @OW@ % @XT@ == 0 ) || ( ox < @OW@u ) ) { out[( ( img*@OH@u + oy )*@OW@u + ox )*@C8@u + c] = r; }
+  }
+}
+"""
+LRN_SPEC_SRC = """
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+CUCL_GLOBAL_KERNEL void @NAME@( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n, float const alpha, float const beta, float const k ) {
+  uint32_t const i = GLOB_ID_1D;
+  bool const live = i < n;
+  int32_t const q = live ? (int32_t)( i % @C8@u ) : 0, lane = LOC_ID_1D & 63;
+  float v[8], sq[8 + 2*@HALF@];     // squares of channels [-HALF, 8 + HALF) relative to this chunk
+  bf16x8_t const mid = live ? in[i] : (bf16x8_t)0;
+  for( int32_t e = 0; e != 8; ++e ) { v[e] = (float)mid[e]; sq[@HALF@ + e] = v[e]*v[e]; }
+  for( int32_t e = 0; e != @HALF@; ++e ) {   // the last HALF squares of the chunk below (lane - 1), the first HALF of the chunk above (lane + 1)
+    sq[e] = __shfl_up( sq[@HALF@ + 8 - @HALF@ + e], 1, 64 );
+    sq[@HALF@ + 8 + e] = __shfl_down( sq[@HALF@ + e], 1, 64 );
+  }
+  bool const has_lo = q > 0, has_hi = q + 1 < @C8@;
+  if( has_lo && lane == 0 ) { bf16x8_t const lo = in[i - 1]; for( int32_t e = 0; e != @HALF@; ++e ) { float const f = (float)lo[8 - @HALF@ + e]; sq[e] = f*f; } }
+  if( has_hi && live && ( lane == 63 || i + 1 >= n ) ) { bf16x8_t const hi = in[i + 1]; for( int32_t e = 0; e != @HALF@; ++e ) { float const f = (float)hi[e]; sq[@HALF@ + 8 + e] = f*f; } }
+  if( !has_lo ) { for( int32_t e = 0; e != @HALF@; ++e ) { sq[e] = 0.0f; } }
+  if( !has_hi ) { for( int32_t e = 0; e != @HALF@; ++e ) { sq[@HALF@ + 8 + e] = 0.0f; } }
+  if( !live ) { return; }
+  float const per_elem = alpha / @LOCAL_SIZE@.0f;
+  bf16x8_t r;
+  for( int32_t e = 0; e != 8; ++e ) {
+    float sumsq = 0.0f;
+    for( int32_t d = 0; d != 2*@HALF@ + 1; ++d ) { sumsq += sq[e + d]; }        // ascending channel order, as the generic kernel
+    r[e] = (__bf16)( v[e] * __builtin_amdgcn_exp2f( -beta * __builtin_amdgcn_logf( k + sumsq * per_elem ) ) );
+  }
+  out[i] = r;
+}
+"""
+
+
+def _spec_compile(rtc, name: str, src: str, subst: Dict[str, object], args: List[str]) -> None:
+    done = rtc.__dict__.setdefault("_nhwc_spec_compiled", set())
+    if name in done:
+        return
+    text = src.replace("@NAME@", name)
+    for k, v in subst.items():
+        text = text.replace("@" + k + "@", str(v))
+    rtc.compile([RtcFuncInfo(name, text, args, Op({"type": "fwd", "func_name": name}, {}))])
+    done.add(name)
+
+
+def pool_call(in_vn: str, out_vn: str, i: Dims, o: Dims, kern, stride, pad, avg: int, rtc=None) -> RtcFuncCall:
+    """i / o: the channels-last dims of the vars (img:y:x:chan, chan a multiple of 8).  With `rtc`: the geometry-specialised kernel (compiled on first use) where
+    every window meets the plane and is small enough to unroll; the generic kernel otherwise."""
     c8 = i.dsz("chan") // 8; n = o.dsz("img") * o.dsz("y") * o.dsz("x") * c8
+    H, W, OH, OW = i.dsz("y"), i.dsz("x"), o.dsz("y"), o.dsz("x")
+    nonempty = all(min(H, oy * stride[0] - pad[0] + kern[0]) > max(0, oy * stride[0] - pad[0]) for oy in (0, OH - 1)) and \
+        all(min(W, ox * stride[1] - pad[1] + kern[1]) > max(0, ox * stride[1] - pad[1]) for ox in (0, OW - 1))
+    if rtc is not None and nonempty and kern[0] * kern[1] <= 64 and i.dims_prod() * 2 < (1 << 31):
+        xt = 4 if OW >= 8 else (2 if OW >= 4 else 1)                 # outputs along x per thread: their windows share input columns (measured: 4 ahead of 1 / 2 / 8)
+        while xt > 1 and ((xt - 1) * stride[1] + kern[1]) * kern[0] > 36:
+            xt //= 2
+        ncol, owg = (xt - 1) * stride[1] + kern[1], (OW + xt - 1) // xt
+        nt = o.dsz("img") * OH * owg * c8
+        name = f"nhwc_pool_c{c8}_{H}x{W}_{OH}x{OW}_k{kern[0]}x{kern[1]}_s{stride[0]}x{stride[1]}_p{pad[0]}x{pad[1]}_{'avg' if avg else 'max'}_t{xt}"
+        _spec_compile(rtc, name, POOL_SPEC_SRC, {"C8": c8, "H": H, "W": W, "OH": OH, "OW": OW, "KH": kern[0], "KW": kern[1], "SY": stride[0], "SX": stride[1],
+                                                 "PY": pad[0], "PX": pad[1], "AVG": int(bool(avg)), "XT": xt, "NCOL": ncol, "OWG": owg}, ["in", "out", "n"])
+        return RtcFuncCall(name, {"in": RtcArg.var(in_vn), "out": RtcArg.var(out_vn), "n": _u32(nt)}, tpb=_TPB, blks=(nt + _TPB - 1) // _TPB)
     am = {"in": RtcArg.var(in_vn), "out": RtcArg.var(out_vn), "n": _u32(n), "C8": _u32(c8), "H": _u32(i.dsz("y")), "W": _u32(i.dsz("x")), "OH": _u32(o.dsz("y")),
           "OW": _u32(o.dsz("x")), "KH": _u32(kern[0]), "KW": _u32(kern[1]), "SY": _u32(stride[0]), "SX": _u32(stride[1]), "PY": _u32(pad[0]), "PX": _u32(pad[1]),
           "avg_pool": _u32(avg)}
     return RtcFuncCall("nhwc_pool", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
 
 
-def lrn_call(in_vn: str, out_vn: str, d: Dims, local_size: int, alpha: float, beta: float, k: float) -> RtcFuncCall:
+def lrn_call(in_vn: str, out_vn: str, d: Dims, local_size: int, alpha: float, beta: float, k: float, rtc=None) -> RtcFuncCall:
     if local_size // 2 > 8:
         raise UnsupErr("channels-last LRN: local_size above 17")
     n = d.dims_prod() // 8
+    if rtc is not None and local_size % 2 == 1 and k > 0.0 and alpha >= 0.0:     # (k + alpha * sum of squares > 0: the log is defined)
+        c8 = d.dsz("chan") // 8; name = f"nhwc_lrn_c{c8}_n{local_size}"
+        _spec_compile(rtc, name, LRN_SPEC_SRC, {"C8": c8, "HALF": local_size // 2, "LOCAL_SIZE": local_size}, ["in", "out", "n", "alpha", "beta", "k"])
+        return RtcFuncCall(name, {"in": RtcArg.var(in_vn), "out": RtcArg.var(out_vn), "n": _u32(n), "alpha": _f32(alpha), "beta": _f32(beta), "k": _f32(k)},
+                           tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
     am = {"in": RtcArg.var(in_vn), "out": RtcArg.var(out_vn), "n": _u32(n), "C8": _u32(d.dsz("chan") // 8), "local_size": _u32(local_size), "alpha": _f32(alpha),
           "beta": _f32(beta), "k": _f32(k)}
     return RtcFuncCall("nhwc_lrn", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)

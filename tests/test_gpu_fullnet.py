@@ -420,3 +420,48 @@ def test_sibling_fusion_is_bit_identical(rtc):
     assert ncalls[1] - ncalls[0] == 18
     for n in nodes:
         assert np.array_equal(res[0][n], res[1][n]), n
+
+
+def test_channels_last_pool_lrn_specialised_kernels(rtc):
+    """The geometry-specialised channels-last pool / LRN kernels (boda_amd/nhwc.py POOL_SPEC_SRC / LRN_SPEC_SRC: literal window / stride / padding / plane
+    sizes, taps as independent loads, x^-beta through exp2 / log2) against the generic kernels with run-time geometry and against the oracle on the values the
+    device consumed: max pools exact both ways; averages equal to the generic kernel bit for bit (same order of additions) and within one bf16 rounding of the
+    oracle; LRN within one bf16 rounding of both.  Windows cut by every edge, ceil-mode last windows, a global average, a window wider than the stride."""
+    from boda_amd.cnn_op import OpTune
+    B, C, H = 3, 40, 23
+    def pipe():
+        p = ConvPipe("pools", "data", Dims.make("float", img=B, chan=C, y=H, x=H))
+        for tag, k, s, pd, avg in [("mx3s2", 3, 2, 0, 0), ("mx3s1p1", 3, 1, 1, 0), ("mx2s2", 2, 2, 0, 0), ("av5s3", 5, 3, 0, 1), ("av3s1p1", 3, 1, 1, 1), ("mx3s2p1", 3, 2, 1, 0),
+                                   ("av7s1", 7, 1, 0, 1), ("mx5s1p2", 5, 1, 2, 0)]:
+            p.add(PipeOp(tag, "Pooling", "data", tag, kern_sz=(k, k), stride=(s, s), in_pad=(pd, pd), avg_pool=avg))
+        p.add(PipeOp("avglob", "Pooling", "data", "avglob", kern_sz=(H, H), stride=(1, 1), avg_pool=1))          # 529 taps: stays on the generic kernel
+        for tag, ls in [("lrn5", 5), ("lrn3", 3), ("lrn9", 9)]:
+            p.add(PipeOp(tag, "LRN", "data", tag, lrn=(ls, 2e-2, 0.75, 1.0)))
+        return p
+    data = (bo.gen_conv_in(B, C, H, H) * np.float32(3.0)).astype(np.float32)
+    res = {}
+    for spec in (True, False):
+        cp = pipe()
+        fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc"), spec_fwd=spec)
+        fwd.init(cp, op_params={})
+        try:
+            names = [c.rfc.rtc_func_name for c in fwd.fwd_calls]
+            assert (sum(n.startswith("nhwc_pool_c") for n in names), sum(n.startswith("nhwc_lrn_c") for n in names)) == ((8, 3) if spec else (0, 0)), names
+            io = {"data": data}
+            fwd.run_fwd(["data"], io, [o.top for o in cp.ops])
+            res[spec] = io
+        finally:
+            fwd.release()
+    x = bo.to_bf16(data); ulp = 2.0 ** -8
+    close = lambda w, g, extra: bool((np.abs(g.astype(np.float64) - w) <= ulp * np.abs(w) + extra * np.maximum(1.0, np.abs(w))).all())
+    for op in pipe().ops:
+        g, gen = res[True][op.top], res[False][op.top]
+        if op.type == "Pooling":
+            w = bo.pool_fwd(x, op.kern_sz, op.stride, op.in_pad, bool(op.avg_pool))
+            assert g.shape == w.shape and np.array_equal(g, gen), op.tag
+            assert (close(w.astype(np.float64), g, 1e-6) if op.avg_pool else np.array_equal(w, g)), op.tag
+        else:
+            w = bo.lrn_fwd(x, *op.lrn).astype(np.float64)
+            assert close(w, g, 1e-5) and close(w, gen, 1e-5), op.tag
+            assert (np.abs(g.astype(np.float64) - gen) <= 2.0 * ulp * np.abs(gen)).all(), op.tag      # (neighbouring bf16 values: at most 2^-7 apart, relative)
+            assert float(np.mean(g != gen)) < 0.02, op.tag     # (a different rounding only where the fp32 value sits on a bf16 tie)
