@@ -438,7 +438,7 @@ class ConvPipeFwd:
         if self.nhwc:   # the caller's input arrives in the reference layout; the first call of every pass transposes it
             self.in_var = cp.in_node + "_ref"
             rtc.create_var_with_dims(self.in_var, cp.nodes[cp.in_node]); self._vars.append(self.in_var)
-            self.fwd_calls.append(FwdCall("xpose_" + cp.in_node, _nhwc.xpose_call("in", self.in_var, cp.in_node, cp.nodes[cp.in_node], vd(cp.in_node), in_anno), "nhwc_xpose_in"))
+            self.fwd_calls.append(FwdCall("xpose_" + cp.in_node, _nhwc.xpose_call("in", self.in_var, cp.in_node, cp.nodes[cp.in_node], vd(cp.in_node), in_anno, rtc if self.spec_fwd else None), "nhwc_xpose_in"))
         pdims = lambda pn: annos[pn[:-len("_filts")]].get_dims("filts") if (self.nhwc and pn.endswith("_filts")) else cp.params[pn]   # (as stored)
         for pn, pd in cp.params.items():
             rtc.create_var_with_dims(pn, pdims(pn)); self._vars.append(pn); self.op_param_names.append(pn)

@@ -234,9 +234,47 @@ def ensure_compiled(rtc) -> None:
     rtc._nhwc_xpose_compiled = True
 
 
-def xpose_call(arg: str, ref_vn: str, vn: str, ref_dims: Dims, dims: Dims, anno: Op = None) -> RtcFuncCall:
+def _spec_compile(rtc, name: str, src: str, subst: Dict[str, object], args: List[str]) -> None:
+    done = rtc.__dict__.setdefault("_nhwc_spec_compiled", set())
+    if name in done:
+        return
+    text = src.replace("@NAME@", name)
+    for k, v in subst.items():
+        text = text.replace("@" + k + "@", str(v))
+    rtc.compile([RtcFuncInfo(name, text, args, Op({"type": "fwd", "func_name": name}, {}))])
+    done.add(name)
+
+
+# The net-input layout pass specialised per geometry (the one layout pass INSIDE a forward step; filters are laid out once at init): one thread per chunk as the
+# generic kernel, sizes literal -- the index arithmetic is multiply-shift and the eight gathers are independent, unconditional loads (clamped address + select).
+XPOSE_IN_SPEC_SRC = """
+typedef __bf16 xps_bf16x8_t __attribute__((ext_vector_type(8)));
+CUCL_GLOBAL_KERNEL void @NAME@( GASQ float const * const in_ref, GASQ xps_bf16x8_t * const in, uint32_t const n ) {
+  uint32_t const i = GLOB_ID_1D;
+  if( i >= n ) { return; }
+  uint32_t const q = i % @C8@u, p = i / @C8@u, X = p % @W2@u, r = p / @W2@u, Y = r % @H2@u, img = r / @H2@u;
+  GASQ float const * const base = in_ref + (size_t)img*( @C@u*@H@u*@W@u );
+  float f[8];
+#pragma unroll
+  for( uint32_t e = 0; e != 8; ++e ) {
+    uint32_t const c2 = 8*q + e, c = c2 / ( @S@u*@S@u ), dy = ( c2 / @S@u ) % @S@u, dx = c2 % @S@u;
+    int32_t const y = (int32_t)( @S@u*Y + dy ) - @PRY@, x = (int32_t)( @S@u*X + dx ) - @PRX@;
+    bool const ok = ( c2 < @C2@u ) && ( y >= 0 ) && ( y < @H@ ) && ( x >= 0 ) && ( x < @W@ );
+    int32_t const yc = ( y < 0 ) ? 0 : ( ( y >= @H@ ) ? @H@ - 1 : y ), xc = ( x < 0 ) ? 0 : ( ( x >= @W@ ) ? @W@ - 1 : x );
+    uint32_t const cc = ( c < @C@u ) ? c : 0u;
+    float const v = base[( cc*@H@u + (uint32_t)yc )*@W@u + (uint32_t)xc];
+    f[e] = ok ? v : 0.0f;
+  }
+  xps_bf16x8_t o;
+  for( uint32_t e = 0; e != 8; ++e ) { o[e] = (__bf16)f[e]; }
+  in[i] = o;
+}
+"""
+
+
+def xpose_call(arg: str, ref_vn: str, vn: str, ref_dims: Dims, dims: Dims, anno: Op = None, rtc=None) -> RtcFuncCall:
     """The layout pass between `<arg>_ref` (reference layout, float) and `<arg>` (kernel layout): in / filts forward, out backward.  `anno`:
-    the annotated op (its nhwc_s2d scalars select the space-to-depth form of in / filts)."""
+    the annotated op (its nhwc_s2d scalars select the space-to-depth form of in / filts).  With `rtc` (arg "in"): the geometry-specialised kernel."""
     s = pry = prx = ofy = ofx = 0
     if anno is not None and anno.has("nhwc_s2d"):
         s, pry, prx = anno.get_u32("nhwc_s2d"), anno.get_u32("nhwc_s2d_pry"), anno.get_u32("nhwc_s2d_prx")
@@ -247,6 +285,12 @@ def xpose_call(arg: str, ref_vn: str, vn: str, ref_dims: Dims, dims: Dims, anno:
         am = {"in_ref": RtcArg.var(ref_vn), "in": RtcArg.var(vn), "n": _u32(n), "C": _u32(C), "H": _u32(ref_dims.dsz("y")), "W": _u32(ref_dims.dsz("x")),
               "C2": _u32(C * (s * s if s else 1)), "C8": _u32(dims.dsz("chan") // 8), "H2": _u32(dims.dsz("y")), "W2": _u32(dims.dsz("x")), "S": _u32(s or 1),
               "PRY": _u32(pry), "PRX": _u32(prx)}
+        if rtc is not None and ref_dims.dims_prod() < (1 << 31):
+            sub = {"C": C, "H": ref_dims.dsz("y"), "W": ref_dims.dsz("x"), "C2": C * (s * s if s else 1), "C8": dims.dsz("chan") // 8, "H2": dims.dsz("y"), "W2": dims.dsz("x"),
+                   "S": s or 1, "PRY": pry, "PRX": prx}
+            name = "nhwc_xpose_in_" + "_".join(f"{k.lower()}{v}" for k, v in sub.items())
+            _spec_compile(rtc, name, XPOSE_IN_SPEC_SRC, sub, ["in_ref", "in", "n"])
+            return RtcFuncCall(name, {"in_ref": RtcArg.var(ref_vn), "in": RtcArg.var(vn), "n": _u32(n)}, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
         return RtcFuncCall("hip_conv_nhwc_xpose_in", am, tpb=_TPB, blks=(n + _TPB - 1) // _TPB)
     if arg == "filts" and dims.has("in_grp"):     # F' for the input-patch kernel
         n = dims.dims_prod() // 8
@@ -443,17 +487,6 @@ CUCL_GLOBAL_KERNEL void @NAME@( GASQ bf16x8_t const * const in, GASQ bf16x8_t * 
   out[i] = r;
 }
 """
-
-
-def _spec_compile(rtc, name: str, src: str, subst: Dict[str, object], args: List[str]) -> None:
-    done = rtc.__dict__.setdefault("_nhwc_spec_compiled", set())
-    if name in done:
-        return
-    text = src.replace("@NAME@", name)
-    for k, v in subst.items():
-        text = text.replace("@" + k + "@", str(v))
-    rtc.compile([RtcFuncInfo(name, text, args, Op({"type": "fwd", "func_name": name}, {}))])
-    done.add(name)
 
 
 def pool_call(in_vn: str, out_vn: str, i: Dims, o: Dims, kern, stride, pad, avg: int, rtc=None) -> RtcFuncCall:
