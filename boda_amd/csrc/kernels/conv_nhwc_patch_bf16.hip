@@ -75,7 +75,16 @@ constexpr int kTI = BI / (WI * 32);
 constexpr int kTJ = BJ / (WJ * 32);
 static_assert(BI % (WI * 32) == 0 && BJ % (WJ * 32) == 0, "tile must be a multiple of the MFMA tile per wave");
 static_assert(CIN % 8 == 0, "channels-last tensors carry whole 16-byte chunks per position");
-constexpr int kTaps = KH * KW, kWp = CW + 2 * PX;
+#ifndef WPITCH
+#define WPITCH 1   // 1: slot pitch padded so that consecutive output positions read consecutive-modulo-16 chunks across row ends (bank-conflict-free fragment reads)
+#endif
+constexpr int kTaps = KH * KW, kWr = CW + 2 * PX;                  // columns of a slot that hold data
+// The MFMA B fragment of 32 consecutive output positions is one ds_read_b128 per lane, served in groups of 16 lanes that must cover 16 different chunks modulo 16
+// (64 banks x 4 bytes).  Consecutive positions of one row are consecutive chunks; at a row end the chunk index jumps by SY * pitch - COW, so with a slot pitch that
+// makes that jump a multiple of 16 the chunk index stays  position + const (mod 16)  across the rows of a tile.  Measured before (AlexNet conv3, 13 x 13 maps,
+// 256 images): SQ_LDS_BANK_CONFLICT = 48 % of SQ_LDS_IDX_ACTIVE, the LDS busy 62 % of the kernel.  The pad columns are never loaded, stored or read.
+constexpr int wpitch() { for (int p = kWr; p < kWr + 16; ++p) if ((SY * p - COW) % 16 == 0) return p; return kWr; }
+constexpr int kWp = WPITCH ? wpitch() : kWr;
 constexpr int kNCG = CIN / 8;                                      // channel groups of the tensor
 constexpr int kNKT = (kNCG + CG - 1) / CG;                         // K steps
 constexpr int kNPr = CG * kTaps;                                   // k-slots (of 8 channels) per K step ...
@@ -88,7 +97,8 @@ constexpr int kSegMax = kSegMax0 < kRowsMax ? kSegMax0 : kRowsMax;
 constexpr int kSlots = (kRowsMax - kSegMax) * SY + kSegMax * KH;   // slots per channel group (upper bound over tile positions)
 constexpr int kCS = kSlots * kWp;                                  // input positions (16-byte chunks) per channel group
 constexpr int kCSp = kCS + ((2 - kCS % 16) + 16) % 16;             // group pitch in chunks: 2 (mod 16) -> the CG chunks of a position land 8 banks apart
-constexpr int kPE = (kCS * CG + kNT - 1) / kNT;                    // patch chunks per thread per K step
+constexpr int kLoadN = kSlots * kWr * CG;                          // patch chunks loaded per K step
+constexpr int kPE = (kLoadN + kNT - 1) / kNT;                      // ... per thread
 constexpr int kIE = (kNP * BI + kNT - 1) / kNT;                    // filter chunks per thread per K step
 constexpr int kEPitch = BI * 2 + 16;                               // epilogue tile [pel][oc] bf16, rows de-phased by 4 banks
 constexpr int kAImg = ADIRECT ? 0 : kNP * BI;                      // chunks of the filter image
@@ -129,13 +139,13 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   int pgoff[kPE], pdst[kPE];
 #pragma unroll
   for (int e = 0; e < kPE; ++e) {
-    int const el = tid + e * kNT, pos = el / CG, g = el - pos * CG, s = pos / kWp, ix = pos - s * kWp - PX;
+    int const el = tid + e * kNT, pos = el / CG, g = el - pos * CG, s = pos / kWr, col = pos - s * kWr, ix = col - PX;
     int const s2 = s - seg0, im2 = s2 / kSegFull;
     int const img = (s < seg0) ? img0 : (img0 + 1 + im2);
     int const iy = (s < seg0) ? (oy0 * SY - PY + s) : (s2 - im2 * kSegFull - PY);
-    bool const ok = (el < kCS * CG) && (img < n_img) && ((unsigned)iy < (unsigned)CH) && ((unsigned)ix < (unsigned)CW);
+    bool const ok = (el < kLoadN) && (img < n_img) && ((unsigned)iy < (unsigned)CH) && ((unsigned)ix < (unsigned)CW);
     pgoff[e] = ok ? (((img * CH + iy) * CW + ix) * (CIN * 2) + g * 16) : kOOB;
-    pdst[e] = g * kCSp + pos;
+    pdst[e] = g * kCSp + s * kWp + col;
   }
   int bj[kTJ]; // MFMA B operand: chunk index of this lane's output position (tap (0,0), group 0)
 #pragma unroll
@@ -178,7 +188,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     if (ABLATE == 3) { asm volatile("" ::"v"(rp[0]), "v"(rf[0])); return; }
     u32x4 *const Is = Is0 + buf * kImgC, *const Js = Js0 + buf * kImgC;
 #pragma unroll
-    for (int e = 0; e < kPE; ++e) if (((e + 1) * kNT <= kCS * CG) || (tid + e * kNT < kCS * CG)) Js[pdst[e]] = rp[e];
+    for (int e = 0; e < kPE; ++e) if (((e + 1) * kNT <= kLoadN) || (tid + e * kNT < kLoadN)) Js[pdst[e]] = rp[e];
 #pragma unroll
     for (int e = 0; e < kIE; ++e) { int const el = tid + e * kNT; if (((e + 1) * kNT <= kNP * BI) || (el < kNP * BI)) Is[el] = rf[e]; }
   };
@@ -212,7 +222,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     auto store_patch = [&](int buf) {
       u32x4 *const Js = Js0 + buf * kImgC;
 #pragma unroll
-      for (int e = 0; e < kPE; ++e) if (((e + 1) * kNT <= kCS * CG) || (tid + e * kNT < kCS * CG)) Js[pdst[e]] = rp[e];
+      for (int e = 0; e < kPE; ++e) if (((e + 1) * kNT <= kLoadN) || (tid + e * kNT < kLoadN)) Js[pdst[e]] = rp[e];
     };
     u32x4 cur[kN][kTI], nxt[kPF][kTI];
     load_patch(0);

@@ -384,7 +384,8 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
   bool adirect = true; if (char const *e = getenv("BODAHIP_NHWC_ADIRECT")) adirect = atoi(e) != 0;
   int cg = std::min(ncg, 4); while (cg > 1 && cg * taps > 40) --cg;     // K step of <= 40 k-slots: 3x3 -> 4 groups (36), 5x5 -> 1 group (25 + a zero slot)
   if (char const *e = getenv("BODAHIP_NHWC_PATCH_CG")) { if (atoi(e) > 0) cg = std::min(ncg, atoi(e)); }   // (experiments)
-  int const wp = g.W + 2 * g.PX;
+  int wp = g.W + 2 * g.PX;                                              // slot pitch: as the kernel's wpitch()
+  for (int p2 = wp; p2 < wp + 16; ++p2) if ((g.SY * p2 - g.OW) % 16 == 0) { wp = p2; break; }
   auto lds_cg = [&](int bi, int bj, int cgx) {
     int const npx = cgx * taps + ((cgx * taps) & 1);
     int const rows_max = (bj - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
