@@ -382,7 +382,15 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
   long const Nj = (long)g.B * g.OH * g.OW;
   // ADIRECT (default): filter fragments straight from global memory, the LDS holds the (double-buffered) patch only.  BODAHIP_NHWC_ADIRECT=0: both operands staged.
   bool adirect = true; if (char const *e = getenv("BODAHIP_NHWC_ADIRECT")) adirect = atoi(e) != 0;
-  int cg = std::min(ncg, 4); while (cg > 1 && cg * taps > 40) --cg;     // K step of <= 40 k-slots: 3x3 -> 4 groups (36), 5x5 -> 1 group (25 + a zero slot)
+  // Channel groups per K step: at most 4, at most 50 k-slots, the count that wastes the fewest zero k-slots over the layer (a ragged last step and the zero slot
+  // of an odd step are MFMAs on zeros: 6 groups of a 3x3 as 4 + 2 cost 72 slots, as 2 + 2 + 2 54 -- AlexNet's space-to-depth conv1 at 256 images 128.7 -> 111.9 us;
+  // 5x5 on 12 groups as 6 x 50 instead of 12 x 26: 209 -> 200 us); ties go to the larger step (fewer barriers).
+  int cg = 1; { long best = -1;
+    for (int c = std::min(ncg, 4); c >= 1; --c) {
+      if (c > 1 && c * taps > 50) continue;
+      long const slots = (long)((ncg + c - 1) / c) * (c * taps + ((c * taps) & 1));
+      if (best < 0 || slots < best) { best = slots; cg = c; }
+    } }
   if (char const *e = getenv("BODAHIP_NHWC_PATCH_CG")) { if (atoi(e) > 0) cg = std::min(ncg, atoi(e)); }   // (experiments)
   int wp = g.W + 2 * g.PX;                                              // slot pitch: as the kernel's wpitch()
   for (int p2 = wp; p2 < wp + 16; ++p2) if ((g.SY * p2 - g.OW) % 16 == 0) { wp = p2; break; }

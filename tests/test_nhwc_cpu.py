@@ -54,11 +54,13 @@ def test_planner_choices():
     # more than one tap, stride 1 in x: the annotation asks for the F' filter form and the function binds the LDS input-patch kernel; filter fragments straight from
     # global memory (ADIRECT), wave tiles of 32 out_chans x 64 or 128 pels, tile by the MFMA work of the busiest SIMD
     pk = plan((64, 512, 7, 7, 512, 3, 3, 1, 1))
-    assert pk[0] == "bodahip_conv_nhwc_patch_bf16" and pk[1].startswith("64x128x288_w2x2") and "-DCG=4" in pk and "-DCIN=512" in pk and "-DADIRECT=1" in pk
-    assert plan((64, 64, 56, 56, 192, 3, 3, 1, 1))[1].startswith("64x256x288_w2x2")        # 2352 tiles: the widest pel tile
+    assert pk[0] == "bodahip_conv_nhwc_patch_bf16" and pk[1].startswith("64x128x144_w2x2") and "-DCG=2" in pk and "-DCIN=512" in pk and "-DADIRECT=1" in pk   # (7-wide rows padded to a pitch of 23 chunks: 2 groups per step keep two workgroups per CU)
+    assert plan((64, 64, 56, 56, 192, 3, 3, 1, 1))[1].startswith("64x256x144_w2x2")        # 2352 tiles: the widest pel tile (2 of the 8 groups per step: two workgroups per CU fit the LDS)
     assert plan((64, 256, 14, 14, 256, 3, 3, 1, 1))[1].startswith("128x128x288_w4x1")      # 196 tiles of four 32 x 128 wave tiles: one round
-    assert plan((64, 160, 7, 7, 320, 3, 3, 1, 1))[1].startswith("32x128x288_w1x4")         # 3136 pels: 250 small tiles rather than 125 on half the CUs
-    assert "-DCG=1" in plan((64, 32, 28, 28, 96, 5, 5, 1, 2))                                # 5x5: one channel group per K step (25 k-slots + a zero slot)
+    assert plan((64, 160, 7, 7, 320, 3, 3, 1, 1))[1].startswith("32x128x144_w1x4")         # 3136 pels: 250 small tiles rather than 125 on half the CUs
+    assert "-DCG=2" in plan((64, 32, 28, 28, 96, 5, 5, 1, 2))                                # 5x5: two channel groups per K step (50 k-slots, no zero slot)
+    assert "-DCG=1" in plan((64, 24, 14, 14, 64, 5, 5, 1, 2))                                # three groups: 3 x 26 slots rather than 2 x 50
+    assert "-DCG=2" in plan((64, 112, 14, 14, 224, 3, 3, 1, 1))                              # 14 groups: 7 x 18 slots rather than 4 x 36
     assert plan((64, 256, 56, 56, 64, 1, 1, 1, 0))[0] == plan((64, 128, 28, 28, 128, 3, 3, 2, 1))[0] == "bodahip_conv_nhwc_bf16"   # 1x1, and stride 2 in x: implicit GEMM
     assert plan((64, 128, 4, 4, 1024, 4, 4, 1, 0))[0] == "bodahip_conv_nhwc_bf16"            # whole-input kernel (an fc layer): implicit GEMM + K slices
     fc = plan((64, 2048, 1, 1, 1000, 1, 1, 1, 0))                                # 64 output rows, K = 2048: K slices + reduce pass
