@@ -14,7 +14,22 @@ from boda_amd.digest import SsdsDiff
 from boda_amd.op import Dims
 from boda_amd.rtc import make_rtc
 from oracle import boda_oracle as bo
-from oracle.net_forward import oracle_forward
+from oracle.net_forward import oracle_forward as _oracle_forward
+import hashlib
+
+_ORACLE_FWD = {}
+
+
+def oracle_forward(cp, data, params, **kw):
+    """The oracle's forward pass, computed once per (net, input, parameters, rounding mode) of this module: several tests compare against the same pass, and
+    GoogLeNet's takes the CPU 15-20 s each time."""
+    h = hashlib.sha1(np.ascontiguousarray(data).tobytes())
+    for k in sorted(params):
+        h.update(k.encode()); h.update(np.ascontiguousarray(params[k]).tobytes()[:4096])
+    key = (cp.name, tuple(cp.nodes[cp.in_node].sizes), len(cp.ops), h.hexdigest(), tuple(sorted(kw.items())))
+    if key not in _ORACLE_FWD:
+        _ORACLE_FWD[key] = _oracle_forward(cp, data, params, **kw)
+    return _ORACLE_FWD[key]
 
 FULLNET_MRD = 5e-4
 BF16_VS_BF16_ORACLE = 1e-2

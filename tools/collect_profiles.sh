@@ -9,7 +9,7 @@ O=$R/gpurun_out/$D
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 SQ="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/calib -o c -- python $R/tools/fetch_calib.py > $O/calib.log 2>&1
+[ -z "$BENCH_ONLY" ] && rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/calib -o c -- python $R/tools/fetch_calib.py > $O/calib.log 2>&1
 prof() {   # key, bench args
   k=$1; shift
   rocprofv3 --kernel-trace --stats -d $O/stats_$k -o p -- python $R/bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_$k.log 2>&1
@@ -17,11 +17,13 @@ prof() {   # key, bench args
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_$k -o p -- python $R/bench.py "$@" --steps 1 --warmup 0 --settle-ms 0 --no-cpu-baseline > $O/write_$k.log 2>&1
   rocprofv3 --kernel-trace --pmc $SQ -d $O/sq_$k -o p -- python $R/bench.py "$@" --steps 1 --warmup 0 --settle-ms 0 --no-cpu-baseline > $O/sq_$k.log 2>&1
 }
+if [ -z "$BENCH_ONLY" ]; then    # BENCH_ONLY=1: only the bench lines (second pass, once profiles/pmc_summary.json carries the current kernel-source hash: roofline.traffic is then filled)
 prof sgemm-ops-full --workload sgemm-ops-full --no-conv-ops
 prof alexnet --workload alexnet
 prof nin --workload nin
 prof googlenet-bf16-nhwc --workload googlenet --dtype bf16 --layout nhwc
 prof resnet50-bf16-nhwc --workload resnet50 --dtype bf16 --layout nhwc
+fi
 cd $R
 python -c "import bench; print(bench.kernel_src_hash())" > $O/kernel_src_hash.txt
 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2>$O/bench_default.err      # the driver's command: headline + conv_ops + configs legs
