@@ -247,6 +247,27 @@ CUCL_GLOBAL_KERNEL void %(rtc_func_name)( GASQ float const * const in, // CUCL I
   int32_t const tx_hi = ( %(in_x_dim) - x0 < %(kern_sz_x_dim) ) ? %(in_x_dim) - x0 : %(kern_sz_x_dim);
   int32_t const w0 = %(GLOB_ID_1D_img_nomod)*%(in_img_stride) + %(GLOB_ID_1D_chan)*%(in_chan_stride) + y0*%(in_y_stride) + x0;
   float acc = %(avg_pool) ? 0.0f : -FLT_MAX;
+#if BODAHIP_POOL_UNCOND
+  // every tap is loaded, unconditionally, from the nearest tap INSIDE the clipped window (so the loads are independent and all in flight together): a duplicate
+  // does not change a maximum, an average adds only the taps that are inside -- same values, same order of additions.  Needs a non-empty window.
+  float v[%(kern_sz_x_dim)][%(kern_sz_y_dim)];
+#pragma unroll
+  for( int32_t tx = 0; tx != %(kern_sz_x_dim); ++tx ) {
+#pragma unroll
+    for( int32_t ty = 0; ty != %(kern_sz_y_dim); ++ty ) {
+      int32_t const cy = ( ty < ty_lo ) ? ty_lo : ( ( ty >= ty_hi ) ? ty_hi - 1 : ty ), cx = ( tx < tx_lo ) ? tx_lo : ( ( tx >= tx_hi ) ? tx_hi - 1 : tx );
+      v[tx][ty] = in[w0 + cy*%(in_y_stride) + cx];
+    }
+  }
+#pragma unroll
+  for( int32_t tx = 0; tx != %(kern_sz_x_dim); ++tx ) {
+#pragma unroll
+    for( int32_t ty = 0; ty != %(kern_sz_y_dim); ++ty ) {
+      bool const ok = ( tx >= tx_lo ) && ( tx < tx_hi ) && ( ty >= ty_lo ) && ( ty < ty_hi );
+      if( %(avg_pool) ) { if( ok ) { acc = acc + v[tx][ty]; } } else { acc = ( v[tx][ty] > acc ) ? v[tx][ty] : acc; }
+    }
+  }
+#else
   for( int32_t tx = 0; tx != %(kern_sz_x_dim); ++tx ) {
     if( tx < tx_lo || tx >= tx_hi ) { continue; }
     for( int32_t ty = 0; ty != %(kern_sz_y_dim); ++ty ) {
@@ -255,6 +276,7 @@ CUCL_GLOBAL_KERNEL void %(rtc_func_name)( GASQ float const * const in, // CUCL I
       acc = %(avg_pool) ? ( acc + v ) : ( ( v > acc ) ? v : acc );
     }
   }
+#endif
   int32_t const n_y = ( ty_hi > ty_lo ) ? ty_hi - ty_lo : 0;
   int32_t const n_x = ( tx_hi > tx_lo ) ? tx_hi - tx_lo : 0;
   if( %(avg_pool) ) { acc /= (float)( n_y*n_x ); }
@@ -299,7 +321,11 @@ CUCL_GLOBAL_KERNEL void %(rtc_func_name)( float const alpha, // CUCL IN :
       sumsq = ( sumsq + entering*entering ) - leaving*leaving;
     }
     if( c_out >= c_first && c_out < %(in_chan_dim) ) {
+#if BODAHIP_LRN_FASTPOW
+      out[pel + c_out*%(in_chan_stride)] = line[kLast - kHalf] * __builtin_amdgcn_exp2f( -%(beta) * __builtin_amdgcn_logf( %(k) + sumsq*per_elem ) );   // (k > 0, alpha >= 0: the argument is positive)
+#else
       out[pel + c_out*%(in_chan_stride)] = line[kLast - kHalf] * powf( %(k) + sumsq*per_elem, -%(beta) );
+#endif
     }
   }
 }
@@ -515,10 +541,15 @@ class ConvPipeFwd:
                 none = lambda yx: Nda(Dims(("y", "x"), tuple(yx), "none"), "none")
                 pop = Op({"type": "Pooling", "func_name": "pool"}, {"in": Nda(i), "out": Nda(o), "kern_sz": none(op.kern_sz), "stride": none(op.stride),
                                                                     "in_pad": none(op.in_pad), "avg_pool": Nda(None, "uint32_t", (int(op.avg_pool),))})
-                sig = pop.to_str()
+                H, W, OH, OW = i.dsz("y"), i.dsz("x"), o.dsz("y"), o.dsz("x")
+                nonempty = all(min(H, oy * op.stride[0] - op.in_pad[0] + op.kern_sz[0]) > max(0, oy * op.stride[0] - op.in_pad[0]) for oy in (0, OH - 1)) and \
+                    all(min(W, ox * op.stride[1] - op.in_pad[1] + op.kern_sz[1]) > max(0, ox * op.stride[1] - op.in_pad[1]) for ox in (0, OW - 1))
+                uncond = int(self.spec_fwd and nonempty and op.kern_sz[0] * op.kern_sz[1] <= 64)     # taps as independent, unconditional loads (see the template)
+                sig = pop.to_str() + f"|uncond={uncond}"
                 cache = rtc.__dict__.setdefault("_pool_funcs", {})      # one generated function per distinct signature (rtc_func_sigs_map_t)
                 if sig not in cache:
                     inst = instantiate(_POOL_T, pop, f"fwd_pool__{len(cache)}")
+                    inst.src = f"#define BODAHIP_POOL_UNCOND {uncond}\n" + inst.src
                     rtc.compile([RtcFuncInfo(inst.func_name, inst.src, inst.arg_names, pop)])
                     cache[sig] = inst
                 inst = cache[sig]
@@ -546,10 +577,12 @@ class ConvPipeFwd:
                 work = Dims(("img", "cblk", "cblk_sz", "y", "x"), (d.dsz("img"), -(-d.dsz("chan") // cblk_sz), cblk_sz, d.dsz("y"), d.dsz("x")), "none")
                 lop = Op({"type": "LRN", "func_name": "lrn"}, {"in": Nda(d), "out": Nda(d), "alpha": f32(alpha), "beta": f32(beta), "k": f32(k),
                                                                "local_size": Nda(None, "uint32_t", (int(ls),)), "work": Nda(work, "none")})
-                sig = lop.to_str()
+                fastpow = int(self.spec_fwd and k > 0.0 and alpha >= 0.0)      # x^-beta as exp2(-beta log2 x): x = k + alpha/n * sum of squares > 0
+                sig = lop.to_str() + f"|fastpow={fastpow}"
                 cache = rtc.__dict__.setdefault("_pool_funcs", {})
                 if sig not in cache:
                     inst = instantiate(_LRN_T, lop, f"fwd_lrn__{len(cache)}")
+                    inst.src = f"#define BODAHIP_LRN_FASTPOW {fastpow}\n" + inst.src
                     rtc.compile([RtcFuncInfo(inst.func_name, inst.src, inst.arg_names, lop)])
                     cache[sig] = inst
                 inst = cache[sig]
