@@ -50,6 +50,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef PF
 #define PF 8       // ADIRECT: k-iterations of filter fragments in flight
 #endif
+#ifndef BPF
+#define BPF 1      // ADIRECT: k-iterations the patch fragment reads (ds_read_b128) run ahead of their MFMAs
+#endif
 #ifndef ABLATE
 #define ABLATE 0   // measurement only (wrong results): 1 = no operand loads, 2 = no fragment reads / MFMAs, 3 = no LDS stores of the staged operands, 4 = no K loop at all
 #endif
@@ -233,24 +236,27 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     for (int kt = 0; kt < ((ABLATE == 4) ? 0 : kNKT); ++kt) {
       u32x4 const *const Js = Js0 + (kt & 1) * kImgC;
       if (kt + 1 < kNKT) load_patch(kt + 1);
-      bf16x8 b[2][kTJ];
+      constexpr int kBD = (BPF < kN) ? BPF : kN, kBR = kBD + 1;   // patch fragments are read kBD k-iterations ahead, through a ring of kBR sets
+      bf16x8 b[kBR][kTJ];
 #pragma unroll
-      for (int t = 0; t < kTJ; ++t) b[0][t] = __builtin_bit_cast(bf16x8, Js[bj[t] + (hi ? slot_off(1) : slot_off(0))]);
+      for (int d = 0; d < kBD; ++d)
+#pragma unroll
+        for (int t = 0; t < kTJ; ++t) b[d][t] = __builtin_bit_cast(bf16x8, Js[bj[t] + (hi ? slot_off(2 * d + 1) : slot_off(2 * d))]);
 #pragma unroll
       for (int s = 0; s < kN; ++s) {
         if (s + kPF < kN) load_a(kt, s + kPF, cur[s + kPF]); else load_a(kt + 1, s + kPF - kN, nxt[s + kPF - kN]);
-        if (s + 1 < kN) {
-          int const jo = hi ? slot_off(2 * s + 3) : slot_off(2 * s + 2);
+        if (s + kBD < kN) {
+          int const jo = hi ? slot_off(2 * (s + kBD) + 1) : slot_off(2 * (s + kBD));
 #pragma unroll
-          for (int t = 0; t < kTJ; ++t) b[(s + 1) & 1][t] = __builtin_bit_cast(bf16x8, Js[bj[t] + jo]);
+          for (int t = 0; t < kTJ; ++t) b[(s + kBD) % kBR][t] = __builtin_bit_cast(bf16x8, Js[bj[t] + jo]);
         }
         if (ABLATE != 2) {
 #pragma unroll
           for (int ta = 0; ta < kTI; ++ta)
 #pragma unroll
             for (int tb = 0; tb < kTJ; ++tb)
-              acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[s][ta]), b[s & 1][tb], acc[ta][tb], 0, 0, 0);
-        } else asm volatile("" ::"v"(cur[s][0]), "v"(b[s & 1][0]));
+              acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[s][ta]), b[s % kBR][tb], acc[ta][tb], 0, 0, 0);
+        } else asm volatile("" ::"v"(cur[s][0]), "v"(b[s % kBR][0]));
         __builtin_amdgcn_sched_barrier(0);
       }
       if (kt + 1 < kNKT) store_patch((kt & 1) ^ 1);
