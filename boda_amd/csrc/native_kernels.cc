@@ -420,10 +420,11 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
     // 30 / 34; GoogLeNet 3x3 64->192 at 56^2: 64x256 63-66, 32x128 91.  Two workgroups per CU must fit the LDS (80 KB each): wide planes take 2 channel groups
     // per K step instead of 4 (level with each other where both fit; 8 groups measured 10-50 % slower).
     int pick = -1, pick_cg = cg; double best = -1;
+    for (long lim = 80 * 1024; pick < 0 && lim <= 160 * 1024; lim *= 2)
     for (int ci = 0; ci < n_cands; ++ci) {
       cand_t const &cd = cands[ci];
-      int cgx = cg; while (cgx > 1 && lds_cg(cd.bi, cd.bj, cgx) > 80 * 1024) cgx = (cgx + 1) / 2;
-      if (lds_cg(cd.bi, cd.bj, cgx) > 80 * 1024) continue;
+      int cgx = cg; while (cgx > 1 && lds_cg(cd.bi, cd.bj, cgx) > lim) cgx = (cgx + 1) / 2;
+      if (lds_cg(cd.bi, cd.bj, cgx) > lim) continue;
       if (cd.bi > 64 && g.OC <= 64) continue;
       long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
       double const pad = ((double)g.OC / (double)(ti * cd.bi)) * ((double)Nj / (double)(tj * cd.bj));
@@ -443,10 +444,11 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
     // 32.3 -> 24.4-25.1; GoogLeNet 96->208 / 128->256 / 160->320 at 14^2 14.7 -> 11.8 / 17.1 -> 13.8 / 20.7 -> 16.7, 64->192 at 56^2 64.6 -> 60.5; 4 channel groups
     // per K step (8: 5-100 % slower, 2: level or 10 % slower); 4 / 8 / 12 fragments in flight: level.
     int pick = -1, pick_cg = cg; double best = 1e30;
+    for (long lim = 80 * 1024; pick < 0 && lim <= 160 * 1024; lim *= 2)      // two workgroups per CU; one where nothing fits that (maps one or two positions wide)
     for (int ci = 0; ci < n_cands; ++ci) {
       cand_t const &cd = cands[ci];
-      int cgx = cg; while (cgx > 1 && lds_cg(cd.bi, cd.bj, cgx) > 80 * 1024) cgx = (cgx + 1) / 2;
-      if (lds_cg(cd.bi, cd.bj, cgx) > 80 * 1024) continue;
+      int cgx = cg; while (cgx > 1 && lds_cg(cd.bi, cd.bj, cgx) > lim) cgx = (cgx + 1) / 2;
+      if (lds_cg(cd.bi, cd.bj, cgx) > lim) continue;
       long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
       double const rounds = (tiles <= num_cus) ? 1.0 : (tiles <= 2l * num_cus) ? 1.7 : ((double)tiles / (double)num_cus + 0.25);
       int const ktj = cd.bj / (cd.wj * 32);

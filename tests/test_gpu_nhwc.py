@@ -75,7 +75,8 @@ EDGE = [  # B, C, H, W, OC, KH, KW, S, P : 1x1 (stride 1 / 2, padded), 3x3, 5x5 
     (1, 16, 14, 14, 130, 7, 7, 2, 3), (5, 32, 7, 7, 64, 1, 1, 2, 0), (2, 6, 10, 10, 12, 3, 3, 1, 0), (1, 1, 5, 5, 1, 5, 5, 1, 2),
     (4, 20, 8, 8, 100, 3, 3, 1, 1), (2, 3, 40, 40, 16, 7, 7, 2, 3), (3, 4, 33, 31, 20, 5, 5, 1, 2), (2, 3, 64, 64, 24, 11, 11, 4, 5),
     (4, 96, 27, 27, 256, 5, 5, 1, 2), (3, 256, 13, 13, 384, 3, 3, 1, 1), (8, 256, 6, 6, 512, 6, 6, 1, 0), (3, 528, 14, 14, 160, 1, 1, 1, 0),
-    (2, 112, 14, 14, 224, 3, 3, 1, 1), (2, 24, 28, 28, 64, 5, 5, 1, 2), (2, 832, 7, 7, 1000, 1, 1, 1, 0)]
+    (2, 112, 14, 14, 224, 3, 3, 1, 1), (2, 24, 28, 28, 64, 5, 5, 1, 2), (2, 832, 7, 7, 1000, 1, 1, 1, 0),
+    (9, 96, 6, 3, 208, 7, 7, 1, 2), (3, 64, 1, 40, 64, 3, 3, 1, 1), (16, 32, 2, 2, 48, 3, 3, 1, 1)]   # maps one or two positions wide / high (a fuzz find: the patch of a 4 x 1 map needs one workgroup per CU)
 
 
 @pytest.mark.parametrize("shape", EDGE, ids=lambda s: "x".join(str(v) for v in s))
