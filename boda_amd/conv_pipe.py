@@ -263,6 +263,7 @@ CUCL_GLOBAL_KERNEL void %(rtc_func_name)( GASQ float const * const in, // CUCL I
   for( int32_t tx = 0; tx != %(kern_sz_x_dim); ++tx ) {
 #pragma unroll
     for( int32_t ty = 0; ty != %(kern_sz_y_dim); ++ty ) {
+      #pragma clang fp reassociate(off) contract(off)      // (fast-math build: an average keeps the written order of its additions)
       bool const ok = ( tx >= tx_lo ) && ( tx < tx_hi ) && ( ty >= ty_lo ) && ( ty < ty_hi );
       if( %(avg_pool) ) { if( ok ) { acc = acc + v[tx][ty]; } } else { acc = ( v[tx][ty] > acc ) ? v[tx][ty] : acc; }
     }

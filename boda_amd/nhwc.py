@@ -446,6 +446,7 @@ CUCL_GLOBAL_KERNEL void @NAME@( GASQ bf16x8_t const * const in, GASQ bf16x8_t * 
       for( int32_t ky = 0; ky != @KH@; ++ky ) {
         bool const ok = ( y0 + ky >= ya ) && ( y0 + ky < yb ) && ( x0 + kx >= xa ) && ( x0 + kx < xb );
         for( int32_t e = 0; e != 8; ++e ) {
+          #pragma clang fp reassociate(off) contract(off)      // (CUCL sources build with fast-math: an average keeps the written order of its additions)
           float const f = (float)v[t*@SX@ + kx][ky][e];
           if( @AVG@ ) { if( ok ) { acc[e] = acc[e] + f; } } else { acc[e] = ( f > acc[e] ) ? f : acc[e]; }
         }
