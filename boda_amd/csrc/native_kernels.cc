@@ -402,14 +402,16 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
     return std::max<long>(ops, out_f32 ? 0 : (long)bj * (bi * 2 + 16));
   };
   auto lds = [&](int bi, int bj) { return lds_cg(bi, bj, cg); };
-  struct cand_t { int bi, bj, wi, wj, minw; };
-  static cand_t const cands_staged[] = {{64, 256, 1, 4, 2}, {64, 128, 1, 4, 2}, {32, 256, 1, 4, 2}, {128, 128, 2, 2, 2}, {32, 128, 1, 4, 2}, {64, 64, 2, 2, 2}};
-  // ADIRECT: wave tiles wide in pels first (32 x 128: one 1-KB filter fragment load per four MFMAs), in order of preference on equal cost
-  static cand_t const cands_direct[] = {{128, 128, 4, 1, 2}, {64, 256, 2, 2, 2}, {64, 128, 2, 2, 2}, {128, 64, 4, 1, 2}, {32, 128, 1, 4, 2}};
+  struct cand_t { int bi, bj, wi, wj, minw, pf; };
+  static cand_t const cands_staged[] = {{64, 256, 1, 4, 2, 0}, {64, 128, 1, 4, 2, 0}, {32, 256, 1, 4, 2, 0}, {128, 128, 2, 2, 2, 0}, {32, 128, 1, 4, 2, 0}, {64, 64, 2, 2, 2, 0}};
+  // ADIRECT: wave tiles wide in pels first (32 x 128: one 1-KB filter fragment load per four MFMAs), in order of preference on equal cost; last the 64 x 128 wave
+  // tile (half the operand bytes per MFMA; 247 registers with four fragments in flight: still two waves per SIMD) for layers with tiles to spare
+  static cand_t const cands_direct[] = {{128, 128, 4, 1, 2, 0}, {64, 256, 2, 2, 2, 0}, {64, 128, 2, 2, 2, 0}, {128, 64, 4, 1, 2, 0}, {32, 128, 1, 4, 2, 0}, {256, 128, 4, 1, 2, 4}};
   cand_t const *const cands = adirect ? cands_direct : cands_staged;
   int const n_cands = adirect ? (int)(sizeof(cands_direct) / sizeof(cand_t)) : (int)(sizeof(cands_staged) / sizeof(cand_t));
   plan_t p; p.nhwc = true; p.nhwc_patch = true; p.bf16 = true; p.kname = "bodahip_conv_nhwc_patch_bf16";
   tile_cfg_t c; c.MT = 32; c.SPLITK = 1; c.PF = 1;
+  int pick_pf = 0;
   if (!tile.empty()) {
     if (!parse_tile(tile, c)) rt_err("bad conv_tile '" + tile + "'");
     c.MT = 32; c.SPLITK = 1; c.PF = 1;
@@ -451,9 +453,10 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
       if (lds_cg(cd.bi, cd.bj, cgx) > lim) continue;
       long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
       double const rounds = (tiles <= num_cus) ? 1.0 : (tiles <= 2l * num_cus) ? 1.7 : ((double)tiles / (double)num_cus + 0.25);
-      int const ktj = cd.bj / (cd.wj * 32);
-      double const cost = rounds * (double)(cd.bi * cd.bj) / (double)(cd.wi * cd.wj) * ((ktj >= 4) ? 1.1 : (ktj >= 2) ? 1.3 : 2.0);   // (fitted to the sweep)
-      if (cost < best * 0.97) { best = cost; pick = ci; pick_cg = cgx; }   // (a later candidate must be clearly cheaper)
+      int const ktj = cd.bj / (cd.wj * 32), kti = cd.bi / (cd.wi * 32);
+      // (fitted to the sweeps; the 64 x 128 wave tile: AlexNet conv2 at 256 images, 1458 tiles, 205 -> 190 us; conv5, 338 tiles, 74 -> 81)
+      double const cost = rounds * (double)(cd.bi * cd.bj) / (double)(cd.wi * cd.wj) * ((kti >= 2 && ktj >= 4) ? 1.02 : (ktj >= 4) ? 1.1 : (ktj >= 2) ? 1.3 : 2.0);
+      if (cost < best * 0.97) { best = cost; pick = ci; pick_cg = cgx; pick_pf = cd.pf; }   // (a later candidate must be clearly cheaper)
     }
     if (pick < 0) unsup_err("hip_conv_nhwc (patch form of filts): no tile fits the LDS for this plane width");
     c.BI = cands[pick].bi; c.BJ = cands[pick].bj; c.WI = cands[pick].wi; c.WJ = cands[pick].wj; c.MINW = cands[pick].minw; cg = pick_cg;
@@ -469,6 +472,7 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
             "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX), "-DCH=" + std::to_string(g.H), "-DCW=" + std::to_string(g.W),
             "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW), string("-DRELU=") + (g.relu ? "1" : "0"), string("-DOUT_F32=") + (out_f32 ? "1" : "0")};
   if (adirect) p.defs.push_back("-DADIRECT=1");
+  if (adirect && (pick_pf || (tile.empty() ? 0 : ((c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) >= 8)))) p.defs.push_back("-DPF=4");   // (128 accumulators: four fragments in flight)
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
   return p;
 }
