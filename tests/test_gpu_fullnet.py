@@ -185,7 +185,7 @@ def test_pool_lrn_relu_kernels_vs_oracle(rtc):
         fwd.release()
 
 
-@pytest.mark.parametrize("net,batch", [("nin", 2), ("googlenet", 2)])
+@pytest.mark.parametrize("net,batch", [("nin", 2), ("googlenet", 1)])
 def test_full_net_forward_bf16_operands(rtc, net, batch):
     """op_tune hip_dtype=bf16 through the full-net driver (config 5's arithmetic on whole nets): every conv goes to a bf16 kernel
     (channel-innermost LDS patch / gather / 1x1, incl. writes into Concat channel slices).  Parity is unpinned for bf16 (the reference
@@ -275,7 +275,7 @@ def test_dependency_graph_with_multi_kernel_calls_bf16(rtc):
         fwd.release()
 
 
-@pytest.mark.parametrize("net,batch", [("nin", 2), ("alexnet", 2), ("googlenet", 2)])
+@pytest.mark.parametrize("net,batch", [("nin", 2), ("alexnet", 2), ("googlenet", 1)])
 def test_full_net_forward_channels_last_bf16(rtc, net, batch):
     """op_tune (hip_dtype=bf16, hip_layout=nhwc) through the full-net driver: every node is a channels-last bf16 tensor in HBM, convs run
     hip_conv_nhwc (incl. writes into Concat channel slices), pools / LRN their channels-last kernels; the input is transposed by the first
