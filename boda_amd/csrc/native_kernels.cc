@@ -406,7 +406,7 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
   static cand_t const cands_staged[] = {{64, 256, 1, 4, 2, 0}, {64, 128, 1, 4, 2, 0}, {32, 256, 1, 4, 2, 0}, {128, 128, 2, 2, 2, 0}, {32, 128, 1, 4, 2, 0}, {64, 64, 2, 2, 2, 0}};
   // ADIRECT: wave tiles wide in pels first (32 x 128: one 1-KB filter fragment load per four MFMAs), in order of preference on equal cost; last the 64 x 128 wave
   // tile (half the operand bytes per MFMA; 247 registers with four fragments in flight: still two waves per SIMD) for layers with tiles to spare
-  static cand_t const cands_direct[] = {{128, 128, 4, 1, 2, 0}, {64, 256, 2, 2, 2, 0}, {64, 128, 2, 2, 2, 0}, {128, 64, 4, 1, 2, 0}, {32, 128, 1, 4, 2, 0}, {256, 128, 4, 1, 2, 4}};
+  static cand_t const cands_direct[] = {{128, 128, 4, 1, 2, 0}, {64, 256, 2, 2, 2, 0}, {64, 128, 2, 2, 2, 0}, {128, 64, 4, 1, 2, 0}, {32, 128, 1, 4, 2, 0}, {128, 256, 2, 2, 2, 4}, {256, 128, 4, 1, 2, 4}};
   cand_t const *const cands = adirect ? cands_direct : cands_staged;
   int const n_cands = adirect ? (int)(sizeof(cands_direct) / sizeof(cand_t)) : (int)(sizeof(cands_staged) / sizeof(cand_t));
   plan_t p; p.nhwc = true; p.nhwc_patch = true; p.bf16 = true; p.kname = "bodahip_conv_nhwc_patch_bf16";
@@ -452,9 +452,10 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
       int cgx = cg; while (cgx > 1 && lds_cg(cd.bi, cd.bj, cgx) > lim) cgx = (cgx + 1) / 2;
       if (lds_cg(cd.bi, cd.bj, cgx) > lim) continue;
       long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
-      double const rounds = (tiles <= num_cus) ? 1.0 : (tiles <= 2l * num_cus) ? 1.7 : ((double)tiles / (double)num_cus + 0.25);
+      double const rounds = (tiles <= num_cus) ? 1.0 : std::max(1.7, (double)tiles / (double)num_cus + 0.25);
       int const ktj = cd.bj / (cd.wj * 32), kti = cd.bi / (cd.wi * 32);
-      // (fitted to the sweeps; the 64 x 128 wave tile: AlexNet conv2 at 256 images, 1458 tiles, 205 -> 190 us; conv5, 338 tiles, 74 -> 81)
+      // (fitted to the sweeps; the 64 x 128 wave tile, as 128 x 256 or 256 x 128 workgroup tiles: AlexNet conv2 at 256 images, 1458 tiles, 201 -> 181 us; the
+      //  space-to-depth conv1, 3025 tiles, 110.6 -> 99.4; conv5, 338 tiles, 72 -> 79-88)
       double const cost = rounds * (double)(cd.bi * cd.bj) / (double)(cd.wi * cd.wj) * ((kti >= 2 && ktj >= 4) ? 1.02 : (ktj >= 4) ? 1.1 : (ktj >= 2) ? 1.3 : 2.0);
       if (cost < best * 0.97) { best = cost; pick = ci; pick_cg = cgx; pick_pf = cd.pf; }   // (a later candidate must be clearly cheaper)
     }

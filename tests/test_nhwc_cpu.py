@@ -58,7 +58,7 @@ def test_planner_choices():
     assert plan((64, 64, 56, 56, 192, 3, 3, 1, 1))[1].startswith("64x256x144_w2x2")        # 2352 tiles: the widest pel tile (2 of the 8 groups per step: two workgroups per CU fit the LDS)
     assert plan((64, 256, 14, 14, 256, 3, 3, 1, 1))[1].startswith("128x128x288_w4x1")      # 196 tiles of four 32 x 128 wave tiles: one round
     big = plan((256, 96, 27, 27, 256, 5, 5, 1, 2))                                            # 1458 tiles of 64 x 128 wave tiles: half the operand bytes per MFMA,
-    assert big[1].startswith("256x128x400_w4x1") and "-DPF=4" in big                          # four fragments in flight keep 128 accumulators at two waves per SIMD
+    assert big[1].startswith("128x256x400_w2x2") and "-DPF=4" in big                          # four fragments in flight keep 128 accumulators at two waves per SIMD
     assert plan((64, 160, 7, 7, 320, 3, 3, 1, 1))[1].startswith("32x128x144_w1x4")         # 3136 pels: 250 small tiles rather than 125 on half the CUs
     assert "-DCG=2" in plan((64, 32, 28, 28, 96, 5, 5, 1, 2))                                # 5x5: two channel groups per K step (50 k-slots, no zero slot)
     assert "-DCG=1" in plan((64, 24, 14, 14, 64, 5, 5, 1, 2))                                # three groups: 3 x 26 slots rather than 2 x 50
