@@ -10,13 +10,15 @@
 // ("slots" of W + 2 PX chunks; consecutive output rows of an image share slots; a tile that crosses into the next image starts a new slot group -- the
 // geometry of gemm_conv_f32.hip's patch mode and of conv_patch_bf16.hip), each input chunk is loaded ONCE per K step with a 16-byte load, and a lane's MFMA B
 // fragment for tap (ky, kx) is one ds_read_b128 at   patch[g][(slot(j) + ky) * Wp + ox(j) + kx].   The contraction index is ordered (group, ky, kx, channel
-// in group) in both operands.  Operands are register-staged (global loads of step s+1 fly under the MFMAs of step s) into a single LDS image.
-// Lanes of a staging load are laid out position-major (CG consecutive lanes = the CG x 16 contiguous bytes of one position), the LDS image group-major with a
-// group pitch that is 2 (mod 16) chunks, so the transposing ds_write_b128s are conflict-free.
+// in group) in both operands.  The patch is register-staged (the global loads of step s+1 fly under the MFMAs of step s); lanes of a staging load are laid out
+// position-major (CG consecutive lanes = the CG x 16 contiguous bytes of one position), the LDS image group-major with a group pitch that is 2 (mod 16) chunks, so
+// the transposing ds_write_b128s are conflict-free, and a slot pitch that keeps the fragment reads conflict-free across row ends (WPITCH below).
+// The FILTERS take one of two paths: by default (ADIRECT=1, see the option below) every wave loads its own MFMA A fragments straight from global memory through a
+// register ring and the LDS holds only the patch, double-buffered; with ADIRECT=0 they are register-staged into the same single LDS image as the patch.
 //
 // Numerics: as conv_nhwc_bf16.hip (fp32 accumulate in the MFMA's own order; parity stated against the oracle on bf16-rounded operands).
 //
-// -D parameters: KNAME BI BJ WI WJ MINW CG CIN KH KW SY PY PX CH CW COH COW RELU OUT_F32 [ADIRECT PF]       (SX == 1)
+// -D parameters: KNAME BI BJ WI WJ MINW CG CIN KH KW SY PY PX CH CW COH COW RELU OUT_F32 [ADIRECT PF BPF WPITCH DBUF ABLATE]       (SX == 1)
 
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
