@@ -159,7 +159,7 @@ def alexnet_ng_conv(batch: int, in_hw: int = 227) -> ConvPipe:
 
 
 def pipe_from_spec(name: str, lines: Sequence[str], batch: int) -> ConvPipe:
-    """ConvPipe from the one-line op records boda_amd.prototxt.pipe_spec writes (fixtures: tests/golden/nets/*.txt)."""
+    """ConvPipe from the one-line op records boda_amd.prototxt.pipe_spec writes (shape data: boda_amd/data/nets/*.txt)."""
     p: Optional[ConvPipe] = None
     for ln in lines:
         f = ln.split()
@@ -195,9 +195,9 @@ def pipe_from_spec(name: str, lines: Sequence[str], batch: int) -> ConvPipe:
 
 def googlenet_conv(batch: int) -> ConvPipe:
     """nets/googlenet_conv (TEST phase, incl. the two auxiliary heads): 64 convs, 9 inception Concats, 2 LRN, 16 pools; the op
-    records are a data fixture written by tests/golden/make_net_ops.py with this project's prototxt reader."""
-    import os
-    fn = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "nets", "googlenet_conv.txt")
+    records are shape data written by boda_amd/data/make_net_ops.py with this project's prototxt reader."""
+    from .op import data_path
+    fn = data_path("nets", "googlenet_conv.txt")
     with open(fn) as f:
         return pipe_from_spec("googlenet_conv", f.read().splitlines(), batch)
 

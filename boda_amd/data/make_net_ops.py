@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/ops/{googlenet_conv,resnet-50}-conv-ops-b1.txt from the reference's net definitions
+"""Generates boda_amd/data/ops/{googlenet_conv,resnet-50}-conv-ops-b1.txt and boda_amd/data/nets/* from the reference's net definitions
 (nets/<net>/train_val.prototxt) with THIS project's prototxt reader + shape inference (boda_amd/prototxt.py).  Run in the
 build container only.  The outputs are data: one op line per Convolution layer, batch 1 (re-batched by the callers);
 layer order and multiplicity preserved (64 GoogLeNet convs incl. the auxiliary heads, 53 ResNet-50 convs + its fc)."""
 import os, sys
-HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(os.path.dirname(HERE)); sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(os.path.dirname(HERE))  # boda_amd/data -> repo root; sys.path.insert(0, ROOT)
 from boda_amd.prototxt import conv_bottoms, conv_ops, pipe_spec
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 for net in ("googlenet_conv", "resnet-50"):

@@ -385,3 +385,10 @@ def parse_op(line: str) -> Op:
 def read_ops(path: str) -> List[Op]:
     with open(path) as f:
         return [parse_op(l) for l in f if l.strip()]
+
+
+def data_path(*parts: str) -> str:
+    """Path of a shape-data file the package ships (boda_amd/data/): the op lists / net records of the BASELINE workloads.  Test fixtures
+    (reference-held digests, the reference's other op lists) live under tests/golden/ and are never read by product code."""
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", *parts)

@@ -16,3 +16,22 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# Order of the -m gpu files (the driver runs `pytest -m gpu -x`): hot-path parity first, the reference's own kernels (F4) next, then the callers
+# either side of the path, and every non-parity test (timing attribution, bench.py subprocesses) last -- so that nothing which is not a parity
+# test can stop the run before a parity test has executed.  Files not named here keep their alphabetical place between the two groups.
+_GPU_ORDER = ["test_gpu_parity.py", "test_gpu_ref_cucl.py", "test_gpu_nhwc.py", "test_gpu_fullnet.py", "test_gpu_multi.py", "test_gpu_adapter.py",
+              "test_gpu_cnn_op_info.py"]
+_GPU_LAST = ["test_gpu_zz_properties.py", "test_gpu_zz_bench.py"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(it):
+        fn = os.path.basename(str(it.fspath))
+        if fn in _GPU_ORDER:
+            return (1, _GPU_ORDER.index(fn))
+        if fn in _GPU_LAST:
+            return (3, _GPU_LAST.index(fn))
+        return (2 if fn.startswith("test_gpu_") else 0, 0)
+    items.sort(key=key)   # stable: the order inside a file is kept

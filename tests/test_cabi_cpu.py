@@ -59,7 +59,8 @@ def test_cpp_op_parser_agrees_with_python_on_every_fixture_line(golden_dir):
     import glob
     from boda_amd.op import parse_op
     n = 0
-    for fn in sorted(glob.glob(os.path.join(golden_dir, "ops", "*.txt"))):
+    from boda_amd.op import data_path
+    for fn in sorted(glob.glob(os.path.join(golden_dir, "ops", "*.txt")) + glob.glob(data_path("ops", "*-conv-ops-b1.txt"))):
         for line in open(fn):
             if line.strip():
                 assert R.parse_op_native(line) == parse_op(line).to_str(), (fn, line[:80])

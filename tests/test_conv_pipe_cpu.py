@@ -29,7 +29,7 @@ def test_googlenet_from_spec_fixture():
     convs = [o for o in cp.ops if o.type == "Convolution"]
     assert len(convs) == 64 and sum(o.type == "Concat" for o in cp.ops) == 9 and sum(o.type == "LRN" for o in cp.ops) == 2
     here = os.path.dirname(os.path.abspath(__file__))
-    want = [parse_op(l) for l in open(os.path.join(here, "golden", "ops", "googlenet_conv-conv-ops-b1.txt")).read().splitlines() if l.strip()]
+    want = [parse_op(l) for l in open(os.path.join(os.path.dirname(here), "boda_amd", "data", "ops", "googlenet_conv-conv-ops-b1.txt")).read().splitlines() if l.strip()]
     assert [cp.conv_op(o).to_str() for o in convs] == [w.to_str() for w in want]
     assert cp.nodes["pool1"].sizes == (1, 64, 56, 56) and cp.nodes["icp2_out"].sizes == (1, 480, 28, 28) and cp.nodes["icp9_out"].sizes == (1, 1024, 7, 7)
     assert cp.nodes[cp.out_node()].sizes == (1, 1000, 1, 1)

@@ -1060,36 +1060,3 @@ def test_ipconv_shapes_through_the_lds_dma_kernel_bit_exact(monkeypatch):
             assert np.array_equal(want, outs["out"]), (shape, SsdsDiff.of(want, outs["out"]).basic_str())
     finally:
         rtc.finish_and_sync(); rtc.close()
-
-
-def test_timing_modes(be):
-    """get_dur under the three attributions of stream time (tune key `timing`): call = a marker pair around every call (default, the reference's semantics);
-    stream = end markers only -- per-call durations then add up EXACTLY to first-begin .. last-end; kernel = events bound to the call's own dispatches."""
-    from boda_amd.rtc import RtcArg, RtcFuncCall, RtcFuncInfo
-    rtc = be.rtc
-    op = _conv_op(8, 64, 28, 28, 64, 3, 3, 1, 1); anno = add_codegen_annotations(op, OpTune()); fn = anno.get_func_name()
-    rtc.compile([RtcFuncInfo("tm_f", "", [a for a, _ in NATIVE_ARGS[fn]], anno)])
-    am, made = {}, []
-    for an, io in NATIVE_ARGS[fn]:
-        if io == "REF":
-            am[an] = RtcArg.ref(anno.get_dims(an)); continue
-        rtc.create_var_with_dims("tm_" + an, anno.get_dims(an)); made.append("tm_" + an); am[an] = RtcArg.var("tm_" + an)
-    try:
-        for mode in ("stream", "kernel", "call", ""):
-            rtc.set_tune("timing", mode)
-            ids = [rtc.run(RtcFuncCall("tm_f", am)) for _ in range(6)]
-            rtc.finish_and_sync()
-            each = [rtc.get_dur(i, i) for i in ids]; whole = rtc.get_dur(ids[0], ids[-1])
-            assert all(0 < d < 50 for d in each) and whole >= max(each), (mode, each, whole)
-            if mode == "stream":
-                assert abs(sum(each) - whole) < 1e-3 * whole + 1e-4, (each, whole)
-            else:
-                assert sum(each) <= whole * 1.001 + 1e-3, (mode, each, whole)
-            rtc.release_per_call_id_data()
-        with pytest.raises(RtErr):
-            rtc.set_tune("timing", "sometimes")
-    finally:
-        rtc.set_tune("timing", "")
-        for vn in made:
-            rtc.release_var(vn)
-        rtc.release_func("tm_f"); rtc.release_per_call_id_data()

@@ -106,13 +106,13 @@ def test_kernel_and_layout_passes_compile_for_gfx950_without_a_device():
 
 
 def test_sibling_fixtures_agree_with_the_net_graphs():
-    """tests/golden/nets/<net>-conv-bottoms.txt (bench.py --group-siblings): the convolutions that share a bottom blob.  GoogLeNet: exactly the groups ConvPipeFwd
+    """boda_amd/data/nets/<net>-conv-bottoms.txt (bench.py --group-siblings): the convolutions that share a bottom blob.  GoogLeNet: exactly the groups ConvPipeFwd
     finds in the pipe (nine inception modules x {1x1, 3x3-reduce, 5x5-reduce}); ResNet-50: the four stage-start pairs branch1 + branch2a."""
     import os
     from boda_amd.conv_pipe import googlenet_conv
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     def groups(net):
-        nb = [l.split() for l in open(os.path.join(root, "tests", "golden", "nets", f"{net}-conv-bottoms.txt")).read().splitlines() if l.strip()]
+        nb = [l.split() for l in open(os.path.join(root, "boda_amd", "data", "nets", f"{net}-conv-bottoms.txt")).read().splitlines() if l.strip()]
         by = {}
         for n, b in nb:
             by.setdefault(b, []).append(n)

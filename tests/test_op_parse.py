@@ -38,3 +38,10 @@ def test_errors():
         parse_lexp("(a=b")
     assert parse_lexp("(a=(b=c\\,d),e=f)") == [("a", [("b", "c,d")]), ("e", "f")]
     assert Dims.make(K=4, M=8).strides == (8, 1)
+
+
+def test_package_shape_data_is_the_fixture(golden_dir):
+    """boda_amd/data/ops/sgemm-ops-full.txt (what bench.py reads: the product never reads tests/) == the reference-identical fixture."""
+    import os
+    from boda_amd.op import data_path
+    assert open(data_path("ops", "sgemm-ops-full.txt"), "rb").read() == open(os.path.join(golden_dir, "ops", "sgemm-ops-full.txt"), "rb").read()

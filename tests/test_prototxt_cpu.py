@@ -1,7 +1,7 @@
 """prototxt reader + shape inference (boda_amd/prototxt.py) and the GoogLeNet / ResNet-50 conv-op fixtures built with it."""
 import os
 from boda_amd.prototxt import parse, conv_ops
-from boda_amd.op import read_ops
+from boda_amd.op import data_path, read_ops
 
 TXT = """
 name: "tiny"  # comment
@@ -31,8 +31,8 @@ def test_parse_and_shape_inference():
 
 
 def test_net_fixtures_consistent(golden_dir):
-    g = read_ops(os.path.join(golden_dir, "ops", "googlenet_conv-conv-ops-b1.txt"))
-    r = read_ops(os.path.join(golden_dir, "ops", "resnet-50-conv-ops-b1.txt"))
+    g = read_ops(data_path("ops", "googlenet_conv-conv-ops-b1.txt"))
+    r = read_ops(data_path("ops", "resnet-50-conv-ops-b1.txt"))
     assert len(g) == 64 and len(r) == 54
     key = lambda o: tuple(o.conv_geom()[k] for k in ("C", "H", "OC", "KH", "SY", "PY"))
     ref_shapes = {key(o) for o in read_ops(os.path.join(golden_dir, "ops", "conv-ops-1-5-20-nin-alex-gn.txt")) if o.conv_geom()["B"] == 1}
