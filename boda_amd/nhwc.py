@@ -55,10 +55,36 @@ def s2d_geom(g: dict):
     return dict(S=s, PRY=pry, PRX=prx, KH2=kh2, KW2=kw2, C2=g["C"] * s * s, H2=g["OH"] + kh2 - 1, W2=g["OW"] + kw2 - 1)
 
 
-def patch_eligible(g: dict) -> bool:
+PATCH_LDS_LIMIT = 160 * 1024
+_PATCH_TILES = ((128, 128), (64, 256), (64, 128), (128, 64), (32, 128), (128, 256), (256, 128))   # (BI, BJ) of plan_conv_nhwc_patch's candidates
+
+
+def patch_min_lds(KH: int, SY: int, W: int, PX: int, OH: int, OW: int, out_f32: bool) -> int:
+    """Bytes of LDS the input-patch kernel needs at least for this plane: plan_conv_nhwc_patch's own bound (csrc/native_kernels.cc, `lds_cg`: the double-buffered
+    patch of ONE channel group -- the zero-padded input rows a tile's output positions touch, at the kernel's slot pitch -- or the epilogue's transposed tile),
+    minimised over the planner's tiles.  The layout of `filts` is chosen when the op is annotated and binds the kernel at run time, so the annotation must know
+    whether any tile fits before it asks for the F' form."""
+    wp = W + 2 * PX
+    for p2 in range(wp, wp + 16):
+        if (SY * p2 - OW) % 16 == 0:
+            wp = p2; break
+    best = None
+    for bi, bj in _PATCH_TILES:
+        rows_max = (bj - 2) // OW + 2
+        seg_max = min((OH - 1 + rows_max - 1) // OH + 1, rows_max)
+        cs = ((rows_max - seg_max) * SY + seg_max * KH) * wp
+        csp = cs + ((2 - cs % 16) + 16) % 16
+        need = max(2 * 16 * csp, 0 if out_f32 else bj * (bi * 2 + 16))
+        best = need if best is None else min(best, need)
+    return best
+
+
+def patch_eligible(g: dict, out_f32: bool = False) -> bool:
     """Layers that run from an LDS input patch (kernels/conv_nhwc_patch_bf16.hip): more than one tap, stride 1 in x, windows that overlap or abut in y, an output
-    map (not the whole-input kernels of fully-connected layers, which stay implicit GEMMs with K slices)."""
-    return g["KH"] * g["KW"] >= 2 and g["SX"] == 1 and g["KH"] >= g["SY"] and g["OH"] * g["OW"] > 1
+    map (not the whole-input kernels of fully-connected layers, which stay implicit GEMMs with K slices) -- and a plane narrow enough for the patch of one channel
+    group to fit the LDS (5x5 on ~500 columns, 3x3 on ~850 do not: those stay on the implicit GEMM, which has no such bound)."""
+    return (g["KH"] * g["KW"] >= 2 and g["SX"] == 1 and g["KH"] >= g["SY"] and g["OH"] * g["OW"] > 1 and
+            patch_min_lds(g["KH"], g["SY"], g["W"], g["PX"], g["OH"], g["OW"], out_f32) <= PATCH_LDS_LIMIT)
 
 
 def patch_filts_dims(f: Dims) -> Dims:
@@ -79,9 +105,11 @@ def annotate(a: Op, out_tn: str = "bfloat16", allow_s2d: bool = True, allow_patc
     if sd is None:
         a.nda_vals["in"] = Nda(dims=nhwc_dims(i), tn="bfloat16")
         # the filters' layout selects the kernel: F' for the input-patch kernel (3x3 / 5x5 ... stride-1-in-x layers), out_chan:y:x:in_chan for the implicit GEMM
-        a.nda_vals["filts"] = Nda(dims=patch_filts_dims(f) if (allow_patch and patch_eligible(g)) else ohwi_dims(f), tn="bfloat16")
+        a.nda_vals["filts"] = Nda(dims=patch_filts_dims(f) if (allow_patch and patch_eligible(g, out_tn == "float")) else ohwi_dims(f), tn="bfloat16")
     else:
         c2p = pad8(sd["C2"])
+        # (a plane too wide for the LDS patch keeps the space-to-depth form but runs it on the implicit GEMM)
+        allow_patch = allow_patch and patch_min_lds(sd["KH2"], 1, sd["W2"], 0, g["OH"], g["OW"], out_tn == "float") <= PATCH_LDS_LIMIT
         a.nda_vals["in"] = Nda(dims=Dims(("img", "y", "x", "chan"), (g["B"], sd["H2"], sd["W2"], c2p), "bfloat16"), tn="bfloat16")
         # (the space-to-depth form is a stride-1 KH2 x KW2 convolution: the input-patch kernel's case)
         a.nda_vals["filts"] = Nda(dims=Dims(("in_grp", "y", "x", "out_chan", "in_chan8"), (c2p // 8, sd["KH2"], sd["KW2"], g["OC"], 8), "bfloat16") if allow_patch else

@@ -76,7 +76,8 @@ EDGE = [  # B, C, H, W, OC, KH, KW, S, P : 1x1 (stride 1 / 2, padded), 3x3, 5x5 
     (4, 20, 8, 8, 100, 3, 3, 1, 1), (2, 3, 40, 40, 16, 7, 7, 2, 3), (3, 4, 33, 31, 20, 5, 5, 1, 2), (2, 3, 64, 64, 24, 11, 11, 4, 5),
     (4, 96, 27, 27, 256, 5, 5, 1, 2), (3, 256, 13, 13, 384, 3, 3, 1, 1), (8, 256, 6, 6, 512, 6, 6, 1, 0), (3, 528, 14, 14, 160, 1, 1, 1, 0),
     (2, 112, 14, 14, 224, 3, 3, 1, 1), (2, 24, 28, 28, 64, 5, 5, 1, 2), (2, 832, 7, 7, 1000, 1, 1, 1, 0),
-    (9, 96, 6, 3, 208, 7, 7, 1, 2), (3, 64, 1, 40, 64, 3, 3, 1, 1), (16, 32, 2, 2, 48, 3, 3, 1, 1)]   # maps one or two positions wide / high (a fuzz find: the patch of a 4 x 1 map needs one workgroup per CU)
+    (9, 96, 6, 3, 208, 7, 7, 1, 2), (3, 64, 1, 40, 64, 3, 3, 1, 1), (16, 32, 2, 2, 48, 3, 3, 1, 1),   # maps one or two positions wide / high (a fuzz find: the patch of a 4 x 1 map needs one workgroup per CU)
+    (1, 8, 6, 520, 16, 5, 5, 1, 2), (1, 3, 16, 2100, 16, 7, 7, 2, 3)]   # planes too wide for the LDS patch of even one channel group: annotated for the implicit GEMM (plain and space-to-depth)
 
 
 @pytest.mark.parametrize("shape", EDGE, ids=lambda s: "x".join(str(v) for v in s))
@@ -84,7 +85,9 @@ def test_nhwc_conv_float_out_vs_oracle(be, shape):
     op = _conv_op(*shape)
     outs, prc = _run(be, op, OpTune(**NHWC_F32))
     from boda_amd import nhwc
-    g = op.conv_geom(); patch = nhwc.patch_eligible(g) or nhwc.s2d_geom(g) is not None   # more than one tap, stride 1 in x (also: the stride-1 space-to-depth form of a conv1-type layer): the LDS input-patch kernel
+    g = op.conv_geom(); patch = nhwc.patch_eligible(g, True) or nhwc.s2d_geom(g) is not None   # more than one tap, stride 1 in x (also: the stride-1 space-to-depth form of a conv1-type layer): the LDS input-patch kernel
+    if shape[3] >= 500:
+        assert not nhwc.patch_eligible(g, True); patch = False                                    # (too wide for the patch: see nhwc.patch_min_lds)
     assert prc.launch["kernel"] == ("bodahip_conv_nhwc_patch_bf16" if patch else "bodahip_conv_nhwc_bf16"), prc.launch
     _check_f32(op, outs, prc)
     if patch:                                          # ... and the implicit-GEMM kernel on the same layer (op_tune hip_patch=0)

@@ -124,3 +124,34 @@ def test_sibling_fixtures_agree_with_the_net_graphs():
     assert len(gg) == 9 and all(len(g) == 3 for g in gg)
     nb, gr = groups("resnet-50")
     assert len(nb) == 54 and gr == sorted((f"res{s}a_branch1", f"res{s}a_branch2a") for s in (2, 3, 4, 5))
+
+
+def test_wide_planes_are_annotated_for_the_kernel_that_can_run_them():
+    """The layout of `filts` binds the kernel, so the annotation asks for the input-patch form only where plan_conv_nhwc_patch finds a tile whose patch fits
+    the 160 KB of LDS (nhwc.patch_min_lds mirrors its bound); wider planes -- and space-to-depth layers on such planes -- stay on the implicit GEMM.  Every
+    annotated op of the sweep must be plannable, and the Python bound must flip exactly where the planner's does."""
+    flips = 0
+    for (kh, pad) in ((3, 1), (5, 2), (2, 0), (7, 3)):
+        last = None
+        for w in list(range(13, 1200, 37)) + [224, 227, 500, 512, 850, 1024]:
+            for out in ("", "f32"):
+                op = _conv_op(1, 16, 8 + kh, w, 32, kh, kh, 1, pad)
+                a = add_codegen_annotations(op, OpTune(hip_dtype="bf16", hip_layout="nhwc", hip_out=out))
+                patch = a.get_dims("filts").has("in_grp")
+                plan = rtc.explain_plan(a)                                     # raises UnsupErr if annotation and planner disagree
+                assert plan.startswith("bodahip_conv_nhwc_patch_bf16 " if patch else "bodahip_conv_nhwc_bf16 "), (kh, w, plan[:60])
+                # the bound is tight: forcing the patch form where the annotation declined it is refused by the planner
+                if not patch:
+                    forced = add_codegen_annotations(op, OpTune(hip_dtype="bf16", hip_layout="nhwc", hip_out=out))
+                    from boda_amd.op import Nda
+                    forced.nda_vals["filts"] = Nda(dims=nhwc.patch_filts_dims(op.get_dims("filts")), tn="bfloat16")
+                    with pytest.raises(UnsupErr, match="no tile fits the LDS"):
+                        rtc.explain_plan(forced)
+                if out == "":
+                    flips += int(last is not None and last != patch and w > 224); last = patch if w not in (224, 227, 500, 512, 850, 1024) else last
+    assert flips >= 2                                                          # the sweep crosses the bound (5x5 near 500 columns, 7x7 earlier)
+    # space-to-depth on a plane too wide for its patch: same form of `in`, implicit-GEMM filters
+    wide = add_codegen_annotations(_conv_op(1, 3, 64, 4100, 32, 7, 7, 2, 3), OpTune(hip_dtype="bf16", hip_layout="nhwc"))
+    assert wide.has("nhwc_s2d") and not wide.get_dims("filts").has("in_grp") and rtc.explain_plan(wide).startswith("bodahip_conv_nhwc_bf16 ")
+    narrow = add_codegen_annotations(_conv_op(1, 3, 64, 224, 32, 7, 7, 2, 3), OpTune(hip_dtype="bf16", hip_layout="nhwc"))
+    assert narrow.get_dims("filts").has("in_grp") and rtc.explain_plan(narrow).startswith("bodahip_conv_nhwc_patch_bf16 ")
