@@ -119,6 +119,22 @@ class ConvPipe:
         return self.ops[-1].top
 
 
+def sibling_runs(ops: List[PipeOp], members: List[PipeOp], fused=frozenset()) -> List[List[PipeOp]]:
+    """Convolutions that read the same node with the same geometry (`members`, definition order) split into runs that may be emitted as ONE call at
+    the run's first member: a later member joins only if no op between the two rewrites the shared bottom -- an in-place op on it that was not fused
+    into its producer (X -> convA; in-place ReLU on X; X -> convB: convB must read the rectified data), or a second writer of the node."""
+    pos = {o.tag: i for i, o in enumerate(ops)}
+    def writes(o: PipeOp, node: str) -> bool:
+        return o.tag not in fused and ((o.in_place and o.type != "Dropout" and node in (o.bots or (o.bot,))) or o.top == node)
+    runs: List[List[PipeOp]] = []
+    for o in members:
+        if runs and not any(writes(q, o.bot) for q in ops[pos[runs[-1][0].tag] + 1:pos[o.tag]]):
+            runs[-1].append(o)
+        else:
+            runs.append([o])
+    return runs
+
+
 def _conv(p, tag, bot, oc, k, s=1, pad=0):
     p.add(PipeOp(tag, "Convolution", bot, tag, out_chans=oc, kern_sz=(k, k), stride=(s, s), in_pad=(pad, pad)))
     p.add(PipeOp("relu_" + tag, "ReLU", tag, tag))
@@ -445,13 +461,14 @@ class ConvPipeFwd:
             for o in cp.ops:
                 if o.type == "Convolution" and not annos[o.tag].has("nhwc_s2d") and not annos[o.tag].get_dims("filts").has("in_grp"):
                     by_key.setdefault((o.bot, tuple(o.kern_sz), tuple(o.stride), tuple(o.in_pad), has_relu[o.tag]), []).append(o)
-            for members in by_key.values():
-                for k in range(0, len(members), 4):
-                    grp = members[k:k + 4]
-                    if len(grp) >= 2:
-                        for o in grp:
-                            group_of[o.tag] = grp
-                        self.groups.append(tuple(o.tag for o in grp))
+            for members0 in by_key.values():
+                for members in sibling_runs(cp.ops, members0, fused):
+                    for k in range(0, len(members), 4):
+                        grp = members[k:k + 4]
+                        if len(grp) >= 2:
+                            for o in grp:
+                                group_of[o.tag] = grp
+                            self.groups.append(tuple(o.tag for o in grp))
         grp_done = set()
         def vd(node: str) -> Dims:   # dims a node's var is created with
             if not self.nhwc:

@@ -843,6 +843,15 @@ static bool winograd_applies(conv_geom_t const &g, string const &algo) {
   if (!(g.KH == 3 && g.KW == 3 && g.SY == 1 && g.SX == 1)) return false;
   return algo == "winograd_all" || (algo == "winograd" && g.C >= 96 && g.OC >= 64);
 }
+// images per chunk of the three-kernel Winograd pipeline (see conv_winograd)
+static long wino_chunk_imgs(conv_geom_t const &g) {
+  int const tpi = ((g.OH + 1) / 2) * ((g.OW + 1) / 2);
+  size_t const per_img = (size_t)16 * (g.C + g.OC) * tpi * 4;
+  size_t chunk_mb = 1024; if (char const *e = getenv("BODAHIP_WINO_CHUNK_MB")) chunk_mb = (size_t)std::max(1, atoi(e));
+  long Bc = std::max<long>(1, std::min<long>(g.B, (long)((chunk_mb << 20) / per_img)));
+  if (Bc >= 4) Bc &= ~3l;
+  return Bc;
+}
 void native_kernels_t::conv_winograd(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, int out_ctot, int out_coff) {
   if (!impl->wino_mod) {
     if (host->nh_capturing()) rt_err("graph capture: Winograd transform kernels are not compiled yet -- run the call list once before capturing it");
@@ -888,10 +897,7 @@ void native_kernels_t::conv_winograd(float const *filts, float const *biases, fl
   // one big batched sgemm (AlexNet conv4 B=256: 713 / 715 vs 674 us) -- the shorter sgemms cost more than the HBM round trip saves;
   // (b) a three-stream pipeline over chunks (input transform k+1 | sgemm k | output transform k-1, event-linked) is slower still
   // (2 / 4 / 8 chunks: 722 / 741 / 808 us): each cross-stream event wait costs more than the ~40 us of transform it would hide.
-  size_t const per_img = (size_t)16 * (g.C + g.OC) * tpi * 4;
-  size_t chunk_mb = 1024; if (char const *e = getenv("BODAHIP_WINO_CHUNK_MB")) chunk_mb = (size_t)std::max(1, atoi(e));
-  long Bc = std::max<long>(1, std::min<long>(g.B, (long)((chunk_mb << 20) / per_img)));
-  if (Bc >= 4) Bc &= ~3l;
+  long const Bc = wino_chunk_imgs(g);
   long const Tc_max = Bc * tpi;
   if ((uint64_t)g.C * Tc_max * 4 >= 0x7ffffff0ull || (uint64_t)g.OC * Tc_max * 4 >= 0x7ffffff0ull) unsup_err("hip_conv (winograd): transformed planes of 2 GiB or more");
   size_t const nU = (size_t)16 * g.C * g.OC, nV = (size_t)16 * g.C * Tc_max, nM = (size_t)16 * g.OC * Tc_max;
@@ -1160,7 +1166,19 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
     else if (bf16 && tile.empty() && s2d_geom(g, g2, pry, prx) && plan_patch_bf16(g2, num_cus, p)) { // conv1-type layers: space-to-depth front end (see conv())
       s2d = "s2d(" + std::to_string(g2.C) + "x" + std::to_string(g2.H) + "x" + std::to_string(g2.W) + ",k" + std::to_string(g2.KH) + "x" + std::to_string(g2.KW) + ")+";
       if (!arch.empty()) { plan_t sp; sp.patch16 = true; sp.bf16 = true; sp.kname = "bodahip_s2d"; sp.defs = {"-DS2D_ONLY=1"}; compile_plan(sp, arch, &log); }
-    } else { auto xe = op.str_vals.find("hip_exact"); p = plan_conv(g, num_cus, tile, bf16, string(), true, !(xe != op.str_vals.end() && xe->second == "0")); }
+    } else {
+      auto xe = op.str_vals.find("hip_exact"); bool const exact = !(xe != op.str_vals.end() && xe->second == "0");
+      // the same resolution as conv(): in tolerance mode (and with no conv_algo / tile given) the 3x3 / stride-1 layers take the F(2x2,3x3) pipeline -- what is
+      // compiled ahead of time and reported is then ITS kernels (the transforms' module and the batched transform-domain sgemm of every chunk size)
+      if (!bf16 && !exact && tile.empty() && winograd_applies(g, "winograd")) {
+        int const tpi = ((g.OH + 1) / 2) * ((g.OW + 1) / 2); long const Bc = wino_chunk_imgs(g);
+        s2d = "winograd(F2x2,3x3)+";
+        if (!arch.empty()) hiprtc_compile(k_src_winograd_f32, "bodahip_winograd", arch, vect_string(), &log, true);
+        long const rem = g.B % Bc;
+        if (rem) { plan_t const rp = plan_sgemm((uint32_t)g.OC, (uint32_t)(rem * tpi), (uint32_t)g.C, num_cus, string(), false, 16); if (!arch.empty()) compile_plan(rp, arch, &log); }
+        p = plan_sgemm((uint32_t)g.OC, (uint32_t)(std::min<long>(Bc, g.B) * tpi), (uint32_t)g.C, num_cus, string(), false, 16);
+      } else p = plan_conv(g, num_cus, tile, bf16, string(), true, exact);
+    }
   } else rt_err("prebuild: op type '" + t + "' has no native kernel");
   if (plan_out) { *plan_out = s2d + p.kname + " " + p.cfg.str(); for (auto const &d : p.defs) *plan_out += " " + d; }
   if (arch.empty()) return 0;

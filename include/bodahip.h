@@ -125,7 +125,11 @@ int bodahip_get_device_info(bodahip_ctx *ctx, char *arch_buf, size_t arch_buf_sz
 /* tile override for the native kernels (the op_tune_t MNt/MNb/Kb analogue): key "sgemm_tile"|"conv_tile",
  * value "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF]]]]" (workgroup tile, K step, waves, min waves per SIMD, K slices, MFMA tile 32|16,
  * K-tiles prefetched 1|2) or "" to restore the heuristic; key "k1_stream" (the streaming kernel for short-K 1x1 / stride-1 convs,
- * kernels/k1_stream_f32.hip): "" automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row / 32-pel blocks per wave) */
+ * kernels/k1_stream_f32.hip): "" automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row / 32-pel blocks per wave);
+ * key "timing": how get_dur attributes stream time to calls -- "" | "call" (markers around every call: the reference's semantics,
+ * src/nvrtc_util.cc:355-385) | "kernel" (events bound to the call's own dispatches) | "stream" (end markers only: per-call durations add up to
+ * the stream time, and a host stall between two launches is billed to the later call).  Switching the mode while call ids are outstanding is
+ * an error (fatal, 2): call bodahip_release_per_call_id_data first; setting the mode already in force is a no-op. */
 int bodahip_set_tune(bodahip_ctx *ctx, const char *key, const char *value);
 int bodahip_last_launch(bodahip_ctx *ctx, char *kernel_buf, size_t kernel_buf_sz, char *cfg_buf, size_t cfg_buf_sz, uint32_t *grid, uint32_t *block,
                         double *flops, double *algo_bytes);

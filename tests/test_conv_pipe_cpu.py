@@ -34,3 +34,24 @@ def test_googlenet_from_spec_fixture():
     assert cp.nodes["pool1"].sizes == (1, 64, 56, 56) and cp.nodes["icp2_out"].sizes == (1, 480, 28, 28) and cp.nodes["icp9_out"].sizes == (1, 1024, 7, 7)
     assert cp.nodes[cp.out_node()].sizes == (1, 1000, 1, 1)
     assert abs(cp.conv_flops() / 1e9 - 3.182) < 1e-3
+
+
+def test_sibling_runs_split_where_the_shared_bottom_is_rewritten():
+    """Sibling fusion emits a group at its first member's place; a member behind an in-place op on the shared bottom must not be hoisted above it."""
+    from boda_amd.conv_pipe import ConvPipe, PipeOp, sibling_runs
+    from boda_amd.op import Dims
+    p = ConvPipe("t", "data", Dims.make("float", img=2, chan=16, y=8, x=8))
+    p.add(PipeOp("x", "Convolution", "data", "x", out_chans=16, kern_sz=(1, 1)))
+    p.add(PipeOp("a", "Convolution", "x", "a", out_chans=8, kern_sz=(1, 1)))
+    p.add(PipeOp("b", "Convolution", "x", "b", out_chans=8, kern_sz=(1, 1)))
+    p.add(PipeOp("relu_x", "ReLU", "x", "x"))                       # in place on the shared bottom, AFTER a and b have read it
+    p.add(PipeOp("c", "Convolution", "x", "c", out_chans=8, kern_sz=(1, 1)))
+    p.add(PipeOp("d", "Convolution", "x", "d", out_chans=8, kern_sz=(1, 1)))
+    m = [o for o in p.ops if o.tag in "abcd"]
+    assert [[o.tag for o in r] for r in sibling_runs(p.ops, m)] == [["a", "b"], ["c", "d"]]
+    assert [[o.tag for o in r] for r in sibling_runs(p.ops, m, fused={"relu_x"})] == [["a", "b", "c", "d"]]   # (a ReLU fused into its producer is not a separate writer)
+    # an in-place op on ANOTHER node between the members changes nothing
+    q = ConvPipe("t2", "data", Dims.make("float", img=2, chan=16, y=8, x=8))
+    q.add(PipeOp("a", "Convolution", "data", "a", out_chans=8, kern_sz=(1, 1))); q.add(PipeOp("relu_a", "ReLU", "a", "a"))
+    q.add(PipeOp("b", "Convolution", "data", "b", out_chans=8, kern_sz=(1, 1)))
+    assert [[o.tag for o in r] for r in sibling_runs(q.ops, [q.ops[0], q.ops[2]])] == [["a", "b"]]

@@ -43,6 +43,7 @@ def test_timing_modes(be):
             am[an] = RtcArg.ref(anno.get_dims(an)); continue
         rtc.create_var_with_dims("tm_" + an, anno.get_dims(an)); made.append("tm_" + an); am[an] = RtcArg.var("tm_" + an)
     try:
+        rtc.finish_and_sync(); rtc.release_per_call_id_data()
         for mode in ("stream", "kernel", "call", ""):
             rtc.set_tune("timing", mode)
             call = RtcFuncCall("tm_f", am)
@@ -65,7 +66,15 @@ def test_timing_modes(be):
             assert err is None, err
         with pytest.raises(RtErr):
             rtc.set_tune("timing", "sometimes")
+        # switching the attribution while call ids are outstanding is an error (the caller still holds them), not a silent release
+        rtc.set_tune("timing", "call"); cid = rtc.run(RtcFuncCall("tm_f", am)); rtc.finish_and_sync()
+        rtc.set_tune("timing", "call")                         # (the mode it already has: nothing happens, the id stays valid)
+        assert rtc.get_dur(cid, cid) > 0
+        with pytest.raises(RtErr, match="outstanding"):
+            rtc.set_tune("timing", "stream")
+        assert rtc.get_dur(cid, cid) > 0
     finally:
+        rtc.finish_and_sync(); rtc.release_per_call_id_data()
         rtc.set_tune("timing", "")
         for vn in made:
             rtc.release_var(vn)
