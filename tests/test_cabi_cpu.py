@@ -144,10 +144,10 @@ def test_prebuild_resolves_the_algorithm_like_conv_does_in_tolerance_mode():
     """op_tune hip_exact=0: conv() sends 3x3 / stride-1 layers with >= 96 input channels to the F(2x2,3x3) pipeline, so what prebuild compiles ahead of
     time and reports must be that pipeline's kernels -- not a direct kernel that never runs (a plan compiled at first use cannot be captured into a graph)."""
     from boda_amd.cnn_op import OpTune, add_codegen_annotations
-    conv3 = _conv(256, 256, 13, 384, 3, 1, 1); conv3.str_vals.pop("func_name")
+    conv3 = _conv(256, 256, 13, 384, 3, 1, 1); conv3.str_vals.pop("func_name"); conv3.nda_vals.pop("conv_has_relu")
     tol = R.explain_plan(add_codegen_annotations(conv3, OpTune(hip_exact=0)))
     assert tol.startswith("winograd(F2x2,3x3)+bodahip_sgemm_f32 ") and "-DEPI=0" in tol
     assert R.explain_plan(add_codegen_annotations(conv3, OpTune())).startswith("bodahip_conv_f32 ")                       # bit-exact default: the direct kernel
-    res2 = _conv(64, 64, 56, 64, 3, 1, 1); res2.str_vals.pop("func_name")
+    res2 = _conv(64, 64, 56, 64, 3, 1, 1); res2.str_vals.pop("func_name"); res2.nda_vals.pop("conv_has_relu")
     assert R.explain_plan(add_codegen_annotations(res2, OpTune(hip_exact=0))).startswith("bodahip_conv_f32 ")            # too few channels for Winograd to pay
     assert R.prebuild(add_codegen_annotations(conv3, OpTune(hip_exact=0))) > 4000                                          # and it cross-compiles
