@@ -99,9 +99,30 @@ def ref_conv_variant(op: Op, tune: OpTune) -> str:
     return "conv_simd" if tune.use_local_mem == 2 else "conv"
 
 
-def add_codegen_annotations(op: Op, tune: OpTune) -> Op:
+_TILE_WISDOM = None   # process-wide per-op best-tile table (boda_amd.wis_ana.TileWisdom), see set_tile_wisdom
+
+
+def set_tile_wisdom(tw) -> None:
+    """Install (or, with None, remove) the per-op best-tile table every later add_codegen_annotations consults: a TileWisdom, or the path of its text
+    form (what `python -m boda_amd.wis_ana --tile-wisdom-out-fn` writes from the wisdom files ops-prof records).  The environment variable
+    BODAHIP_TILE_WISDOM=<path> installs one at import."""
+    global _TILE_WISDOM
+    if isinstance(tw, str):
+        from .wis_ana import TileWisdom
+        tw = TileWisdom.load(tw)
+    _TILE_WISDOM = tw
+
+
+def add_codegen_annotations(op: Op, tune: OpTune, tile_wisdom=None) -> Op:
     """-> annotated copy of `op` with func_name (and conv_has_relu for convs) set.  Raises UnsupErr for variants
-    this backend does not provide."""
+    this backend does not provide.  A tile recorded for this op in `tile_wisdom` (or the table installed with set_tile_wisdom) is given to
+    the function when the tune names none: it then overrides the native planner's cost model for this function's calls only."""
+    tw = tile_wisdom if tile_wisdom is not None else _TILE_WISDOM
+    if tw is not None and not tune.hip_tile and not tune.hip_dtype and not tune.hip_layout and tune.hip_exact:   # (the table is recorded for the bit-exact fp32 functions)
+        t = tw.tile_for(op)
+        if t:
+            import dataclasses
+            tune = dataclasses.replace(tune, hip_tile=t)
     a = op.copy()
     t = a.get_type()
     native = (tune.use_be in ("", "hip"))
@@ -146,3 +167,8 @@ NATIVE_ARGS: Dict[str, tuple] = {
     "hip_conv_winograd": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
     "hip_conv_nhwc": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
 }
+
+
+import os as _os
+if _os.environ.get("BODAHIP_TILE_WISDOM"):
+    set_tile_wisdom(_os.environ["BODAHIP_TILE_WISDOM"])

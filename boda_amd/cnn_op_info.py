@@ -107,6 +107,8 @@ class OpInfoToLatex:
     def ai_mkn(self) -> str:
         if self.show:
             return " %s & %s & %s & %s " % (_mkn(self.M, self.K, self.N), self._pp(pp_bytes, self.bytes), self._pp(pp_flops, self.flops), self._pp(pp_val, self.flops / self.bytes))
+        if self.print_format == 2:
+            return "%.3g" % float(self.flops)           # (wis-ana's ops table: the one place the reference checks print_format == 2, src/latex-util.H:52-53)
         return " %s " % self._pp(pp_flops, self.flops)
 
     def info_row(self, brief: bool = False) -> str:

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <dlfcn.h>
+#include <chrono>
 #include <fstream>
 #include <sstream>
 #include <sys/stat.h>
@@ -88,6 +89,11 @@ std::vector<char> hiprtc_compile(string const &src, string const &name, string c
     std::ifstream f(cfn, std::ios::binary);
     if (f) { std::vector<char> code((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>()); if (!code.empty()) return code; }
   }
+  // BODAHIP_CACHE_LOG=<file>: one line per code object that had to be compiled (what __graft_entry__.build() did not pre-specialise)
+  struct miss_log_t { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); string what;
+    ~miss_log_t() { if (char const *fn = getenv("BODAHIP_CACHE_LOG")) { if (FILE *lf = fopen(fn, "a")) {
+      fprintf(lf, "compiled %.0f ms: %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what.c_str()); fclose(lf); } } } } miss_log;
+  miss_log.what = name + " [" + arch + "]"; for (auto const &o : opts) miss_log.what += " " + o;
   hiprtcProgram prog;
   hiprtc_err_chk(hiprtcCreateProgram(&prog, src.c_str(), (name + ".hip").c_str(), 0, nullptr, nullptr), "hiprtcCreateProgram");
   vect_string all = {"--offload-arch=" + arch, "-O3", "-std=c++17"};

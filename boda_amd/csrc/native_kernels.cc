@@ -1140,8 +1140,11 @@ static conv_geom_t geom_from_dims(dims_t const &f, dims_t const &in, dims_t cons
 
 // AOT: compile (into the on-disk code-object cache) the specialisation that run() would pick for `op`.  No device needed.
 // With arch == "" nothing is compiled and *plan_out receives "<kernel> <tile> <-D options>": the planner's decision (host-logic tests).
-size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile, string *plan_out) {
+size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile_arg, string *plan_out) {
   string const &t = op.get_type();
+  // a tile that travels with the function (str_val hip_tile: per-op tuned tiles, see tile_override_t) is what run() would use
+  auto const ht = op.str_vals.find("hip_tile");
+  string const tile = (tile_arg.empty() && ht != op.str_vals.end()) ? ht->second : tile_arg;
   plan_t p; string log, s2d;
   bool const bf16 = op.has_func_name() && (op.get_func_name() == "hip_sgemm_bf16" || op.get_func_name() == "hip_conv_bf16");
   if (t == "sgemm") {
