@@ -51,6 +51,9 @@
 #include <hip/hip_runtime.h> // offline (hipcc) builds only; hiprtc provides the device runtime implicitly
 #endif
 
+#ifndef ST_AUX
+#define ST_AUX 0   // cache policy of the paired output stores (experiments: bit 0 sc0, bit 1 nt, bit 4 sc1)
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -724,9 +727,9 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
             auto const sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, va), __builtin_bit_cast(unsigned, vb), false, false);
             int const rc = rowc(ta, r);
             if (!(edge && (ibl + rc >= p.Mi)))
-              __builtin_amdgcn_raw_buffer_store_b32((int)sw[0], rD, (int)jpart, (int)((unsigned)rc * S4), 0);
+              __builtin_amdgcn_raw_buffer_store_b32((int)sw[0], rD, (int)jpart, (int)((unsigned)rc * S4), ST_AUX);
             if (!(edge && (ibl + rc + 4 >= p.Mi)))
-              __builtin_amdgcn_raw_buffer_store_b32((int)sw[1], rD, (int)jpart, (int)((unsigned)(rc + 4) * S4), 0);
+              __builtin_amdgcn_raw_buffer_store_b32((int)sw[1], rD, (int)jpart, (int)((unsigned)(rc + 4) * S4), ST_AUX);
           }
       }
     };

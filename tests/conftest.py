@@ -2,6 +2,12 @@ import os
 import sys
 import pytest
 
+# The CPU oracle (and be=cpu) are OpenMP code checking SMALL cases: on the GPU box's 128+ hardware threads every parallel region of a batch-2 layer costs
+# ~100 ms of fork / join across the whole machine (measured: oracle conv_fwd 183 ms per call there against 20 ms on 8 cores -- 250 s of a 670 s suite).
+# A bounded team is faster for everything the tests run; set before any OpenMP runtime loads.  (bench.py subprocesses drop these again: tests/test_gpu_zz_bench.py.)
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -14,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(args, env_extra=None, timeout=600):
-    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "OMP_NUM_THREADS", "OMP_WAIT_POLICY"):   # (the OMP bounds are the test session's, tests/conftest.py: the driver runs bench.py without them)
+        env.pop(k, None)
     env.update(env_extra or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -32,6 +34,23 @@ def test_bench_launches_itself_for_two_ranks(workload):
     assert "broadcast once" in out["config"]["weights"] and "failed" not in out["config"]["weights"]
     assert out["config"]["rccl_ranks"] == 2
     assert "cpu_baseline" not in out                                        # rank 0 at N=1 only
+
+
+@pytest.mark.parametrize("args", [["--workload", "nin-net", "--batch", "128"],                                           # BASELINE configs[3] per GPU: 1024 images over 8
+                                  ["--workload", "googlenet", "--dtype", "bf16", "--layout", "nhwc", "--graph", "--batch", "64"]],   # configs[4] per GPU: 512 over 8
+                         ids=["config4_nin-net_b128", "config5_googlenet_b64_bf16"])
+def test_eight_ranks_at_the_per_gpu_shapes_of_configs_4_and_5(args):
+    """The command the driver runs on an 8-GPU node (`bench.py --gpus 8 ...`), end to end once: eight ranks, each at the per-GPU shape of the BASELINE config, here
+    all on GPU 0 over gloo.  Whole-job value = 8 x the per-rank units over the slowest rank's time; weights broadcast once from rank 0."""
+    r, lines = _bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--settle-ms", "0"] + args, {"BENCH_SAME_GPU": "1"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["rccl_ranks"] == 8
+    assert "broadcast once" in out["config"]["weights"] and "failed" not in out["config"]["weights"]
+    assert "parallelism" in out["config"] and "x8" in out["config"]["parallelism"]
+    if "nin-net" in args:
+        assert "batch 128/GPU" in out["config"]["workload"] and out["images_per_s"] > 0
 
 
 def test_world_size_mismatch_is_an_error():
