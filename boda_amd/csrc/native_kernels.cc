@@ -60,7 +60,7 @@ bool native_kernels_t::is_native_func_name(string const &fn) {
 void native_kernels_t::check_compile_time(rtc_func_info_t const &fi) {
   string const &fn = fi.op.get_func_name();
   if (fn == "hip_sgemm" || fn == "cublas_sgemm" || fn == "hip_sgemm_bf16") return;
-  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd" || fn == "hip_conv_nhwc" || fn == "hip_conv_nhwc_grp") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
+  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd" || fn == "hip_conv_nhwc" || fn == "hip_conv_nhwc_grp" || fn == "hip_conv_nhwc_multi") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
   rt_err("unknown/unhandled native hip function: " + fn);
 }
 void native_kernels_t::set_tune(string const &key, string const &val) {
@@ -160,7 +160,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(host->nh_launch(k.func, grid, 1, (uint32_t)c.threads(), params), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, patch16 = false, nhwc = false, nhwc_patch = false; int rows = 0, cg = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false; int rows = 0, cg = 0; };
 
 // Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
 //   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
@@ -612,7 +612,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
 }
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
-  return hiprtc_compile(p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.stream ? k_src_k1_stream_f32 : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
+  return hiprtc_compile(p.nhwc_multi ? k_src_conv_nhwc_multi_bf16 : p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.stream ? k_src_k1_stream_f32 : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
 }
 
 // grow-only scratch shared by the split-K slabs and the Winograd-domain tensors (like the reference's cudnn scratch var)
@@ -1056,6 +1056,115 @@ struct grp_args_t { // must match kernels/conv_nhwc_bf16.hip
   int n; int oc0[4]; int noc[4];
   void *D[4]; unsigned D_bytes[4]; int ctot[4]; int coff[4];
 };
+// ---- hip_conv_nhwc_multi: several INDEPENDENT channels-last convolutions as one launch (kernels/conv_nhwc_multi_bf16.hip) ------------------------------------
+struct multi_prob_t { // must match prob_t of kernels/conv_nhwc_multi_bf16.hip (128 bytes)
+  void const *I; void const *J; void *D; float const *bias;
+  unsigned I_bytes, J_bytes, D_bytes; int Mi;
+  int Nj, CIN, KH, KW;
+  int SY, SX, PY, PX;
+  int CH, CW, COH, COW;
+  int kCG, kKC, nK, relu;
+  int out_ctot, out_coff, tiles_i, tiles_j;
+};
+static_assert(sizeof(multi_prob_t) == 128, "multi_prob_t must stay 128 bytes (kernel-side prob_t)");
+struct multi_tile_t { int prob, tile_i, tile_j, pad; };
+struct multi_args_t { multi_prob_t const *probs; multi_tile_t const *tiles; int n_tiles; int n_probs; };
+
+// One tile shape for the whole launch (the kernel is specialised on it, not on any member's geometry).  tile: "BIxBJxBKxWIxWJ[xMINW[x1[x32[xNBUF]]]]" or "".
+// Default 64 x 128 x 64, 2 x 2 waves, a ring of three: 72 KB of LDS, two workgroups per CU -- the members are small (that is why they are here) and mostly narrow in
+// out_chan (16-256), so a taller tile would mostly multiply zeros; candidates are priced by the operand bytes the launch streams through the LDS, padding included.
+static plan_t plan_conv_nhwc_multi(std::vector<conv_geom_t> const &gs, string const &tile, bool out_f32) {
+  plan_t p; p.nhwc = true; p.nhwc_multi = true; p.bf16 = true; p.kname = "bodahip_conv_nhwc_multi_bf16";
+  tile_cfg_t c; c.MT = 32; c.SPLITK = 1; c.PF = 3; c.BI = 64; c.BJ = 128; c.BK = 64; c.WI = 2; c.WJ = 2; c.MINW = 2;
+  if (!tile.empty()) {
+    int nbuf = 3;
+    if (!parse_tile(tile, c)) rt_err("bad conv_tile '" + tile + "'");
+    { int nf = 1; for (char ch : tile) if (ch == 'x' || ch == ':') ++nf; if (nf >= 9) nbuf = c.PF; }
+    c.MT = 32; c.SPLITK = 1; c.PF = nbuf;
+  } else {
+    struct cand_t { int bi, bj, wi, wj; };
+    static cand_t const cands[] = {{64, 128, 2, 2}, {128, 128, 2, 2}, {32, 128, 1, 4}};
+    double best = 1e300;
+    for (cand_t const &cd : cands) {
+      double cost = 0;
+      for (conv_geom_t const &g : gs) {
+        long const Nj = (long)g.B * g.OH * g.OW, kc = (long)(g.C / 8) * g.KH * g.KW, nk = (kc + 7) / 8;
+        long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj;
+        cost += (double)(ti * tj) * ((double)nk * (cd.bi + cd.bj) + 0.5 * cd.bi);   // K steps x rows streamed, + the epilogue's share
+      }
+      if (cost < best * 0.97) { best = cost; c.BI = cd.bi; c.BJ = cd.bj; c.WI = cd.wi; c.WJ = cd.wj; }
+    }
+  }
+  int const cpr = c.BK / 8, nw = c.WI * c.WJ;
+  bool ok = (c.BK == 32 || c.BK == 64) && c.BI > 0 && c.BJ > 0 && c.WI > 0 && c.WJ > 0 && c.threads() <= 1024 && (c.BI % (c.WI * 32) == 0) && (c.BJ % (c.WJ * 32) == 0) &&
+            ((c.BI * cpr) % 64 == 0) && ((c.BJ * cpr) % 64 == 0) && ((c.BI * cpr / 64) % nw == 0) && ((c.BJ * cpr / 64) % nw == 0) &&
+            (c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) * 16 <= 256 && c.MINW >= 1 && c.PF >= 2 && c.PF <= 4;
+  long const lds = std::max<long>((long)c.PF * (c.BI + c.BJ) * c.BK * 2, out_f32 ? 0 : (long)c.BJ * (c.BI * 2 + 16));
+  if (!ok || lds > 160 * 1024) unsup_err("hip_conv_nhwc_multi: unsupported tile configuration " + c.str());
+  p.cfg = c;
+  p.defs = {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI), "-DWJ=" + std::to_string(c.WJ),
+            "-DMINW=" + std::to_string(c.MINW), string("-DOUT_F32=") + (out_f32 ? "1" : "0"), "-DNBUF=" + std::to_string(c.PF)};
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return p;
+}
+
+void native_kernels_t::conv_nhwc_multi(int n, multi_member_t const *ms, bool out_f32) {
+  if (n < 1 || n > 256) unsup_err("hip_conv_nhwc_multi: 1..256 members");
+  std::vector<conv_geom_t> gs; for (int m = 0; m < n; ++m) gs.push_back(ms[m].g);
+  plan_t const p = plan_conv_nhwc_multi(gs, tune_of(impl, "conv_tile"), out_f32);
+  tile_cfg_t const &cfg = p.cfg;
+  std::vector<multi_prob_t> probs((size_t)n); std::vector<multi_tile_t> tiles;
+  double flops = 0, bytes = 0;
+  for (int m = 0; m < n; ++m) {
+    conv_geom_t const &g = ms[m].g; multi_prob_t &q = probs[(size_t)m]; memset(&q, 0, sizeof(q));
+    if (g.C % 8) unsup_err("hip_conv_nhwc_multi: in_chan of a channels-last bf16 tensor must be a multiple of 8");
+    if (g.H >= 32768 || g.W >= 32768) unsup_err("hip_conv_nhwc_multi: planes of 32768 rows / columns or more are not supported");
+    long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+    if (Nj < 1 || g.OC < 1) rt_err("hip_conv_nhwc_multi: empty member");
+    if (Nj > 0x7fffffffl || Kt > 0x7fffffffl) unsup_err("hip_conv_nhwc_multi: dims exceed int32");
+    int const ctot = ms[m].out_ctot > 0 ? ms[m].out_ctot : g.OC, coff = ms[m].out_ctot > 0 ? ms[m].out_coff : 0;
+    uint64_t const in_bytes = (uint64_t)g.B * g.C * g.H * g.W * 2, f_bytes = (uint64_t)g.OC * Kt * 2, out_bytes = (uint64_t)Nj * ctot * (out_f32 ? 4 : 2);
+    if (in_bytes >= 0x7ffffff0ull || f_bytes >= 0x7ffffff0ull || out_bytes >= 0x7ffffff0ull) unsup_err("hip_conv_nhwc_multi: tensors of 2 GiB or more are not supported (32-bit buffer offsets)");
+    q.I = ms[m].filts; q.J = ms[m].in; q.D = ms[m].out; q.bias = ms[m].biases;
+    q.I_bytes = (unsigned)f_bytes; q.J_bytes = (unsigned)in_bytes; q.D_bytes = (unsigned)out_bytes; q.Mi = g.OC; q.Nj = (int)Nj;
+    q.CIN = g.C; q.KH = g.KH; q.KW = g.KW; q.SY = g.SY; q.SX = g.SX; q.PY = g.PY; q.PX = g.PX; q.CH = g.H; q.CW = g.W; q.COH = g.OH; q.COW = g.OW;
+    q.kCG = g.C / 8; q.kKC = q.kCG * g.KH * g.KW; q.nK = (q.kKC + cfg.BK / 8 - 1) / (cfg.BK / 8); q.relu = g.relu ? 1 : 0;
+    q.out_ctot = ctot; q.out_coff = coff; q.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; q.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
+    // this member's tiles, XCD-aware: consecutive workgroups go to consecutive XCDs, so the eight of a round are eight different pel tiles of one out_chan tile and
+    // an XCD walks the out_chan tiles of "its" pel tiles back to back -- an input tile is fetched into one L2
+    for (int tj0 = 0; tj0 < q.tiles_j; tj0 += 8)
+      for (int ti = 0; ti < q.tiles_i; ++ti)
+        for (int tj = tj0; tj < std::min(q.tiles_j, tj0 + 8); ++tj) tiles.push_back(multi_tile_t{m, ti, tj, q.nK});
+    flops += 2.0 * Nj * g.OC * Kt;
+    bytes += 2.0 * ((double)g.B * g.C * g.H * g.W + (double)g.OC * Kt) + (out_f32 ? 4.0 : 2.0) * (double)Nj * g.OC + 4.0 * g.OC;
+  }
+  // longest tiles first (the hardware hands workgroups to CUs as CUs free up: a longest-processing-time-first schedule); the sort is stable, so members of equal
+  // length keep their order and their XCD-aware tile order
+  std::stable_sort(tiles.begin(), tiles.end(), [](multi_tile_t const &x, multi_tile_t const &y) { return x.pad > y.pad; });
+  if (tiles.size() > 0x7fffffffull) unsup_err("hip_conv_nhwc_multi: too many tiles");
+  // the descriptor table and the tile list live in device memory, one copy per distinct call (pointers included): built on the first call, reused after
+  size_t const pb = probs.size() * sizeof(multi_prob_t), tb = tiles.size() * sizeof(multi_tile_t), tb_off = (pb + 255) & ~size_t(255);
+  string key = "multi:" + cfg.str();
+  { uint64_t h = 1469598103934665603ull; auto mix = [&](void const *d, size_t nb) { for (size_t i = 0; i < nb; ++i) { h ^= ((unsigned char const *)d)[i]; h *= 1099511628211ull; } };
+    mix(probs.data(), pb); mix(tiles.data(), tb); key += ":" + std::to_string(h) + ":" + std::to_string(pb + tb); }
+  auto it = impl->ktabs.find(key);
+  if (it == impl->ktabs.end()) {
+    if (host->nh_capturing()) rt_err("graph capture: the descriptor table of this hip_conv_nhwc_multi call is not on the device yet -- run the call list once before capturing it");
+    void *dev = nullptr;
+    hip_err_chk(hipMalloc(&dev, tb_off + tb), "hipMalloc(multi table)");
+    hip_err_chk(hipMemcpyAsync(dev, probs.data(), pb, hipMemcpyHostToDevice, host->nh_stream()), "hipMemcpyAsync(multi probs)");
+    hip_err_chk(hipMemcpyAsync((char *)dev + tb_off, tiles.data(), tb, hipMemcpyHostToDevice, host->nh_stream()), "hipMemcpyAsync(multi tiles)");
+    hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize(multi table)");   // (the host vectors die with this call)
+    it = impl->ktabs.emplace(key, dev).first;
+  }
+  kernel_t &k = get_kernel(impl, host, p);
+  multi_args_t ma; ma.probs = (multi_prob_t const *)it->second; ma.tiles = (multi_tile_t const *)((char *)it->second + tb_off); ma.n_tiles = (int)tiles.size(); ma.n_probs = n;
+  void *params[] = {&ma};
+  hip_err_chk(host->nh_launch(k.func, (uint32_t)tiles.size(), 1, (uint32_t)cfg.threads(), params), "hipModuleLaunchKernel(conv_nhwc_multi_bf16)");
+  last_launch.kernel = p.kname + "(x" + std::to_string(n) + ")"; last_launch.cfg = cfg; last_launch.grid = (uint32_t)tiles.size(); last_launch.block = cfg.threads();
+  last_launch.flops = flops; last_launch.algo_bytes = bytes;
+}
+
 // Horizontally fused channels-last convolutions (hip_conv_nhwc_grp): n <= 4 members that read the same `in` with the same kernel geometry; filts / biases hold
 // the members stacked along out_chan, member m at rows [m_oc0, m_oc0 + noc[m]) with m_oc0 = sum of the earlier members' out_chans each rounded up to `pad`.
 void native_kernels_t::conv_nhwc_grp(void const *filts, float const *biases, void const *in, conv_geom_t const &g, bool out_f32, int n, int const *noc, void *const *outs,
@@ -1161,9 +1270,17 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
   }
   else if (t == "Convolution") {
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
-    conv_geom_t const g = geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims(op.has("out") ? "out" : "out_0"), op.get_dims("stride"), op.get_dims("in_pad"), relu);
+    bool const multi = op.has_func_name() && op.get_func_name() == "hip_conv_nhwc_multi";
+    conv_geom_t g; memset(&g, 0, sizeof(g));
+    if (!multi) g = geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims(op.has("out") ? "out" : "out_0"), op.get_dims("stride"), op.get_dims("in_pad"), relu);
     conv_geom_t g2; int pry = 0, prx = 0;
-    if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc" && op.get_dims("filts").sz() == 5) p = plan_conv_nhwc_patch(g, num_cus, tile, op.get_dims("out").tn == "float");
+    if (multi) {
+      int const n = (int)op.get_dims("multi").dsz("n"); std::vector<conv_geom_t> gs;
+      for (int m = 0; m < n; ++m) { string const sfx = "_" + std::to_string(m);
+        gs.push_back(geom_from_dims(op.get_dims("filts" + sfx), op.get_dims("in" + sfx), op.get_dims("out" + sfx), op.get_dims("stride" + sfx), op.get_dims("in_pad" + sfx), relu)); }
+      p = plan_conv_nhwc_multi(gs, tile, op.get_dims("out_0").tn == "float");
+    }
+    else if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc" && op.get_dims("filts").sz() == 5) p = plan_conv_nhwc_patch(g, num_cus, tile, op.get_dims("out").tn == "float");
     else if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc") p = plan_conv_nhwc(g, num_cus, tile, op.get_dims("out").tn == "float");
     else if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc_grp") { dims_t const &grp = op.get_dims("grp"); p = plan_conv_nhwc(g, num_cus, tile, op.get_dims("out_0").tn == "float", (int)grp.dims(grp.sz() - 1)); }
     else if (bf16 && tile.empty() && s2d_geom(g, g2, pry, prx) && plan_patch_bf16(g2, num_cus, p)) { // conv1-type layers: space-to-depth front end (see conv())
@@ -1305,6 +1422,51 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW || out0.dsz("img") != (uint32_t)g.B) rt_err("hip_conv_nhwc_grp: out dims do not match in/filts/stride/in_pad");
     tile_override_t const tov(impl, "conv_tile", fi.op);
     conv_nhwc_grp(host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), host->nh_var_ptr(inm), g, out_f32, n, noc, outs, ctot, coff, (int)grp.dims(n));
+    return;
+  }
+  if (fn == "hip_conv_nhwc_multi") {
+    // n independent channels-last convolutions (REF `multi`: dims n = the member count), member m: vars filts_<m> (out_chan:y:x:in_chan) biases_<m> in_<m> out_<m>,
+    // REFs stride_<m> in_pad_<m>, optional by-value out_chan_off_<m>; ReLU: conv_has_relu for all, or bit m of the optional uint32 relu_mask
+    auto mi = am.find("multi");
+    if (mi == am.end()) rt_err("hip_conv_nhwc_multi: the REF arg 'multi' (dims n=<members>) is required");
+    int const n = (int)mi->second.get_dims(host->nh_rtc()).dsz("n");
+    if (n < 1 || n > 256) unsup_err("hip_conv_nhwc_multi: 1..256 members");
+    bool const relu_all = fi.op.get_u32("conv_has_relu") != 0; bool const has_mask = fi.op.has("relu_mask"); uint32_t const mask = has_mask ? fi.op.get_u32("relu_mask") : 0u;
+    if (has_mask && n > 32) unsup_err("hip_conv_nhwc_multi: relu_mask covers 32 members");
+    std::vector<native_kernels_t::multi_member_t> ms((size_t)n); string out_tn;
+    for (int m = 0; m < n; ++m) {
+      string const sfx = "_" + std::to_string(m);
+      string const fnm = var_of(am, "filts" + sfx), bnm = var_of(am, "biases" + sfx), inm = var_of(am, "in" + sfx), onm = var_of(am, "out" + sfx);
+      dims_t const f = host->nh_var_dims(fnm), bi = host->nh_var_dims(bnm), in = host->nh_var_dims(inm), out = host->nh_var_dims(onm);
+      need_float(bi, "biases");
+      if (f.tn != "bfloat16" || in.tn != "bfloat16") unsup_err("hip_conv_nhwc_multi: filts / in must have type bfloat16");
+      if (out.tn != "bfloat16" && out.tn != "float") unsup_err("hip_conv_nhwc_multi: out must have type bfloat16 or float");
+      if (m == 0) out_tn = out.tn; else if (out.tn != out_tn) rt_err("hip_conv_nhwc_multi: the members' outputs must have one type");
+      assert_st(f.sz() == 4 && in.sz() == 4 && out.sz() == 4 && bi.sz() == 1);
+      if (!(f.names(0) == "out_chan" && f.names(1) == "y" && f.names(2) == "x" && f.names(3) == "in_chan")) rt_err("hip_conv_nhwc_multi: filts must be out_chan:y:x:in_chan, got " + f.pretty_str());
+      for (dims_t const *d : {&in, &out}) if (!(d->names(0) == "img" && d->names(1) == "y" && d->names(2) == "x" && d->names(3) == "chan")) rt_err("hip_conv_nhwc_multi: in / out must be img:y:x:chan, got " + d->pretty_str());
+      auto si = am.find("stride" + sfx), pi = am.find("in_pad" + sfx);
+      if (si == am.end() || pi == am.end()) rt_err("hip_conv_nhwc_multi: 'stride_<m>' and 'in_pad_<m>' REF args are required");
+      dims_t const stride = si->second.get_dims(host->nh_rtc()), in_pad = pi->second.get_dims(host->nh_rtc());
+      assert_st(stride.sz() == 2); assert_st(in_pad.sz() == 2);
+      native_kernels_t::multi_member_t &mm = ms[(size_t)m];
+      mm.g = geom_from_dims(f, in, out, stride, in_pad, has_mask ? ((mask >> m) & 1u) != 0 : relu_all);
+      conv_geom_t const &g = mm.g;
+      if (f.dsz("in_chan") != (uint32_t)g.C) rt_err("hip_conv_nhwc_multi: filts.in_chan != in.chan (member " + std::to_string(m) + ")");
+      mm.out_ctot = 0; mm.out_coff = 0;
+      auto oi = am.find("out_chan_off" + sfx);
+      if (oi != am.end()) {
+        if (oi->second.is_var() || !oi->second.v || !oi->second.v->rp_elems()) rt_err("hip_conv_nhwc_multi: out_chan_off_<m> must be a by-value uint32");
+        mm.out_coff = (int)*(uint32_t const *)oi->second.v->rp_elems(); mm.out_ctot = (int)out.dsz("chan");
+        if (mm.out_coff < 0 || mm.out_coff + g.OC > mm.out_ctot) rt_err("hip_conv_nhwc_multi: out_chan_off + out_chan exceeds the channels of out");
+      }
+      if (bi.dsz("out_chan") != (uint32_t)g.OC || (!mm.out_ctot && out.dsz("chan") != (uint32_t)g.OC) || out.dsz("img") != (uint32_t)g.B) rt_err("hip_conv_nhwc_multi: inconsistent biases / out dims (member " + std::to_string(m) + ")");
+      if (!g.SY || !g.SX) rt_err("hip_conv_nhwc_multi: zero stride");
+      if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW) rt_err("hip_conv_nhwc_multi: out dims do not match in / filts / stride / in_pad (member " + std::to_string(m) + ")");
+      mm.filts = host->nh_var_ptr(fnm); mm.biases = (float const *)host->nh_var_ptr(bnm); mm.in = host->nh_var_ptr(inm); mm.out = host->nh_var_ptr(onm);
+    }
+    tile_override_t const tov(impl, "conv_tile", fi.op);
+    conv_nhwc_multi(n, ms.data(), out_tn == "float");
     return;
   }
   if (fn == "hip_conv_nhwc") {

@@ -11,6 +11,8 @@
 //                                       reference's k1conv / tconv (src/rtc_prof.cc:92-121)
 //     hip_conv_nhwc_grp                 up to four hip_conv_nhwc that read the same `in` with the same kernel geometry, as ONE launch (stacked filts / biases, outputs
 //                                       out_0 .. out_3): an inception module's same-input 1x1 convs, a ResNet stage's branch1 + branch2a
+//     hip_conv_nhwc_multi               up to 256 INDEPENDENT hip_conv_nhwc convolutions (own tensors, any geometries) as ONE launch: the tile lists of a per-layer op list's
+//                                       small members handed to the hardware dispatcher together, longest first (kernels/conv_nhwc_multi_bf16.hip)
 //     hip_conv_winograd                 same contract as hip_conv; 3x3 / stride-1 layers through F(2x2,3x3) Winograd (mrd <= ~2e-3)
 // and lands them on kernels/gemm_conv_f32.hip (and, for short-K 1x1 convs with a long pel axis, kernels/k1_stream_f32.hip),
 // specialised with hiprtc per shape class at first use.
@@ -73,6 +75,9 @@ struct native_kernels_t {
   // horizontally fused channels-last convolutions (same `in`, same kernel geometry; filts / biases stacked along out_chan, members padded to `pad` rows)
   void conv_nhwc_grp(void const *filts, float const *biases, void const *in, conv_geom_t const &g, bool out_f32, int n, int const *noc, void *const *outs,
                      int const *ctot, int const *coff, int pad);
+  // several independent channels-last convolutions as ONE launch (kernels/conv_nhwc_multi_bf16.hip); members: raw device pointers + geometry (g.C = stored channels)
+  struct multi_member_t { void const *filts; float const *biases; void const *in; void *out; conv_geom_t g; int out_ctot, out_coff; };
+  void conv_nhwc_multi(int n, multi_member_t const *members, bool out_f32);
   void conv_winograd(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, int out_ctot, int out_coff);
 
   // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"; key "k1_stream" -> "off" | "WIxWJxOCBxCB[xMINW]";

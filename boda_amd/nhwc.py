@@ -163,6 +163,44 @@ def annotate_group(annos: List[Op]) -> Op:
     return Op({"type": "Convolution", "func_name": GRP_FUNC}, nv)
 
 
+MULTI_FUNC = "hip_conv_nhwc_multi"
+_MULTI_MEMBER_ARGS = ("filts", "biases", "in", "stride", "in_pad", "out")
+
+
+def multi_eligible(anno: Op) -> bool:
+    """A member of a multi-problem launch: a plain hip_conv_nhwc function on the implicit-GEMM kernel (filts out_chan:y:x:in_chan) -- not the input-patch form, not
+    space-to-depth (both bind other kernels with another summation order)."""
+    return anno.get_func_name() == FUNC and not anno.has("nhwc_s2d") and not anno.get_dims("filts").has("in_grp")
+
+
+def annotate_multi(annos: List[Op]) -> Op:
+    """`hip_conv_nhwc_multi`: up to 256 annotated hip_conv_nhwc ops -- INDEPENDENT convolutions, each with its own tensors and its own geometry -- as ONE function whose
+    launch hands all their tiles to the chip together (kernels/conv_nhwc_multi_bf16.hip).  Member m's args carry the suffix _<m>.  Per member the arithmetic is that of
+    its own hip_conv_nhwc call on the implicit-GEMM kernel, bit for bit.  The reference runs one function per op (src/rtc_fwd.cc:545-549); this is the launch-bound
+    regime's answer on MI355X (54-64 launches per config-5 list, most of them 50-200 tiles for 256 CUs)."""
+    if not (1 <= len(annos) <= 256):
+        raise UnsupErr("hip_conv_nhwc_multi: 1..256 members")
+    nv = {"multi": Nda(dims=Dims(("n",), (len(annos),), "none"), tn="none")}
+    relu = [a.get_u32("conv_has_relu") for a in annos]
+    for m, a in enumerate(annos):
+        if not multi_eligible(a):
+            raise UnsupErr("hip_conv_nhwc_multi: members must be plain hip_conv_nhwc functions (out_chan:y:x:in_chan filters)")
+        if a.get_dims("out").tn != annos[0].get_dims("out").tn:
+            raise UnsupErr("hip_conv_nhwc_multi: members differ in output type")
+        for an in _MULTI_MEMBER_ARGS + ("kern_sz",):
+            nv[f"{an}_{m}"] = a.nda_vals[an]
+    nv["conv_has_relu"] = Nda(dims=None, tn="uint32_t", v=(int(all(relu)),))
+    if any(relu) != all(relu):
+        if len(annos) > 32:
+            raise UnsupErr("hip_conv_nhwc_multi: more than 32 members must agree in ReLU")
+        nv["relu_mask"] = Nda(dims=None, tn="uint32_t", v=(sum(int(bool(r)) << m for m, r in enumerate(relu)),))
+    return Op({"type": "Convolution", "func_name": MULTI_FUNC}, nv)
+
+
+def multi_arg_names(n: int) -> List[str]:
+    return ["multi"] + [f"{an}_{m}" for m in range(n) for an in _MULTI_MEMBER_ARGS]
+
+
 def group_arg_names(n: int) -> List[str]:
     return ["filts", "biases", "in", "stride", "in_pad", "grp"] + [f"out_{m}" for m in range(n)]
 

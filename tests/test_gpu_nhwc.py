@@ -235,3 +235,158 @@ def test_fused_sibling_convs_equal_the_separate_calls(be, case):
         for vn in made:
             rtc.release_var(vn)
         rtc.release_per_call_id_data()
+
+
+class _OpList:
+    """A per-layer op list on the device, as bench.py builds it: every op its own function and its own tensors, inputs generated in the reference layout and brought
+    to the kernel's layout by the layout passes.  member i: function name funcs[i], annotated op annos[i], call calls[i], vars `<pfx><i>_<arg>`."""
+
+    def __init__(self, rtc, shapes, tune_of, pfx):
+        from boda_amd import gen_data as gd, nhwc
+        from boda_amd.cnn_op import NATIVE_ARGS
+        from boda_amd.rtc import RtcArg, RtcFuncCall, RtcFuncInfo
+        self.rtc, self.pfx, self.made, self.funcs, self.calls, self.annos, self.ops = rtc, pfx, [], [], [], [], []
+        nhwc.ensure_compiled(rtc)
+        for i, shp in enumerate(shapes):
+            op = _conv_op(*shp); anno = add_codegen_annotations(op, tune_of(i)); fn = anno.get_func_name(); gen_fn = f"{pfx}_{i}"
+            rtc.compile([RtcFuncInfo(gen_fn, "", [x for x, _ in NATIVE_ARGS[fn]], anno)]); self.funcs.append(gen_fn)
+            am = {}
+            for an, io in NATIVE_ARGS[fn]:
+                if io == "REF":
+                    am[an] = RtcArg.ref(anno.get_dims(an)); continue
+                vn = f"{pfx}{i}_{an}"; rtc.create_var_with_dims(vn, anno.get_dims(an)); self.made.append(vn); am[an] = RtcArg.var(vn)
+                if io == "IN":
+                    rd = anno.get_dims(an + "_ref") if anno.has(an + "_ref") else anno.get_dims(an)
+                    if rd != anno.get_dims(an):
+                        rtc.create_var_with_dims(vn + "_ref", rd); self.made.append(vn + "_ref")
+                        rtc.run(gd.gen_call("Convolution", an, vn + "_ref", rd, 5, 0.0)); rtc.run(nhwc.xpose_call(an, vn + "_ref", vn, rd, anno.get_dims(an), anno))
+                    else:
+                        rtc.run(gd.gen_call("Convolution", an, vn, rd, 5, 0.0))
+            self.calls.append(RtcFuncCall(gen_fn, am)); self.annos.append(anno); self.ops.append(op)
+
+    def out(self, i):
+        return self.rtc.copy_var_to_nda(f"{self.pfx}{i}_out")
+
+    def zero_outs(self):
+        for i in range(len(self.calls)):
+            self.rtc.set_var_to_zero(f"{self.pfx}{i}_out")
+
+    def release(self):
+        self.rtc.finish_and_sync()
+        for vn in self.made:
+            self.rtc.release_var(vn)
+        for f in self.funcs:
+            self.rtc.release_func(f)
+        self.rtc.release_per_call_id_data()
+
+
+def test_edge_free_graph_of_an_op_list_equals_call_by_call(be):
+    """bench.py --graph --independent: a per-layer op list's ops share no tensor, so the captured graph gets no edges and its launches may overlap.  Same kernels, same
+    arguments: every op's output must be bit-identical to its call-by-call run -- including three K-sliced members (partial tiles in the backend's ONE scratch buffer:
+    multi-kernel calls stay chained inside and ordered among themselves) and an input-patch member."""
+    rtc = be.rtc
+    shapes = [(64, 832, 7, 7, 384, 1, 1, 1, 0), (64, 832, 7, 7, 128, 1, 1, 1, 0), (16, 192, 14, 14, 96, 1, 1, 1, 0), (8, 96, 14, 14, 208, 3, 3, 1, 1), (4, 64, 28, 28, 32, 1, 1, 2, 0),
+              (64, 1024, 7, 7, 512, 1, 1, 1, 0)]
+    # (members 0, 1 and 5: K slices forced through the function's own tile, so the scratch-sharing case is there whatever the planner thinks of the shape)
+    ol = _OpList(rtc, shapes, lambda i: OpTune(hip_tile=("64x64x64x2x2x2x4" if i in (0, 1, 5) else ""), **NHWC), "efg")
+    try:
+        want, sliced = [], 0
+        for i, c in enumerate(ol.calls):
+            rtc.run(c); sliced += "_s" in rtc.last_launch()["cfg"]
+            want.append(ol.out(i))
+        assert sliced == 3
+        rtc.finish_and_sync(); rtc.release_per_call_id_data()
+        rtc.graph_begin()
+        for c in ol.calls:
+            rtc.run(c)
+        gid = rtc.graph_end_deps([[] for _ in ol.calls])
+        for rep in range(3):
+            ol.zero_outs()
+            rtc.graph_launch(gid); rtc.finish_and_sync()
+            for i in range(len(ol.calls)):
+                assert np.array_equal(ol.out(i), want[i]), (rep, shapes[i])
+        rtc.graph_destroy(gid)
+    finally:
+        ol.release()
+
+
+MULTI_SHAPES = [  # B, C, H, W, OC, KH, KW, S, P -- what a config-5 list holds besides its big layers, plus edges: ragged out_chans / pels, stride 2, padding, windows
+    (8, 192, 28, 28, 96, 1, 1, 1, 0), (8, 192, 28, 28, 16, 1, 1, 1, 0), (16, 480, 14, 14, 192, 1, 1, 1, 0), (16, 528, 14, 14, 160, 1, 1, 1, 0), (64, 832, 7, 7, 384, 1, 1, 1, 0),
+    (64, 832, 7, 7, 48, 1, 1, 1, 0), (4, 256, 56, 56, 128, 1, 1, 2, 0), (2, 1024, 14, 14, 2048, 1, 1, 2, 0), (3, 40, 15, 15, 100, 3, 3, 1, 1), (2, 24, 9, 13, 33, 5, 5, 1, 2),
+    (2, 3, 33, 33, 48, 7, 7, 2, 3), (5, 19, 11, 11, 40, 1, 1, 1, 0), (64, 1024, 1, 1, 1000, 1, 1, 1, 0), (1, 8, 6, 6, 40, 6, 6, 1, 0), (2, 8, 7, 7, 16, 1, 1, 1, 1),
+    (7, 128, 4, 4, 1024, 4, 4, 1, 0), (2, 112, 14, 14, 224, 3, 3, 1, 1), (1, 16, 3, 3, 8, 3, 3, 2, 1)]
+
+
+@pytest.mark.parametrize("out,tile", [("", ""), ("f32", ""), ("", "64x128x64x2x2x2"), ("", "32x128x64x1x4x2x1x32x2"), ("f32", "128x64x32x2x2x2x1x32x4"), ("", "64x64x32x2x2x2x1x32x3")])
+def test_multi_problem_launch_is_bit_identical_to_separate_launches(be, out, tile):
+    """hip_conv_nhwc_multi (kernels/conv_nhwc_multi_bf16.hip): 18 independent convolutions of unlike geometry in ONE launch.  Per output the MFMA chain is that of the
+    member's own hip_conv_nhwc launch on the implicit-GEMM kernel (ascending 16-k groups, zero beyond K): results must be bit-identical to the separate launches (run
+    here without K slices and without the input-patch / space-to-depth forms, which sum in another order) -- and inside the stated bf16 bound of the oracle."""
+    from boda_amd import nhwc
+    from boda_amd.rtc import RtcArg, RtcFuncCall, RtcFuncInfo
+    rtc = be.rtc
+    tune = OpTune(hip_dtype="bf16", hip_layout="nhwc", hip_out=out, hip_patch=0, hip_s2d=0, hip_tile="64x64x64x2x2x2x1")
+    ol = _OpList(rtc, MULTI_SHAPES, lambda i: tune, "mp")
+    fn = "mp_multi"
+    try:
+        want = []
+        for i, c in enumerate(ol.calls):
+            rtc.run(c); ll = rtc.last_launch()
+            assert ll["kernel"] == "bodahip_conv_nhwc_bf16" and "_s" not in ll["cfg"], ll
+            want.append(ol.out(i))
+        manno = nhwc.annotate_multi(ol.annos)
+        if tile:
+            manno.str_vals["hip_tile"] = tile
+        else:
+            manno.str_vals.pop("hip_tile", None)
+        rtc.compile([RtcFuncInfo(fn, "", nhwc.multi_arg_names(len(ol.calls)), manno)])
+        am = {"multi": RtcArg.ref(manno.get_dims("multi"))}
+        for m, c in enumerate(ol.calls):
+            for an in ("filts", "biases", "in", "stride", "in_pad", "out"):
+                am[f"{an}_{m}"] = c.arg_map[an]
+        ol.zero_outs()
+        cid = rtc.run(RtcFuncCall(fn, am)); ll = rtc.last_launch()
+        assert ll["kernel"] == f"bodahip_conv_nhwc_multi_bf16(x{len(ol.calls)})" and ll["flops"] > 0, ll
+        if tile:
+            assert ll["cfg"].startswith("x".join(tile.split("x")[:3])), ll
+        rtc.finish_and_sync(); assert rtc.get_dur(cid, cid) > 0
+        for i in range(len(ol.calls)):
+            got = ol.out(i)
+            assert np.array_equal(got, want[i]), (MULTI_SHAPES[i], ll["cfg"], int((got != want[i]).sum()))
+        # ... and the same call inside a captured graph (descriptor table already on the device), replayed twice
+        rtc.release_per_call_id_data()
+        rtc.graph_begin(); rtc.run(RtcFuncCall(fn, am)); gid, n1 = rtc.graph_end(); assert n1 == 1
+        for _ in range(2):
+            ol.zero_outs(); rtc.graph_launch(gid); rtc.finish_and_sync()
+            assert all(np.array_equal(ol.out(i), want[i]) for i in range(len(ol.calls)))
+        rtc.graph_destroy(gid)
+        # against the oracle on bf16-rounded operands (float outputs; a few members of each kind)
+        if out == "f32":
+            for i in (0, 6, 8, 10, 13, 17):
+                op = ol.ops[i]; g = op.conv_geom()
+                ins = bo.run_op(op, 5)
+                ref = bo.conv_fwd(bo.to_bf16(ins["in"]), bo.to_bf16(ins["filts"]), ins["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
+                back = np.ascontiguousarray(np.transpose(want[i], (0, 3, 1, 2)))
+                sd = SsdsDiff.of(ref, back)
+                assert not sd.has_nan() and sd.mrd < _bound(g["C"] * g["KH"] * g["KW"]), (MULTI_SHAPES[i], sd.basic_str())
+    finally:
+        try:
+            rtc.release_func(fn)
+        except Exception:
+            pass
+        ol.release()
+
+
+def test_multi_problem_launch_refuses_what_it_cannot_run(be):
+    from boda_amd import nhwc
+    from boda_amd.op import UnsupErr
+    patch = add_codegen_annotations(_conv_op(2, 64, 14, 14, 64, 3, 3, 1, 1), OpTune(**NHWC))
+    plain = add_codegen_annotations(_conv_op(2, 64, 14, 14, 64, 1, 1, 1, 0), OpTune(**NHWC))
+    f32 = add_codegen_annotations(_conv_op(2, 64, 14, 14, 64, 1, 1, 1, 0), OpTune(**NHWC_F32))
+    assert nhwc.multi_eligible(plain) and not nhwc.multi_eligible(patch)
+    with pytest.raises(UnsupErr):
+        nhwc.annotate_multi([plain, patch])          # the input-patch form binds another kernel (another summation order)
+    with pytest.raises(UnsupErr):
+        nhwc.annotate_multi([plain, f32])            # one output type per launch
+    with pytest.raises(UnsupErr):
+        nhwc.annotate_multi([])

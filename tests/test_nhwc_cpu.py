@@ -155,3 +155,25 @@ def test_wide_planes_are_annotated_for_the_kernel_that_can_run_them():
     assert wide.has("nhwc_s2d") and not wide.get_dims("filts").has("in_grp") and rtc.explain_plan(wide).startswith("bodahip_conv_nhwc_bf16 ")
     narrow = add_codegen_annotations(_conv_op(1, 3, 64, 224, 32, 7, 7, 2, 3), OpTune(hip_dtype="bf16", hip_layout="nhwc"))
     assert narrow.get_dims("filts").has("in_grp") and rtc.explain_plan(narrow).startswith("bodahip_conv_nhwc_patch_bf16 ")
+
+
+def test_multi_problem_annotation_and_plan():
+    """hip_conv_nhwc_multi: member args with the suffix _<m>, one tile shape for the launch (the kernel is specialised on the tile, not on any member's geometry), the C++
+    op parser takes the (long) line, and the kernel cross-compiles."""
+    shapes = [(64, 480, 14, 14, 192, 1, 1, 1, 0), (64, 832, 7, 7, 48, 1, 1, 1, 0), (64, 256, 56, 56, 128, 1, 1, 2, 0), (64, 24, 14, 14, 64, 5, 5, 1, 2)]
+    annos = [add_codegen_annotations(_conv_op(*s), OpTune(hip_dtype="bf16", hip_layout="nhwc", hip_patch=0)) for s in shapes]
+    m = nhwc.annotate_multi(annos)
+    assert m.get_func_name() == "hip_conv_nhwc_multi" and m.get_dims("multi").dsz("n") == 4 and m.get_u32("conv_has_relu") == 1 and not m.has("relu_mask")
+    assert nhwc.multi_arg_names(2) == ["multi", "filts_0", "biases_0", "in_0", "stride_0", "in_pad_0", "out_0", "filts_1", "biases_1", "in_1", "stride_1", "in_pad_1", "out_1"]
+    assert m.get_dims("in_2") == annos[2].get_dims("in") and m.get_dims("stride_2").sizes == (2, 2) and m.get_dims("kern_sz_3").sizes == (5, 5)
+    assert rtc.parse_op_native(m.to_str()) == m.to_str()
+    plan = rtc.explain_plan(m)
+    assert plan.startswith("bodahip_conv_nhwc_multi_bf16 ") and "-DOUT_F32=0" in plan and "-DCIN" not in plan and "-DKH" not in plan      # nothing of a member's geometry
+    assert rtc.explain_plan(m, tile="32x128x64x1x4x2x1x32x2").startswith("bodahip_conv_nhwc_multi_bf16 32x128x64_w1x4_p2 ")
+    with pytest.raises(UnsupErr):
+        rtc.explain_plan(m, tile="64x96x64x2x2")                                                                                             # (a wave tile is whole 32x32 MFMA blocks)
+    assert rtc.prebuild(m) > 8000
+    # members that differ in ReLU: a mask instead of the common flag
+    annos[1].nda_vals["conv_has_relu"].v = (0,)
+    mm = nhwc.annotate_multi(annos)
+    assert mm.get_u32("conv_has_relu") == 0 and mm.get_u32("relu_mask") == 0b1101
