@@ -92,7 +92,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SWAPST (((BJ / (WJ * 32)) % 2 == 0) && !HALF) // paired 256-byte row stores in the epilogue (see there); 0 forces the plain per-block stores
 #endif
 #ifndef PF
-#define PF 1 // K-tiles prefetched ahead in registers: 1 | 2 (two register sets; for workgroups that run alone on their CU)
+#define PF 1 // K-tiles prefetched ahead in registers: 1 | 2 (two register sets; for workgroups that run alone on their CU) | 4 | 6 | 8 (a ring of register sets: tile-starved long-K shapes)
 #endif
 #ifndef MT
 #define MT 32 // MFMA tile: 32 -> v_mfma_f32_32x32x2_f32 (default), 16 -> v_mfma_f32_16x16x4_f32 (4x more, smaller wave tiles for
@@ -657,6 +657,28 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     MMA_KTILE(Is1, Js1);
     if (kt + 2 < nkt) STORE_IJ(ri2, rj2, Is0, Js0);
     __syncthreads();
+  }
+#elif PF >= 3
+  // PF K-tiles in flight (PF even: 4 | 6 | 8), for the tile-starved long-K shapes whose workgroups run one wave per SIMD and have registers to spare
+  // (fully-connected layers: K = 4096 / 9216 on 64-256 tiles): a K step's MFMA phase is ~0.2-0.5 us, an HBM fetch under load 1-2 us, so two tiles ahead
+  // leave the matrix pipe idle half of the time.  Register set s = tile mod PF; the LDS stays double-buffered.  In step kt: multiply tile kt out of LDS
+  // stage kt & 1, store tile kt + 1 (whose loads were issued PF steps ago) to the other stage, then refill its register set with tile kt + 1 + PF.
+  // Same ascending-k MFMA chain per output: bit-identical results.
+  static_assert(PF % 2 == 0 && PF <= 8, "PF: 1 | 2 | 4 | 6 | 8");
+  float rri[PF][kNI], rrj[PF][kNJ];
+#pragma unroll
+  for (int u = 1; u <= PF; ++u) if (u < nkt) { LOAD_I(rri[u % PF], u); LOAD_J(rrj[u % PF], u); }
+  for (int kb = 0; kb < nkt; kb += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      int const kt = kb + u;
+      if (kt < nkt) {
+        MMA_KTILE((u & 1) ? Is1 : Is0, (u & 1) ? Js1 : Js0);
+        if (kt + 1 < nkt) STORE_IJ(rri[(u + 1) % PF], rrj[(u + 1) % PF], (u & 1) ? Is0 : Is1, (u & 1) ? Js0 : Js1);
+        if (kt + 1 + PF < nkt) { LOAD_I(rri[(u + 1) % PF], kt + 1 + PF); LOAD_J(rrj[(u + 1) % PF], kt + 1 + PF); }
+        __syncthreads();
+      }
+    }
   }
 #else
   for (int kt = 0; kt < nkt; ++kt) {

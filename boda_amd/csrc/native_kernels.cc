@@ -88,7 +88,8 @@ static void check_cfg(tile_cfg_t const &c, bool gather) {
             (c.BK % 2 == 0) && (c.MT == 32 || c.BK % 4 == 0) && (c.BI % 4 == 0) && (c.BJ % 4 == 0);
   if (gather) ok = ok && ((c.BK * c.BJ) % nt == 0); // the gathers give every thread whole elements / rows
   if (gather) ok = ok && (nt % c.BJ == 0) && (c.BJ % 64 == 0);
-  ok = ok && c.SPLITK >= 1 && c.SPLITK <= 64 && c.MINW >= 1 && (c.PF == 1 || c.PF == 2);
+  ok = ok && c.SPLITK >= 1 && c.SPLITK <= 64 && c.MINW >= 1 && (c.PF == 1 || c.PF == 2 || c.PF == 4 || c.PF == 6 || c.PF == 8);
+  if (c.PF > 2) ok = ok && ((long)c.PF * c.BK * (c.BI + c.BJ) / nt <= 192);   // (the ring of register sets: PF x staged elements per thread)
   int const accs = (c.BI / (c.WI * c.MT)) * (c.BJ / (c.WJ * c.MT));
   ok = ok && accs * (c.MT == 32 ? 16 : 4) <= 256;
   uint64_t const lds = 2ull * c.BK * (c.BI + 4 + c.BJ + 4) * 4;
@@ -1071,29 +1072,19 @@ struct multi_tile_t { int prob, tile_i, tile_j, pad; };
 struct multi_args_t { multi_prob_t const *probs; multi_tile_t const *tiles; int n_tiles; int n_probs; };
 
 // One tile shape for the whole launch (the kernel is specialised on it, not on any member's geometry).  tile: "BIxBJxBKxWIxWJ[xMINW[x1[x32[xNBUF]]]]" or "".
-// Default 64 x 128 x 64, 2 x 2 waves, a ring of three: 72 KB of LDS, two workgroups per CU -- the members are small (that is why they are here) and mostly narrow in
-// out_chan (16-256), so a taller tile would mostly multiply zeros; candidates are priced by the operand bytes the launch streams through the LDS, padding included.
+// Default 64 x 128 x 64, 2 x 2 waves, a ring of TWO (48 KB of LDS: three workgroups, i.e. three waves per SIMD, per CU) -- the members are small (that is why they
+// are here), mostly narrow in out_chan (16-256) and short in K (3-13 steps), so what hides their latency is co-resident workgroups, not a deeper ring.  Measured on
+// MI355X (tools/r4f.sh: the 44 implicit-GEMM members of the GoogLeNet list at 64 images as one launch, us): 64x128x64 ring 2 / three per CU 205 | 64x128x32 ring 4 222 |
+// 64x256x32 ring 3 224 | 64x64x64 266 | 128x128x64 ring 3 326 (the members one by one: 533, of which 260 are launch floors).
 static plan_t plan_conv_nhwc_multi(std::vector<conv_geom_t> const &gs, string const &tile, bool out_f32) {
+  (void)gs;
   plan_t p; p.nhwc = true; p.nhwc_multi = true; p.bf16 = true; p.kname = "bodahip_conv_nhwc_multi_bf16";
-  tile_cfg_t c; c.MT = 32; c.SPLITK = 1; c.PF = 3; c.BI = 64; c.BJ = 128; c.BK = 64; c.WI = 2; c.WJ = 2; c.MINW = 2;
+  tile_cfg_t c; c.MT = 32; c.SPLITK = 1; c.PF = 2; c.BI = 64; c.BJ = 128; c.BK = 64; c.WI = 2; c.WJ = 2; c.MINW = 3;
   if (!tile.empty()) {
     int nbuf = 3;
     if (!parse_tile(tile, c)) rt_err("bad conv_tile '" + tile + "'");
     { int nf = 1; for (char ch : tile) if (ch == 'x' || ch == ':') ++nf; if (nf >= 9) nbuf = c.PF; }
     c.MT = 32; c.SPLITK = 1; c.PF = nbuf;
-  } else {
-    struct cand_t { int bi, bj, wi, wj; };
-    static cand_t const cands[] = {{64, 128, 2, 2}, {128, 128, 2, 2}, {32, 128, 1, 4}};
-    double best = 1e300;
-    for (cand_t const &cd : cands) {
-      double cost = 0;
-      for (conv_geom_t const &g : gs) {
-        long const Nj = (long)g.B * g.OH * g.OW, kc = (long)(g.C / 8) * g.KH * g.KW, nk = (kc + 7) / 8;
-        long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj;
-        cost += (double)(ti * tj) * ((double)nk * (cd.bi + cd.bj) + 0.5 * cd.bi);   // K steps x rows streamed, + the epilogue's share
-      }
-      if (cost < best * 0.97) { best = cost; c.BI = cd.bi; c.BJ = cd.bj; c.WI = cd.wi; c.WJ = cd.wj; }
-    }
   }
   int const cpr = c.BK / 8, nw = c.WI * c.WJ;
   bool ok = (c.BK == 32 || c.BK == 64) && c.BI > 0 && c.BJ > 0 && c.WI > 0 && c.WJ > 0 && c.threads() <= 1024 && (c.BI % (c.WI * 32) == 0) && (c.BJ % (c.WJ * 32) == 0) &&

@@ -168,7 +168,7 @@ def test_multi_problem_annotation_and_plan():
     assert m.get_dims("in_2") == annos[2].get_dims("in") and m.get_dims("stride_2").sizes == (2, 2) and m.get_dims("kern_sz_3").sizes == (5, 5)
     assert rtc.parse_op_native(m.to_str()) == m.to_str()
     plan = rtc.explain_plan(m)
-    assert plan.startswith("bodahip_conv_nhwc_multi_bf16 ") and "-DOUT_F32=0" in plan and "-DCIN" not in plan and "-DKH" not in plan      # nothing of a member's geometry
+    assert plan.startswith("bodahip_conv_nhwc_multi_bf16 64x128x64_w2x2_p2 ") and "-DMINW=3" in plan and "-DOUT_F32=0" in plan and "-DCIN" not in plan and "-DKH" not in plan      # nothing of a member's geometry
     assert rtc.explain_plan(m, tile="32x128x64x1x4x2x1x32x2").startswith("bodahip_conv_nhwc_multi_bf16 32x128x64_w1x4_p2 ")
     with pytest.raises(UnsupErr):
         rtc.explain_plan(m, tile="64x96x64x2x2")                                                                                             # (a wave tile is whole 32x32 MFMA blocks)
