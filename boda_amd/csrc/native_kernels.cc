@@ -115,8 +115,9 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather, bo
     {96, 128, 32, 1, 2, 2, 32, 1, 0.85, true, true},  {64, 64, 32, 2, 2, 2, 32, 1, 0.70, true, true}};
   static cand_t const cands_f32[] = {
     {128, 128, 16, 2, 2, 2, 32, 1, 1.00, true, true},  {256, 256, 16, 2, 4, 1, 32, 2, 1.02, false, true}, {96, 256, 16, 1, 4, 2, 32, 1, 0.95, true, false},
-    {96, 128, 16, 1, 2, 2, 32, 1, 0.90, false, true},  {64, 64, 16, 2, 2, 2, 32, 2, 0.93, true, true},    {32, 64, 32, 2, 4, 1, 16, 2, 0.60, true, true},
-    {32, 32, 64, 2, 2, 1, 16, 2, 0.45, false, true}}; // (BK 64 + two K-tiles in flight: AlexNet fc8 24 -> 32 TF/s in sequence)
+    {96, 128, 16, 1, 2, 2, 32, 1, 0.90, false, true},  {64, 64, 16, 2, 2, 2, 32, 2, 0.93, true, true},    {32, 64, 32, 2, 4, 1, 16, 4, 0.60, true, true},
+    {32, 32, 32, 2, 2, 1, 16, 8, 0.45, false, true}}; // (a ring of register-staged K tiles, round 4 -- tools/fc_pf_sweep.py, isolated layers, us: AlexNet fc8 32x32x64 two tiles in
+  // flight 63.6 -> 32x32x32 eight in flight 51.1; GoogLeNet's classifier at 64 images 18.8 -> 16.3; fc6 at 128 images on 32x64x32: two in flight 181 -> four 148.5)
   tile_cfg_t best_c; double best = -1;
   // launches shorter than ~200 us at full rate also pay ramp-up / tail: about 0.6 tile-times per CU (measured NiN 1x1 layers at
   // B=128: 507 128x128 tiles 83 TF/s, 2028 64x64 tiles 88-91), which favours finer tiles there
@@ -134,7 +135,11 @@ static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather, bo
     double score = cd.base * pad * bal;
     if (short_kernel) { double const x = (double)tiles / num_cus; score *= x / (x + kShortTail); }
     if (score > best) { best = score; best_c.BI = cd.bi; best_c.BJ = cd.bj; best_c.BK = (cd.bi == 64 && cd.bj == 64 && !gather && !bf16) ? 32 : cd.bk; // (k-contiguous / plain operands, usually cold from HBM: twice the bytes in flight; AlexNet fc6/fc7 in sequence 63 -> 78 TF/s)
-      best_c.WI = cd.wi; best_c.WJ = cd.wj; best_c.MINW = cd.minw; best_c.MT = cd.mt; best_c.PF = cd.pf; best_c.SPLITK = 1; }
+      best_c.WI = cd.wi; best_c.WJ = cd.wj; best_c.MINW = cd.minw; best_c.MT = cd.mt; best_c.PF = cd.pf; best_c.SPLITK = 1;
+      // one workgroup per CU and a long K loop (fully-connected layers: 256 tiles, K = 4096 / 9216): four K tiles in flight instead of two (fc6 252.7 -> 237.8 us,
+      // fc7 116.6 -> 111.6; with several workgroups per CU -- sgemm 2048^3 / 3072^3 -- the deeper ring only costs registers: 164 -> 170 us)
+      if (!bf16 && cd.bi == 64 && cd.bj == 64 && cd.mt == 32 && !gather && tiles <= num_cus && K >= 2048) best_c.PF = 4;
+      if (cd.mt == 16 && gather) best_c.PF = 2; }   // (the deeper rings were measured on k-contiguous operands only)
   }
   return best_c;
 }

@@ -594,7 +594,7 @@ def test_conv_writes_channel_slice_of_wider_output(be):
         rtc.release_func("slice_conv"); rtc.release_per_call_id_data()
 
 
-@pytest.mark.parametrize("tile", ["", "64x256x32x1x4x2", "128x128x16x2x2x2"])
+@pytest.mark.parametrize("tile", ["", "64x256x32x1x4x2", "128x128x16x2x2x2", "64x64x32x2x2x1x1x32x4"])   # (the last: a ring of four register-staged K tiles, every operand mode)
 def test_conv_random_shapes_bit_exact(be, tile):
     """Seeded random-shape sweep (tools/fuzz_conv.py; kernel sizes 1..11, strides 1..4, paddings, ragged channel counts): whatever
     operand mode the planner picks, with the default and with two forced workgroup tiles, equals the oracle bit for bit.
@@ -610,7 +610,7 @@ def test_conv_random_shapes_bit_exact(be, tile):
         assert np.array_equal(want, outs["out"]), (sh, prc.launch["cfg"])
 
 
-@pytest.mark.parametrize("tile", ["", "128x128x16x2x2x2", "256x256x16x4x4x1", "32x32x64x2x2x1x1x16x2"])
+@pytest.mark.parametrize("tile", ["", "128x128x16x2x2x2", "256x256x16x4x4x1", "32x32x64x2x2x1x1x16x2", "32x32x32x2x2x1x1x16x8", "64x64x32x2x2x1x1x32x4", "64x64x16x2x2x1x1x32x6"])   # (the last three: rings of 8 / 4 / 6 register-staged K tiles)
 def test_sgemm_random_shapes_bit_exact(be, tile):
     """Seeded random (M, N, K) incl. sizes that are not multiples of 4 / of the tile: default plan and three forced tiles == oracle."""
     rng = np.random.default_rng(3 + len(tile))
