@@ -80,6 +80,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define NBUF 2   // LDS ring depth: the loads of K step s + NBUF - 1 are issued before the MFMAs of step s (NBUF - 2 steps of loads stay in flight across a barrier)
 #endif
 
+// BODAHIP_AS_MEMBER (set by the host when it builds a hip_conv_nhwc_set kernel, native_kernels.cc: conv_nhwc_set): this file is then included once per member
+// specialisation inside a namespace of its own, and instead of a kernel it defines the same body as   __device__ void KNAME(gemm_args_t const &p, int bid, char *smem)
+// -- one workgroup of a larger grid running tile `bid` of this member, in LDS the wrapper kernel owns.  Nothing else changes: a member computes exactly what
+// its own launch computes.
+#ifdef BODAHIP_AS_MEMBER
+#define BODAHIP_BID member_bid
+#else
+#define BODAHIP_BID blockIdx.x
+#endif
+#ifndef BODAHIP_ARGS_DEFINED
 struct gemm_args_t { // identical to gemm_conv_f32.hip (one host-side struct); I = filts, J = in
   float const *I; float const *J; float *D; float const *bias;
   int Mi, Nj, K;
@@ -99,6 +109,7 @@ struct grp_args_t { // GROUPS: member m owns fused out_chans [oc0[m], oc0[m] + n
   int n; int oc0[4]; int noc[4];
   void *D[4]; unsigned D_bytes[4]; int ctot[4]; int coff[4];
 };
+#endif // BODAHIP_ARGS_DEFINED
 
 #ifdef REDUCE_ONLY
 // out[pel][out_coff + oc] = cvt( relu( bias[oc] + sum_s ws[s][pel][oc] ) );  args: ws, ws_slab (floats per slab), splitk, D, Mi = OC, Nj = pels, out_ctot / out_coff.
@@ -171,13 +182,18 @@ __device__ __forceinline__ rsrc_t make_rsrc(void const *p, unsigned bytes) { ret
 __device__ __forceinline__ constexpr int swz(int row) { return (row / kRP) & (kCPR - 1); }
 } // namespace
 
-#if GROUPS
+#ifdef BODAHIP_AS_MEMBER
+static_assert(!SPLITK && !GROUPS && !IN_F32, "a member of a set: one kernel, plain arguments");
+constexpr int member_smem_bytes = kSmem, member_threads = WI * WJ * 64, member_minw = MINW;
+__device__ __forceinline__ void KNAME(gemm_args_t const &p, int const member_bid, char *const smem) {
+#elif GROUPS
 static_assert(!SPLITK && !IN_F32, "fused convolutions: no K slices, bf16 tensors");
 extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p, grp_args_t const q) {
+  __shared__ __attribute__((aligned(1024))) char smem[kSmem];
 #else
 extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p) {
-#endif
   __shared__ __attribute__((aligned(1024))) char smem[kSmem];
+#endif
   int const tid = threadIdx.x, lane = tid & 63;
   int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int const wi = wave / WJ, wj = wave % WJ;
@@ -186,9 +202,9 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   int tile_i, tile_j; // XCD-aware workgroup -> tile map (as gemm_conv_f32.hip)
   {
 #if SPLITK
-    int const bid = blockIdx.x / p.splitk;
+    int const bid = BODAHIP_BID / p.splitk;
 #else
-    int const bid = blockIdx.x;
+    int const bid = BODAHIP_BID;
 #endif
     int const nb = p.tiles_i * p.tiles_j;
     int const q = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
@@ -306,7 +322,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };   // (the step's last MFMAs, which the compiler may sink below it, only read registers;
   // their ds_reads were issued -- queued in the LDS, in order -- before this wave arrived, i.e. before any other wave can issue the DMA that refills the slot)
 #if SPLITK
-  int const k_begin = (int)(blockIdx.x % p.splitk) * p.kt_per, nk = max(0, min(kNK, k_begin + p.kt_per) - k_begin);   // this slice's K steps
+  int const k_begin = (int)(BODAHIP_BID % p.splitk) * p.kt_per, nk = max(0, min(kNK, k_begin + p.kt_per) - k_begin);   // this slice's K steps
 #else
   constexpr int k_begin = 0, nk = (ABLATE == 4) ? 0 : kNK;
 #endif
@@ -380,7 +396,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   // ---- epilogue.  C/D layout of the 32x32 MFMA family: column j = lane & 31, rows i = 8*g + 4*(lane >> 5) + e for register 4*g + e:
   // a lane holds 4 consecutive out_chans of one pel per register quad
 #if SPLITK
-  rsrc_t const rD = make_rsrc(p.ws + (long)(blockIdx.x % p.splitk) * p.ws_slab, (unsigned)p.Nj * (unsigned)p.Mi * 4u), rB = make_rsrc(p.bias, 0u);  // (no bias here: every load reads 0)
+  rsrc_t const rD = make_rsrc(p.ws + (long)(BODAHIP_BID % p.splitk) * p.ws_slab, (unsigned)p.Nj * (unsigned)p.Mi * 4u), rB = make_rsrc(p.bias, 0u);  // (no bias here: every load reads 0)
   int const o_ctot = p.Mi, o_coff = 0;
 #elif GROUPS
   // the member this tile row belongs to (workgroup-uniform); from here on `e_i0` / `e_Mi` are the tile's first out_chan and the out_chan count INSIDE the member

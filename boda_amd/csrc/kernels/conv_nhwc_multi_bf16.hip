@@ -36,6 +36,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef NBUF
 #define NBUF 3
 #endif
+#ifndef SAFE_BARRIER
+#define SAFE_BARRIER 0
+#endif
 
 struct prob_t {   // one member convolution (128 bytes; host mirror: native_kernels.cc)
   void const *I; void const *J; void *D; float const *bias;     // filts, in, out, biases
@@ -185,6 +188,9 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(multi_arg
     // loads still wanted in flight after this wait: those of steps step + 2 .. step + NBUF - 1 that exist
     int const newest = (nk - 1 < step + NBUF - 1) ? nk - 1 : step + NBUF - 1;
     wait_loads(NBUF == 2 ? 0 : newest - (step + 1));
+#if SAFE_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of the step have RETURNED before it releases the slot to the other waves' LDS-DMA
+#endif
     barrier();
     cur = (cur + 1 == NBUF) ? 0 : cur + 1;
   }

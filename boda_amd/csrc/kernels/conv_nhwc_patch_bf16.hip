@@ -59,6 +59,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define ABLATE 0   // measurement only (wrong results): 1 = no operand loads, 2 = no fragment reads / MFMAs, 3 = no LDS stores of the staged operands, 4 = no K loop at all
 #endif
 
+// BODAHIP_AS_MEMBER: see conv_nhwc_bf16.hip -- this file as one member of a hip_conv_nhwc_set kernel ( __device__ void KNAME(gemm_args_t const &p, int bid, char *smem) ).
+#ifdef BODAHIP_AS_MEMBER
+#define BODAHIP_BID member_bid
+#else
+#define BODAHIP_BID blockIdx.x
+#endif
+#ifndef BODAHIP_ARGS_DEFINED
 struct gemm_args_t { // identical to gemm_conv_f32.hip (one host-side struct); I = F', J = in
   float const *I; float const *J; float *D; float const *bias;
   int Mi, Nj, K;
@@ -73,6 +80,7 @@ struct gemm_args_t { // identical to gemm_conv_f32.hip (one host-side struct); I
   int const *ktab; int ktab_n;
   long bsI, bsJ, bsD;
 };
+#endif // BODAHIP_ARGS_DEFINED
 
 namespace {
 constexpr int kNT = WI * WJ * 64;
@@ -118,8 +126,13 @@ __device__ __forceinline__ u32x4 bload4(rsrc_t r, int voff) { return __builtin_a
 constexpr int slot_off(int q) { return (q >= kNPr) ? 0 : ((q / kTaps) * kCSp + ((q % kTaps) / KW) * kWp + (q % KW)); } // (the pad slot reads tap 0: its filter row is zero)
 } // namespace
 
+#ifdef BODAHIP_AS_MEMBER
+constexpr int member_smem_bytes = kSmem, member_threads = WI * WJ * 64, member_minw = MINW;
+__device__ __forceinline__ void KNAME(gemm_args_t const &p, int const member_bid, char *const smem) {
+#else
 extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p) {
   __shared__ __attribute__((aligned(16))) char smem[kSmem];
+#endif
   u32x4 *const Is0 = reinterpret_cast<u32x4 *>(smem);              // A operand: [k-slot][out_chan] chunks
   u32x4 *const Js0 = Is0 + kAImg;                                 // input patch: [group][slot][padded column] chunks, group pitch kCSp
   int const tid = threadIdx.x, lane = tid & 63;
@@ -128,7 +141,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 
   int tile_i, tile_j; // XCD-aware workgroup -> tile map (as gemm_conv_f32.hip)
   {
-    int const bid = blockIdx.x, nb = p.tiles_i * p.tiles_j;
+    int const bid = BODAHIP_BID, nb = p.tiles_i * p.tiles_j;
     int const q = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
     int const nid = ((xcd < rr) ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
     int const group_sz = GROUP_I * p.tiles_j, gid = nid / group_sz, first_i = gid * GROUP_I;

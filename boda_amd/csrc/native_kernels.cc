@@ -60,7 +60,7 @@ bool native_kernels_t::is_native_func_name(string const &fn) {
 void native_kernels_t::check_compile_time(rtc_func_info_t const &fi) {
   string const &fn = fi.op.get_func_name();
   if (fn == "hip_sgemm" || fn == "cublas_sgemm" || fn == "hip_sgemm_bf16") return;
-  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd" || fn == "hip_conv_nhwc" || fn == "hip_conv_nhwc_grp" || fn == "hip_conv_nhwc_multi") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
+  if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd" || fn == "hip_conv_nhwc" || fn == "hip_conv_nhwc_grp" || fn == "hip_conv_nhwc_multi" || fn == "hip_conv_nhwc_set") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
   rt_err("unknown/unhandled native hip function: " + fn);
 }
 void native_kernels_t::set_tune(string const &key, string const &val) {
@@ -301,7 +301,7 @@ static bool plan_patch_bf16(conv_geom_t const &g, int num_cus, plan_t &p) {
 // (buffer_load ... lds), 32x32x16 bf16 MFMA.  g.C is the STORED channel count (a multiple of 8).  tile: "BIxBJxBKxWIxWJ[xMINW]" or "".
 // grp_pad > 0: horizontally fused convolutions (-DGROUPS=1): g.OC is the stacked, padded out_chan count, every member starts at a multiple of grp_pad -> tiles
 // may not be taller than grp_pad and must divide it; no K slices.
-static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &tile, bool out_f32, int grp_pad = 0) {
+static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &tile, bool out_f32, int grp_pad = 0, bool allow_split = true) {
   if (g.C % 8) unsup_err("hip_conv_nhwc: in_chan of a channels-last bf16 tensor must be a multiple of 8 (the layout pass pads)");
   if (g.H >= 32768 || g.W >= 32768) unsup_err("hip_conv_nhwc: planes of 32768 rows / columns or more are not supported");
   long const Nj = (long)g.B * g.OH * g.OW;
@@ -335,7 +335,7 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
     //     ~45 % of the CU's bf16 MFMA rate (AlexNet / NiN conv2, 5x5 96->256 at 256 images: 128x128 305, 128x256 254, 256x256 243 us).
     static cand_t const cands[] = {{128, 128, 2, 2, 2}, {64, 128, 1, 4, 2}, {64, 64, 2, 2, 2}, {32, 128, 1, 4, 2}, {32, 64, 1, 2, 2}, {128, 256, 2, 4, 1}, {256, 256, 4, 4, 1}};
     long const nk = (kc + c.BK / 8 - 1) / (c.BK / 8);
-    bool const may_split = getenv("BODAHIP_NO_NHWC_SPLITK") == nullptr && !grp_pad;
+    bool const may_split = getenv("BODAHIP_NO_NHWC_SPLITK") == nullptr && !grp_pad && allow_split;
     double best = 1e30;
     for (cand_t const &cd : cands) {
       if (grp_pad && (cd.bi > grp_pad || grp_pad % cd.bi)) continue;
@@ -1161,6 +1161,142 @@ void native_kernels_t::conv_nhwc_multi(int n, multi_member_t const *ms, bool out
   last_launch.flops = flops; last_launch.algo_bytes = bytes;
 }
 
+// ---- hip_conv_nhwc_set: a few INDEPENDENT channels-last convolutions, each on ITS OWN specialised kernel code, as one launch ---------------------------------------
+// The counterpart of conv_nhwc_multi for the members that deserve their specialisation (an inception module's 3x3 / 5x5 / pool-projection convolutions: three launches
+// of 100-200 tiles each on 256 CUs, which a dependency-wired hipGraph does not overlap -- a cross-branch edge costs about what such a kernel takes): the kernel
+// sources are instantiated once per distinct member plan inside one translation unit (BODAHIP_AS_MEMBER: kernels/conv_nhwc_bf16.hip, conv_nhwc_patch_bf16.hip become
+// __device__ functions), a wrapper kernel maps its workgroup to (member, tile) and calls the member's code.  Same code, same arguments, same tile -> same bits as the
+// member's own launch.  Members that cannot join (another workgroup size, K slices) are launched on their own by the same call.
+struct set_member_plan_t { plan_t p; gemm_args_t ga; long tiles; int variant; double tile_cost; };
+static char const *const k_set_macros[] = {"BI", "BJ", "BK", "WI", "WJ", "MINW", "CIN", "KH", "KW", "SY", "SX", "PY", "PX", "CH", "CW", "COH", "COW", "RELU", "OUT_F32", "NBUF", "CG",
+                                           "ADIRECT", "PF", "BPF", "WPITCH", "DBUF", "ABLATE", "GROUP_I", "IN_F32", "SPLITK", "INTERLEAVE", "GROUPS", "KNAME", "BODAHIP_BID"};
+static string set_kernel_source(std::vector<plan_t const *> const &variants, int threads, int minw) {
+  std::ostringstream o;
+  o << "// generated by native_kernels.cc (conv_nhwc_set): " << variants.size() << " member specialisations in one kernel\n";
+  o << "#define BODAHIP_AS_MEMBER 1\n#define BODAHIP_ARGS_DEFINED 1\n";
+  o << "struct gemm_args_t { float const *I; float const *J; float *D; float const *bias; int Mi, Nj, K; int ldI, ldJ, ldD; int C, H, W, OH, OW; int tiles_i, tiles_j; int splitk, kt_per;\n"
+       "  float *ws; long ws_slab; unsigned I_bytes, J_bytes; unsigned D_bytes; int out_ctot, out_coff; int const *ktab; int ktab_n; long bsI, bsJ, bsD; };\n"
+       "struct grp_args_t { int n; int oc0[4]; int noc[4]; void *D[4]; unsigned D_bytes[4]; int ctot[4]; int coff[4]; };\n";
+  for (size_t v = 0; v < variants.size(); ++v) {
+    plan_t const &p = *variants[v];
+    for (string const &d : p.defs) {   // "-DNAME=value"
+      size_t const eq = d.find('=');
+      if (d.compare(0, 2, "-D") != 0 || eq == string::npos) rt_err("conv_nhwc_set: unexpected kernel option '" + d + "'");
+      o << "#define " << d.substr(2, eq - 2) << " " << d.substr(eq + 1) << "\n";
+    }
+    o << "#define KNAME run\nnamespace member_v" << v << " {\n" << (p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : k_src_conv_nhwc_bf16) << "\n}\n";
+    for (char const *m : k_set_macros) o << "#undef " << m << "\n";
+  }
+  o << "struct set_args_t { gemm_args_t const *m; int const *ends; int const *variant; int n; };\n";
+  // the largest LDS need of the members, as a constant expression
+  o << "namespace { constexpr int set_max(int a, int b) { return a > b ? a : b; }\nconstexpr int kSmemAll = ";
+  for (size_t v = 0; v < variants.size(); ++v) o << "set_max(member_v" << v << "::member_smem_bytes, ";
+  o << "16"; for (size_t v = 0; v < variants.size(); ++v) o << ")"; o << "; }\n";
+  for (size_t v = 0; v < variants.size(); ++v) o << "static_assert(member_v" << v << "::member_threads == " << threads << ", \"members of a set share one workgroup size\");\n";
+  o << "extern \"C\" __global__ __launch_bounds__(" << threads << ", " << minw << ") void bodahip_conv_nhwc_set(set_args_t const a) {\n"
+       "  __shared__ __attribute__((aligned(1024))) char smem[kSmemAll];\n"
+       "  int const bid = blockIdx.x;\n"
+       "  int k = 0; while (k + 1 < a.n && bid >= __builtin_amdgcn_readfirstlane(a.ends[k])) ++k;      // (workgroup-uniform; a set has a handful of members)\n"
+       "  int const local = bid - (k ? __builtin_amdgcn_readfirstlane(a.ends[k - 1]) : 0);\n"
+       "  int const var = __builtin_amdgcn_readfirstlane(a.variant[k]);\n"
+       "  gemm_args_t p;\n"
+       "  { int const *src = reinterpret_cast<int const *>(a.m + k); int *dst = reinterpret_cast<int *>(&p);\n"
+       "#pragma unroll\n"
+       "    for (int i = 0; i < (int)(sizeof(gemm_args_t) / 4); ++i) dst[i] = __builtin_amdgcn_readfirstlane(src[i]); }\n"
+       "  switch (var) {\n";
+  for (size_t v = 0; v < variants.size(); ++v) o << "    case " << v << ": member_v" << v << "::run(p, local, smem); break;\n";
+  o << "    default: break;\n  }\n}\n";
+  return o.str();
+}
+
+static gemm_args_t nhwc_member_args(native_kernels_t::multi_member_t const &mm, tile_cfg_t const &cfg, bool out_f32, char const *what) {
+  conv_geom_t const &g = mm.g;
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  int const ctot = mm.out_ctot > 0 ? mm.out_ctot : g.OC, coff = mm.out_ctot > 0 ? mm.out_coff : 0;
+  uint64_t const in_bytes = (uint64_t)g.B * g.C * g.H * g.W * 2, f_bytes = (uint64_t)g.OC * Kt * 2, out_bytes = (uint64_t)Nj * ctot * (out_f32 ? 4 : 2);
+  if (Nj > 0x7fffffffl || Kt > 0x7fffffffl || in_bytes >= 0x7ffffff0ull || f_bytes >= 0x7ffffff0ull || out_bytes >= 0x7ffffff0ull) unsup_err(string(what) + ": tensors of 2 GiB or more are not supported (32-bit buffer offsets)");
+  gemm_args_t ga; memset(&ga, 0, sizeof(ga));
+  ga.I = (float const *)mm.filts; ga.J = (float const *)mm.in; ga.D = (float *)mm.out; ga.bias = mm.biases;
+  ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
+  ga.I_bytes = (unsigned)f_bytes; ga.J_bytes = (unsigned)in_bytes; ga.D_bytes = (unsigned)out_bytes; ga.out_ctot = ctot; ga.out_coff = coff; ga.splitk = 1;
+  ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
+  return ga;
+}
+
+void native_kernels_t::conv_nhwc_set(int n, multi_member_t const *ms, bool const *patch_filts, bool out_f32) {
+  if (n < 1 || n > 16) unsup_err("hip_conv_nhwc_set: 1..16 members");
+  std::vector<set_member_plan_t> mp((size_t)n);
+  std::vector<int> in_set, alone;
+  for (int m = 0; m < n; ++m) {
+    conv_geom_t const &g = ms[m].g;
+    if (!((long)g.B * g.OH * g.OW) || !g.OC) rt_err("hip_conv_nhwc_set: empty member");
+    set_member_plan_t &q = mp[(size_t)m];
+    q.p = patch_filts[m] ? plan_conv_nhwc_patch(g, host->nh_num_cus(), string(), out_f32) : plan_conv_nhwc(g, host->nh_num_cus(), string(), out_f32, 0, /*allow_split=*/false);
+    q.ga = nhwc_member_args(ms[m], q.p.cfg, out_f32, "hip_conv_nhwc_set");
+    q.tiles = (long)q.ga.tiles_i * q.ga.tiles_j;
+    q.tile_cost = (double)q.p.cfg.BI * q.p.cfg.BJ * (double)g.C * g.KH * g.KW;
+    (q.p.cfg.threads() == 256 ? in_set : alone).push_back(m);
+  }
+  if (in_set.size() < 2) { alone.insert(alone.end(), in_set.begin(), in_set.end()); in_set.clear(); }
+  double flops = 0, bytes = 0;
+  for (int m = 0; m < n; ++m) { conv_geom_t const &g = ms[m].g; double const Nj = (double)g.B * g.OH * g.OW, Kt = (double)g.C * g.KH * g.KW;
+    flops += 2.0 * Nj * g.OC * Kt; bytes += 2.0 * ((double)g.B * g.C * g.H * g.W + (double)g.OC * Kt) + (out_f32 ? 4.0 : 2.0) * Nj * g.OC + 4.0 * g.OC; }
+  for (int m : alone) {   // members with another workgroup size: their own launch, the plan they would have taken anyway
+    kernel_t &k = get_kernel(impl, host, mp[(size_t)m].p);
+    void *params[] = {&mp[(size_t)m].ga};
+    hip_err_chk(host->nh_launch(k.func, (uint32_t)mp[(size_t)m].tiles, 1, (uint32_t)mp[(size_t)m].p.cfg.threads(), params), "hipModuleLaunchKernel(conv_nhwc_set, lone member)");
+  }
+  if (!in_set.empty()) {
+    // longest tiles first: the dispatcher hands workgroups out in grid order
+    std::stable_sort(in_set.begin(), in_set.end(), [&](int x, int y) { return mp[(size_t)x].tile_cost > mp[(size_t)y].tile_cost; });
+    std::vector<plan_t const *> variants; std::vector<string> vkeys; int minw = 8;
+    for (int m : in_set) {
+      string key = mp[(size_t)m].p.kname; for (auto const &d : mp[(size_t)m].p.defs) key += " " + d;
+      size_t v = 0; while (v < vkeys.size() && vkeys[v] != key) ++v;
+      if (v == vkeys.size()) { vkeys.push_back(key); variants.push_back(&mp[(size_t)m].p); }
+      mp[(size_t)m].variant = (int)v; minw = std::min(minw, mp[(size_t)m].p.cfg.MINW);
+    }
+    string skey = "set:"; for (auto const &vk : vkeys) skey += "[" + vk + "]";
+    auto kit = impl->kernels.find(skey);
+    if (kit == impl->kernels.end()) {
+      if (host->nh_capturing()) rt_err("graph capture: this hip_conv_nhwc_set kernel is not compiled yet -- run the call list once before capturing it");
+      string log;
+      std::vector<char> code = hiprtc_compile(set_kernel_source(variants, 256, std::max(1, minw)), "bodahip_conv_nhwc_set", host->nh_arch(), vect_string(), &log, true);
+      kernel_t k;
+      hip_err_chk(hipModuleLoadData(&k.mod, code.data()), "hipModuleLoadData(conv_nhwc_set)");
+      hip_err_chk(hipModuleGetFunction(&k.func, k.mod, "bodahip_conv_nhwc_set"), "hipModuleGetFunction(conv_nhwc_set)");
+      kit = impl->kernels.emplace(skey, k).first;
+    }
+    // member table (arguments, grid ends, variant ids) in device memory: one copy per distinct call
+    size_t const ns = in_set.size();
+    std::vector<gemm_args_t> args; std::vector<int> ends, vars; long tot = 0;
+    for (int m : in_set) { args.push_back(mp[(size_t)m].ga); tot += mp[(size_t)m].tiles; ends.push_back((int)tot); vars.push_back(mp[(size_t)m].variant); }
+    if (tot > 0x7fffffffl) unsup_err("hip_conv_nhwc_set: too many tiles");
+    size_t const ab = ns * sizeof(gemm_args_t), eo = (ab + 255) & ~size_t(255), vo = eo + ((ns * 4 + 255) & ~size_t(255)), total = vo + ns * 4;
+    string tkey = "settab:";
+    { uint64_t h = 1469598103934665603ull; auto mix = [&](void const *d, size_t nb) { for (size_t i = 0; i < nb; ++i) { h ^= ((unsigned char const *)d)[i]; h *= 1099511628211ull; } };
+      mix(args.data(), ab); mix(ends.data(), ns * 4); mix(vars.data(), ns * 4); mix(skey.data(), skey.size()); tkey += std::to_string(h) + ":" + std::to_string(total); }
+    auto it = impl->ktabs.find(tkey);
+    if (it == impl->ktabs.end()) {
+      if (host->nh_capturing()) rt_err("graph capture: the member table of this hip_conv_nhwc_set call is not on the device yet -- run the call list once before capturing it");
+      void *dev = nullptr;
+      hip_err_chk(hipMalloc(&dev, total), "hipMalloc(set table)");
+      hip_err_chk(hipMemcpyAsync(dev, args.data(), ab, hipMemcpyHostToDevice, host->nh_stream()), "hipMemcpyAsync(set args)");
+      hip_err_chk(hipMemcpyAsync((char *)dev + eo, ends.data(), ns * 4, hipMemcpyHostToDevice, host->nh_stream()), "hipMemcpyAsync(set ends)");
+      hip_err_chk(hipMemcpyAsync((char *)dev + vo, vars.data(), ns * 4, hipMemcpyHostToDevice, host->nh_stream()), "hipMemcpyAsync(set variants)");
+      hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize(set table)");
+      it = impl->ktabs.emplace(tkey, dev).first;
+    }
+    struct { gemm_args_t const *m; int const *ends; int const *variant; int n; } sa;
+    sa.m = (gemm_args_t const *)it->second; sa.ends = (int const *)((char *)it->second + eo); sa.variant = (int const *)((char *)it->second + vo); sa.n = (int)ns;
+    void *params[] = {&sa};
+    hip_err_chk(host->nh_launch(kit->second.func, (uint32_t)tot, 1, 256, params), "hipModuleLaunchKernel(conv_nhwc_set)");
+    last_launch.cfg = mp[(size_t)in_set[0]].p.cfg; last_launch.grid = (uint32_t)tot; last_launch.block = 256;
+  } else { last_launch.cfg = mp[0].p.cfg; last_launch.grid = (uint32_t)mp[0].tiles; last_launch.block = (uint32_t)mp[0].p.cfg.threads(); }
+  last_launch.kernel = "bodahip_conv_nhwc_set(x" + std::to_string(in_set.size()) + (alone.empty() ? string() : ("+" + std::to_string(alone.size()))) + ")";
+  last_launch.flops = flops; last_launch.algo_bytes = bytes;
+}
+
 // Horizontally fused channels-last convolutions (hip_conv_nhwc_grp): n <= 4 members that read the same `in` with the same kernel geometry; filts / biases hold
 // the members stacked along out_chan, member m at rows [m_oc0, m_oc0 + noc[m]) with m_oc0 = sum of the earlier members' out_chans each rounded up to `pad`.
 void native_kernels_t::conv_nhwc_grp(void const *filts, float const *biases, void const *in, conv_geom_t const &g, bool out_f32, int n, int const *noc, void *const *outs,
@@ -1267,6 +1403,26 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
   else if (t == "Convolution") {
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
     bool const multi = op.has_func_name() && op.get_func_name() == "hip_conv_nhwc_multi";
+    if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc_set") {   // the wrapper kernel of the members' specialisations (and the kernels of members that stay alone)
+      int const n = (int)op.get_dims("multi").dsz("n"); bool const out_f32 = op.get_dims("out_0").tn == "float";
+      std::vector<plan_t> plans; std::vector<plan_t const *> variants; std::vector<string> vkeys; int minw = 8; size_t bytes = 0; string desc;
+      for (int m = 0; m < n; ++m) { string const sfx = "_" + std::to_string(m);
+        dims_t f = op.get_dims("filts" + sfx); bool const pf = f.sz() == 5;
+        if (pf) f = dims_t({f.dims(3), f.dims(1), f.dims(2), f.dims(0) * 8}, {"out_chan", "y", "x", "in_chan"}, f.tn);
+        bool const relu_m = op.has("relu_mask") ? (((op.get_u32("relu_mask") >> m) & 1u) != 0) : relu;
+        conv_geom_t const g = geom_from_dims(f, op.get_dims("in" + sfx), op.get_dims("out" + sfx), op.get_dims("stride" + sfx), op.get_dims("in_pad" + sfx), relu_m);
+        plans.push_back(pf ? plan_conv_nhwc_patch(g, num_cus, string(), out_f32) : plan_conv_nhwc(g, num_cus, string(), out_f32, 0, false)); }
+      for (plan_t const &q : plans) {
+        if (q.cfg.threads() != 256) { if (!arch.empty()) bytes += compile_plan(q, arch, &log).size(); desc += " alone:" + q.kname + ":" + q.cfg.str(); continue; }
+        string key = q.kname; for (auto const &d : q.defs) key += " " + d;
+        if (std::find(vkeys.begin(), vkeys.end(), key) == vkeys.end()) { vkeys.push_back(key); variants.push_back(&q); desc += " " + q.kname + ":" + q.cfg.str(); }
+        minw = std::min(minw, q.cfg.MINW);
+      }
+      if (plan_out) *plan_out = "bodahip_conv_nhwc_set variants=" + std::to_string(variants.size()) + desc;
+      if (arch.empty()) return 0;
+      if (variants.size() >= 1) bytes += hiprtc_compile(set_kernel_source(variants, 256, std::max(1, minw)), "bodahip_conv_nhwc_set", arch, vect_string(), &log, true).size();
+      return bytes;
+    }
     conv_geom_t g; memset(&g, 0, sizeof(g));
     if (!multi) g = geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims(op.has("out") ? "out" : "out_0"), op.get_dims("stride"), op.get_dims("in_pad"), relu);
     conv_geom_t g2; int pry = 0, prx = 0;
@@ -1420,7 +1576,8 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     conv_nhwc_grp(host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), host->nh_var_ptr(inm), g, out_f32, n, noc, outs, ctot, coff, (int)grp.dims(n));
     return;
   }
-  if (fn == "hip_conv_nhwc_multi") {
+  if (fn == "hip_conv_nhwc_multi" || fn == "hip_conv_nhwc_set") {
+    bool const is_set = (fn == "hip_conv_nhwc_set");   // (a set's members keep their own specialised kernels -- implicit-GEMM or input-patch form, by the dims of their filts)
     // n independent channels-last convolutions (REF `multi`: dims n = the member count), member m: vars filts_<m> (out_chan:y:x:in_chan) biases_<m> in_<m> out_<m>,
     // REFs stride_<m> in_pad_<m>, optional by-value out_chan_off_<m>; ReLU: conv_has_relu for all, or bit m of the optional uint32 relu_mask
     auto mi = am.find("multi");
@@ -1429,11 +1586,15 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     if (n < 1 || n > 256) unsup_err("hip_conv_nhwc_multi: 1..256 members");
     bool const relu_all = fi.op.get_u32("conv_has_relu") != 0; bool const has_mask = fi.op.has("relu_mask"); uint32_t const mask = has_mask ? fi.op.get_u32("relu_mask") : 0u;
     if (has_mask && n > 32) unsup_err("hip_conv_nhwc_multi: relu_mask covers 32 members");
-    std::vector<native_kernels_t::multi_member_t> ms((size_t)n); string out_tn;
+    std::vector<native_kernels_t::multi_member_t> ms((size_t)n); string out_tn; std::vector<char> patch_f((size_t)n, 0);
     for (int m = 0; m < n; ++m) {
       string const sfx = "_" + std::to_string(m);
       string const fnm = var_of(am, "filts" + sfx), bnm = var_of(am, "biases" + sfx), inm = var_of(am, "in" + sfx), onm = var_of(am, "out" + sfx);
-      dims_t const f = host->nh_var_dims(fnm), bi = host->nh_var_dims(bnm), in = host->nh_var_dims(inm), out = host->nh_var_dims(onm);
+      dims_t f = host->nh_var_dims(fnm); dims_t const bi = host->nh_var_dims(bnm), in = host->nh_var_dims(inm), out = host->nh_var_dims(onm);
+      if (is_set && f.sz() == 5) {   // the input-patch form F'[in_grp][ky][kx][out_chan][8]
+        if (!(f.names(0) == "in_grp" && f.names(1) == "y" && f.names(2) == "x" && f.names(3) == "out_chan" && f.names(4) == "in_chan8" && f.dims(4) == 8)) rt_err("hip_conv_nhwc_set: 5-d filts must be in_grp:y:x:out_chan:in_chan8(=8), got " + f.pretty_str());
+        f = dims_t({f.dims(3), f.dims(1), f.dims(2), f.dims(0) * 8}, {"out_chan", "y", "x", "in_chan"}, f.tn); patch_f[(size_t)m] = 1;
+      }
       need_float(bi, "biases");
       if (f.tn != "bfloat16" || in.tn != "bfloat16") unsup_err("hip_conv_nhwc_multi: filts / in must have type bfloat16");
       if (out.tn != "bfloat16" && out.tn != "float") unsup_err("hip_conv_nhwc_multi: out must have type bfloat16 or float");
@@ -1460,6 +1621,12 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
       if (!g.SY || !g.SX) rt_err("hip_conv_nhwc_multi: zero stride");
       if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW) rt_err("hip_conv_nhwc_multi: out dims do not match in / filts / stride / in_pad (member " + std::to_string(m) + ")");
       mm.filts = host->nh_var_ptr(fnm); mm.biases = (float const *)host->nh_var_ptr(bnm); mm.in = host->nh_var_ptr(inm); mm.out = host->nh_var_ptr(onm);
+    }
+    if (is_set) {
+      std::vector<char> pf(patch_f); bool pfb[16]; if (n > 16) unsup_err("hip_conv_nhwc_set: 1..16 members");
+      for (int m = 0; m < n; ++m) pfb[m] = pf[(size_t)m] != 0;
+      conv_nhwc_set(n, ms.data(), pfb, out_tn == "float");
+      return;
     }
     tile_override_t const tov(impl, "conv_tile", fi.op);
     conv_nhwc_multi(n, ms.data(), out_tn == "float");

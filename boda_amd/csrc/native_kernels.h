@@ -13,6 +13,8 @@
 //                                       out_0 .. out_3): an inception module's same-input 1x1 convs, a ResNet stage's branch1 + branch2a
 //     hip_conv_nhwc_multi               up to 256 INDEPENDENT hip_conv_nhwc convolutions (own tensors, any geometries) as ONE launch: the tile lists of a per-layer op list's
 //                                       small members handed to the hardware dispatcher together, longest first (kernels/conv_nhwc_multi_bf16.hip)
+//     hip_conv_nhwc_set                 up to 16 independent hip_conv_nhwc convolutions, each on ITS OWN specialised kernel code, as one launch: an inception module's
+//                                       3x3 / 5x5 / pool-projection convolutions (the kernel sources instantiated per member inside one wrapper kernel, built at run time)
 //     hip_conv_winograd                 same contract as hip_conv; 3x3 / stride-1 layers through F(2x2,3x3) Winograd (mrd <= ~2e-3)
 // and lands them on kernels/gemm_conv_f32.hip (and, for short-K 1x1 convs with a long pel axis, kernels/k1_stream_f32.hip),
 // specialised with hiprtc per shape class at first use.
@@ -78,6 +80,8 @@ struct native_kernels_t {
   // several independent channels-last convolutions as ONE launch (kernels/conv_nhwc_multi_bf16.hip); members: raw device pointers + geometry (g.C = stored channels)
   struct multi_member_t { void const *filts; float const *biases; void const *in; void *out; conv_geom_t g; int out_ctot, out_coff; };
   void conv_nhwc_multi(int n, multi_member_t const *members, bool out_f32);
+  // a few independent channels-last convolutions, each on its own specialised kernel code (implicit-GEMM or input-patch form), as one launch (wrapper kernel built at run time)
+  void conv_nhwc_set(int n, multi_member_t const *members, bool const *patch_filts, bool out_f32);
   void conv_winograd(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, int out_ctot, int out_coff);
 
   // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"; key "k1_stream" -> "off" | "WIxWJxOCBxCB[xMINW]";

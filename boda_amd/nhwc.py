@@ -197,6 +197,38 @@ def annotate_multi(annos: List[Op]) -> Op:
     return Op({"type": "Convolution", "func_name": MULTI_FUNC}, nv)
 
 
+SET_FUNC = "hip_conv_nhwc_set"
+
+
+def set_eligible(anno: Op) -> bool:
+    """A member of a set: any hip_conv_nhwc function -- implicit-GEMM or input-patch form of filts (the member keeps its own specialised kernel code); not the
+    space-to-depth conv1 form, whose input layout belongs to the net's first layout pass."""
+    return anno.get_func_name() == FUNC and not anno.has("nhwc_s2d")
+
+
+def annotate_set(annos: List[Op]) -> Op:
+    """`hip_conv_nhwc_set`: 2..16 annotated hip_conv_nhwc ops -- independent convolutions -- as ONE function whose launch runs every member on ITS OWN specialised
+    kernel code (kernels/conv_nhwc_bf16.hip or conv_nhwc_patch_bf16.hip, instantiated per member inside one wrapper kernel that the backend builds at run time).
+    Where hip_conv_nhwc_multi trades the specialisation for any number of members, a set keeps it for a few: an inception module's 3x3 / 5x5 / pool-projection
+    convolutions, which are three launches of 100-200 tiles each on 256 CUs.  Args as hip_conv_nhwc_multi (suffix _<m>); results are those of the members' own
+    launches, bit for bit (members that would slice K on their own run unsliced here: the other members fill the chip)."""
+    if not (2 <= len(annos) <= 16):
+        raise UnsupErr("hip_conv_nhwc_set: 2..16 members")
+    nv = {"multi": Nda(dims=Dims(("n",), (len(annos),), "none"), tn="none")}
+    relu = [a.get_u32("conv_has_relu") for a in annos]
+    for m, a in enumerate(annos):
+        if not set_eligible(a):
+            raise UnsupErr("hip_conv_nhwc_set: members must be hip_conv_nhwc functions (not the space-to-depth form)")
+        if a.get_dims("out").tn != annos[0].get_dims("out").tn:
+            raise UnsupErr("hip_conv_nhwc_set: members differ in output type")
+        for an in _MULTI_MEMBER_ARGS + ("kern_sz",):
+            nv[f"{an}_{m}"] = a.nda_vals[an]
+    nv["conv_has_relu"] = Nda(dims=None, tn="uint32_t", v=(int(all(relu)),))
+    if any(relu) != all(relu):     # (ReLU is a constant of each member's own kernel instantiation: members may differ)
+        nv["relu_mask"] = Nda(dims=None, tn="uint32_t", v=(sum(int(bool(r)) << m for m, r in enumerate(relu)),))
+    return Op({"type": "Convolution", "func_name": SET_FUNC}, nv)
+
+
 def multi_arg_names(n: int) -> List[str]:
     return ["multi"] + [f"{an}_{m}" for m in range(n) for an in _MULTI_MEMBER_ARGS]
 

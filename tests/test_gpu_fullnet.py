@@ -419,7 +419,7 @@ def test_sibling_fusion_is_bit_identical(rtc):
     nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
     res, ncalls = [], []
     for fuse in (True, False):
-        fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc"), fuse_siblings=fuse)
+        fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc"), fuse_siblings=fuse, fuse_levels=False)   # (level sets: their own test below)
         fwd.init(cp, op_params=params)
         try:
             io = {"data": data}
@@ -433,6 +433,42 @@ def test_sibling_fusion_is_bit_identical(rtc):
         finally:
             fwd.release()
     assert ncalls[1] - ncalls[0] == 18
+    for n in nodes:
+        assert np.array_equal(res[0][n], res[1][n]), n
+
+
+def test_level_set_fusion_is_bit_identical(rtc, monkeypatch):
+    """Channels-last GoogLeNet with the independent convolutions that fill each inception Concat (3x3, 5x5, pool projection) as ONE hip_conv_nhwc_set launch --
+    every member on its own specialised kernel code -- against the same net with those convs launched one by one: every node equal bit for bit, 18 launches fewer.
+    (K slices off for both runs: a lone tile-starved member may slice K, a member of a set never does.)"""
+    from boda_amd.cnn_op import OpTune
+    monkeypatch.setenv("BODAHIP_NO_NHWC_SPLITK", "1")
+    cp = googlenet_conv(3)
+    params = _params(cp)
+    data = bo.gen_conv_in(*cp.nodes["data"].sizes)
+    nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
+    res, ncalls = [], []
+    for fuse in (True, False):
+        fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc"), fuse_levels=fuse)
+        fwd.init(cp, op_params=params)
+        try:
+            io = {"data": data}
+            fwd.run_fwd(["data"], io, nodes)
+            res.append(io); ncalls.append(len(fwd.fwd_calls))
+            if fuse:
+                # every inception module's 3x3 / 5x5 / pool-projection convs share a set; the auxiliary heads' convs join the trunk's sets of their level
+                for k in range(1, 10):
+                    assert any({f"icp{k}_out1", f"icp{k}_out2", f"icp{k}_out3"} <= set(g) for g in fwd.level_sets), (k, fwd.level_sets)
+                assert any("cls1_reduction" in g for g in fwd.level_sets) and len(fwd.level_sets) >= 9
+                n = fwd.capture_graph(parallel=True); out = cp.out_node()
+                deps = fwd.call_deps; tags = [c.tag for c in fwd.fwd_calls]
+                i_set = next(i for i, t in enumerate(tags) if "icp1_out1" in t.split("+"))       # the set runs after the sibling group (its reduce convs) and after the module's pool
+                assert {tags[d] for d in deps[i_set]} == {"icp1_reduction1+icp1_reduction2+icp1_out0", "icp1_pool"}, [tags[d] for d in deps[i_set]]
+                rtc.set_var_to_zero(fwd.var_of(out)); fwd.run_graph()
+                assert np.array_equal(fwd._fetch(out), io[out])
+        finally:
+            fwd.release()
+    assert ncalls[1] - ncalls[0] >= 18
     for n in nodes:
         assert np.array_equal(res[0][n], res[1][n]), n
 

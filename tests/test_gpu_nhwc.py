@@ -377,6 +377,53 @@ def test_multi_problem_launch_is_bit_identical_to_separate_launches(be, out, til
         ol.release()
 
 
+@pytest.mark.parametrize("out", ["", "f32"])
+def test_level_set_is_bit_identical_to_separate_launches(be, out):
+    """hip_conv_nhwc_set: an inception module's independent convolutions -- 3x3 and 5x5 on the input-patch kernel, 1x1 on the implicit GEMM -- in ONE launch, every
+    member on ITS OWN specialised kernel code (the kernel sources instantiated per member inside a wrapper kernel built at run time).  Same code, same arguments,
+    same tiles: the results are those of the members' own launches bit for bit; a member with another workgroup size is launched on its own by the same call."""
+    from boda_amd import nhwc
+    from boda_amd.rtc import RtcArg, RtcFuncCall, RtcFuncInfo
+    rtc = be.rtc
+    shapes = [(64, 96, 14, 14, 208, 3, 3, 1, 1), (64, 16, 14, 14, 48, 5, 5, 1, 2), (64, 480, 14, 14, 64, 1, 1, 1, 0), (8, 128, 28, 28, 192, 3, 3, 1, 1), (8, 256, 28, 28, 64, 1, 1, 1, 0),
+              (3, 40, 15, 15, 100, 3, 3, 1, 1), (64, 160, 7, 7, 320, 3, 3, 1, 1), (64, 832, 7, 7, 128, 1, 1, 1, 0)]
+    tune = OpTune(hip_dtype="bf16", hip_layout="nhwc", hip_out=out)
+    ol = _OpList(rtc, shapes, lambda i: tune, "ls")
+    fn = "ls_set"
+    try:
+        want, kernels = [], set()
+        for i, c in enumerate(ol.calls):
+            rtc.run(c); ll = rtc.last_launch(); kernels.add(ll["kernel"])
+            assert "_s" not in ll["cfg"], (shapes[i], ll)          # (shapes the planner does not slice: the set never slices)
+            want.append(ol.out(i))
+        assert kernels == {"bodahip_conv_nhwc_bf16", "bodahip_conv_nhwc_patch_bf16"}
+        sanno = nhwc.annotate_set(ol.annos)
+        rtc.compile([RtcFuncInfo(fn, "", nhwc.multi_arg_names(len(ol.calls)), sanno)])
+        am = {"multi": RtcArg.ref(sanno.get_dims("multi"))}
+        for m, c in enumerate(ol.calls):
+            for an in ("filts", "biases", "in", "stride", "in_pad", "out"):
+                am[f"{an}_{m}"] = c.arg_map[an]
+        ol.zero_outs()
+        cid = rtc.run(RtcFuncCall(fn, am)); ll = rtc.last_launch()
+        assert ll["kernel"].startswith("bodahip_conv_nhwc_set(x"), ll
+        rtc.finish_and_sync(); assert rtc.get_dur(cid, cid) > 0
+        for i in range(len(ol.calls)):
+            got = ol.out(i)
+            assert np.array_equal(got, want[i]), (shapes[i], ll, int((got != want[i]).sum()))
+        rtc.release_per_call_id_data()
+        rtc.graph_begin(); rtc.run(RtcFuncCall(fn, am)); gid, n1 = rtc.graph_end(); assert n1 == 1
+        for _ in range(2):
+            ol.zero_outs(); rtc.graph_launch(gid); rtc.finish_and_sync()
+            assert all(np.array_equal(ol.out(i), want[i]) for i in range(len(ol.calls)))
+        rtc.graph_destroy(gid)
+    finally:
+        try:
+            rtc.release_func(fn)
+        except Exception:
+            pass
+        ol.release()
+
+
 def test_multi_problem_launch_refuses_what_it_cannot_run(be):
     from boda_amd import nhwc
     from boda_amd.op import UnsupErr

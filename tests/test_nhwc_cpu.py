@@ -177,3 +177,29 @@ def test_multi_problem_annotation_and_plan():
     annos[1].nda_vals["conv_has_relu"].v = (0,)
     mm = nhwc.annotate_multi(annos)
     assert mm.get_u32("conv_has_relu") == 0 and mm.get_u32("relu_mask") == 0b1101
+
+
+def test_level_set_annotation_and_wrapper_kernel():
+    """hip_conv_nhwc_set: members keep their own plans (input-patch or implicit GEMM by the dims of their filts); one wrapper kernel holds one instantiation of the
+    kernel sources per distinct plan and cross-compiles; members with another workgroup size stay launches of their own."""
+    T = OpTune(hip_dtype="bf16", hip_layout="nhwc")
+    shapes = [(64, 96, 14, 14, 208, 3, 3, 1, 1), (64, 16, 14, 14, 48, 5, 5, 1, 2), (64, 480, 14, 14, 64, 1, 1, 1, 0)]      # icp3: 3x3, 5x5, pool projection
+    annos = [add_codegen_annotations(_conv_op(*s), T) for s in shapes]
+    assert all(nhwc.set_eligible(a) for a in annos) and [nhwc.multi_eligible(a) for a in annos] == [False, False, True]
+    m = nhwc.annotate_set(annos)
+    assert m.get_func_name() == "hip_conv_nhwc_set" and m.get_dims("multi").dsz("n") == 3
+    assert m.get_dims("filts_0").names == ("in_grp", "y", "x", "out_chan", "in_chan8") and m.get_dims("filts_2").names == ("out_chan", "y", "x", "in_chan")
+    assert rtc.parse_op_native(m.to_str()) == m.to_str()
+    plan = rtc.explain_plan(m)
+    assert plan.startswith("bodahip_conv_nhwc_set variants=3 ") and plan.count("bodahip_conv_nhwc_patch_bf16:") == 2 and plan.count("bodahip_conv_nhwc_bf16:") == 1
+    for a, part in zip(annos, plan.split()[2:]):      # every member's plan is the one its own launch takes (K slices apart)
+        assert rtc.explain_plan(a).split()[1] == part.split(":")[1] or "_s" in rtc.explain_plan(a).split()[1]
+    assert rtc.prebuild(m) > 20000
+    # two members on the same plan share one instantiation
+    twin = nhwc.annotate_set([annos[2], add_codegen_annotations(_conv_op(*shapes[2]), T)])
+    assert rtc.explain_plan(twin).startswith("bodahip_conv_nhwc_set variants=1 ")
+    with pytest.raises(UnsupErr):
+        nhwc.annotate_set(annos[:1])
+    s2d = add_codegen_annotations(_conv_op(64, 3, 224, 224, 64, 7, 7, 2, 3), T)
+    with pytest.raises(UnsupErr):
+        nhwc.annotate_set([annos[0], s2d])
