@@ -369,7 +369,7 @@ class ConvPipeFwd:
     """`has_conv_fwd_t` with mode=rtc over an rtc backend (src/has_conv_fwd.H:16-25, src/rtc_fwd.cc:43-577)."""
     mode = "rtc"
 
-    def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False, fuse_siblings: bool = True, fuse_levels: bool = True,
+    def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False, fuse_siblings: bool = True, fuse_levels: bool = True, fuse_pools: bool = False,
                  spec_fwd: bool = True):
         self.rtc, self.op_tune = rtc, op_tune or OpTune()
         self.spec_fwd = spec_fwd     # channels-last nets: pool / LRN kernels specialised per geometry (False: the generic kernels with run-time geometry)
@@ -378,6 +378,11 @@ class ConvPipeFwd:
         self.fuse_siblings = fuse_siblings
         self.fuse_levels = fuse_levels       # channels-last nets: the independent convolutions that fill one Concat (an inception module's 3x3 / 5x5 / pool projection) as ONE hip_conv_nhwc_set launch
         self.level_sets: List[Tuple[str, ...]] = []
+        self.fuse_pools = fuse_pools         # channels-last nets: a stride-1 max pooling whose only reader is a 1x1 convolution is taken into that convolution (its input must be non-negative).
+        # Opt-in: measured on GoogLeNet at 64 images it removes nine launches and 0.10 ms of pooling time but the window maximum (nine LDS reads + 32 packed max per B fragment)
+        # costs the convolution more than that -- 78.9 k img/s without, 75.1 k with (tools/r4k.sh)
+        self.fused_pools: Dict[str, str] = {}  # pooling tag -> the convolution that took it
+        self._lazy: Dict[str, FwdCall] = {}    # nodes no call of the forward pass writes any more (a fused pooling's output): the call that materialises one when it is asked for
         self.groups: List[Tuple[str, ...]] = []      # tags of the members of each fused call
         self.per_call_fn, self.enable_double_run = per_call_fn, enable_double_run
         self.fwd_calls: List[FwdCall] = []
@@ -456,6 +461,35 @@ class ConvPipeFwd:
                 s2d_ok = self.nhwc and len(in_readers) == 1 and in_readers[0] is o
                 annos[o.tag] = add_codegen_annotations(cp.conv_op(o), dataclasses.replace(self.op_tune, hip_s2d=int(s2d_ok)) if self.nhwc else self.op_tune)
         in_anno = annos[in_readers[0].tag] if (self.nhwc and len(in_readers) == 1 and in_readers[0].type == "Convolution") else None
+        # pooling -> 1x1 convolution pairs (channels-last nets; an inception module's pool -> pool projection): the pooling is taken into the convolution where that is
+        # legal -- max, stride 1, the convolution its only reader, and a NON-NEGATIVE input (the kernel pads the window with zeros and orders bf16 patterns as integers:
+        # right exactly for values >= 0).  Non-negative nodes: outputs of a conv with fused ReLU / a ReLU / a pooling, LRN or Dropout of such / a Concat of such.
+        conv_in: Dict[str, str] = {}    # convolution tag -> the node it reads instead of its bottom
+        if self.nhwc and self.fuse_pools:
+            nonneg = set()
+            for o in cp.ops:
+                if (o.type == "Convolution" and has_relu[o.tag]) or o.type == "ReLU":
+                    nonneg.add(o.top)
+                elif o.type in ("Pooling", "Dropout") and o.bot in nonneg:
+                    nonneg.add(o.top)
+                elif o.type == "LRN" and o.bot in nonneg and o.lrn[3] > 0 and o.lrn[1] >= 0:
+                    nonneg.add(o.top)
+                elif o.type == "Concat" and all(b in nonneg for b in o.bots):
+                    nonneg.add(o.top)
+            n_readers: Dict[str, List[PipeOp]] = {}
+            for o in cp.ops:
+                if o.tag not in fused:
+                    for b in (o.bots or (o.bot,)):
+                        n_readers.setdefault(b, []).append(o)
+            for o in cp.ops:
+                rd = n_readers.get(o.top, [])
+                if not (o.type == "Pooling" and not o.in_place and o.bot in nonneg and len(rd) == 1 and rd[0].type == "Convolution" and _nhwc.multi_eligible(annos[rd[0].tag])):
+                    continue
+                q = rd[0]; pin = cp.nodes[o.bot]
+                if pin.dsz("chan") % 8 or not _nhwc.pool_fusable(cp.conv_op(q).conv_geom(), (pin.dsz("y"), pin.dsz("x")), o.kern_sz, o.stride, o.in_pad, bool(o.avg_pool)):
+                    continue
+                _nhwc.fuse_pool(annos[q.tag], pin, tuple(o.kern_sz), tuple(o.in_pad))
+                self.fused_pools[o.tag] = q.tag; conv_in[q.tag] = o.bot
         # sibling convolutions (channels-last nets): same bottom node, same kernel / stride / padding / fused ReLU, plain hip_conv_nhwc members
         group_of: Dict[str, List[PipeOp]] = {}     # tag of a member -> its group (list of ops, definition order)
         if self.nhwc and self.fuse_siblings:
@@ -533,7 +567,7 @@ class ConvPipeFwd:
                 anno.nda_vals["conv_has_relu"].v = (has_relu[op.tag],)
                 fn = anno.get_func_name(); gen_fn = f"{fn}__{cp.name}_{op.tag}"
                 rtc.compile([RtcFuncInfo(gen_fn, "", [a for a, _ in NATIVE_ARGS[fn]], anno)]); self._funcs.append(gen_fn)
-                am = {"filts": RtcArg.var(op.tag + "_filts"), "biases": RtcArg.var(op.tag + "_biases"), "in": RtcArg.var(vn(op.bot)),
+                am = {"filts": RtcArg.var(op.tag + "_filts"), "biases": RtcArg.var(op.tag + "_biases"), "in": RtcArg.var(vn(conv_in.get(op.tag, op.bot))),
                       "stride": RtcArg.ref(anno.get_dims("stride")), "in_pad": RtcArg.ref(anno.get_dims("in_pad")), "out": RtcArg.var(op.top)}
                 if op.top in self.slices:
                     cat, c_off, _ = self.slices[op.top]
@@ -541,6 +575,9 @@ class ConvPipeFwd:
                 elif self.nhwc and vd(op.top).dsz("chan") != op.out_chans:
                     am["out_chan_off"] = _u32(0)     # (the var carries zero pad channels: the conv writes the first out_chans of each row)
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(gen_fn, am), fn, cop.flops()))
+            elif self.nhwc and op.type == "Pooling" and op.tag in self.fused_pools:     # taken into its convolution: only materialised when somebody asks for the node
+                self._lazy[op.top] = FwdCall(op.tag, _nhwc.pool_call(vn(op.bot), op.top, vd(op.bot), vd(op.top), op.kern_sz, op.stride, op.in_pad, int(op.avg_pool),
+                                                                      rtc if self.spec_fwd else None), "nhwc_pool")
             elif self.nhwc and op.type == "Pooling":
                 self.fwd_calls.append(FwdCall(op.tag, _nhwc.pool_call(vn(op.bot), op.top, vd(op.bot), vd(op.top), op.kern_sz, op.stride, op.in_pad, int(op.avg_pool),
                                                                       rtc if self.spec_fwd else None), "nhwc_pool"))
@@ -649,7 +686,13 @@ class ConvPipeFwd:
         flops_of = {o.tag: cp.conv_op(o).flops() for o in cp.ops if o.type == "Convolution"}
         for l in sorted(by_level):
             idxs = by_level[l]
-            elig = [i for i in idxs if self.fwd_calls[i].func == _nhwc.FUNC and _nhwc.set_eligible(self._annos[self.fwd_calls[i].tag])]
+            def joins(i: int) -> bool:   # a plain convolution whose own plan does not slice K (a sliced member would run unsliced in a set and set its pace:
+                c = self.fwd_calls[i]    # GoogLeNet's 4x4 auxiliary-head conv, K = 2048 on 8 tiles, 12 us sliced on its own against 44 us as a member)
+                if c.func != _nhwc.FUNC or not _nhwc.set_eligible(self._annos[c.tag]):
+                    return False
+                from .rtc import explain_plan
+                return "_s" not in explain_plan(self._annos[c.tag], getattr(self, "_num_cus", 256)).split()[1]
+            elig = [i for i in idxs if joins(i)]
             out_tn = {self._annos[self.fwd_calls[i].tag].get_dims("out").tn for i in elig}
             if len(elig) < 2 or len(out_tn) != 1:
                 new_calls += [self.fwd_calls[i] for i in idxs]; continue
@@ -702,6 +745,8 @@ class ConvPipeFwd:
             c.call_id = rtc.run(c.rfc)
         rtc.finish_and_sync()
         for v in to_get_vns:
+            if v in self._lazy:      # (a fused pooling's output: no call of the pass writes it)
+                rtc.run(self._lazy[v].rfc); rtc.finish_and_sync()
             if v in self.slices:     # a conv output that only exists as a channel range of its Concat output
                 cat, c_off, ch = self.slices[v]
                 fwd[v] = np.ascontiguousarray(self._fetch(cat)[:, c_off:c_off + ch])

@@ -9,12 +9,12 @@ using namespace bodahip;
 namespace bodahip {
 void *hip_compute_stream(rtc_compute_t *rtc);
 void hip_compute_set_timing(rtc_compute_t *rtc, int mode);
-void hip_compute_graph_begin(rtc_compute_t *rtc);
-uint32_t hip_compute_graph_end(rtc_compute_t *rtc);
-uint32_t hip_compute_graph_launch(rtc_compute_t *rtc, uint32_t id);
-uint32_t hip_compute_graph_num_calls(rtc_compute_t *rtc, uint32_t id);
-void hip_compute_graph_destroy(rtc_compute_t *rtc, uint32_t id);
-uint32_t hip_compute_graph_end_deps(rtc_compute_t *rtc, uint32_t n, uint32_t const *ptr, uint32_t const *idx);
+void hip_any_graph_begin(rtc_compute_t *rtc);      // (hip_multi.cc: one device or all the devices of a multi-device backend)
+uint32_t hip_any_graph_end(rtc_compute_t *rtc);
+uint32_t hip_any_graph_launch(rtc_compute_t *rtc, uint32_t id);
+uint32_t hip_any_graph_num_calls(rtc_compute_t *rtc, uint32_t id);
+void hip_any_graph_destroy(rtc_compute_t *rtc, uint32_t id);
+uint32_t hip_any_graph_end_deps(rtc_compute_t *rtc, uint32_t n, uint32_t const *ptr, uint32_t const *idx);
 native_kernels_t *hip_compute_native(rtc_compute_t *rtc);
 void hip_compute_compile_code_object(rtc_compute_t *rtc, void const *code, size_t code_sz, vect_rtc_func_info_t const &fis);
 p_rtc_compute_t make_hip_multi_compute(std::vector<int> const &device_ordinals);
@@ -145,15 +145,15 @@ int bodahip_copy_from_var(bodahip_ctx *ctx, void *host, const bodahip_dims *dims
   ABI_TRY if (!host) rt_err("null host pointer"); R(ctx).copy_var_to_nda(std::make_shared<nda_t>(to_dims(dims), host), S(vn, "vn")); ABI_CATCH }
 int bodahip_get_raw_ptr(bodahip_ctx *ctx, const char *vn, void **p) { ABI_TRY if (!p) rt_err("null out"); *p = R(ctx).get_var_raw_native_pointer(S(vn, "vn"))->rp_elems(); ABI_CATCH }
 
-int bodahip_graph_begin(bodahip_ctx *ctx) { ABI_TRY hip_compute_graph_begin(&R(ctx)); ABI_CATCH }
+int bodahip_graph_begin(bodahip_ctx *ctx) { ABI_TRY hip_any_graph_begin(&R(ctx)); ABI_CATCH }
 int bodahip_graph_end(bodahip_ctx *ctx, uint32_t *graph_id, uint32_t *n_calls) {
-  ABI_TRY if (!graph_id) rt_err("null graph_id_out"); *graph_id = hip_compute_graph_end(&R(ctx)); if (n_calls) *n_calls = hip_compute_graph_num_calls(&R(ctx), *graph_id); ABI_CATCH }
+  ABI_TRY if (!graph_id) rt_err("null graph_id_out"); *graph_id = hip_any_graph_end(&R(ctx)); if (n_calls) *n_calls = hip_any_graph_num_calls(&R(ctx), *graph_id); ABI_CATCH }
 int bodahip_graph_launch(bodahip_ctx *ctx, uint32_t graph_id, uint32_t *call_id) {
-  ABI_TRY uint32_t const id = hip_compute_graph_launch(&R(ctx), graph_id); if (call_id) *call_id = id; ABI_CATCH }
+  ABI_TRY uint32_t const id = hip_any_graph_launch(&R(ctx), graph_id); if (call_id) *call_id = id; ABI_CATCH }
 int bodahip_graph_end_deps(bodahip_ctx *ctx, uint32_t n_calls, const uint32_t *dep_ptr, const uint32_t *dep_idx, uint32_t *graph_id) {
   ABI_TRY if (!graph_id || !dep_ptr) rt_err("null argument"); static uint32_t const none = 0;
-  *graph_id = hip_compute_graph_end_deps(&R(ctx), n_calls, dep_ptr, dep_idx ? dep_idx : &none); ABI_CATCH }
-int bodahip_graph_destroy(bodahip_ctx *ctx, uint32_t graph_id) { ABI_TRY hip_compute_graph_destroy(&R(ctx), graph_id); ABI_CATCH }
+  *graph_id = hip_any_graph_end_deps(&R(ctx), n_calls, dep_ptr, dep_idx ? dep_idx : &none); ABI_CATCH }
+int bodahip_graph_destroy(bodahip_ctx *ctx, uint32_t graph_id) { ABI_TRY hip_any_graph_destroy(&R(ctx), graph_id); ABI_CATCH }
 int bodahip_get_stream(bodahip_ctx *ctx, void **s) { ABI_TRY if (!s) rt_err("null out"); *s = hip_compute_stream(hip_multi_sub(&R(ctx), 0)); ABI_CATCH }
 int bodahip_get_device_info(bodahip_ctx *ctx, char *arch_buf, size_t n, int *num_cus, int *clock_khz) {
   ABI_TRY

@@ -34,6 +34,12 @@
 namespace bodahip {
 
 void *hip_compute_stream(rtc_compute_t *rtc);
+void hip_compute_graph_begin(rtc_compute_t *rtc);
+uint32_t hip_compute_graph_end(rtc_compute_t *rtc);
+uint32_t hip_compute_graph_launch(rtc_compute_t *rtc, uint32_t id);
+uint32_t hip_compute_graph_num_calls(rtc_compute_t *rtc, uint32_t id);
+void hip_compute_graph_destroy(rtc_compute_t *rtc, uint32_t id);
+uint32_t hip_compute_graph_end_deps(rtc_compute_t *rtc, uint32_t n, uint32_t const *ptr, uint32_t const *idx);
 void hip_compute_set_shard_aware(rtc_compute_t *rtc);
 uint32_t hip_compute_run_shard(rtc_compute_t *rtc, rtc_func_call_t const &rfc, uint32_t blks, uint32_t gid_off, uint32_t gid_last, std::map<string, int64_t> const &var_bias);
 
@@ -43,6 +49,9 @@ struct multi_var_t { dims_t dims; int shard_dim = -1; };   // logical dims; inde
 struct gen_func_t {
   bool has_ix = false, uses_group = false;
   string ix_arg; vect_string use_dims;
+  string n_arg;            // `n=<arg>`: the ids enumerate <by-value uint32 arg> items in all, batch-major over <ix_arg>'s leading `img` (kernels that walk 16-byte chunks or
+                           // several outputs per thread: ids per image = that count / images -- the dims of <ix_arg> alone cannot say it)
+  bool wave_local = false; // `wave_local`: LOC_ID_1D is used only as the lane number, for shuffles between consecutive ids (a shard's first id need not start a wave)
 };
 static bool ident_char(char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_'; }
 static bool has_token(string const &s, char const *tok) {
@@ -73,10 +82,17 @@ static gen_func_t scan_gen_func(string const &all_src, string const &func_name) 
     if (ix != "GLOB_ID_1D") { g.uses_group = true; continue; }
     if (g.has_ix) { g.has_ix = false; g.uses_group = true; return g; }   // (two declarations of the same index: not a form we know)
     g.has_ix = !arg.empty(); g.ix_arg = arg;
-    while (is >> opt) if (startswith(opt, "use_dims=")) {
-      string cur; for (char c : opt.substr(9)) { if (c == ':') { if (!cur.empty()) g.use_dims.push_back(cur); cur.clear(); } else cur.push_back(c); }
-      if (!cur.empty()) g.use_dims.push_back(cur);
+    while (is >> opt) {
+      if (startswith(opt, "use_dims=")) {
+        string cur; for (char c : opt.substr(9)) { if (c == ':') { if (!cur.empty()) g.use_dims.push_back(cur); cur.clear(); } else cur.push_back(c); }
+        if (!cur.empty()) g.use_dims.push_back(cur);
+      } else if (startswith(opt, "n=")) g.n_arg = opt.substr(2);
+      else if (opt == "wave_local") g.wave_local = true;
     }
+  }
+  if (g.wave_local && g.has_ix) {   // only LOC_ID_1D (the lane number) is excused; real workgroup cooperation is not
+    g.uses_group = false;
+    for (char const *t : {"GRP_ID_1D", "LOC_SZ_1D", "LOCSHAR_MEM", "BARRIER_SYNC"}) if (has_token(body, t)) g.uses_group = true;
   }
   return g;
 }
@@ -92,6 +108,44 @@ struct hip_multi_compute_t : public rtc_compute_t {
   std::vector<std::vector<uint32_t>> calls;   // multi call id -> per-device call ids
   std::vector<char> peer_ok;                   // device i reachable from device 0 by hipMemcpyPeerAsync
   bool init_done = false;
+  // hipGraph capture over all devices: every device's stream captures its share of the calls (one graph per device), a replay launches them all and gets ONE call id
+  static constexpr uint32_t kCapturedCallId = 0xfffffffeu;   // (what run() returns while capturing, as the single-device backend)
+  bool capturing = false, cap_skipped = false;               // cap_skipped: some captured call launched nothing on some device (an empty shard)
+  struct mgraph_t { std::vector<uint32_t> ids; uint32_t n_calls = 0; bool live = false; };
+  std::vector<mgraph_t> mgraphs;
+  void graph_begin() {
+    assert_st(init_done);
+    if (capturing) rt_err("graph_begin: a capture is already in progress");
+    for (auto &s : subs) hip_compute_graph_begin(s.get());
+    capturing = true; cap_skipped = false;
+  }
+  uint32_t graph_end_common(uint32_t n_calls, uint32_t const *dep_ptr, uint32_t const *dep_idx) {
+    if (!capturing) rt_err("graph_end: no capture in progress");
+    capturing = false;
+    mgraph_t g; g.live = true;
+    bool const with_deps = dep_ptr != nullptr;
+    string err;
+    for (auto &s : subs) {   // every device's capture is closed whatever happens on another
+      try {
+        if (with_deps && cap_skipped) { (void)hip_compute_graph_end(s.get()); err = "graph_end_deps: a captured call launched nothing on some device (a batch smaller than the device count): dependencies cannot be attributed"; continue; }
+        g.ids.push_back(with_deps ? hip_compute_graph_end_deps(s.get(), n_calls, dep_ptr, dep_idx) : hip_compute_graph_end(s.get()));
+      } catch (std::exception const &e) { err = e.what(); }
+    }
+    if (!err.empty()) rt_err(err);
+    g.n_calls = hip_compute_graph_num_calls(subs[0].get(), g.ids[0]);
+    mgraphs.push_back(g);
+    return (uint32_t)mgraphs.size() - 1;
+  }
+  mgraph_t &get_graph(uint32_t id) { if (id >= mgraphs.size() || !mgraphs[id].live) rt_err("invalid graph id " + std::to_string(id)); return mgraphs[id]; }
+  uint32_t graph_launch(uint32_t id) {
+    if (capturing) rt_err("graph_launch during capture");
+    mgraph_t &g = get_graph(id);
+    std::vector<uint32_t> ids;
+    for (size_t i = 0; i < n(); ++i) ids.push_back(hip_compute_graph_launch(subs[i].get(), g.ids[i]));   // enqueued on every device in turn; the devices replay concurrently
+    calls.push_back(ids);
+    return (uint32_t)calls.size() - 1;
+  }
+  void graph_destroy(uint32_t id) { mgraph_t &g = get_graph(id); for (size_t i = 0; i < n(); ++i) hip_compute_graph_destroy(subs[i].get(), g.ids[i]); g.live = false; }
 
   explicit hip_multi_compute_t(std::vector<int> const &devs_) : devs(devs_) {
     be = "hip";
@@ -268,6 +322,7 @@ struct hip_multi_compute_t : public rtc_compute_t {
     }
     std::vector<uint32_t> ids;
     for (auto &s : subs) ids.push_back(s->run(rfc));   // enqueue on every device's stream in turn; the devices then run concurrently
+    if (capturing) return kCapturedCallId;             // (recorded into every device's graph: no call id of its own)
     calls.push_back(ids);
     return (uint32_t)calls.size() - 1;
   }
@@ -287,12 +342,18 @@ struct hip_multi_compute_t : public rtc_compute_t {
       if (T && v.dims.dims(0) != T) unsup_err(why + "with different batch sizes (" + std::to_string(T) + " and " + std::to_string(v.dims.dims(0)) + ")");
       T = v.dims.dims(0);
     }
-    if (!T) { calls.push_back(std::vector<uint32_t>(n(), kNoCall)); return (uint32_t)calls.size() - 1; }   // (an empty batch: nothing to run anywhere)
+    if (!T) { if (capturing) { cap_skipped = true; return kCapturedCallId; } calls.push_back(std::vector<uint32_t>(n(), kNoCall)); return (uint32_t)calls.size() - 1; }   // (an empty batch: nothing to run anywhere)
     auto ai = rfc.arg_map.find(g.ix_arg);
     if (ai == rfc.arg_map.end() || !ai->second.is_valid()) rt_err(why + "binds no argument named '" + g.ix_arg + "', the one its index is declared over");
     dims_t const ixd = ai->second.is_var() ? must_find(vis, ai->second.n).dims : ai->second.v->dims;
     uint64_t W = 1; bool lead_ok = false;
-    {
+    if (!g.n_arg.empty()) {   // ids = <n_arg> items, batch-major
+      auto ni = rfc.arg_map.find(g.n_arg);
+      if (ni == rfc.arg_map.end() || !ni->second.is_valid() || ni->second.is_var() || !ni->second.v->rp_elems() || ni->second.v->dims.tsz() != 4) rt_err(why + "its index count '" + g.n_arg + "' is not a by-value 32-bit argument of the call");
+      uint64_t const tot = *(uint32_t const *)ni->second.v->rp_elems();
+      lead_ok = ixd.sz() > 0 && ixd.names(0) == "img" && ixd.dims(0) == T && tot % T == 0;
+      W = tot / T;
+    } else {
       vect_string names; std::vector<uint32_t> sizes;
       if (g.use_dims.empty()) for (uint32_t k = 0; k < ixd.sz(); ++k) { names.push_back(ixd.names(k)); sizes.push_back(ixd.dims(k)); }
       else for (auto const &u : g.use_dims) { names.push_back(u); sizes.push_back(ixd.dsz(u)); }
@@ -305,7 +366,7 @@ struct hip_multi_compute_t : public rtc_compute_t {
     std::vector<uint32_t> ids;
     for (size_t i = 0; i < n(); ++i) {
       uint32_t const b = chunk_begin(T, i), e = chunk_begin(T, i + 1);
-      if (e == b) { ids.push_back(kNoCall); continue; }
+      if (e == b) { ids.push_back(kNoCall); if (capturing) cap_skipped = true; continue; }
       std::map<string, int64_t> bias;
       for (auto const &kv : rfc.arg_map) {
         if (!kv.second.is_valid() || !kv.second.is_var()) continue;
@@ -315,10 +376,11 @@ struct hip_multi_compute_t : public rtc_compute_t {
       uint64_t const work = (uint64_t)(e - b) * W;
       ids.push_back(hip_compute_run_shard(subs[i].get(), rfc, (uint32_t)((work + rfc.tpb - 1) / rfc.tpb), (uint32_t)(b * W), (uint32_t)(e * W - 1), bias));
     }
+    if (capturing) return kCapturedCallId;
     calls.push_back(ids);
     return (uint32_t)calls.size() - 1;
   }
-  void finish_and_sync() override { for (auto &s : subs) s->finish_and_sync(); }
+  void finish_and_sync() override { if (capturing) { capturing = false; } for (auto &s : subs) s->finish_and_sync(); }
   void release_per_call_id_data() override { for (auto &s : subs) s->release_per_call_id_data(); calls.clear(); }
   float get_dur(uint32_t const &b, uint32_t const &e) override {
     if (b >= calls.size() || e >= calls.size()) rt_err("invalid call_id");
@@ -337,6 +399,14 @@ rtc_compute_t *hip_multi_sub(rtc_compute_t *rtc, uint32_t i) {   // device i's o
   if (i >= m->n()) rt_err("multi-device backend: device index out of range");
   return m->subs[i].get();
 }
+// graph entry points of the C ABI: a multi-device backend captures / replays on all its devices, a single-device one as before
+void hip_any_graph_begin(rtc_compute_t *rtc) { if (auto *m = dynamic_cast<hip_multi_compute_t *>(rtc)) m->graph_begin(); else hip_compute_graph_begin(rtc); }
+uint32_t hip_any_graph_end(rtc_compute_t *rtc) { if (auto *m = dynamic_cast<hip_multi_compute_t *>(rtc)) return m->graph_end_common(0, nullptr, nullptr); return hip_compute_graph_end(rtc); }
+uint32_t hip_any_graph_end_deps(rtc_compute_t *rtc, uint32_t n, uint32_t const *ptr, uint32_t const *idx) {
+  if (auto *m = dynamic_cast<hip_multi_compute_t *>(rtc)) return m->graph_end_common(n, ptr, idx); return hip_compute_graph_end_deps(rtc, n, ptr, idx); }
+uint32_t hip_any_graph_launch(rtc_compute_t *rtc, uint32_t id) { if (auto *m = dynamic_cast<hip_multi_compute_t *>(rtc)) return m->graph_launch(id); return hip_compute_graph_launch(rtc, id); }
+uint32_t hip_any_graph_num_calls(rtc_compute_t *rtc, uint32_t id) { if (auto *m = dynamic_cast<hip_multi_compute_t *>(rtc)) return m->get_graph(id).n_calls; return hip_compute_graph_num_calls(rtc, id); }
+void hip_any_graph_destroy(rtc_compute_t *rtc, uint32_t id) { if (auto *m = dynamic_cast<hip_multi_compute_t *>(rtc)) m->graph_destroy(id); else hip_compute_graph_destroy(rtc, id); }
 uint32_t hip_multi_num_devices(rtc_compute_t *rtc) { hip_multi_compute_t *m = dynamic_cast<hip_multi_compute_t *>(rtc); return m ? (uint32_t)m->n() : 1u; }
 
 } // namespace bodahip

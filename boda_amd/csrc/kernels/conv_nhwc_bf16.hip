@@ -319,8 +319,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
       default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBUF > 7 ? 6 * kLoadsPerStep : 0) : "memory"); break;
     }
   };
-  auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };   // (the step's last MFMAs, which the compiler may sink below it, only read registers;
-  // their ds_reads were issued -- queued in the LDS, in order -- before this wave arrived, i.e. before any other wave can issue the DMA that refills the slot)
+  auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };   // (the step's last MFMAs, which the compiler may sink below it, only read registers)
 #if SPLITK
   int const k_begin = (int)(BODAHIP_BID % p.splitk) * p.kt_per, nk = max(0, min(kNK, k_begin + p.kt_per) - k_begin);   // this slice's K steps
 #else
@@ -389,6 +388,10 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     int const newest = (nk - 1 < step + NBUF - 1) ? nk - 1 : step + NBUF - 1;
     int const fl = newest - (step + 1);
     wait_loads(NBUF == 2 ? 0 : fl);
+    // ... and this wave's fragment reads of the step must have RETURNED before it releases the slot: an LDS-DMA write of another wave does not queue behind ds_reads
+    // that were merely issued (found with the multi-problem launch, tools/multi_stress.py: 32x128 tiles / 1x4 waves / ring of two -- intermittently wrong outputs
+    // without this wait, none in 240 launches with it; the same hazard exists here for every ring depth, the slot refilled at the top of step s is the one step s-1 read)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     barrier();
     cur = (cur + 1 == NBUF) ? 0 : cur + 1;
   }

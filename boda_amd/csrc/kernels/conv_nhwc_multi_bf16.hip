@@ -36,9 +36,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef NBUF
 #define NBUF 3
 #endif
-#ifndef SAFE_BARRIER
-#define SAFE_BARRIER 0
-#endif
 
 struct prob_t {   // one member convolution (128 bytes; host mirror: native_kernels.cc)
   void const *I; void const *J; void *D; float const *bias;     // filts, in, out, biases
@@ -188,9 +185,9 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(multi_arg
     // loads still wanted in flight after this wait: those of steps step + 2 .. step + NBUF - 1 that exist
     int const newest = (nk - 1 < step + NBUF - 1) ? nk - 1 : step + NBUF - 1;
     wait_loads(NBUF == 2 ? 0 : newest - (step + 1));
-#if SAFE_BARRIER
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of the step have RETURNED before it releases the slot to the other waves' LDS-DMA
-#endif
+    // this wave's fragment reads of the step must have RETURNED before it releases the slot: an LDS-DMA write of another wave does NOT queue behind ds_reads that
+    // were merely issued (measured, tools/multi_stress.py: 32x128 tiles / 1x4 waves / ring of two without this wait: 17 of 40 launches with 64-1300 wrong outputs)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     barrier();
     cur = (cur + 1 == NBUF) ? 0 : cur + 1;
   }

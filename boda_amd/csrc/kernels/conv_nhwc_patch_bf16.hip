@@ -18,7 +18,7 @@
 //
 // Numerics: as conv_nhwc_bf16.hip (fp32 accumulate in the MFMA's own order; parity stated against the oracle on bf16-rounded operands).
 //
-// -D parameters: KNAME BI BJ WI WJ MINW CG CIN KH KW SY PY PX CH CW COH COW RELU OUT_F32 [ADIRECT PF BPF WPITCH DBUF ABLATE]       (SX == 1)
+// -D parameters: KNAME BI BJ WI WJ MINW CG CIN KH KW SY PY PX CH CW COH COW RELU OUT_F32 [ADIRECT PF BPF WPITCH DBUF ABLATE POOL]       (SX == 1)
 
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
@@ -58,6 +58,15 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef ABLATE
 #define ABLATE 0   // measurement only (wrong results): 1 = no operand loads, 2 = no fragment reads / MFMAs, 3 = no LDS stores of the staged operands, 4 = no K loop at all
 #endif
+#ifndef POOL
+#define POOL 0     // 1: MAX POOLING FUSED INTO THE CONSUMING 1x1 CONVOLUTION (an inception module's pool -> pool-projection pair, test/rtc/pool.cucl + a k1conv in the
+#endif             // reference: two functions, src/rtc_fwd.cc:545-549):   out[oc][pel] = relu( bias + sum_c F[oc][c] * max_{ky,kx in KH x KW} in[pel + (ky,kx) - pad][c] ).
+                   // The patch of a K step is what the KH x KW window needs -- exactly the rows this kernel stages for a KH x KW convolution -- and a lane's B fragment is the
+                   // element-wise maximum of the KH*KW patch reads instead of one of them; the filters are 1x1 (F'[g][0][0][oc][8]: one k-slot per channel group).  The
+                   // maximum is taken on the bf16 bit patterns as signed 16-bit integers (v_pk_max_i16), which orders NON-NEGATIVE values like their floats, and window
+                   // positions outside the plane read the patch's zero padding: both are right exactly when the input is non-negative (the output of a ReLU, of a pooling
+                   // or concatenation of such) -- the caller's obligation (boda_amd/conv_pipe.py checks the producers).  Per output the MFMA chain is the 1x1 convolution's
+                   // own (ascending 16-channel groups): bit-identical to pooling and convolution run apart.
 
 // BODAHIP_AS_MEMBER: see conv_nhwc_bf16.hip -- this file as one member of a hip_conv_nhwc_set kernel ( __device__ void KNAME(gemm_args_t const &p, int bid, char *smem) ).
 #ifdef BODAHIP_AS_MEMBER
@@ -100,7 +109,8 @@ constexpr int wpitch() { for (int p = kWr; p < kWr + 16; ++p) if ((SY * p - COW)
 constexpr int kWp = WPITCH ? wpitch() : kWr;
 constexpr int kNCG = CIN / 8;                                      // channel groups of the tensor
 constexpr int kNKT = (kNCG + CG - 1) / CG;                         // K steps
-constexpr int kNPr = CG * kTaps;                                   // k-slots (of 8 channels) per K step ...
+static_assert(!POOL || ADIRECT, "the fused-pooling form reads its filter fragments directly");
+constexpr int kNPr = POOL ? CG : CG * kTaps;                       // k-slots (of 8 channels) per K step (POOL: one per channel group -- the window is reduced before the MFMA) ...
 constexpr int kNP = kNPr + (kNPr & 1);                             // ... padded to whole MFMAs (two slots each): an odd count gets one all-zero filter slot
 static_assert(KH >= SY, "patch slots assume overlapping or abutting windows in y");
 constexpr int kRowsMax = (BJ - 2) / COW + 2;                       // output rows a BJ-pel tile can touch
@@ -123,7 +133,19 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(void const *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)bytes, 0x00020000); }
 __device__ __forceinline__ u32x4 bload4(rsrc_t r, int voff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0); }
 // chunk offset of k-slot q = (g, ky, kx) inside the patch, relative to a lane's output position
-constexpr int slot_off(int q) { return (q >= kNPr) ? 0 : ((q / kTaps) * kCSp + ((q % kTaps) / KW) * kWp + (q % KW)); } // (the pad slot reads tap 0: its filter row is zero)
+constexpr int slot_off(int q) { return (q >= kNPr) ? 0 : (POOL ? q * kCSp : ((q / kTaps) * kCSp + ((q % kTaps) / KW) * kWp + (q % KW))); } // (the pad slot reads tap 0: its filter row is zero)
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+// the B fragment of one output position and k-slot: the patch chunk at `at` -- or, POOL, the maximum over the window whose tap (0, 0) is at `at`
+__device__ __forceinline__ bf16x8 frag_b(u32x4 const *Js, int at) {
+#if POOL
+  s16x8 m = __builtin_bit_cast(s16x8, Js[at]);
+#pragma unroll
+  for (int t = 1; t < kTaps; ++t) m = __builtin_elementwise_max(m, __builtin_bit_cast(s16x8, Js[at + (t / KW) * kWp + (t % KW)]));
+  return __builtin_bit_cast(bf16x8, m);
+#else
+  return __builtin_bit_cast(bf16x8, Js[at]);
+#endif
+}
 } // namespace
 
 #ifdef BODAHIP_AS_MEMBER
@@ -256,14 +278,14 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #pragma unroll
       for (int d = 0; d < kBD; ++d)
 #pragma unroll
-        for (int t = 0; t < kTJ; ++t) b[d][t] = __builtin_bit_cast(bf16x8, Js[bj[t] + (hi ? slot_off(2 * d + 1) : slot_off(2 * d))]);
+        for (int t = 0; t < kTJ; ++t) b[d][t] = frag_b(Js, bj[t] + (hi ? slot_off(2 * d + 1) : slot_off(2 * d)));
 #pragma unroll
       for (int s = 0; s < kN; ++s) {
         if (s + kPF < kN) load_a(kt, s + kPF, cur[s + kPF]); else load_a(kt + 1, s + kPF - kN, nxt[s + kPF - kN]);
         if (s + kBD < kN) {
           int const jo = hi ? slot_off(2 * (s + kBD) + 1) : slot_off(2 * (s + kBD));
 #pragma unroll
-          for (int t = 0; t < kTJ; ++t) b[(s + kBD) % kBR][t] = __builtin_bit_cast(bf16x8, Js[bj[t] + jo]);
+          for (int t = 0; t < kTJ; ++t) b[(s + kBD) % kBR][t] = frag_b(Js, bj[t] + jo);
         }
         if (ABLATE != 2) {
 #pragma unroll

@@ -381,7 +381,8 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
 }
 // Channels-last bf16 convolution from an LDS input patch (kernels/conv_nhwc_patch_bf16.hip): KH x KW kernels with more than one tap, stride 1 in x; filters in the
 // F'[in_grp][ky][kx][out_chan][8] form.  A K step is CG groups of 8 channels x all taps.  tile: "BIxBJx0xWIxWJ[xMINW]" or "".
-static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string const &tile, bool out_f32) {
+// pool: g.KH x g.KW / g.PY, g.PX describe a MAX-POOLING window fused in front of a 1x1 convolution (-DPOOL=1: the filters hold one k-slot per channel group).
+static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string const &tile, bool out_f32, bool pool = false) {
   if (g.C % 8) unsup_err("hip_conv_nhwc: in_chan of a channels-last bf16 tensor must be a multiple of 8");
   int const taps = g.KH * g.KW, ncg = g.C / 8;
   if (!(g.SX == 1 && taps >= 2 && g.KH >= g.SY)) unsup_err("hip_conv_nhwc (patch form of filts): needs stride 1 in x and more than one tap");
@@ -397,6 +398,7 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
       long const slots = (long)((ncg + c - 1) / c) * (c * taps + ((c * taps) & 1));
       if (best < 0 || slots < best) { best = slots; cg = c; }
     } }
+  if (pool) { if (!adirect) unsup_err("hip_conv_nhwc (fused pooling): needs the direct filter path"); cg = std::min(ncg, 4); }   // (one k-slot per group: four groups = two MFMA k-iterations per step)
   if (char const *e = getenv("BODAHIP_NHWC_PATCH_CG")) { if (atoi(e) > 0) cg = std::min(ncg, atoi(e)); }   // (experiments)
   int wp = g.W + 2 * g.PX;                                              // slot pitch: as the kernel's wpitch()
   for (int p2 = wp; p2 < wp + 16; ++p2) if ((g.SY * p2 - g.OW) % 16 == 0) { wp = p2; break; }
@@ -469,7 +471,7 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
     c.BI = cands[pick].bi; c.BJ = cands[pick].bj; c.WI = cands[pick].wi; c.WJ = cands[pick].wj; c.MINW = cands[pick].minw; cg = pick_cg;
   }
   while (cg > 1 && lds(c.BI, c.BJ) > 160 * 1024) cg = (cg + 1) / 2;
-  p.cg = cg; c.BK = cg * 8 * taps;
+  p.cg = cg; c.BK = pool ? cg * 8 : cg * 8 * taps;
   bool ok = c.BI > 0 && c.BJ > 0 && c.WI > 0 && c.WJ > 0 && c.threads() <= 1024 && (c.BI % (c.WI * 32) == 0) && (c.BJ % (c.WJ * 32) == 0) &&
             (c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) * 16 <= 256 && c.MINW >= 1 && lds(c.BI, c.BJ) <= 160 * 1024;
   if (!ok) unsup_err("hip_conv_nhwc (patch form of filts): unsupported tile configuration " + c.str());
@@ -479,6 +481,7 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
             "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX), "-DCH=" + std::to_string(g.H), "-DCW=" + std::to_string(g.W),
             "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW), string("-DRELU=") + (g.relu ? "1" : "0"), string("-DOUT_F32=") + (out_f32 ? "1" : "0")};
   if (adirect) p.defs.push_back("-DADIRECT=1");
+  if (pool) p.defs.push_back("-DPOOL=1");
   if (adirect && (pick_pf || (tile.empty() ? 0 : ((c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) >= 8)))) p.defs.push_back("-DPF=4");   // (128 accumulators: four fragments in flight)
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
   return p;
@@ -1169,7 +1172,7 @@ void native_kernels_t::conv_nhwc_multi(int n, multi_member_t const *ms, bool out
 // member's own launch.  Members that cannot join (another workgroup size, K slices) are launched on their own by the same call.
 struct set_member_plan_t { plan_t p; gemm_args_t ga; long tiles; int variant; double tile_cost; };
 static char const *const k_set_macros[] = {"BI", "BJ", "BK", "WI", "WJ", "MINW", "CIN", "KH", "KW", "SY", "SX", "PY", "PX", "CH", "CW", "COH", "COW", "RELU", "OUT_F32", "NBUF", "CG",
-                                           "ADIRECT", "PF", "BPF", "WPITCH", "DBUF", "ABLATE", "GROUP_I", "IN_F32", "SPLITK", "INTERLEAVE", "GROUPS", "KNAME", "BODAHIP_BID"};
+                                           "ADIRECT", "PF", "BPF", "WPITCH", "DBUF", "ABLATE", "POOL", "GROUP_I", "IN_F32", "SPLITK", "INTERLEAVE", "GROUPS", "KNAME", "BODAHIP_BID"};
 static string set_kernel_source(std::vector<plan_t const *> const &variants, int threads, int minw) {
   std::ostringstream o;
   o << "// generated by native_kernels.cc (conv_nhwc_set): " << variants.size() << " member specialisations in one kernel\n";
@@ -1211,7 +1214,7 @@ static string set_kernel_source(std::vector<plan_t const *> const &variants, int
 
 static gemm_args_t nhwc_member_args(native_kernels_t::multi_member_t const &mm, tile_cfg_t const &cfg, bool out_f32, char const *what) {
   conv_geom_t const &g = mm.g;
-  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = mm.pool ? (long)g.C : (long)g.C * g.KH * g.KW;
   int const ctot = mm.out_ctot > 0 ? mm.out_ctot : g.OC, coff = mm.out_ctot > 0 ? mm.out_coff : 0;
   uint64_t const in_bytes = (uint64_t)g.B * g.C * g.H * g.W * 2, f_bytes = (uint64_t)g.OC * Kt * 2, out_bytes = (uint64_t)Nj * ctot * (out_f32 ? 4 : 2);
   if (Nj > 0x7fffffffl || Kt > 0x7fffffffl || in_bytes >= 0x7ffffff0ull || f_bytes >= 0x7ffffff0ull || out_bytes >= 0x7ffffff0ull) unsup_err(string(what) + ": tensors of 2 GiB or more are not supported (32-bit buffer offsets)");
@@ -1231,15 +1234,15 @@ void native_kernels_t::conv_nhwc_set(int n, multi_member_t const *ms, bool const
     conv_geom_t const &g = ms[m].g;
     if (!((long)g.B * g.OH * g.OW) || !g.OC) rt_err("hip_conv_nhwc_set: empty member");
     set_member_plan_t &q = mp[(size_t)m];
-    q.p = patch_filts[m] ? plan_conv_nhwc_patch(g, host->nh_num_cus(), string(), out_f32) : plan_conv_nhwc(g, host->nh_num_cus(), string(), out_f32, 0, /*allow_split=*/false);
+    q.p = patch_filts[m] ? plan_conv_nhwc_patch(g, host->nh_num_cus(), string(), out_f32, ms[m].pool) : plan_conv_nhwc(g, host->nh_num_cus(), string(), out_f32, 0, /*allow_split=*/false);
     q.ga = nhwc_member_args(ms[m], q.p.cfg, out_f32, "hip_conv_nhwc_set");
     q.tiles = (long)q.ga.tiles_i * q.ga.tiles_j;
-    q.tile_cost = (double)q.p.cfg.BI * q.p.cfg.BJ * (double)g.C * g.KH * g.KW;
+    q.tile_cost = (double)q.p.cfg.BI * q.p.cfg.BJ * (double)g.C * (ms[m].pool ? 2 : g.KH * g.KW);
     (q.p.cfg.threads() == 256 ? in_set : alone).push_back(m);
   }
   if (in_set.size() < 2) { alone.insert(alone.end(), in_set.begin(), in_set.end()); in_set.clear(); }
   double flops = 0, bytes = 0;
-  for (int m = 0; m < n; ++m) { conv_geom_t const &g = ms[m].g; double const Nj = (double)g.B * g.OH * g.OW, Kt = (double)g.C * g.KH * g.KW;
+  for (int m = 0; m < n; ++m) { conv_geom_t const &g = ms[m].g; double const Nj = (double)g.B * g.OH * g.OW, Kt = ms[m].pool ? (double)g.C : (double)g.C * g.KH * g.KW;
     flops += 2.0 * Nj * g.OC * Kt; bytes += 2.0 * ((double)g.B * g.C * g.H * g.W + (double)g.OC * Kt) + (out_f32 ? 4.0 : 2.0) * Nj * g.OC + 4.0 * g.OC; }
   for (int m : alone) {   // members with another workgroup size: their own launch, the plan they would have taken anyway
     kernel_t &k = get_kernel(impl, host, mp[(size_t)m].p);
@@ -1332,12 +1335,13 @@ void native_kernels_t::conv_nhwc_grp(void const *filts, float const *biases, voi
   last_launch.algo_bytes = 2.0 * ((double)g.B * g.C * g.H * g.W + real_oc * Kt) + (out_f32 ? 4.0 : 2.0) * (double)Nj * real_oc + 4.0 * real_oc;
 }
 
-void native_kernels_t::conv_nhwc(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, bool out_f32, int out_ctot, int out_coff, bool patch_filts) {
+void native_kernels_t::conv_nhwc(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, bool out_f32, int out_ctot, int out_coff, bool patch_filts, bool pool) {
   if (out_ctot <= 0) { out_ctot = g.OC; out_coff = 0; }
-  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  if (pool && !patch_filts) rt_err("hip_conv_nhwc: fused pooling needs the patch form of filts");
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = pool ? (long)g.C : (long)g.C * g.KH * g.KW;
   if (!Nj || !g.OC) return;
   if (Nj > 0x7fffffffl || Kt > 0x7fffffffl) unsup_err("hip_conv_nhwc: dims exceed int32");
-  plan_t const p = patch_filts ? plan_conv_nhwc_patch(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), out_f32) : plan_conv_nhwc(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), out_f32);
+  plan_t const p = patch_filts ? plan_conv_nhwc_patch(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), out_f32, pool) : plan_conv_nhwc(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), out_f32);
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
   gemm_args_t ga; memset(&ga, 0, sizeof(ga));
@@ -1379,6 +1383,17 @@ static conv_geom_t geom_from_dims(dims_t const &f, dims_t const &in, dims_t cons
   return g;
 }
 
+// Max pooling fused in front of a 1x1 convolution (annotation: uint32 nhwc_pool[<sfx>] = 1, REF-style dims pool_sz[<sfx>] / pool_pad[<sfx>] carried by the op): the
+// function's `in` is the POOLING's input; the geometry handed to the patch kernel takes the pooling's window and padding (stride 1), the filters stay 1x1.
+static bool apply_pool_window(op_base_t const &op, string const &sfx, conv_geom_t &g, char const *what) {
+  if (!op.has("nhwc_pool" + sfx) || !op.get_u32("nhwc_pool" + sfx)) return false;
+  dims_t const &ks = op.get_dims("pool_sz" + sfx), &pp = op.get_dims("pool_pad" + sfx);
+  if (!(g.KH == 1 && g.KW == 1 && g.SY == 1 && g.SX == 1 && g.PY == 0 && g.PX == 0)) rt_err(string(what) + ": fused pooling needs a 1x1 / stride-1 / unpadded convolution");
+  g.KH = (int)ks.dsz("y"); g.KW = (int)ks.dsz("x"); g.PY = (int)pp.dsz("y"); g.PX = (int)pp.dsz("x");
+  if (g.KH * g.KW < 2 || g.KH * g.KW > 25) unsup_err(string(what) + ": fused pooling windows of 2..25 positions");
+  return true;
+}
+
 // AOT: compile (into the on-disk code-object cache) the specialisation that run() would pick for `op`.  No device needed.
 // With arch == "" nothing is compiled and *plan_out receives "<kernel> <tile> <-D options>": the planner's decision (host-logic tests).
 size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile_arg, string *plan_out) {
@@ -1410,8 +1425,9 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
         dims_t f = op.get_dims("filts" + sfx); bool const pf = f.sz() == 5;
         if (pf) f = dims_t({f.dims(3), f.dims(1), f.dims(2), f.dims(0) * 8}, {"out_chan", "y", "x", "in_chan"}, f.tn);
         bool const relu_m = op.has("relu_mask") ? (((op.get_u32("relu_mask") >> m) & 1u) != 0) : relu;
-        conv_geom_t const g = geom_from_dims(f, op.get_dims("in" + sfx), op.get_dims("out" + sfx), op.get_dims("stride" + sfx), op.get_dims("in_pad" + sfx), relu_m);
-        plans.push_back(pf ? plan_conv_nhwc_patch(g, num_cus, string(), out_f32) : plan_conv_nhwc(g, num_cus, string(), out_f32, 0, false)); }
+        conv_geom_t g = geom_from_dims(f, op.get_dims("in" + sfx), op.get_dims("out" + sfx), op.get_dims("stride" + sfx), op.get_dims("in_pad" + sfx), relu_m);
+        bool const pool_m = apply_pool_window(op, sfx, g, "hip_conv_nhwc_set");
+        plans.push_back(pf ? plan_conv_nhwc_patch(g, num_cus, string(), out_f32, pool_m) : plan_conv_nhwc(g, num_cus, string(), out_f32, 0, false)); }
       for (plan_t const &q : plans) {
         if (q.cfg.threads() != 256) { if (!arch.empty()) bytes += compile_plan(q, arch, &log).size(); desc += " alone:" + q.kname + ":" + q.cfg.str(); continue; }
         string key = q.kname; for (auto const &d : q.defs) key += " " + d;
@@ -1432,7 +1448,16 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
         gs.push_back(geom_from_dims(op.get_dims("filts" + sfx), op.get_dims("in" + sfx), op.get_dims("out" + sfx), op.get_dims("stride" + sfx), op.get_dims("in_pad" + sfx), relu)); }
       p = plan_conv_nhwc_multi(gs, tile, op.get_dims("out_0").tn == "float");
     }
-    else if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc" && op.get_dims("filts").sz() == 5) p = plan_conv_nhwc_patch(g, num_cus, tile, op.get_dims("out").tn == "float");
+    else if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc" && op.get_dims("filts").sz() == 5) {
+      conv_geom_t gp = g; bool pool = false;
+      if (op.has("nhwc_pool") && op.get_u32("nhwc_pool")) {   // (filts are in_grp:1:1:out_chan:8: geom_from_dims read in_grp / 1 as out_chan / y -- rebuild from the logical dims)
+        dims_t const &f5 = op.get_dims("filts");
+        dims_t const fl({f5.dims(3), f5.dims(1), f5.dims(2), f5.dims(0) * 8}, {"out_chan", "y", "x", "in_chan"}, f5.tn);
+        gp = geom_from_dims(fl, op.get_dims("in"), op.get_dims("out"), op.get_dims("stride"), op.get_dims("in_pad"), relu);
+        pool = apply_pool_window(op, string(), gp, "hip_conv_nhwc");
+      }
+      p = plan_conv_nhwc_patch(gp, num_cus, tile, op.get_dims("out").tn == "float", pool);
+    }
     else if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc") p = plan_conv_nhwc(g, num_cus, tile, op.get_dims("out").tn == "float");
     else if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc_grp") { dims_t const &grp = op.get_dims("grp"); p = plan_conv_nhwc(g, num_cus, tile, op.get_dims("out_0").tn == "float", (int)grp.dims(grp.sz() - 1)); }
     else if (bf16 && tile.empty() && s2d_geom(g, g2, pry, prx) && plan_patch_bf16(g2, num_cus, p)) { // conv1-type layers: space-to-depth front end (see conv())
@@ -1608,6 +1633,7 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
       assert_st(stride.sz() == 2); assert_st(in_pad.sz() == 2);
       native_kernels_t::multi_member_t &mm = ms[(size_t)m];
       mm.g = geom_from_dims(f, in, out, stride, in_pad, has_mask ? ((mask >> m) & 1u) != 0 : relu_all);
+      if (is_set) { mm.pool = apply_pool_window(fi.op, sfx, mm.g, "hip_conv_nhwc_set"); if (mm.pool && !patch_f[(size_t)m]) rt_err("hip_conv_nhwc_set: fused pooling needs the patch form of filts"); }
       conv_geom_t const &g = mm.g;
       if (f.dsz("in_chan") != (uint32_t)g.C) rt_err("hip_conv_nhwc_multi: filts.in_chan != in.chan (member " + std::to_string(m) + ")");
       mm.out_ctot = 0; mm.out_coff = 0;
@@ -1655,6 +1681,8 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     assert_st(stride.sz() == 2); assert_st(in_pad.sz() == 2);
     conv_geom_t g = geom_from_dims(f, in, out, stride, in_pad, fi.op.get_u32("conv_has_relu") != 0);
     if (f.dsz("in_chan") != (uint32_t)g.C) rt_err("hip_conv_nhwc: filts.in_chan != in.chan");
+    bool const pool = apply_pool_window(fi.op, string(), g, "hip_conv_nhwc");
+    if (pool && !patch_filts) rt_err("hip_conv_nhwc: fused pooling needs the in_grp:y:x:out_chan:in_chan8 form of filts");
     int out_ctot = 0, out_coff = 0;
     auto oi = am.find("out_chan_off");
     if (oi != am.end()) {
@@ -1666,7 +1694,7 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     if (!g.SY || !g.SX) rt_err("hip_conv_nhwc: zero stride");
     if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW) rt_err("hip_conv_nhwc: out dims do not match in/filts/stride/in_pad");
     tile_override_t const tov(impl, "conv_tile", fi.op);
-    conv_nhwc(host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), host->nh_var_ptr(inm), host->nh_var_ptr(onm), g, out.tn == "float", out_ctot, out_coff, patch_filts);
+    conv_nhwc(host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), host->nh_var_ptr(inm), host->nh_var_ptr(onm), g, out.tn == "float", out_ctot, out_coff, patch_filts, pool);
     return;
   }
   if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd") {

@@ -73,12 +73,12 @@ struct native_kernels_t {
             char const *algo = nullptr);
 
   // channels-last bf16 tensors (kernels/conv_nhwc_bf16.hip): filts out_chan:y:x:in_chan, in / out img:y:x:chan; g.C = stored channels (multiple of 8)
-  void conv_nhwc(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, bool out_f32, int out_ctot = 0, int out_coff = 0, bool patch_filts = false);   // patch_filts: filts are F'[in_grp][ky][kx][out_chan][8] -> the LDS input-patch kernel
+  void conv_nhwc(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, bool out_f32, int out_ctot = 0, int out_coff = 0, bool patch_filts = false, bool pool = false);   // pool: g.KH x g.KW / g.PY, g.PX are a max-pooling window fused in front of 1x1 filters (patch form); patch_filts: filts are F'[in_grp][ky][kx][out_chan][8] -> the LDS input-patch kernel
   // horizontally fused channels-last convolutions (same `in`, same kernel geometry; filts / biases stacked along out_chan, members padded to `pad` rows)
   void conv_nhwc_grp(void const *filts, float const *biases, void const *in, conv_geom_t const &g, bool out_f32, int n, int const *noc, void *const *outs,
                      int const *ctot, int const *coff, int pad);
   // several independent channels-last convolutions as ONE launch (kernels/conv_nhwc_multi_bf16.hip); members: raw device pointers + geometry (g.C = stored channels)
-  struct multi_member_t { void const *filts; float const *biases; void const *in; void *out; conv_geom_t g; int out_ctot, out_coff; };
+  struct multi_member_t { void const *filts; float const *biases; void const *in; void *out; conv_geom_t g; int out_ctot, out_coff; bool pool = false; };   // pool: g's window / padding are a max pooling fused in front of 1x1 filters
   void conv_nhwc_multi(int n, multi_member_t const *members, bool out_f32);
   // a few independent channels-last convolutions, each on its own specialised kernel code (implicit-GEMM or input-patch form), as one launch (wrapper kernel built at run time)
   void conv_nhwc_set(int n, multi_member_t const *members, bool const *patch_filts, bool out_f32);

@@ -124,6 +124,34 @@ def annotate(a: Op, out_tn: str = "bfloat16", allow_s2d: bool = True, allow_patc
     a.set_func_name(FUNC)
 
 
+def pool_fusable(g: dict, in_hw: Tuple[int, int], kern: Tuple[int, int], stride: Tuple[int, int], pad: Tuple[int, int], avg: bool, out_f32: bool = False) -> bool:
+    """Can a pooling (window kern, stride, pad; on planes in_hw) be taken into the 1x1 convolution `g` that consumes it?  Max pooling with stride 1 in front of a
+    1x1 / stride-1 / unpadded convolution whose input plane is the pooling's output, a window of 2..25 positions, and a plane narrow enough for the LDS patch.
+    (The caller also owes non-negative pooling input: see kernels/conv_nhwc_patch_bf16.hip, POOL.)"""
+    if avg or tuple(stride) != (1, 1) or not (2 <= kern[0] * kern[1] <= 25):
+        return False
+    if not (g["KH"] == g["KW"] == 1 and g["SY"] == g["SX"] == 1 and g["PY"] == g["PX"] == 0):
+        return False
+    H, W = in_hw
+    if (H + 2 * pad[0] - kern[0] + 1, W + 2 * pad[1] - kern[1] + 1) != (g["H"], g["W"]) or g["OH"] * g["OW"] <= 1:
+        return False
+    return patch_min_lds(kern[0], 1, W, pad[1], g["OH"], g["OW"], out_f32) <= PATCH_LDS_LIMIT
+
+
+def fuse_pool(a: Op, pool_in: Dims, kern: Tuple[int, int], pad: Tuple[int, int]) -> None:
+    """In place: an annotated 1x1 hip_conv_nhwc function takes the max pooling in front of it (pool_fusable).  Its `in` becomes the POOLING's input, its filters take
+    the input-patch form (one k-slot per channel group), and the window travels with the function: uint32 nhwc_pool, dims pool_sz / pool_pad.  The reference
+    runs the two as two functions (test/rtc/pool.cucl, then the conv; src/rtc_fwd.cc:545-549); here the window maximum is taken while the MFMA B fragment is formed."""
+    if a.get_func_name() != FUNC or a.has("nhwc_s2d") or a.get_dims("filts").has("in_grp"):
+        raise UnsupErr("fuse_pool: needs a plain hip_conv_nhwc function")
+    none = lambda y, x: Nda(Dims(("y", "x"), (y, x), "none"), "none")
+    a.nda_vals["filts"] = Nda(dims=patch_filts_dims(a.get_dims("filts_ref")), tn="bfloat16")
+    a.nda_vals["in_ref"] = Nda(dims=pool_in, tn=pool_in.tn)
+    a.nda_vals["in"] = Nda(dims=nhwc_dims(pool_in), tn="bfloat16")
+    a.set_u32("nhwc_pool", 1)
+    a.nda_vals["pool_sz"] = none(*kern); a.nda_vals["pool_pad"] = none(*pad)
+
+
 GRP_FUNC = "hip_conv_nhwc_grp"
 
 
@@ -170,7 +198,7 @@ _MULTI_MEMBER_ARGS = ("filts", "biases", "in", "stride", "in_pad", "out")
 def multi_eligible(anno: Op) -> bool:
     """A member of a multi-problem launch: a plain hip_conv_nhwc function on the implicit-GEMM kernel (filts out_chan:y:x:in_chan) -- not the input-patch form, not
     space-to-depth (both bind other kernels with another summation order)."""
-    return anno.get_func_name() == FUNC and not anno.has("nhwc_s2d") and not anno.get_dims("filts").has("in_grp")
+    return anno.get_func_name() == FUNC and not anno.has("nhwc_s2d") and not anno.get_dims("filts").has("in_grp") and not anno.has("nhwc_pool")
 
 
 def annotate_multi(annos: List[Op]) -> Op:
@@ -223,6 +251,9 @@ def annotate_set(annos: List[Op]) -> Op:
             raise UnsupErr("hip_conv_nhwc_set: members differ in output type")
         for an in _MULTI_MEMBER_ARGS + ("kern_sz",):
             nv[f"{an}_{m}"] = a.nda_vals[an]
+        if a.has("nhwc_pool"):     # (a member with max pooling fused in front of it)
+            for an in ("nhwc_pool", "pool_sz", "pool_pad"):
+                nv[f"{an}_{m}"] = a.nda_vals[an]
     nv["conv_has_relu"] = Nda(dims=None, tn="uint32_t", v=(int(all(relu)),))
     if any(relu) != all(relu):     # (ReLU is a constant of each member's own kernel instantiation: members may differ)
         nv["relu_mask"] = Nda(dims=None, tn="uint32_t", v=(sum(int(bool(r)) << m for m, r in enumerate(relu)),))
@@ -253,6 +284,7 @@ typedef __bf16 xp_bf16x8_t __attribute__((ext_vector_type(8)));
 CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_in( GASQ float const * const in_ref, GASQ xp_bf16x8_t * const in, uint32_t const n, uint32_t const C,
                                                  uint32_t const H, uint32_t const W, uint32_t const C2, uint32_t const C8, uint32_t const H2,
                                                  uint32_t const W2, uint32_t const S, uint32_t const PRY, uint32_t const PRX ) {
+  // CUCL IX GLOB_ID_1D in n=n
   uint32_t const i = GLOB_ID_1D;
   if( i >= n ) { return; }
   uint32_t const q = i % C8, X = ( i / C8 ) % W2, Y = ( i / ( C8*W2 ) ) % H2, img = i / ( C8*W2*H2 );
@@ -301,12 +333,14 @@ CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_filts_patch( GASQ float const * cons
 }
 // out img:y:x:chan (bf16 / float) -> out_ref img:chan:y:x float
 CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_out_bf16( GASQ __bf16 const * const out, GASQ float * const out_ref, uint32_t const n, uint32_t const C, uint32_t const HW ) {
+  // CUCL IX GLOB_ID_1D out_ref
   uint32_t const i = GLOB_ID_1D;
   if( i >= n ) { return; }
   uint32_t const pel = i % HW, c = ( i / HW ) % C, img = i / ( C * HW );
   out_ref[i] = (float)out[( img*HW + pel )*C + c];
 }
 CUCL_GLOBAL_KERNEL void hip_conv_nhwc_xpose_out_f32( GASQ float const * const out, GASQ float * const out_ref, uint32_t const n, uint32_t const C, uint32_t const HW ) {
+  // CUCL IX GLOB_ID_1D out_ref
   uint32_t const i = GLOB_ID_1D;
   if( i >= n ) { return; }
   uint32_t const pel = i % HW, c = ( i / HW ) % C, img = i / ( C * HW );
@@ -348,6 +382,7 @@ def _spec_compile(rtc, name: str, src: str, subst: Dict[str, object], args: List
 XPOSE_IN_SPEC_SRC = """
 typedef __bf16 xps_bf16x8_t __attribute__((ext_vector_type(8)));
 CUCL_GLOBAL_KERNEL void @NAME@( GASQ float const * const in_ref, GASQ xps_bf16x8_t * const in, uint32_t const n ) {
+  // CUCL IX GLOB_ID_1D in n=n
   uint32_t const i = GLOB_ID_1D;
   if( i >= n ) { return; }
   uint32_t const q = i % @C8@u, p = i / @C8@u, X = p % @W2@u, r = p / @W2@u, Y = r % @H2@u, img = r / @H2@u;
@@ -423,6 +458,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 CUCL_GLOBAL_KERNEL void nhwc_pool( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n, uint32_t const C8, uint32_t const H,
                                    uint32_t const W, uint32_t const OH, uint32_t const OW, uint32_t const KH, uint32_t const KW, uint32_t const SY,
                                    uint32_t const SX, uint32_t const PY, uint32_t const PX, uint32_t const avg_pool ) {
+  // CUCL IX GLOB_ID_1D out n=n
   uint32_t const i = GLOB_ID_1D;
   if( i >= n ) { return; }
   uint32_t const c = i % C8, ox = ( i / C8 ) % OW, oy = ( i / ( C8*OW ) ) % OH, img = i / ( C8*OW*OH );
@@ -448,6 +484,7 @@ CUCL_GLOBAL_KERNEL void nhwc_pool( GASQ bf16x8_t const * const in, GASQ bf16x8_t
 // instead of from memory: every element is loaded once.  Lanes at a position's first / last chunk, and at the wave's edges, take zero / reload.
 CUCL_GLOBAL_KERNEL void nhwc_lrn( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n, uint32_t const C8, uint32_t const local_size,
                                   float const alpha, float const beta, float const k ) {
+  // CUCL IX GLOB_ID_1D out n=n wave_local
   uint32_t const i = GLOB_ID_1D;
   bool const live = i < n;
   int32_t const q = live ? (int32_t)( i % C8 ) : 0, half = local_size / 2, lane = LOC_ID_1D & 63;
@@ -475,12 +512,14 @@ CUCL_GLOBAL_KERNEL void nhwc_lrn( GASQ bf16x8_t const * const in, GASQ bf16x8_t 
 }
 // stand-alone ReLU (one that could not be fused into its conv)
 CUCL_GLOBAL_KERNEL void nhwc_relu( GASQ __bf16 * const inout, uint32_t const n ) {
+  // CUCL IX GLOB_ID_1D inout n=n
   uint32_t const i = GLOB_ID_1D;
   if( i < n ) { if( (float)inout[i] <= 0.0f ) { inout[i] = (__bf16)0.0f; } }
 }
 // Concat: copy one input (C8_in chunks per position) into its channel range of the output (src/rtc_fwd.cc:267-280)
 CUCL_GLOBAL_KERNEL void nhwc_copy( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n, uint32_t const C8_in, uint32_t const C8_out,
                                    uint32_t const off8 ) {
+  // CUCL IX GLOB_ID_1D in n=n
   uint32_t const i = GLOB_ID_1D;
   if( i >= n ) { return; }
   uint32_t const pel = i / C8_in;
@@ -515,6 +554,7 @@ POOL_SPEC_SRC = """
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 // one thread: XT consecutive outputs along x of one (img, oy, 8 channels); the (XT-1)*SX + KW input columns they touch are loaded once ( x KH rows)
 CUCL_GLOBAL_KERNEL void @NAME@( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n ) {
+  // CUCL IX GLOB_ID_1D out n=n
   uint32_t const i = GLOB_ID_1D;
   if( i >= n ) { return; }
   uint32_t const c = i % @C8@u, p = i / @C8@u, xg = p % @OWG@u, q = p / @OWG@u, oy = q % @OH@u, img = q / @OH@u;
@@ -560,6 +600,7 @@ CUCL_GLOBAL_KERNEL void @NAME@( GASQ bf16x8_t const * const in, GASQ bf16x8_t * 
 LRN_SPEC_SRC = """
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 CUCL_GLOBAL_KERNEL void @NAME@( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n, float const alpha, float const beta, float const k ) {
+  // CUCL IX GLOB_ID_1D out n=n wave_local
   uint32_t const i = GLOB_ID_1D;
   bool const live = i < n;
   int32_t const q = live ? (int32_t)( i % @C8@u ) : 0, lane = LOC_ID_1D & 63;

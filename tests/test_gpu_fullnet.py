@@ -293,7 +293,8 @@ def test_full_net_forward_channels_last_bf16(rtc, net, batch):
     fwd.init(cp, op_params=params)
     try:
         funcs = [c.func for c in fwd.fwd_calls]
-        assert funcs[0] == "nhwc_xpose_in" and funcs.count("hip_conv_nhwc") + sum(len(g) for g in fwd.groups) == sum(o.type == "Convolution" for o in cp.ops)
+        assert funcs[0] == "nhwc_xpose_in" and funcs.count("hip_conv_nhwc") + sum(len(g) for g in fwd.groups) + sum(len(g) for g in fwd.level_sets) == sum(o.type == "Convolution" for o in cp.ops)
+        assert funcs.count("hip_conv_nhwc_set") == len(fwd.level_sets) and (len(fwd.level_sets) >= 1 if net == "googlenet" else not fwd.level_sets)   # (at one image most layers slice K on their own and stay out of the sets)
         assert funcs.count("hip_conv_nhwc_grp") == len(fwd.groups) == (9 if net == "googlenet" else 0)   # an inception module's 1x1 / 3x3-reduce / 5x5-reduce convs: one launch
         assert not any(f.startswith("fwd_") or f == "hip_conv" for f in funcs)
         nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
@@ -471,6 +472,54 @@ def test_level_set_fusion_is_bit_identical(rtc, monkeypatch):
     assert ncalls[1] - ncalls[0] >= 18
     for n in nodes:
         assert np.array_equal(res[0][n], res[1][n]), n
+
+
+def test_pool_fused_into_its_1x1_convolution_is_bit_identical(rtc, monkeypatch):
+    """Channels-last nets: a stride-1 max pooling whose only reader is a 1x1 convolution is taken into that convolution (kernels/conv_nhwc_patch_bf16.hip, POOL: the
+    window maximum is formed while the MFMA B fragment is read from the LDS patch; the reference runs pool.cucl and the conv as two functions).  Legal for
+    non-negative inputs only -- ConvPipeFwd checks the producers -- and then bit-identical to pooling and convolution run apart: max is exact, the 1x1
+    convolution's MFMA chain is its own.  Small net (windows 3x3 / pad 1, 2x2 / pad 0, 5x5 / pad 2; ragged channel counts), then GoogLeNet node for node."""
+    from boda_amd.cnn_op import OpTune
+    monkeypatch.setenv("BODAHIP_NO_NHWC_SPLITK", "1")
+    def small():
+        p = ConvPipe("pf", "data", Dims.make("float", img=5, chan=3, y=19, x=17))
+        p.add(PipeOp("c0", "Convolution", "data", "c0", out_chans=40, kern_sz=(3, 3), in_pad=(1, 1))); p.add(PipeOp("relu_c0", "ReLU", "c0", "c0"))
+        p.add(PipeOp("pa", "Pooling", "c0", "pa", kern_sz=(3, 3), stride=(1, 1), in_pad=(1, 1))); p.add(PipeOp("qa", "Convolution", "pa", "qa", out_chans=24, kern_sz=(1, 1)))
+        p.add(PipeOp("relu_qa", "ReLU", "qa", "qa"))
+        p.add(PipeOp("pb", "Pooling", "c0", "pb", kern_sz=(2, 2), stride=(1, 1))); p.add(PipeOp("qb", "Convolution", "pb", "qb", out_chans=72, kern_sz=(1, 1)))
+        p.add(PipeOp("pc", "Pooling", "qa", "pc", kern_sz=(5, 5), stride=(1, 1), in_pad=(2, 2))); p.add(PipeOp("qc", "Convolution", "pc", "qc", out_chans=16, kern_sz=(1, 1)))
+        p.add(PipeOp("relu_qc", "ReLU", "qc", "qc"))
+        # not fusable: average pooling; stride 2; a pooling of the (signed) raw data; a pooling read by two ops
+        p.add(PipeOp("pd", "Pooling", "c0", "pd", kern_sz=(3, 3), stride=(1, 1), in_pad=(1, 1), avg_pool=1)); p.add(PipeOp("qd", "Convolution", "pd", "qd", out_chans=8, kern_sz=(1, 1)))
+        p.add(PipeOp("pe", "Pooling", "c0", "pe", kern_sz=(3, 3), stride=(2, 2))); p.add(PipeOp("qe", "Convolution", "pe", "qe", out_chans=8, kern_sz=(1, 1)))
+        p.add(PipeOp("pg", "Pooling", "qb", "pg", kern_sz=(3, 3), stride=(1, 1), in_pad=(1, 1))); p.add(PipeOp("qg", "Convolution", "pg", "qg", out_chans=8, kern_sz=(1, 1)))   # qb has no ReLU: may be negative
+        p.add(PipeOp("ph", "Pooling", "c0", "ph", kern_sz=(3, 3), stride=(1, 1), in_pad=(1, 1))); p.add(PipeOp("qh", "Convolution", "ph", "qh", out_chans=8, kern_sz=(1, 1)))
+        p.add(PipeOp("qh2", "Convolution", "ph", "qh2", out_chans=8, kern_sz=(3, 3), in_pad=(1, 1)))
+        return p
+    for cp, want_fused in ((small(), {"pa": "qa", "pb": "qb", "pc": "qc"}), (googlenet_conv(3), {f"icp{k}_pool": f"icp{k}_out3" for k in range(1, 10)})):
+        params = _params(cp)
+        data = bo.gen_conv_in(*cp.nodes["data"].sizes)
+        nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
+        res = []
+        for fuse in (True, False):
+            fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc"), fuse_pools=fuse)
+            fwd.init(cp, op_params=params)
+            try:
+                io = {"data": data}
+                fwd.run_fwd(["data"], io, nodes)
+                res.append(io)
+                if fuse:
+                    assert fwd.fused_pools == want_fused, fwd.fused_pools
+                    assert not any(c.tag in want_fused for c in fwd.fwd_calls)                      # the poolings are gone from the pass ...
+                    n = fwd.capture_graph(); out = cp.out_node()
+                    rtc.set_var_to_zero(fwd.var_of(out)); fwd.run_graph()
+                    assert np.array_equal(fwd._fetch(out), io[out])
+                else:
+                    assert not fwd.fused_pools
+            finally:
+                fwd.release()
+        for n in nodes:                                                                              # ... and every node (the poolings' own outputs, materialised on demand, included) is the same
+            assert np.array_equal(res[0][n], res[1][n]), (cp.name, n)
 
 
 def test_channels_last_pool_lrn_specialised_kernels(rtc):

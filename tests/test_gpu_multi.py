@@ -190,6 +190,46 @@ def test_full_net_forward_on_a_multi_device_backend_equals_single_device(single,
     assert np.abs(res[1][cp.out_node()]).max() > 0
 
 
+@pytest.mark.parametrize("net,batch,ndev", [("googlenet", 7, 3), ("alexnet", 5, 2)])
+def test_channels_last_net_and_graph_replay_on_a_multi_device_backend(single, net, batch, ndev, monkeypatch):
+    """BASELINE config 5's form behind the boundary: a channels-last bf16 net through ConvPipeFwd on (be=hip,devices=0:0:..) -- the layout pass, pool / LRN / Concat
+    kernels over each shard's ids (they walk 16-byte chunks: `// CUCL IX GLOB_ID_1D <arg> n=<count>`; the LRN kernels are `wave_local`), sibling groups, level sets
+    and fused poolings on every shard -- node for node bit-identical to one device; then the whole pass captured into one hipGraph PER DEVICE and replayed as one call."""
+    from boda_amd import gen_data as gd
+    from boda_amd.cnn_op import OpTune
+    from boda_amd.conv_pipe import ConvPipeFwd, alexnet_ng_conv, googlenet_conv
+    monkeypatch.setenv("BODAHIP_NO_NHWC_SPLITK", "1")      # (a shard's tile count differs from the whole batch's: keep the planner from slicing K on one side only)
+    cp_of = {"googlenet": googlenet_conv, "alexnet": alexnet_ng_conv}[net]
+    res = []
+    for be in ("(be=hip,devices=" + ":".join(["0"] * ndev) + ")", None):
+        rtc = make_rtc(be) if be else single
+        if be:
+            rtc.init()
+        cp = cp_of(batch)
+        fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc")); fwd.init(cp)
+        try:
+            rtc.run(gd.gen_call("Convolution", "in", fwd.in_var, cp.nodes["data"], 5, 0.0)); rtc.finish_and_sync()
+            nodes = [nn for nn in cp.nodes if nn != "data" and nn in {o.top for o in cp.ops if o.type != "Dropout"}]
+            io = {}
+            fwd.run_fwd([], io, nodes)
+            res.append(io)
+            if be:
+                out = cp.out_node()
+                n = fwd.capture_graph(); assert n == len(fwd.fwd_calls)
+                for _ in range(2):
+                    rtc.set_var_to_zero(fwd.var_of(out)); ms = fwd.run_graph(); assert ms > 0
+                    assert np.array_equal(fwd._fetch(out), io[out])
+                if net == "googlenet":
+                    assert len(fwd.level_sets) >= 9 and len(fwd.fused_pools) == 9 and len(fwd.groups) == 9
+        finally:
+            fwd.release(); rtc.release_per_call_id_data()
+            if be:
+                rtc.close()
+    for nn in res[1]:
+        assert np.array_equal(res[0][nn], res[1][nn]), nn
+    assert np.abs(res[1][cp.out_node()]).max() > 0
+
+
 def test_ops_prof_end_to_end_on_a_sharded_backend(golden_dir):
     """The ops-prof protocol (src/rtc_prof.cc:44-126,194-371: vars, inputs generated ON DEVICE, run, read back, digests vs the reference's wisdom
     file) through ONE backend over three shards: the reference-held digests of test/good_tr/conv-debug are met by the gathered outputs."""
