@@ -119,6 +119,39 @@ class ConvPipe:
         return self.ops[-1].top
 
 
+class DryRtc:
+    """A backend that records instead of running: ConvPipeFwd.init() on it yields the functions a net compiles (`.infos`: every RtcFuncInfo, native and generated)
+    without a device -- what `__graft_entry__.build()` pre-specialises so that a fresh GPU box starts warm (sibling groups, level sets, fused poolings included)."""
+
+    def __init__(self):
+        self.infos: List[RtcFuncInfo] = []; self._dims: Dict[str, Dims] = {}
+        self._gen_data_compiled = True; self._fwd_funcs_compiled = True
+
+    def compile(self, infos, *a, **k):
+        self.infos += list(infos)
+
+    def create_var_with_dims(self, vn, dims):
+        self._dims[vn] = dims
+
+    def get_var_dims(self, vn):
+        return self._dims[vn]
+
+    def copy_var_to_nda(self, vn, dims=None):
+        d = dims or self._dims[vn]
+        return np.zeros(d.sizes if d.sizes else (1,), dtype={"float": np.float32, "bfloat16": np.uint16}.get(d.tn, np.float32))
+
+    def get_plat_tag(self):
+        return "dry"
+
+    def run(self, rfc):
+        return 0
+
+    def __getattr__(self, name):       # everything else (release / sync / copies to the device): nothing to do
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return lambda *a, **k: None
+
+
 def sibling_runs(ops: List[PipeOp], members: List[PipeOp], fused=frozenset()) -> List[List[PipeOp]]:
     """Convolutions that read the same node with the same geometry (`members`, definition order) split into runs that may be emitted as ONE call at
     the run's first member: a later member joins only if no op between the two rewrites the shared bottom -- an in-place op on it that was not fused
@@ -369,7 +402,7 @@ class ConvPipeFwd:
     """`has_conv_fwd_t` with mode=rtc over an rtc backend (src/has_conv_fwd.H:16-25, src/rtc_fwd.cc:43-577)."""
     mode = "rtc"
 
-    def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False, fuse_siblings: bool = True, fuse_levels: bool = True, fuse_pools: bool = False,
+    def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False, fuse_siblings: bool = True, fuse_levels: bool = True, fuse_pools: bool = True, sets_take_groups: bool = True,
                  spec_fwd: bool = True):
         self.rtc, self.op_tune = rtc, op_tune or OpTune()
         self.spec_fwd = spec_fwd     # channels-last nets: pool / LRN kernels specialised per geometry (False: the generic kernels with run-time geometry)
@@ -378,9 +411,11 @@ class ConvPipeFwd:
         self.fuse_siblings = fuse_siblings
         self.fuse_levels = fuse_levels       # channels-last nets: the independent convolutions that fill one Concat (an inception module's 3x3 / 5x5 / pool projection) as ONE hip_conv_nhwc_set launch
         self.level_sets: List[Tuple[str, ...]] = []
+        self.sets_take_groups = sets_take_groups
         self.fuse_pools = fuse_pools         # channels-last nets: a stride-1 max pooling whose only reader is a 1x1 convolution is taken into that convolution (its input must be non-negative).
-        # Opt-in: measured on GoogLeNet at 64 images it removes nine launches and 0.10 ms of pooling time but the window maximum (nine LDS reads + 32 packed max per B fragment)
-        # costs the convolution more than that -- 78.9 k img/s without, 75.1 k with (tools/r4k.sh)
+        # Measured on GoogLeNet at 64 images (tools/r4k.sh, r4l.sh): by itself it LOSES -- nine launches and 0.10 ms of pooling time go, but the window maximum (nine LDS
+        # reads + 32 packed max per B fragment) makes the convolution a 12-24 us launch of its own at the module's first level: 78.9 -> 75.1 k img/s.  Together with
+        # sets_take_groups -- the pool projection then shares ONE launch with the module's sibling group, both read the module's input -- it wins: 79.8 -> 83.0 k img/s
         self.fused_pools: Dict[str, str] = {}  # pooling tag -> the convolution that took it
         self._lazy: Dict[str, FwdCall] = {}    # nodes no call of the forward pass writes any more (a fused pooling's output): the call that materialises one when it is asked for
         self.groups: List[Tuple[str, ...]] = []      # tags of the members of each fused call
@@ -545,6 +580,7 @@ class ConvPipeFwd:
                         rtc.create_var_with_dims(o.top, vd(o.top)); self._vars.append(o.top); made.add(o.top)
                 ganno = _nhwc.annotate_group([annos[o.tag] for o in grp])
                 gname = "+".join(o.tag for o in grp); gen_fn = f"{_nhwc.GRP_FUNC}__{cp.name}_{grp[0].tag}"
+                annos[gname] = ganno          # (a sibling group may in turn join a level set)
                 rtc.compile([RtcFuncInfo(gen_fn, "", _nhwc.group_arg_names(len(grp)), ganno)]); self._funcs.append(gen_fn)
                 fv, bv = f"{gen_fn}_filts", f"{gen_fn}_biases"
                 rtc.create_var_with_dims(fv, ganno.get_dims("filts")); rtc.create_var_with_dims(bv, ganno.get_dims("biases")); self._vars += [fv, bv]
@@ -688,12 +724,14 @@ class ConvPipeFwd:
             idxs = by_level[l]
             def joins(i: int) -> bool:   # a plain convolution whose own plan does not slice K (a sliced member would run unsliced in a set and set its pace:
                 c = self.fwd_calls[i]    # GoogLeNet's 4x4 auxiliary-head conv, K = 2048 on 8 tiles, 12 us sliced on its own against 44 us as a member)
+                if c.func == _nhwc.GRP_FUNC:
+                    return self.sets_take_groups   # (a sibling group as a member: the GROUPS form of the implicit-GEMM kernel inside the wrapper)
                 if c.func != _nhwc.FUNC or not _nhwc.set_eligible(self._annos[c.tag]):
                     return False
                 from .rtc import explain_plan
                 return "_s" not in explain_plan(self._annos[c.tag], getattr(self, "_num_cus", 256)).split()[1]
             elig = [i for i in idxs if joins(i)]
-            out_tn = {self._annos[self.fwd_calls[i].tag].get_dims("out").tn for i in elig}
+            out_tn = {(self._annos[self.fwd_calls[i].tag].get_dims("out_0") if self.fwd_calls[i].func == _nhwc.GRP_FUNC else self._annos[self.fwd_calls[i].tag].get_dims("out")).tn for i in elig}
             if len(elig) < 2 or len(out_tn) != 1:
                 new_calls += [self.fwd_calls[i] for i in idxs]; continue
             new_calls += [self.fwd_calls[i] for i in idxs if i not in elig]
@@ -709,7 +747,7 @@ class ConvPipeFwd:
                 for m, c in enumerate(members):
                     for an, v in c.rfc.arg_map.items():
                         am[f"{an}_{m}"] = v
-                new_calls.append(FwdCall("+".join(c.tag for c in members), RtcFuncCall(gen_fn, am), _nhwc.SET_FUNC, sum(flops_of[c.tag] for c in members)))
+                new_calls.append(FwdCall("+".join(c.tag for c in members), RtcFuncCall(gen_fn, am), _nhwc.SET_FUNC, sum(flops_of[t] for c in members for t in c.tag.split("+"))))
                 self.level_sets.append(tuple(c.tag for c in members))
         self.fwd_calls = new_calls
 

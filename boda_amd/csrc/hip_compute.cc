@@ -447,10 +447,10 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
   struct graph_t { hipGraph_t g = nullptr; hipGraphExec_t exec = nullptr; uint32_t n_calls = 0; };
   std::vector<graph_t> graphs;
   uint32_t cap_calls = 0;
-  void graph_begin() {
-    assert_st(init_done); use_dev();
+  void graph_begin(bool sync_first = true) {   // sync_first = false: the caller has drained this stream already (a multi-device backend opening one capture per device:
+    assert_st(init_done); use_dev();            // no synchronising call is allowed from this thread once the first of them is open)
     if (capturing) rt_err("graph_begin: a capture is already in progress");
-    finish_and_sync();
+    if (sync_first) finish_and_sync();
     hip_err_chk(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
     capturing = true; cap_calls = 0; cap_last.clear();
   }
@@ -565,6 +565,8 @@ struct hip_compute_t : public rtc_compute_t, public native_host_t {
 p_rtc_compute_t make_hip_compute(int device_ordinal) { return std::make_shared<hip_compute_t>(device_ordinal); }
 static hip_compute_t &as_hip(rtc_compute_t *rtc) { hip_compute_t *h = dynamic_cast<hip_compute_t *>(rtc); if (!h) rt_err("not a hip_compute_t"); return *h; }
 void hip_compute_graph_begin(rtc_compute_t *rtc) { as_hip(rtc).graph_begin(); }
+void hip_compute_graph_begin_drained(rtc_compute_t *rtc) { as_hip(rtc).graph_begin(false); }
+void hip_compute_graph_abort(rtc_compute_t *rtc) { as_hip(rtc).graph_abort(); }
 uint32_t hip_compute_graph_end(rtc_compute_t *rtc) { return as_hip(rtc).graph_end(); }
 uint32_t hip_compute_graph_launch(rtc_compute_t *rtc, uint32_t id) { return as_hip(rtc).graph_launch(id); }
 uint32_t hip_compute_graph_num_calls(rtc_compute_t *rtc, uint32_t id) { return as_hip(rtc).graph_num_calls(id); }

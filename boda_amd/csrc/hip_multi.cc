@@ -35,6 +35,8 @@ namespace bodahip {
 
 void *hip_compute_stream(rtc_compute_t *rtc);
 void hip_compute_graph_begin(rtc_compute_t *rtc);
+void hip_compute_graph_begin_drained(rtc_compute_t *rtc);
+void hip_compute_graph_abort(rtc_compute_t *rtc);
 uint32_t hip_compute_graph_end(rtc_compute_t *rtc);
 uint32_t hip_compute_graph_launch(rtc_compute_t *rtc, uint32_t id);
 uint32_t hip_compute_graph_num_calls(rtc_compute_t *rtc, uint32_t id);
@@ -116,7 +118,10 @@ struct hip_multi_compute_t : public rtc_compute_t {
   void graph_begin() {
     assert_st(init_done);
     if (capturing) rt_err("graph_begin: a capture is already in progress");
-    for (auto &s : subs) hip_compute_graph_begin(s.get());
+    for (auto &s : subs) s->finish_and_sync();      // every stream drained BEFORE the first capture opens: a synchronising call is not allowed from this thread afterwards
+    size_t opened = 0;
+    try { for (; opened < n(); ++opened) hip_compute_graph_begin_drained(subs[opened].get()); }
+    catch (...) { for (size_t i = 0; i < opened; ++i) hip_compute_graph_abort(subs[i].get()); throw; }
     capturing = true; cap_skipped = false;
   }
   uint32_t graph_end_common(uint32_t n_calls, uint32_t const *dep_ptr, uint32_t const *dep_idx) {
@@ -380,7 +385,10 @@ struct hip_multi_compute_t : public rtc_compute_t {
     calls.push_back(ids);
     return (uint32_t)calls.size() - 1;
   }
-  void finish_and_sync() override { if (capturing) { capturing = false; } for (auto &s : subs) s->finish_and_sync(); }
+  void finish_and_sync() override {
+    if (capturing) { capturing = false; for (auto &s : subs) hip_compute_graph_abort(s.get()); rt_err("finish_and_sync during graph capture"); }
+    for (auto &s : subs) s->finish_and_sync();
+  }
   void release_per_call_id_data() override { for (auto &s : subs) s->release_per_call_id_data(); calls.clear(); }
   float get_dur(uint32_t const &b, uint32_t const &e) override {
     if (b >= calls.size() || e >= calls.size()) rt_err("invalid call_id");

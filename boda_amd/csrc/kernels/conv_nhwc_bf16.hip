@@ -183,9 +183,9 @@ __device__ __forceinline__ constexpr int swz(int row) { return (row / kRP) & (kC
 } // namespace
 
 #ifdef BODAHIP_AS_MEMBER
-static_assert(!SPLITK && !GROUPS && !IN_F32, "a member of a set: one kernel, plain arguments");
+static_assert(!SPLITK && !IN_F32, "a member of a set: one kernel, no K slices");
 constexpr int member_smem_bytes = kSmem, member_threads = WI * WJ * 64, member_minw = MINW;
-__device__ __forceinline__ void KNAME(gemm_args_t const &p, int const member_bid, char *const smem) {
+__device__ __forceinline__ void KNAME(gemm_args_t const &p, grp_args_t const &q, int const member_bid, char *const smem) {   // (q: read by the GROUPS form only)
 #elif GROUPS
 static_assert(!SPLITK && !IN_F32, "fused convolutions: no K slices, bf16 tensors");
 extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p, grp_args_t const q) {
@@ -207,8 +207,8 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     int const bid = BODAHIP_BID;
 #endif
     int const nb = p.tiles_i * p.tiles_j;
-    int const q = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
-    int const nid = ((xcd < rr) ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    int const qn = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    int const nid = ((xcd < rr) ? xcd * (qn + 1) : rr * (qn + 1) + (xcd - rr) * qn) + idx;
     int const group_sz = GROUP_I * p.tiles_j, gid = nid / group_sz, first_i = gid * GROUP_I;
     int const gsz = min(p.tiles_i - first_i, GROUP_I), in_g = nid - gid * group_sz;
     tile_i = first_i + in_g % gsz; tile_j = in_g / gsz;

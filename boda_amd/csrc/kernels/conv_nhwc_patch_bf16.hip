@@ -150,7 +150,7 @@ __device__ __forceinline__ bf16x8 frag_b(u32x4 const *Js, int at) {
 
 #ifdef BODAHIP_AS_MEMBER
 constexpr int member_smem_bytes = kSmem, member_threads = WI * WJ * 64, member_minw = MINW;
-__device__ __forceinline__ void KNAME(gemm_args_t const &p, int const member_bid, char *const smem) {
+__device__ __forceinline__ void KNAME(gemm_args_t const &p, grp_args_t const &, int const member_bid, char *const smem) {   // (one member signature for both kernel files)
 #else
 extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p) {
   __shared__ __attribute__((aligned(16))) char smem[kSmem];

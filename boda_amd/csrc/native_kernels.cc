@@ -1170,7 +1170,7 @@ void native_kernels_t::conv_nhwc_multi(int n, multi_member_t const *ms, bool out
 // sources are instantiated once per distinct member plan inside one translation unit (BODAHIP_AS_MEMBER: kernels/conv_nhwc_bf16.hip, conv_nhwc_patch_bf16.hip become
 // __device__ functions), a wrapper kernel maps its workgroup to (member, tile) and calls the member's code.  Same code, same arguments, same tile -> same bits as the
 // member's own launch.  Members that cannot join (another workgroup size, K slices) are launched on their own by the same call.
-struct set_member_plan_t { plan_t p; gemm_args_t ga; long tiles; int variant; double tile_cost; };
+struct set_member_plan_t { plan_t p; gemm_args_t ga; grp_args_t q; long tiles; int variant; double tile_cost; };
 static char const *const k_set_macros[] = {"BI", "BJ", "BK", "WI", "WJ", "MINW", "CIN", "KH", "KW", "SY", "SX", "PY", "PX", "CH", "CW", "COH", "COW", "RELU", "OUT_F32", "NBUF", "CG",
                                            "ADIRECT", "PF", "BPF", "WPITCH", "DBUF", "ABLATE", "POOL", "GROUP_I", "IN_F32", "SPLITK", "INTERLEAVE", "GROUPS", "KNAME", "BODAHIP_BID"};
 static string set_kernel_source(std::vector<plan_t const *> const &variants, int threads, int minw) {
@@ -1190,7 +1190,7 @@ static string set_kernel_source(std::vector<plan_t const *> const &variants, int
     o << "#define KNAME run\nnamespace member_v" << v << " {\n" << (p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : k_src_conv_nhwc_bf16) << "\n}\n";
     for (char const *m : k_set_macros) o << "#undef " << m << "\n";
   }
-  o << "struct set_args_t { gemm_args_t const *m; int const *ends; int const *variant; int n; };\n";
+  o << "struct set_args_t { gemm_args_t const *m; int const *ends; int const *variant; grp_args_t const *g; int n; };\n";
   // the largest LDS need of the members, as a constant expression
   o << "namespace { constexpr int set_max(int a, int b) { return a > b ? a : b; }\nconstexpr int kSmemAll = ";
   for (size_t v = 0; v < variants.size(); ++v) o << "set_max(member_v" << v << "::member_smem_bytes, ";
@@ -1207,7 +1207,7 @@ static string set_kernel_source(std::vector<plan_t const *> const &variants, int
        "#pragma unroll\n"
        "    for (int i = 0; i < (int)(sizeof(gemm_args_t) / 4); ++i) dst[i] = __builtin_amdgcn_readfirstlane(src[i]); }\n"
        "  switch (var) {\n";
-  for (size_t v = 0; v < variants.size(); ++v) o << "    case " << v << ": member_v" << v << "::run(p, local, smem); break;\n";
+  for (size_t v = 0; v < variants.size(); ++v) o << "    case " << v << ": member_v" << v << "::run(p, a.g[k], local, smem); break;\n";
   o << "    default: break;\n  }\n}\n";
   return o.str();
 }
@@ -1234,19 +1234,37 @@ void native_kernels_t::conv_nhwc_set(int n, multi_member_t const *ms, bool const
     conv_geom_t const &g = ms[m].g;
     if (!((long)g.B * g.OH * g.OW) || !g.OC) rt_err("hip_conv_nhwc_set: empty member");
     set_member_plan_t &q = mp[(size_t)m];
+    memset(&q.q, 0, sizeof(q.q));
+    if (ms[m].grp_n > 0) {   // a horizontally fused member: the GROUPS form of the implicit-GEMM kernel, its members' destinations in q
+      if (patch_filts[m] || ms[m].pool) rt_err("hip_conv_nhwc_set: a fused (grp) member takes out_chan:y:x:in_chan filters");
+      q.p = plan_conv_nhwc(g, host->nh_num_cus(), string(), out_f32, ms[m].grp_pad);
+      multi_member_t mm = ms[m]; mm.out_ctot = 0; mm.out_coff = 0;
+      q.ga = nhwc_member_args(mm, q.p.cfg, out_f32, "hip_conv_nhwc_set"); q.ga.D = nullptr; q.ga.D_bytes = 0;
+      long const Njg = (long)g.B * g.OH * g.OW; int tot = 0;
+      q.q.n = ms[m].grp_n;
+      for (int j = 0; j < ms[m].grp_n; ++j) {
+        q.q.oc0[j] = tot; q.q.noc[j] = ms[m].grp_noc[j]; tot += (ms[m].grp_noc[j] + ms[m].grp_pad - 1) / ms[m].grp_pad * ms[m].grp_pad;
+        uint64_t const ob = (uint64_t)Njg * ms[m].grp_ctot[j] * (out_f32 ? 4 : 2);
+        if (ob >= 0x7ffffff0ull) unsup_err("hip_conv_nhwc_set: out of 2 GiB or more");
+        q.q.D[j] = ms[m].grp_out[j]; q.q.D_bytes[j] = (unsigned)ob; q.q.ctot[j] = ms[m].grp_ctot[j]; q.q.coff[j] = ms[m].grp_coff[j];
+      }
+      if (tot != g.OC) rt_err("hip_conv_nhwc_set: a fused member's filts hold " + std::to_string(g.OC) + " out_chans, its members need " + std::to_string(tot));
+    } else {
     q.p = patch_filts[m] ? plan_conv_nhwc_patch(g, host->nh_num_cus(), string(), out_f32, ms[m].pool) : plan_conv_nhwc(g, host->nh_num_cus(), string(), out_f32, 0, /*allow_split=*/false);
     q.ga = nhwc_member_args(ms[m], q.p.cfg, out_f32, "hip_conv_nhwc_set");
+    }
     q.tiles = (long)q.ga.tiles_i * q.ga.tiles_j;
     q.tile_cost = (double)q.p.cfg.BI * q.p.cfg.BJ * (double)g.C * (ms[m].pool ? 2 : g.KH * g.KW);
     (q.p.cfg.threads() == 256 ? in_set : alone).push_back(m);
   }
   if (in_set.size() < 2) { alone.insert(alone.end(), in_set.begin(), in_set.end()); in_set.clear(); }
   double flops = 0, bytes = 0;
-  for (int m = 0; m < n; ++m) { conv_geom_t const &g = ms[m].g; double const Nj = (double)g.B * g.OH * g.OW, Kt = ms[m].pool ? (double)g.C : (double)g.C * g.KH * g.KW;
+  for (int m = 0; m < n; ++m) { conv_geom_t g = ms[m].g; double const Nj = (double)g.B * g.OH * g.OW, Kt = ms[m].pool ? (double)g.C : (double)g.C * g.KH * g.KW;
+    if (ms[m].grp_n > 0) { int roc = 0; for (int j = 0; j < ms[m].grp_n; ++j) roc += ms[m].grp_noc[j]; g.OC = roc; }   // (a fused member's own out_chans: zero padding rows are not credit)
     flops += 2.0 * Nj * g.OC * Kt; bytes += 2.0 * ((double)g.B * g.C * g.H * g.W + (double)g.OC * Kt) + (out_f32 ? 4.0 : 2.0) * Nj * g.OC + 4.0 * g.OC; }
   for (int m : alone) {   // members with another workgroup size: their own launch, the plan they would have taken anyway
     kernel_t &k = get_kernel(impl, host, mp[(size_t)m].p);
-    void *params[] = {&mp[(size_t)m].ga};
+    void *params[] = {&mp[(size_t)m].ga, &mp[(size_t)m].q};     // (the second argument is read by the GROUPS form only)
     hip_err_chk(host->nh_launch(k.func, (uint32_t)mp[(size_t)m].tiles, 1, (uint32_t)mp[(size_t)m].p.cfg.threads(), params), "hipModuleLaunchKernel(conv_nhwc_set, lone member)");
   }
   if (!in_set.empty()) {
@@ -1272,13 +1290,13 @@ void native_kernels_t::conv_nhwc_set(int n, multi_member_t const *ms, bool const
     }
     // member table (arguments, grid ends, variant ids) in device memory: one copy per distinct call
     size_t const ns = in_set.size();
-    std::vector<gemm_args_t> args; std::vector<int> ends, vars; long tot = 0;
-    for (int m : in_set) { args.push_back(mp[(size_t)m].ga); tot += mp[(size_t)m].tiles; ends.push_back((int)tot); vars.push_back(mp[(size_t)m].variant); }
+    std::vector<gemm_args_t> args; std::vector<grp_args_t> gargs; std::vector<int> ends, vars; long tot = 0;
+    for (int m : in_set) { args.push_back(mp[(size_t)m].ga); gargs.push_back(mp[(size_t)m].q); tot += mp[(size_t)m].tiles; ends.push_back((int)tot); vars.push_back(mp[(size_t)m].variant); }
     if (tot > 0x7fffffffl) unsup_err("hip_conv_nhwc_set: too many tiles");
-    size_t const ab = ns * sizeof(gemm_args_t), eo = (ab + 255) & ~size_t(255), vo = eo + ((ns * 4 + 255) & ~size_t(255)), total = vo + ns * 4;
+    size_t const ab = ns * sizeof(gemm_args_t), eo = (ab + 255) & ~size_t(255), vo = eo + ((ns * 4 + 255) & ~size_t(255)), go = vo + ((ns * 4 + 255) & ~size_t(255)), total = go + ns * sizeof(grp_args_t);
     string tkey = "settab:";
     { uint64_t h = 1469598103934665603ull; auto mix = [&](void const *d, size_t nb) { for (size_t i = 0; i < nb; ++i) { h ^= ((unsigned char const *)d)[i]; h *= 1099511628211ull; } };
-      mix(args.data(), ab); mix(ends.data(), ns * 4); mix(vars.data(), ns * 4); mix(skey.data(), skey.size()); tkey += std::to_string(h) + ":" + std::to_string(total); }
+      mix(args.data(), ab); mix(gargs.data(), ns * sizeof(grp_args_t)); mix(ends.data(), ns * 4); mix(vars.data(), ns * 4); mix(skey.data(), skey.size()); tkey += std::to_string(h) + ":" + std::to_string(total); }
     auto it = impl->ktabs.find(tkey);
     if (it == impl->ktabs.end()) {
       if (host->nh_capturing()) rt_err("graph capture: the member table of this hip_conv_nhwc_set call is not on the device yet -- run the call list once before capturing it");
@@ -1287,11 +1305,13 @@ void native_kernels_t::conv_nhwc_set(int n, multi_member_t const *ms, bool const
       hip_err_chk(hipMemcpyAsync(dev, args.data(), ab, hipMemcpyHostToDevice, host->nh_stream()), "hipMemcpyAsync(set args)");
       hip_err_chk(hipMemcpyAsync((char *)dev + eo, ends.data(), ns * 4, hipMemcpyHostToDevice, host->nh_stream()), "hipMemcpyAsync(set ends)");
       hip_err_chk(hipMemcpyAsync((char *)dev + vo, vars.data(), ns * 4, hipMemcpyHostToDevice, host->nh_stream()), "hipMemcpyAsync(set variants)");
+      hip_err_chk(hipMemcpyAsync((char *)dev + go, gargs.data(), ns * sizeof(grp_args_t), hipMemcpyHostToDevice, host->nh_stream()), "hipMemcpyAsync(set grp args)");
       hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize(set table)");
       it = impl->ktabs.emplace(tkey, dev).first;
     }
-    struct { gemm_args_t const *m; int const *ends; int const *variant; int n; } sa;
-    sa.m = (gemm_args_t const *)it->second; sa.ends = (int const *)((char *)it->second + eo); sa.variant = (int const *)((char *)it->second + vo); sa.n = (int)ns;
+    struct { gemm_args_t const *m; int const *ends; int const *variant; grp_args_t const *g; int n; } sa;
+    sa.m = (gemm_args_t const *)it->second; sa.ends = (int const *)((char *)it->second + eo); sa.variant = (int const *)((char *)it->second + vo);
+    sa.g = (grp_args_t const *)((char *)it->second + go); sa.n = (int)ns;
     void *params[] = {&sa};
     hip_err_chk(host->nh_launch(kit->second.func, (uint32_t)tot, 1, 256, params), "hipModuleLaunchKernel(conv_nhwc_set)");
     last_launch.cfg = mp[(size_t)in_set[0]].p.cfg; last_launch.grid = (uint32_t)tot; last_launch.block = 256;
@@ -1419,9 +1439,14 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
     bool const multi = op.has_func_name() && op.get_func_name() == "hip_conv_nhwc_multi";
     if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc_set") {   // the wrapper kernel of the members' specialisations (and the kernels of members that stay alone)
-      int const n = (int)op.get_dims("multi").dsz("n"); bool const out_f32 = op.get_dims("out_0").tn == "float";
+      int const n = (int)op.get_dims("multi").dsz("n"); bool const out_f32 = op.get_dims(op.has("out_0") ? "out_0" : "out_0_0").tn == "float";
       std::vector<plan_t> plans; std::vector<plan_t const *> variants; std::vector<string> vkeys; int minw = 8; size_t bytes = 0; string desc;
       for (int m = 0; m < n; ++m) { string const sfx = "_" + std::to_string(m);
+        if (op.has("grp" + sfx)) {   // a horizontally fused member
+          dims_t const &grp = op.get_dims("grp" + sfx);
+          conv_geom_t const gg = geom_from_dims(op.get_dims("filts" + sfx), op.get_dims("in" + sfx), op.get_dims("out_0" + sfx), op.get_dims("stride" + sfx), op.get_dims("in_pad" + sfx), relu);
+          plans.push_back(plan_conv_nhwc(gg, num_cus, string(), out_f32, (int)grp.dims(grp.sz() - 1))); continue;
+        }
         dims_t f = op.get_dims("filts" + sfx); bool const pf = f.sz() == 5;
         if (pf) f = dims_t({f.dims(3), f.dims(1), f.dims(2), f.dims(0) * 8}, {"out_chan", "y", "x", "in_chan"}, f.tn);
         bool const relu_m = op.has("relu_mask") ? (((op.get_u32("relu_mask") >> m) & 1u) != 0) : relu;
@@ -1614,6 +1639,39 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     std::vector<native_kernels_t::multi_member_t> ms((size_t)n); string out_tn; std::vector<char> patch_f((size_t)n, 0);
     for (int m = 0; m < n; ++m) {
       string const sfx = "_" + std::to_string(m);
+      if (is_set && am.find("grp" + sfx) != am.end()) {   // a horizontally fused member (the args of hip_conv_nhwc_grp, every name with the member's suffix)
+        string const fnm = var_of(am, "filts" + sfx), bnm = var_of(am, "biases" + sfx), inm = var_of(am, "in" + sfx);
+        dims_t const f = host->nh_var_dims(fnm), bi = host->nh_var_dims(bnm), in = host->nh_var_dims(inm);
+        need_float(bi, "biases");
+        if (f.tn != "bfloat16" || in.tn != "bfloat16") unsup_err("hip_conv_nhwc_set: filts / in must have type bfloat16");
+        if (!(f.sz() == 4 && f.names(0) == "out_chan" && f.names(3) == "in_chan" && in.sz() == 4)) rt_err("hip_conv_nhwc_set: a fused member's filts must be out_chan:y:x:in_chan");
+        auto si = am.find("stride" + sfx), pi = am.find("in_pad" + sfx);
+        if (si == am.end() || pi == am.end()) rt_err("hip_conv_nhwc_set: 'stride_<m>' and 'in_pad_<m>' REF args are required");
+        dims_t const stride = si->second.get_dims(host->nh_rtc()), in_pad = pi->second.get_dims(host->nh_rtc()), grp = am.find("grp" + sfx)->second.get_dims(host->nh_rtc());
+        int const gn = (int)grp.sz() - 1;
+        if (gn < 1 || gn > 4 || grp.names(gn) != "pad") rt_err("hip_conv_nhwc_set: grp_<m> must be (m0=..,..,pad=..) with 1..4 members");
+        native_kernels_t::multi_member_t &mm = ms[(size_t)m];
+        mm.grp_n = gn; mm.grp_pad = (int)grp.dims(gn); dims_t out0;
+        for (int j = 0; j < gn; ++j) {
+          string const onm = var_of(am, "out_" + std::to_string(j) + sfx);
+          dims_t const out = host->nh_var_dims(onm);
+          if (out.tn != "bfloat16" && out.tn != "float") unsup_err("hip_conv_nhwc_set: outputs must have type bfloat16 or float");
+          if (j == 0) out0 = out;
+          if (m == 0 && j == 0) out_tn = out.tn; else if (out.tn != out_tn) rt_err("hip_conv_nhwc_set: the members' outputs must have one type");
+          mm.grp_noc[j] = (int)grp.dims(j); mm.grp_ctot[j] = (int)out.dsz("chan"); mm.grp_coff[j] = 0; mm.grp_out[j] = host->nh_var_ptr(onm);
+          auto oi = am.find("out_chan_off_" + std::to_string(j) + sfx);
+          if (oi != am.end()) {
+            if (oi->second.is_var() || !oi->second.v || !oi->second.v->rp_elems()) rt_err("hip_conv_nhwc_set: out_chan_off must be a by-value uint32");
+            mm.grp_coff[j] = (int)*(uint32_t const *)oi->second.v->rp_elems();
+          } else if (mm.grp_ctot[j] != mm.grp_noc[j]) rt_err("hip_conv_nhwc_set: a fused member writes a wider tensor: out_chan_off is required");
+          if (mm.grp_coff[j] < 0 || mm.grp_coff[j] + mm.grp_noc[j] > mm.grp_ctot[j]) rt_err("hip_conv_nhwc_set: out_chan_off + out_chans exceeds the channels of the output");
+        }
+        mm.g = geom_from_dims(f, in, out0, stride, in_pad, has_mask ? ((mask >> m) & 1u) != 0 : relu_all);
+        if (f.dsz("in_chan") != (uint32_t)mm.g.C || bi.dsz("out_chan") != (uint32_t)mm.g.OC) rt_err("hip_conv_nhwc_set: inconsistent filts / biases / in dims of a fused member");
+        if (!mm.g.SY || !mm.g.SX || (mm.g.H + 2 * mm.g.PY - mm.g.KH) / mm.g.SY + 1 != mm.g.OH || (mm.g.W + 2 * mm.g.PX - mm.g.KW) / mm.g.SX + 1 != mm.g.OW) rt_err("hip_conv_nhwc_set: out dims of a fused member do not match");
+        mm.filts = host->nh_var_ptr(fnm); mm.biases = (float const *)host->nh_var_ptr(bnm); mm.in = host->nh_var_ptr(inm); mm.out = nullptr; mm.out_ctot = 0; mm.out_coff = 0;
+        continue;
+      }
       string const fnm = var_of(am, "filts" + sfx), bnm = var_of(am, "biases" + sfx), inm = var_of(am, "in" + sfx), onm = var_of(am, "out" + sfx);
       dims_t f = host->nh_var_dims(fnm); dims_t const bi = host->nh_var_dims(bnm), in = host->nh_var_dims(inm), out = host->nh_var_dims(onm);
       if (is_set && f.sz() == 5) {   // the input-patch form F'[in_grp][ky][kx][out_chan][8]

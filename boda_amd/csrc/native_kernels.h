@@ -78,7 +78,9 @@ struct native_kernels_t {
   void conv_nhwc_grp(void const *filts, float const *biases, void const *in, conv_geom_t const &g, bool out_f32, int n, int const *noc, void *const *outs,
                      int const *ctot, int const *coff, int pad);
   // several independent channels-last convolutions as ONE launch (kernels/conv_nhwc_multi_bf16.hip); members: raw device pointers + geometry (g.C = stored channels)
-  struct multi_member_t { void const *filts; float const *biases; void const *in; void *out; conv_geom_t g; int out_ctot, out_coff; bool pool = false; };   // pool: g's window / padding are a max pooling fused in front of 1x1 filters
+  struct multi_member_t { void const *filts; float const *biases; void const *in; void *out; conv_geom_t g; int out_ctot, out_coff; bool pool = false;
+                          // a horizontally fused member (hip_conv_nhwc_grp as a member of a set): filts / biases stacked, g.OC = the padded total, `out` unused
+                          int grp_n = 0; int grp_noc[4] = {0, 0, 0, 0}; void *grp_out[4] = {nullptr, nullptr, nullptr, nullptr}; int grp_ctot[4] = {0, 0, 0, 0}, grp_coff[4] = {0, 0, 0, 0}; int grp_pad = 0; };   // pool: g's window / padding are a max pooling fused in front of 1x1 filters
   void conv_nhwc_multi(int n, multi_member_t const *members, bool out_f32);
   // a few independent channels-last convolutions, each on its own specialised kernel code (implicit-GEMM or input-patch form), as one launch (wrapper kernel built at run time)
   void conv_nhwc_set(int n, multi_member_t const *members, bool const *patch_filts, bool out_f32);

@@ -244,11 +244,17 @@ def annotate_set(annos: List[Op]) -> Op:
         raise UnsupErr("hip_conv_nhwc_set: 2..16 members")
     nv = {"multi": Nda(dims=Dims(("n",), (len(annos),), "none"), tn="none")}
     relu = [a.get_u32("conv_has_relu") for a in annos]
+    out_tn = lambda a: a.get_dims("out_0" if a.get_func_name() == GRP_FUNC else "out").tn
     for m, a in enumerate(annos):
-        if not set_eligible(a):
-            raise UnsupErr("hip_conv_nhwc_set: members must be hip_conv_nhwc functions (not the space-to-depth form)")
-        if a.get_dims("out").tn != annos[0].get_dims("out").tn:
+        if out_tn(a) != out_tn(annos[0]):
             raise UnsupErr("hip_conv_nhwc_set: members differ in output type")
+        if a.get_func_name() == GRP_FUNC:     # a horizontally fused member (hip_conv_nhwc_grp): its args keep their names, plus the member's suffix
+            for an, v in a.nda_vals.items():
+                if an != "conv_has_relu":
+                    nv[f"{an}_{m}"] = v
+            continue
+        if not set_eligible(a):
+            raise UnsupErr("hip_conv_nhwc_set: members must be hip_conv_nhwc / hip_conv_nhwc_grp functions (not the space-to-depth form)")
         for an in _MULTI_MEMBER_ARGS + ("kern_sz",):
             nv[f"{an}_{m}"] = a.nda_vals[an]
         if a.has("nhwc_pool"):     # (a member with max pooling fused in front of it)

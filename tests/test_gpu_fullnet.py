@@ -293,9 +293,10 @@ def test_full_net_forward_channels_last_bf16(rtc, net, batch):
     fwd.init(cp, op_params=params)
     try:
         funcs = [c.func for c in fwd.fwd_calls]
-        assert funcs[0] == "nhwc_xpose_in" and funcs.count("hip_conv_nhwc") + sum(len(g) for g in fwd.groups) + sum(len(g) for g in fwd.level_sets) == sum(o.type == "Convolution" for o in cp.ops)
+        in_sets = [t for g in fwd.level_sets for t in g]      # (a member is a convolution's tag, or a sibling group's "a+b+c")
+        assert funcs[0] == "nhwc_xpose_in" and funcs.count("hip_conv_nhwc") + sum(len(g) for g in fwd.groups) + sum("+" not in t for t in in_sets) == sum(o.type == "Convolution" for o in cp.ops)
         assert funcs.count("hip_conv_nhwc_set") == len(fwd.level_sets) and (len(fwd.level_sets) >= 1 if net == "googlenet" else not fwd.level_sets)   # (at one image most layers slice K on their own and stay out of the sets)
-        assert funcs.count("hip_conv_nhwc_grp") == len(fwd.groups) == (9 if net == "googlenet" else 0)   # an inception module's 1x1 / 3x3-reduce / 5x5-reduce convs: one launch
+        assert funcs.count("hip_conv_nhwc_grp") + sum("+" in t for t in in_sets) == len(fwd.groups) == (9 if net == "googlenet" else 0)   # an inception module's 1x1 / 3x3-reduce / 5x5-reduce convs: one launch (or one member of its level's set)
         assert not any(f.startswith("fwd_") or f == "hip_conv" for f in funcs)
         nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
         io = {"data": data}
@@ -458,13 +459,17 @@ def test_level_set_fusion_is_bit_identical(rtc, monkeypatch):
             res.append(io); ncalls.append(len(fwd.fwd_calls))
             if fuse:
                 # every inception module's 3x3 / 5x5 / pool-projection convs share a set; the auxiliary heads' convs join the trunk's sets of their level
+                # every inception module is two launches: its sibling group + the pool projection (the pooling fused into it: both read the module's input), then its
+                # 3x3 and 5x5 convs; the auxiliary heads' convs join the trunk's sets of their level
                 for k in range(1, 10):
-                    assert any({f"icp{k}_out1", f"icp{k}_out2", f"icp{k}_out3"} <= set(g) for g in fwd.level_sets), (k, fwd.level_sets)
-                assert any("cls1_reduction" in g for g in fwd.level_sets) and len(fwd.level_sets) >= 9
+                    grp = f"icp{k}_reduction1+icp{k}_reduction2+icp{k}_out0"
+                    assert any({grp, f"icp{k}_out3"} <= set(g) for g in fwd.level_sets), (k, fwd.level_sets)
+                    assert any({f"icp{k}_out1", f"icp{k}_out2"} <= set(g) for g in fwd.level_sets), (k, fwd.level_sets)
+                assert any("cls1_reduction" in g for g in fwd.level_sets) and len(fwd.level_sets) >= 18
                 n = fwd.capture_graph(parallel=True); out = cp.out_node()
                 deps = fwd.call_deps; tags = [c.tag for c in fwd.fwd_calls]
-                i_set = next(i for i, t in enumerate(tags) if "icp1_out1" in t.split("+"))       # the set runs after the sibling group (its reduce convs) and after the module's pool
-                assert {tags[d] for d in deps[i_set]} == {"icp1_reduction1+icp1_reduction2+icp1_out0", "icp1_pool"}, [tags[d] for d in deps[i_set]]
+                i_set = next(i for i, c in enumerate(fwd.fwd_calls) if "icp1_out1" in c.tag.split("+") and c.func == "hip_conv_nhwc_set")   # the 3x3 / 5x5 set runs after the set that holds the reduce convs
+                assert len(deps[i_set]) == 1 and "icp1_reduction1" in tags[deps[i_set][0]].split("+"), [tags[d] for d in deps[i_set]]
                 rtc.set_var_to_zero(fwd.var_of(out)); fwd.run_graph()
                 assert np.array_equal(fwd._fetch(out), io[out])
         finally:
@@ -510,6 +515,8 @@ def test_pool_fused_into_its_1x1_convolution_is_bit_identical(rtc, monkeypatch):
                 res.append(io)
                 if fuse:
                     assert fwd.fused_pools == want_fused, fwd.fused_pools
+                    if cp.name != "pf":     # GoogLeNet: the pool projection now reads the module's input and shares its level's set with the module's sibling GROUP
+                        assert any("icp3_out3" in g and "icp3_reduction1+icp3_reduction2+icp3_out0" in g for g in fwd.level_sets), fwd.level_sets
                     assert not any(c.tag in want_fused for c in fwd.fwd_calls)                      # the poolings are gone from the pass ...
                     n = fwd.capture_graph(); out = cp.out_node()
                     rtc.set_var_to_zero(fwd.var_of(out)); fwd.run_graph()

@@ -206,7 +206,7 @@ def test_channels_last_net_and_graph_replay_on_a_multi_device_backend(single, ne
         if be:
             rtc.init()
         cp = cp_of(batch)
-        fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc")); fwd.init(cp)
+        fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc"), fuse_pools=True); fwd.init(cp)
         try:
             rtc.run(gd.gen_call("Convolution", "in", fwd.in_var, cp.nodes["data"], 5, 0.0)); rtc.finish_and_sync()
             nodes = [nn for nn in cp.nodes if nn != "data" and nn in {o.top for o in cp.ops if o.type != "Dropout"}]
