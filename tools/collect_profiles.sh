@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh final'
-# then, back here:  python tools/make_profile_summaries.py gpurun_out/final r03
+# then, back here:  python tools/make_profile_summaries.py gpurun_out/final r04
 # Kernel-trace stats and the PMC passes are separate runs (one --pmc set per run, never combined with other trace domains).
 D=${1:-final}
 R=$PWD
@@ -35,11 +35,21 @@ for w in googlenet resnet50; do
   python bench.py --workload $w --dtype bf16 --layout nhwc --graph --steps 20 --warmup 5 --no-patch --no-cpu-baseline > $O/bench_${w}_bf16_nhwc_graph_nopatch.json 2>/dev/null
 done
 python bench.py --workload googlenet --dtype bf16 --layout nhwc --graph --steps 20 --warmup 5 --group-siblings --no-cpu-baseline > $O/bench_googlenet_bf16_nhwc_graph_grouped.json 2>/dev/null
+# round 4: the lists with the graph's edges removed, and with their implicit-GEMM members as ONE multi-problem launch
+for w in googlenet resnet50; do
+  python bench.py --workload $w --dtype bf16 --layout nhwc --graph --independent --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_${w}_bf16_nhwc_graph_independent.json 2>/dev/null
+  python bench.py --workload $w --dtype bf16 --layout nhwc --graph --multi --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_${w}_bf16_nhwc_graph_multi.json 2>/dev/null
+  python bench.py --workload $w --dtype bf16 --layout nhwc --graph --independent --multi --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_${w}_bf16_nhwc_graph_independent_multi.json 2>/dev/null
+done
+python bench.py --workload googlenet --dtype bf16 --layout nhwc --graph --independent --multi --sets 8 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_googlenet_bf16_nhwc_graph_independent_multi_sets8.json 2>/dev/null
 for w in nin-net alexnet-net googlenet-net; do
   python bench.py --workload $w --no-cpu-baseline --graph --parallel-branches > $O/bench_${w}_graph.json 2>/dev/null
-  python bench.py --workload $w --dtype bf16 --layout nhwc --no-cpu-baseline --graph --parallel-branches --steps 20 --warmup 5 > $O/bench_${w}_bf16_nhwc_graph.json 2>/dev/null
-  python bench.py --workload $w --dtype bf16 --layout nhwc --no-cpu-baseline --graph --parallel-branches --steps 20 --warmup 5 --no-patch --no-fuse-siblings > $O/bench_${w}_bf16_nhwc_graph_r02kernels.json 2>/dev/null
+  python bench.py --workload $w --dtype bf16 --layout nhwc --no-cpu-baseline --graph --steps 20 --warmup 5 > $O/bench_${w}_bf16_nhwc_graph.json 2>/dev/null      # round 4 default: level sets, groups in sets, fused poolings; chain graph
+  python bench.py --workload $w --dtype bf16 --layout nhwc --no-cpu-baseline --graph --parallel-branches --steps 20 --warmup 5 --no-fuse-levels --no-fuse-pools > $O/bench_${w}_bf16_nhwc_graph_r03form.json 2>/dev/null   # the round-3 form on this box
 done
+python bench.py --workload googlenet-net --dtype bf16 --layout nhwc --no-cpu-baseline --graph --steps 20 --warmup 5 --no-fuse-pools > $O/bench_googlenet-net_bf16_nhwc_graph_nopoolfusion.json 2>/dev/null
+python bench.py --workload googlenet-net --dtype bf16 --layout nhwc --no-cpu-baseline --graph --steps 20 --warmup 5 --no-groups-in-sets > $O/bench_googlenet-net_bf16_nhwc_graph_nogroupsinsets.json 2>/dev/null
+cd /tmp; rocprofv3 --kernel-trace --stats -d $O/stats_googlenet-net-bf16-nhwc -o p -- python $R/bench.py --workload googlenet-net --dtype bf16 --layout nhwc --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_googlenet-net.log 2>&1; cd $R
 python bench.py --workload alexnet --exact 0 --no-cpu-baseline > $O/bench_alexnet_tolerance.json 2>/dev/null
 python bench.py --workload nin-net --batch 128 --no-cpu-baseline > $O/bench_nin-net_b128.json 2>/dev/null
 python bench.py --workload nin-net --batch 128 --exact 0 --no-cpu-baseline > $O/bench_nin-net_b128_tolerance.json 2>/dev/null
