@@ -166,7 +166,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(host->nh_launch(k.func, grid, 1, (uint32_t)c.threads(), params), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false; int rows = 0, cg = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false; int rows = 0, cg = 0; };
 
 // Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
 //   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
@@ -179,6 +179,36 @@ static bool plan_k1_stream(conv_geom_t const &g, int num_cus, string const &spec
   int WI = 0, WJ = 0, OCB = 0, CB = 0, MINW = 0;
   auto regs = [&](int ocb, int cb) { return (g.C + 1) / 2 * cb + 2 * 16 * ocb * cb + 30; }; // operand ring + two accumulator sets
   auto lds = [&](int wi, int ocb) { long const oct = wi * ocb * 32; return 4 * ((long)((g.C + 1) / 2 * 2) * (oct | 1) + oct); };
+  // kernels/k1_quad_f32.hip (16 bytes per lane both ways: 128-pel blocks of one image per wave, every wave all of the workgroup's out_chans): spec "qWJxOCBxRING[xMINW]";
+  // automatic for the NiN cccp1/2 class -- at most 96 out_chans (one accumulator set of OCB*64 registers, two waves per SIMD), a short K loop, a long pel axis
+  {
+    int QWJ = 0, QOCB = 0, QRING = 0, QMINW = 0;
+    int const ksteps = (g.C + 1) / 2;
+    if (!spec.empty() && spec[0] == 'q') {
+      int v[4] = {0, 0, 0, 0}, n = 0; size_t i = 1;
+      while (i < spec.size() && n < 4) { size_t j = spec.find('x', i); if (j == string::npos) j = spec.size(); v[n++] = atoi(spec.substr(i, j - i).c_str()); i = j + 1; }
+      if (n < 3) rt_err("bad k1_stream spec '" + spec + "' (qWJxOCBxRING[xMINW])");
+      QWJ = v[0]; QOCB = v[1]; QRING = v[2]; QMINW = v[3];
+      if (QWJ < 1 || QWJ > 16 || QOCB < 1 || QOCB > 3 || QRING < 1 || QRING > 16 || ksteps % QRING || g.OH * g.OW < 4 || lds(1, QOCB) > 160 * 1024)
+        unsup_err("k1_stream: unsupported configuration '" + spec + "' for this shape");
+    } else if (spec.empty() && !getenv("BODAHIP_NO_K1_QUAD") && g.OC > 64 && g.OC <= 96 && g.C <= 128 && g.OH * g.OW >= 512 && Nj >= 150000) {
+      // measured (MI355X, tools/k1s_probe.py, NiN cccp1 at 256 / 128 images, us): tiled kernel 159.5 / 88.6; q4x3x8 two workgroups per CU 156.5 / 95.7; q8x3x8 153.5 / 93.7;
+      // q4x3x8x1 (one workgroup of four waves per CU, six / three blocks per wave) 153.0 / 84.6; rings of 12 / 16 steps 204 / 208 (with the epilogue's 48 stores
+      // they overflow the 6-bit vmcnt and every wait becomes a drain)
+      QWJ = 4; QOCB = (g.OC + 31) / 32; QRING = 8; QMINW = 1; while (ksteps % QRING) --QRING;
+      if (lds(1, QOCB) > 80 * 1024) QWJ = 0;
+    }
+    if (QWJ) {
+      if (!QMINW) QMINW = (QOCB == 3) ? 2 : ((QOCB == 2) ? 3 : 4);   // registers: OCB*64 accumulators + 4*RING operands + ~30
+      QMINW = (int)std::max(1l, std::min((long)QMINW, std::max(1l, (160l * 1024) / lds(1, QOCB)) * ((QWJ + 3) / 4)));
+      p.stream = true; p.quad = true; p.kname = "bodahip_k1_quad_f32";
+      p.cfg.BI = QOCB * 32; p.cfg.BJ = QWJ * 128; p.cfg.BK = g.C; p.cfg.WI = 1; p.cfg.WJ = QWJ; p.cfg.MINW = QMINW; p.cfg.SPLITK = 1; p.cfg.MT = 32; p.cfg.PF = QRING;
+      p.defs = {"-DKC=" + std::to_string(g.C), "-DHW=" + std::to_string(g.OH * g.OW), "-DWJ=" + std::to_string(QWJ), "-DOCB=" + std::to_string(QOCB),
+                "-DRING=" + std::to_string(QRING), "-DMINW=" + std::to_string(QMINW), string("-DRELU=") + (g.relu ? "1" : "0"), string("-DEDGE_OC=") + ((g.OC % (QOCB * 32)) ? "1" : "0")};
+      if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+      return true;
+    }
+  }
   if (!spec.empty()) {
     int v[5] = {0, 0, 0, 0, 0}, n = 0; size_t i = 0;
     while (i < spec.size() && n < 5) { size_t j = spec.find('x', i); if (j == string::npos) j = spec.size(); v[n++] = atoi(spec.substr(i, j - i).c_str()); i = j + 1; }
@@ -621,7 +651,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
 }
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
-  return hiprtc_compile(p.nhwc_multi ? k_src_conv_nhwc_multi_bf16 : p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.stream ? k_src_k1_stream_f32 : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
+  return hiprtc_compile(p.nhwc_multi ? k_src_conv_nhwc_multi_bf16 : p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.stream ? (p.quad ? k_src_k1_quad_f32 : k_src_k1_stream_f32) : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
 }
 
 // grow-only scratch shared by the split-K slabs and the Winograd-domain tensors (like the reference's cudnn scratch var)
@@ -1043,8 +1073,10 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
     // persistent workgroups: as many as fit the chip at the kernel's occupancy, trimmed to the smallest count with the same number of
     // super-blocks per workgroup (an even deal); workgroup w of an out_chan tile takes super-blocks w, w + kt_per, ...
     long const slots = std::max(1l, (long)host->nh_num_cus() * std::max(1, cfg.MINW * 4 / (cfg.WI * cfg.WJ)) / ga.tiles_i);
+    if (p.quad) ga.tiles_j = (int)(((long)g.B * ((g.OH * g.OW + 127) / 128) + cfg.WJ - 1) / cfg.WJ);   // super-blocks of WJ 128-pel blocks, blocks never straddle images
     long const per = (ga.tiles_j + slots - 1) / slots;
     ga.kt_per = (int)((ga.tiles_j + per - 1) / per); ga.splitk = 1;
+    if (p.quad && ga.kt_per >= 8) ga.kt_per = (ga.kt_per + 7) / 8 * 8;   // a multiple of 8 workgroups: the kernel then gives each XCD a contiguous range of super-blocks
     void *params[] = {&ga};
     hip_err_chk(host->nh_launch(k.func, (uint32_t)(ga.kt_per * ga.tiles_i), 1, (uint32_t)cfg.threads(), params), "hipModuleLaunchKernel(k1_stream)");
     last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(ga.kt_per * ga.tiles_i); last_launch.block = cfg.threads();
@@ -1499,7 +1531,7 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
         long const rem = g.B % Bc;
         if (rem) { plan_t const rp = plan_sgemm((uint32_t)g.OC, (uint32_t)(rem * tpi), (uint32_t)g.C, num_cus, string(), false, 16); if (!arch.empty()) compile_plan(rp, arch, &log); }
         p = plan_sgemm((uint32_t)g.OC, (uint32_t)(std::min<long>(Bc, g.B) * tpi), (uint32_t)g.C, num_cus, string(), false, 16);
-      } else p = plan_conv(g, num_cus, tile, bf16, string(), true, exact);
+      } else { char const *k1e = getenv("BODAHIP_K1_STREAM"); p = plan_conv(g, num_cus, tile, bf16, k1e ? string(k1e) : string(), true, exact); }   // (the env var a backend instance reads its k1_stream tune from)
     }
   } else rt_err("prebuild: op type '" + t + "' has no native kernel");
   if (plan_out) { *plan_out = s2d + p.kname + " " + p.cfg.str(); for (auto const &d : p.defs) *plan_out += " " + d; }

@@ -378,15 +378,17 @@ class HipCompute:
         return {"kernel": k.value.decode(), "cfg": c.value.decode(), "grid": g.value, "block": b.value, "flops": fl.value, "algo_bytes": by.value}
 
     def torch_view(self, vn: str):
-        """Zero-copy torch tensor over a var's device memory (for torch.distributed / RCCL collectives on weights)."""
+        """Zero-copy torch tensor over a var's device memory (for torch.distributed / RCCL collectives on weights).  bf16 storage is viewed as bytes (last dim x 2):
+        the collectives move bytes, and gloo takes neither uint16 nor int16."""
         import torch
         d = self.get_var_dims(vn)
         ptr = self.get_var_raw_native_pointer(vn)
-        tstr = {"float": "<f4", "half": "<f2", "bfloat16": "<u2", "int32_t": "<i4", "uint32_t": "<u4", "uint8_t": "|u1"}[d.tn]
+        tstr = {"float": "<f4", "half": "<f2", "bfloat16": "<i2", "int32_t": "<i4", "uint32_t": "<u4", "uint8_t": "|u1"}[d.tn]
 
         class _Holder:
             __cuda_array_interface__ = {"shape": tuple(d.sizes), "typestr": tstr, "data": (ptr, False), "version": 3, "strides": None}
-        return torch.as_tensor(_Holder(), device=f"cuda:{self.device_ordinal}")
+        t = torch.as_tensor(_Holder(), device=f"cuda:{self.device_ordinal}")
+        return t.view(torch.uint8) if d.tn == "bfloat16" else t
 
 
 def compile_offline(src_or_opts: str, native_template: Optional[str] = None, arch: str = "gfx950", add_prelude: bool = True,

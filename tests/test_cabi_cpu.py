@@ -101,7 +101,9 @@ def test_planner_picks_the_documented_kernel_and_operand_mode_per_shape():
     p = ex(_conv(64, 64, 56, 256, 1))                             # ResNet-50 res2 64 -> 256 at B=64: the streaming 1x1 kernel, one out_chan tile
     assert p.startswith("bodahip_k1_stream_f32 256x64x64_w8x1") and "-DKC=64" in p and "-DHW=3136" in p and "-DOCB=1" in p and "-DCB=2" in p and "-DEDGE_OC=0" in p
     assert ex(_conv(4, 64, 56, 256, 1)).startswith("bodahip_conv_f32 ")            # ... but not at small batch
-    assert ex(_conv(256, 96, 55, 96, 1)).startswith("bodahip_conv_f32 96x256x16_w1x4")        # NiN cccp1: tiled kernel (ties the streaming one since the paired stores)
+    p = ex(_conv(256, 96, 55, 96, 1))                             # NiN cccp1: the 16-bytes-per-lane streaming kernel (round 4), one workgroup of four waves per CU, ring of 8 K steps
+    assert p.startswith("bodahip_k1_quad_f32 96x512x96_w1x4") and "-DKC=96" in p and "-DHW=3025" in p and "-DOCB=3" in p and "-DRING=8" in p and "-DMINW=1" in p and "-DEDGE_OC=0" in p
+    assert ex(_conv(256, 96, 6, 96, 1)).startswith("bodahip_conv_f32 ")                       # ... only on long pel axes
     assert ex(_conv(256, 96, 55, 96, 1), tile="64x64x16x2x2x2").startswith("bodahip_conv_f32 64x64x16_w2x2")  # an explicit tile wins
     # bf16: channel-innermost LDS patch for stride-1-in-x kernels on >= 16 channels (a multiple of 8), the gather kernel otherwise;
     # split-K only for tile-starved long-K shapes (fc6), never for the big layers

@@ -698,6 +698,15 @@ K1S_CASES = [  # (B, C, H, W, OC, spec): odd / tiny in_chan counts, out_chans th
     (2, 128, 8, 8, 130, "4x2x1x1"),
     (2, 1, 9, 7, 33, "1x4x2x2"),
     (6, 24, 20, 20, 64, "1x8x2x1"),
+    # kernels/k1_quad_f32.hip ("qWJxOCBxRING": 128-pel blocks of one image, 16 bytes per lane): planes shorter than a block, tail blocks whose surplus
+    (3, 96, 11, 9, 96, "q4x3x8"),           # columns clamp to the last four pels, the smallest plane (4 pels), odd in_chan counts, ragged out_chans, two out_chan
+    (2, 7, 5, 5, 40, "q2x2x4"),             # tiles, rings of one step and of every step, more workgroup slots than blocks and fewer
+    (5, 33, 13, 13, 70, "q4x3x1"),
+    (1, 2, 2, 2, 3, "q1x1x1"),
+    (2, 64, 23, 23, 130, "q4x3x8"),
+    (6, 24, 20, 20, 64, "q8x2x6"),
+    (9, 96, 55, 55, 96, "q4x3x8"),
+    (3, 32, 16, 16, 32, "q2x1x16"),
 ]
 
 
@@ -725,7 +734,7 @@ def test_k1_stream_kernel_bit_exact(be, case, relu):
         am["out_chan_off"] = RtcArg.scalar(2, "uint32_t")
         rtc.set_tune("k1_stream", spec)
         rtc.run(RtcFuncCall("k1s_conv", am)); rtc.finish_and_sync()
-        assert rtc.last_launch()["kernel"] == "bodahip_k1_stream_f32"
+        assert rtc.last_launch()["kernel"] == ("bodahip_k1_quad_f32" if spec.startswith("q") else "bodahip_k1_stream_f32")
         got = rtc.copy_var_to_nda("k1_out")
         want = bo.conv_fwd(x, f, b, (1, 1), (0, 0), relu)
         assert np.array_equal(got[:, 2:2 + OC], want), SsdsDiff.of(want, got[:, 2:2 + OC]).basic_str()
@@ -740,11 +749,12 @@ def test_k1_stream_kernel_bit_exact(be, case, relu):
         rtc.release_func("k1s_conv"); rtc.release_per_call_id_data()
 
 
-def test_k1_stream_auto_choice_matches_tiled_kernel(be):
-    """At the sizes where the planner picks the streaming kernel by itself (ResNet-50 res2 at B=64: 64 -> 256 chans on 56x56) its output is
-    bit-identical to the tiled kernel's (which the oracle pins at small sizes), and a spec never captures shapes it does not cover."""
+@pytest.mark.parametrize("shape,kernel", [((64, 64, 56, 56, 256), "bodahip_k1_stream_f32"), ((52, 96, 55, 55, 96), "bodahip_k1_quad_f32")], ids=["res2_64to256", "nin_cccp1"])
+def test_k1_stream_auto_choice_matches_tiled_kernel(be, shape, kernel):
+    """At the sizes where the planner picks a streaming kernel by itself (ResNet-50 res2 at B=64: 64 -> 256 chans on 56x56; NiN cccp1 / cccp2: 96 -> 96 on 55x55 planes, the
+    16-bytes-per-lane kernel) its output is bit-identical to the tiled kernel's (which the oracle pins at small sizes), and a spec never captures shapes it does not cover."""
     rtc = be.rtc
-    op = _conv_op(64, 64, 56, 56, 256, 1, 1, 1, 0)
+    op = _conv_op(*shape, 1, 1, 1, 0)
     anno = add_codegen_annotations(op, OpTune()); fn = anno.get_func_name()
     rtc.compile([RtcFuncInfo("k1s_auto", "", [a for a, _ in NATIVE_ARGS[fn]], anno)])
     am = {}
@@ -754,7 +764,7 @@ def test_k1_stream_auto_choice_matches_tiled_kernel(be):
         if io == "IN": rtc.run(gd.gen_call("Convolution", an, "k1a_" + an, anno.get_dims(an), 5, 0.0))
     try:
         rtc.run(RtcFuncCall("k1s_auto", am)); rtc.finish_and_sync()
-        assert rtc.last_launch()["kernel"] == "bodahip_k1_stream_f32"
+        assert rtc.last_launch()["kernel"] == kernel
         a = rtc.copy_var_to_nda("k1a_out")
         rtc.set_tune("k1_stream", "off"); rtc.set_var_to_zero("k1a_out")
         rtc.run(RtcFuncCall("k1s_auto", am)); rtc.finish_and_sync()

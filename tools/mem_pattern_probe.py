@@ -27,7 +27,14 @@ CUCL_GLOBAL_KERNEL void %(name)( GASQ float const * const in, GASQ float * const
 #endif
 #if MODE & 2
 #pragma unroll
-    for( int oc = 0; oc < OC; oc += 2 ) { *(GASQ vf *)( out + ( (size_t)img*OC + oc + hi )*HW + p0 ) = acc + (float)oc; }
+    for( int oc = 0; oc < OC; oc += 2 ) {
+#if ALIGNW   // ceiling probe: every row's store starts on a 128-byte line (what an LDS-shifted epilogue would write); coverage is approximate
+      size_t e = ( (size_t)img*OC + oc + hi )*HW + b*(32*VW); e &= ~(size_t)31; e += VW*j; if( e > (size_t)TOT - VW ) { e = (size_t)TOT - VW; }
+      *(GASQ vf *)( out + e ) = acc + (float)oc;
+#else
+      *(GASQ vf *)( out + ( (size_t)img*OC + oc + hi )*HW + p0 ) = acc + (float)oc;
+#endif
+    }
 #else
     if( acc[0] == 123.456f ) { out[u] = acc[0]; }
 #endif
@@ -38,13 +45,13 @@ B, C, HW, OC = [int(x) for x in os.environ.get("SHAPE", "256:96:3025:96").split(
 rtc = make_rtc(); rtc.init()
 rtc.create_var_with_dims("in", Dims(("n",), (B * C * HW,), "float")); rtc.create_var_with_dims("out", Dims(("n",), (B * OC * HW,), "float"))
 u32 = lambda v: RtcArg.scalar(int(v), "uint32_t")
-CHUNK = int(os.environ.get("CHUNK", "0"))
+CHUNK = int(os.environ.get("CHUNK", "0")); ALIGNW = int(os.environ.get("ALIGNW", "0"))
 for vw in (1, 2, 4):
     nblk = -(-HW // (32 * vw))
     for mode in (3,):
         for wpc in (8, 16, 32):   # waves per CU
             name = f"memp_{vw}_{mode}"
-            src = f"#define CHUNK {CHUNK}\n#define VW {vw}\n#define MODE {mode}\n#define C {C}\n#define OC {OC}\n#define HW {HW}\n#define NBLK {nblk}\n" + SRC.replace("%(name)", name)
+            src = f"#define ALIGNW {ALIGNW}\n#define TOT {B*OC*HW}\n#define CHUNK {CHUNK}\n#define VW {vw}\n#define MODE {mode}\n#define C {C}\n#define OC {OC}\n#define HW {HW}\n#define NBLK {nblk}\n" + SRC.replace("%(name)", name)
             if wpc == 8: rtc.compile([RtcFuncInfo(name, src, ["in", "out", "n_units", "stride"], Op({"type": "memp", "func_name": name}, {}))])
             n_units = B * nblk; waves = min(n_units, 256 * wpc); per = -(-n_units // waves); waves = -(-n_units // per)
             call = RtcFuncCall(name, {"in": RtcArg.var("in"), "out": RtcArg.var("out"), "n_units": u32(n_units), "stride": u32(waves)}, tpb=256, blks=-(-waves // 4))
