@@ -91,6 +91,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SWAPST
 #define SWAPST (((BJ / (WJ * 32)) % 2 == 0) && !HALF) // paired 256-byte row stores in the epilogue (see there); 0 forces the plain per-block stores
 #endif
+#ifndef STF
+#define STF 0 // PF >= 3 only: 1 = the LDS stores of tile kt + 1 are issued before the MFMAs of tile kt (they drain under the MFMA phase)
+#endif
 #ifndef PF
 #define PF 1 // K-tiles prefetched ahead in registers: 1 | 2 (two register sets; for workgroups that run alone on their CU) | 4 | 6 | 8 (a ring of register sets: tile-starved long-K shapes)
 #endif
@@ -673,9 +676,17 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     for (int u = 0; u < PF; ++u) {
       int const kt = kb + u;
       if (kt < nkt) {
+#if STF
+        // store first: tile kt + 1 goes to the other LDS stage BEFORE this step's MFMAs are issued (that stage was last read in step kt - 1, behind the barrier), so the
+        // transposing ds_writes and their completion wait drain under the MFMA phase instead of standing between it and the barrier
+        if (kt + 1 < nkt) STORE_IJ(rri[(u + 1) % PF], rrj[(u + 1) % PF], (u & 1) ? Is0 : Is1, (u & 1) ? Js0 : Js1);
+        if (kt + 1 + PF < nkt) { LOAD_I(rri[(u + 1) % PF], kt + 1 + PF); LOAD_J(rrj[(u + 1) % PF], kt + 1 + PF); }
+        MMA_KTILE((u & 1) ? Is1 : Is0, (u & 1) ? Js1 : Js0);
+#else
         MMA_KTILE((u & 1) ? Is1 : Is0, (u & 1) ? Js1 : Js0);
         if (kt + 1 < nkt) STORE_IJ(rri[(u + 1) % PF], rrj[(u + 1) % PF], (u & 1) ? Is0 : Is1, (u & 1) ? Js0 : Js1);
         if (kt + 1 + PF < nkt) { LOAD_I(rri[(u + 1) % PF], kt + 1 + PF); LOAD_J(rrj[(u + 1) % PF], kt + 1 + PF); }
+#endif
         __syncthreads();
       }
     }

@@ -166,7 +166,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(host->nh_launch(k.func, grid, 1, (uint32_t)c.threads(), params), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false; int rows = 0, cg = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, fc = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false; int rows = 0, cg = 0; };
 
 // Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
 //   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
@@ -633,6 +633,22 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   }
   if (p.patch && tile.empty()) p.cfg.PF = pf_for(p.cfg);
   if (!bf16 && !exact && tile.empty() && allow_splitk) tolerance_splitk(p, g, num_cus, Nj, Kt);
+  // fully-connected layers on 64x64 tiles (one accumulator per wave, usually one workgroup per CU): kernels/fc_f32.hip -- x-major LDS images written with ds_write_b128 and
+  // read four k at a time, the staging slotted between the MFMAs.  BODAHIP_FC = off | BKFxPF.  Measured (MI355X, AlexNet at 256 images, isolated launches, us): see the kernel header
+  char const *fc_env = getenv("BODAHIP_FC");   // (an explicit BKFxPF forces the kernel onto every layer it covers: tests)
+  if (!bf16 && p.ipconv && tile.empty() && Kt % 4 == 0 && p.cfg.SPLITK == 1 && ((p.cfg.BI == 64 && p.cfg.BJ == 64 && p.cfg.MT == 32) || (fc_env && *fc_env && string(fc_env) != "off"))) {
+    char const *e = fc_env;
+    if (!(e && string(e) == "off")) {
+      int bkf = 64, pf = 2, spec = 2;   // spec: 0 = four waves that stage and multiply | 1 = four multiplying + four staging waves, two LDS stages | 2 = the same with three stages
+      if (e && *e) { int const n = sscanf(e, "%dx%dx%d", &bkf, &pf, &spec);
+        if (n < 2 || (bkf != 32 && bkf != 64) || pf < 2 || pf > 8 || (pf & 1) || spec < 0 || spec > 2) rt_err(string("bad BODAHIP_FC '") + e + "' (off | BKFxPF[xV]: 32|64 x 2|4|6|8 [x 0|1|2])"); }
+      // (cfg.WJ = 4 with SPEC: eight waves, four of them staging)
+      p.fc = true; p.kname = "bodahip_fc_f32"; p.cfg.BI = 64; p.cfg.BJ = 64; p.cfg.MT = 32; p.cfg.BK = bkf; p.cfg.PF = pf; p.cfg.MINW = 1; p.cfg.WI = 2; p.cfg.WJ = spec ? 4 : 2;
+      p.defs = {"-DBKF=" + std::to_string(bkf), "-DPF=" + std::to_string(pf), "-DSPEC=" + std::to_string(spec ? 1 : 0), "-DNS3=" + std::to_string(spec == 2 ? 1 : 0), string("-DRELU=") + (g.relu ? "1" : "0")};
+      if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
+      return p;
+    }
+  }
   if (bf16) bf16_cfg(p.cfg, !p.ipconv, g.OC, Nj, Kt, allow_splitk ? num_cus : 0, !tile.empty());
   else check_cfg(p.cfg, !p.ipconv && !p.patch);
   p.defs = cfg_defs(p.cfg);
@@ -651,7 +667,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
 }
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
-  return hiprtc_compile(p.nhwc_multi ? k_src_conv_nhwc_multi_bf16 : p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.stream ? (p.quad ? k_src_k1_quad_f32 : k_src_k1_stream_f32) : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
+  return hiprtc_compile(p.nhwc_multi ? k_src_conv_nhwc_multi_bf16 : p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.fc ? k_src_fc_f32 : p.stream ? (p.quad ? k_src_k1_quad_f32 : k_src_k1_stream_f32) : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
 }
 
 // grow-only scratch shared by the split-K slabs and the Winograd-domain tensors (like the reference's cudnn scratch var)
@@ -1064,6 +1080,14 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   else if (!p.ipconv && !p.k1 && !p.patch && !p.stream && !p.patch16) { ktab_t const kt = get_ktab(impl, host, g); ga.ktab = kt.d; ga.ktab_n = kt.n; }
   ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
   if (p.patch16) { launch_patch16(impl, host, p, k, ga, filts, g, 0); 
+    last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(ga.tiles_i * ga.tiles_j); last_launch.block = cfg.threads();
+    last_launch.flops = 2.0 * Nj * g.OC * Kt;
+    last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
+    return;
+  }
+  if (p.fc) {
+    void *params[] = {&ga};
+    hip_err_chk(host->nh_launch(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j), 1, (uint32_t)cfg.threads(), params), "hipModuleLaunchKernel(fc_f32)");
     last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(ga.tiles_i * ga.tiles_j); last_launch.block = cfg.threads();
     last_launch.flops = 2.0 * Nj * g.OC * Kt;
     last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);

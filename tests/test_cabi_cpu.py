@@ -94,8 +94,10 @@ def test_planner_picks_the_documented_kernel_and_operand_mode_per_shape():
     assert mode(p, "J_MODE") == "6" and "-DJROWS=" in p
     p = ex(_conv(256, 256, 27, 256, 1))                           # NiN cccp3: 1x1, tiled kernel (K = 256 is not "short")
     assert p.startswith("bodahip_conv_f32 ") and mode(p, "J_MODE") == "5"
-    p = ex(_conv(256, 256, 6, 4096, 6))                           # AlexNet fc6: output 1x1 = contiguous images
-    assert mode(p, "J_MODE") in ("3", "4")
+    p = ex(_conv(256, 256, 6, 4096, 6))                           # AlexNet fc6: 256 tiles of 64 x 64 -> the fully-connected kernel (round 4): eight waves, three LDS stages
+    assert p.startswith("bodahip_fc_f32 64x64x64_w2x4_p2") and "-DSPEC=1" in p and "-DNS3=1" in p
+    p = ex(_conv(20, 256, 6, 4096, 6))                            # ... at 20 images (64 tiles): tile-starved, thin 16x16-MFMA tiles of the tiled kernel, contiguous images
+    assert p.startswith("bodahip_conv_f32 ") and mode(p, "J_MODE") in ("3", "4")
     p = ex(_conv(256, 96, 27, 256, 3, 2, 1))                      # stride 2 in x: per-element table gather
     assert mode(p, "J_MODE") == "2"
     p = ex(_conv(64, 64, 56, 256, 1))                             # ResNet-50 res2 64 -> 256 at B=64: the streaming 1x1 kernel, one out_chan tile

@@ -777,6 +777,81 @@ def test_k1_stream_auto_choice_matches_tiled_kernel(be, shape, kernel):
         rtc.release_func("k1s_auto"); rtc.release_per_call_id_data()
 
 
+FC_CASES = [  # (B, C, H, W, OC, BODAHIP_FC): ragged images / out_chans (one and several tiles each way), K tails (K % BKF != 0, fewer K tiles than the ring holds),
+    (5, 4, 3, 3, 7, "64x4x0"),            # both K steps and both ring depths, a 1x1 window (AlexNet fc7 form) and a real window (fc6 form)
+    (70, 8, 2, 2, 130, "32x2x1"),
+    (64, 256, 1, 1, 64, "64x8"),
+    (3, 31, 4, 4, 65, "32x6"),
+    (129, 12, 5, 5, 200, "64x2"),
+    (20, 256, 6, 6, 96, "64x4"),
+]
+
+
+@pytest.mark.parametrize("case", FC_CASES, ids=lambda c: "x".join(str(v) for v in c[:5]) + "_" + c[5])
+@pytest.mark.parametrize("relu", [True, False])
+def test_fc_kernel_bit_exact(be, case, relu, monkeypatch):
+    """kernels/fc_f32.hip (whole-input windows: x-major LDS images, four k per operand read, staging between the MFMAs) forced onto small shapes: same bits as the oracle,
+    as the tiled kernel, and a guard band around its channel slice of a wider output stays untouched."""
+    rtc = be.rtc
+    B, C, H, W, OC, spec = case
+    op = _conv_op(B, C, H, W, OC, H, W, 1, 0)
+    anno = add_codegen_annotations(op, OpTune())
+    anno.nda_vals["conv_has_relu"].v = (int(relu),)
+    fn = anno.get_func_name()
+    rtc.compile([RtcFuncInfo("fc_conv", "", [a for a, _ in NATIVE_ARGS[fn]], anno)])
+    x = bo.gen_conv_in(B, C, H, W); f = bo.gen_conv_filts(OC, C, H, W); b = bo.gen_conv_biases(OC)
+    wide = Dims.make("float", img=B, chan=OC + 5, y=1, x=1)
+    names = {"in": ("fc_in", anno.get_dims("in"), x), "filts": ("fc_f", anno.get_dims("filts"), f), "biases": ("fc_b", anno.get_dims("biases"), b),
+             "out": ("fc_out", wide, np.full(wide.sizes, 7.0, np.float32))}
+    for vn, d, arr in names.values():
+        rtc.create_var_with_dims(vn, d); rtc.copy_nda_to_var(vn, arr)
+    try:
+        am = {an: RtcArg.var(names[an][0]) for an in names}
+        am["stride"] = RtcArg.ref(anno.get_dims("stride")); am["in_pad"] = RtcArg.ref(anno.get_dims("in_pad"))
+        am["out_chan_off"] = RtcArg.scalar(3, "uint32_t")
+        monkeypatch.setenv("BODAHIP_FC", spec)
+        rtc.run(RtcFuncCall("fc_conv", am)); rtc.finish_and_sync()
+        assert rtc.last_launch()["kernel"] == "bodahip_fc_f32"
+        got = rtc.copy_var_to_nda("fc_out")
+        want = bo.conv_fwd(x, f, b, (1, 1), (0, 0), relu)
+        assert np.array_equal(got[:, 3:3 + OC], want), SsdsDiff.of(want, got[:, 3:3 + OC]).basic_str()
+        assert (got[:, :3] == 7).all() and (got[:, 3 + OC:] == 7).all()
+        monkeypatch.setenv("BODAHIP_FC", "off")
+        rtc.run(RtcFuncCall("fc_conv", am)); rtc.finish_and_sync()
+        assert rtc.last_launch()["kernel"] == "bodahip_conv_f32" and np.array_equal(rtc.copy_var_to_nda("fc_out"), got)
+    finally:
+        for vn, _, _ in names.values():
+            rtc.release_var(vn)
+        rtc.release_func("fc_conv"); rtc.release_per_call_id_data()
+
+
+def test_fc_kernel_is_the_planners_choice_for_alexnet_fc6_fc7(be, monkeypatch):
+    """AlexNet fc6 / fc7 at 256 images (256 tiles of 64 x 64) take the fc kernel by themselves; its output is bit-identical to the tiled kernel's."""
+    rtc = be.rtc
+    for (C, H, OC) in ((256, 6, 4096), (4096, 1, 4096)):
+        op = _conv_op(256, C, H, H, OC, H, H, 1, 0)
+        anno = add_codegen_annotations(op, OpTune()); fn = anno.get_func_name()
+        rtc.compile([RtcFuncInfo("fc_auto", "", [a for a, _ in NATIVE_ARGS[fn]], anno)])
+        am = {}
+        for an, io in NATIVE_ARGS[fn]:
+            if io == "REF": am[an] = RtcArg.ref(anno.get_dims(an)); continue
+            rtc.create_var_with_dims("fca_" + an, anno.get_dims(an)); am[an] = RtcArg.var("fca_" + an)
+            if io == "IN": rtc.run(gd.gen_call("Convolution", an, "fca_" + an, anno.get_dims(an), 5, 0.0))
+        try:
+            monkeypatch.delenv("BODAHIP_FC", raising=False)
+            rtc.run(RtcFuncCall("fc_auto", am)); rtc.finish_and_sync()
+            assert rtc.last_launch()["kernel"] == "bodahip_fc_f32"
+            a = rtc.copy_var_to_nda("fca_out")
+            monkeypatch.setenv("BODAHIP_FC", "off"); rtc.set_var_to_zero("fca_out")
+            rtc.run(RtcFuncCall("fc_auto", am)); rtc.finish_and_sync()
+            assert rtc.last_launch()["kernel"] == "bodahip_conv_f32"
+            assert np.array_equal(a, rtc.copy_var_to_nda("fca_out")) and float(np.abs(a).max()) > 0
+        finally:
+            for an, io in NATIVE_ARGS[fn]:
+                if io != "REF": rtc.release_var("fca_" + an)
+            rtc.release_func("fc_auto"); rtc.release_per_call_id_data()
+
+
 WINO_CASES = [  # (B, C, H, W, OC, pad): odd and even planes, no / unit / double padding, 1-wide planes, ragged channel counts
     (3, 6, 10, 10, 12, 1), (2, 5, 13, 13, 7, 1), (5, 16, 7, 9, 33, 0), (1, 3, 3, 3, 4, 0), (2, 8, 4, 5, 8, 2), (9, 24, 14, 14, 40, 1), (2, 1, 6, 1, 2, 1),
     (3, 19, 9, 11, 68, 1), (4, 40, 13, 13, 128, 1),   # several 8-channel stages (ragged last one), several 64-out_chan blocks and 64-tile blocks of the fused kernel

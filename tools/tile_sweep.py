@@ -17,6 +17,7 @@ ap.add_argument("--tiles", default="")
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--dtype", default="")
 ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--mode", type=int, default=5)   # gen_data mode: 5 = the reference's random pattern, 1 = all zeros (clock / power experiments)
 a = ap.parse_args()
 ops = {"alexnet": lambda: bench.alexnet_b256_ops(a.batch), "nin": lambda: bench.nin_ops(a.batch), "sgemm": bench.sgemm_full_ops,
        "googlenet": lambda: bench.net_conv_ops("googlenet_conv", a.batch), "resnet50": lambda: bench.net_conv_ops("resnet-50", a.batch)}[a.workload]()
@@ -28,7 +29,7 @@ for i in sel:
     for t in tiles:
         try:
             anno = add_codegen_annotations(op, OpTune(hip_tile=t, hip_dtype=a.dtype))
-            _, prc = profile_rcg_call(be, anno, 5, run_iter=a.iters, want_outs=False, tile=t)
+            _, prc = profile_rcg_call(be, anno, a.mode, run_iter=a.iters, want_outs=False, tile=t)
             best = min(prc.all_secs[1:]) if len(prc.all_secs) > 1 else prc.all_secs[0]
             g = op.conv_geom() if op.get_type() == "Convolution" else op.sgemm_geom()
             desc = (f"C{g['C']} {g['H']}x{g['W']} OC{g['OC']} k{g['KH']}s{g['SY']}" if "OC" in g else f"M{g['M']} N{g['N']} K{g['K']}")
