@@ -166,7 +166,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(host->nh_launch(k.func, grid, 1, (uint32_t)c.threads(), params), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, fc = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false; int rows = 0, cg = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, fc = false, big = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false; int rows = 0, cg = 0; };
 
 // Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
 //   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
@@ -265,7 +265,7 @@ static void bf16_cfg(tile_cfg_t &c, bool gather, long Mi = 0, long Nj = 0, long 
   if (!ok) unsup_err("native bf16 kernel: unsupported tile configuration " + c.str());
 }
 
-static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string const &tile, bool bf16 = false, int batch = 1) {
+static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string const &tile, bool bf16 = false, int batch = 1, bool allow_big = true) {
   (void)K;
   plan_t p; p.kname = bf16 ? "bodahip_sgemm_bf16" : "bodahip_sgemm_f32"; p.bf16 = bf16;
   p.cfg = choose_cfg((int)M, (int)std::min<uint64_t>((uint64_t)N * batch, 0x7fffffffull), (int)K, num_cus, false, bf16); // (a batch deals batch x the tiles)
@@ -277,6 +277,19 @@ static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string
     return p;
   }
   check_cfg(p.cfg, false);
+  // 256x256 tiles of plain fp32 operands: kernels/sgemm_big_f32.hip -- eight multiplying waves + four staging waves, three LDS stages (BODAHIP_SGEMM_BIG = off | BKSxPF).
+  // cfg.WI x WJ = 3 x 4 stands for its twelve waves.
+  if (allow_big && batch == 1 && p.cfg.BI == 256 && p.cfg.BJ == 256 && p.cfg.MT == 32 && p.cfg.SPLITK == 1 && M % 4 == 0 && N % 4 == 0) {
+    char const *e = getenv("BODAHIP_SGEMM_BIG");
+    if (!(e && string(e) == "off")) {
+      int bks = 8, pf = 2;   // measured (MI355X, 12288^3 / 8192^3 / 6144^3, TF/s): gemm_conv_f32.hip on the same tile 140.2 / 140.4 / 133.6; 16x2 144.7 / 144.5 / 129.0; 8x2 145.1 / 144.8 / 137.7; 8x4 145.1 / 144.8 / 135.4; 16x4 142.0 / 142.2 / 136.5 (four LDS stages)
+      if (e && *e) { if (sscanf(e, "%dx%d", &bks, &pf) != 2 || bks < 4 || bks > 32 || bks % 4 || (pf != 2 && pf != 4)) rt_err(string("bad BODAHIP_SGEMM_BIG '") + e + "' (off | BKSxPF)"); }
+      p.big = true; p.kname = "bodahip_sgemm_big_f32"; p.cfg.BK = bks; p.cfg.PF = pf; p.cfg.WI = 3; p.cfg.WJ = 4; p.cfg.MINW = 1;
+      p.defs = {"-DBKS=" + std::to_string(bks), "-DPF=" + std::to_string(pf)};
+      if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
+      return p;
+    }
+  }
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((M % 4 == 0) ? "0" : "1"));
   p.defs.push_back(string("-DJ_MODE=") + ((N % 4 == 0) ? "0" : "1"));
@@ -667,7 +680,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
 }
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
-  return hiprtc_compile(p.nhwc_multi ? k_src_conv_nhwc_multi_bf16 : p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.fc ? k_src_fc_f32 : p.stream ? (p.quad ? k_src_k1_quad_f32 : k_src_k1_stream_f32) : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
+  return hiprtc_compile(p.nhwc_multi ? k_src_conv_nhwc_multi_bf16 : p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.big ? k_src_sgemm_big_f32 : p.fc ? k_src_fc_f32 : p.stream ? (p.quad ? k_src_k1_quad_f32 : k_src_k1_stream_f32) : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
 }
 
 // grow-only scratch shared by the split-K slabs and the Winograd-domain tensors (like the reference's cudnn scratch var)
@@ -824,7 +837,7 @@ void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t 
       return;
     }
   }
-  plan_t p = plan_sgemm(M, N, K, host->nh_num_cus(), tune_of(impl, "sgemm_tile"), bf16);
+  plan_t p = plan_sgemm(M, N, K, host->nh_num_cus(), tune_of(impl, "sgemm_tile"), bf16, 1, !half);
   if (half) {
     if (p.cfg.SPLITK > 1) unsup_err("hip_sgemm: split-K tiles are not supported for half-typed tensors");
     p.kname = "bodahip_sgemm_f16s"; p.defs.push_back("-DHALF=1");
@@ -1489,7 +1502,7 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
       if (!arch.empty()) compile_plan(p, arch, &log);
       p = tp;
     } else p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, tile, bf16);
-    if (a.tn == "half") { s2d.clear(); p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, tile, false); p.kname = "bodahip_sgemm_f16s"; p.defs.push_back("-DHALF=1"); }
+    if (a.tn == "half") { s2d.clear(); p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, tile, false, 1, false); p.kname = "bodahip_sgemm_f16s"; p.defs.push_back("-DHALF=1"); }
   }
   else if (t == "Convolution") {
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;

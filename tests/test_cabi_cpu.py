@@ -124,7 +124,7 @@ def test_planner_sgemm_tiles_follow_problem_size():
     def sg(M, N, K, fn="hip_sgemm"):
         return parse_op(f"(str_vals=(type=sgemm,func_name={fn}),nda_vals=(a=(dims=(K={K},M={M})),b=(dims=(K={K},N={N})),c=(dims=(M={M},N={N}))))")
     big, small = R.explain_plan(sg(8192, 8192, 8192)), R.explain_plan(sg(256, 256, 256))
-    assert big.startswith("bodahip_sgemm_f32 256x256") and "-DI_MODE=0" in big and "-DSPLITK" not in big
+    assert big.startswith("bodahip_sgemm_big_f32 256x256x8_w3x4_p2") and "-DBKS=8" in big and "-DPF=2" in big     # round 4: eight multiplying + four staging waves
     assert small.startswith("bodahip_sgemm_f32 ") and small.split()[1] != big.split()[1]
     assert "-DI_MODE=1" in R.explain_plan(sg(130, 64, 50)) and "-DJ_MODE=1" in R.explain_plan(sg(128, 66, 50))     # scalar staging for ragged M / N
     assert R.explain_plan(sg(8192, 8192, 8192), tile="128x128x16x2x2x2x4").count("-DSPLITK=1") == 1           # split-K only as an explicit tune
@@ -132,7 +132,7 @@ def test_planner_sgemm_tiles_follow_problem_size():
     # two-level tiling: 7168^3 is 784 tiles of 256x256 = 3 rounds of 256 CUs + 16 -> 27 tile rows (756 tiles) on the large tile, the last 256 rows on small
     # tiles; 8192^3 (1024 = 4 rounds exactly) is not split; an explicit tile or BODAHIP_NO_SGEMM_SPLIT switches it off
     sp = R.explain_plan(sg(7168, 7168, 7168))
-    assert sp.startswith("rows<6912:256x256x16_w2x4_p2+rest:bodahip_sgemm_f32 64x64x32_w2x2_p2"), sp
+    assert sp.startswith("rows<6912:256x256x8_w3x4_p2+rest:bodahip_sgemm_f32 64x64x32_w2x2_p2"), sp
     assert R.explain_plan(sg(10240, 10240, 10240)).startswith("rows<9728:") and not R.explain_plan(sg(12288, 12288, 12288)).startswith("rows<")
     assert R.explain_plan(sg(7168, 7168, 7168), tile="128x128x16x2x2x2").startswith("bodahip_sgemm_f32 128x128")
     assert not R.explain_plan(sg(7168, 7170, 7168)).startswith("rows<")        # ragged N: scalar staging, no split
