@@ -91,6 +91,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SWAPST
 #define SWAPST (((BJ / (WJ * 32)) % 2 == 0) && !HALF) // paired 256-byte row stores in the epilogue (see there); 0 forces the plain per-block stores
 #endif
+#ifndef SPECW
+#define SPECW 0 // 1: as many STAGING waves as multiplying waves (threads WI*WJ*64 .. 2*WI*WJ*64 - 1): they do all global loads, gathers and LDS stores (two K tiles in
+#endif          // flight in their registers), the multiplying waves only read operands and issue MFMAs.  Same barriers, same k order: bit-identical results.
 #ifndef STF
 #define STF 0 // PF >= 3 only: 1 = the LDS stores of tile kt + 1 are issued before the MFMAs of tile kt (they drain under the MFMA phase)
 #endif
@@ -502,9 +505,14 @@ __device__ __forceinline__ void mma_ktile(acc_t (&acc)[kTI][kTJ], float const *_
 }
 } // namespace
 
-extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p) {
+extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) void KNAME(gemm_args_t const p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (kITile + kJTile)];
+#if SPECW
+  bool const stager = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= WI * WJ;
+  int const tid = threadIdx.x - (stager ? kNT : 0);   // id among the staging threads / among the multiplying threads
+#else
   int const tid = threadIdx.x;
+#endif
   int const lane = tid & 63;
   int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int const wi = wave / WJ, wj = wave % WJ;
@@ -609,10 +617,15 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #endif
 
   rsrc_t const rI = make_rsrc(p.I + (long)blockIdx.y * p.bsI, p.I_bytes), rJ = make_rsrc(p.J + (long)blockIdx.y * p.bsJ, p.J_bytes); // kernel args and block ids only: provably wave-uniform
-  load_tile<I_MODE, BI, kNI>(ri, rI, p.ldI, i0, p.Mi, kt_begin * BK, p.K, tid);
-  load_J(rj, rJ, p, j0, kt_begin * BK, tid GATHER_ARG);
-  store_tile<I_MODE, BI, kLDI, kNI>(ri, Is0, tid);
-  store_J(rj, Js0, tid GATHER_ARG);
+#if SPECW
+  if (stager)
+#endif
+  {
+    load_tile<I_MODE, BI, kNI>(ri, rI, p.ldI, i0, p.Mi, kt_begin * BK, p.K, tid);
+    load_J(rj, rJ, p, j0, kt_begin * BK, tid GATHER_ARG);
+    store_tile<I_MODE, BI, kLDI, kNI>(ri, Is0, tid);
+    store_J(rj, Js0, tid GATHER_ARG);
+  }
   __syncthreads();
 
   // MFMA operand fetch: lane l holds A[i = l % MT][k = l / MT] and B[k = l / MT][j = l % MT]
@@ -644,7 +657,32 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 #define STORE_IJ(RI, RJ, IS, JS) do { store_tile<I_MODE, BI, kLDI, kNI>(RI, IS, tid); store_J(RJ, JS, tid GATHER_ARG); } while (0)
 #endif
 
-#if PF == 2
+#if SPECW
+  // Two roles, the same sequence of barriers.  The staging waves keep two K tiles in flight in two register sets: in step kt they write tile kt + 1 (loaded two steps
+  // ago) to the other LDS stage and refill its registers with tile kt + 3.
+  if (stager) {
+    float ri2[kNI], rj2[kNJ];
+    if (nkt > 1) { LOAD_I(ri, 1); LOAD_J(rj, 1); }
+    if (nkt > 2) { LOAD_I(ri2, 2); LOAD_J(rj2, 2); }
+    for (int kt = 0; kt < nkt; kt += 2) {
+      if (kt + 1 < nkt) STORE_IJ(ri, rj, Is1, Js1);
+      if (kt + 3 < nkt) { LOAD_I(ri, kt + 3); LOAD_J(rj, kt + 3); }
+      __syncthreads();
+      if (kt + 1 >= nkt) break;
+      if (kt + 2 < nkt) STORE_IJ(ri2, rj2, Is0, Js0);
+      if (kt + 4 < nkt) { LOAD_I(ri2, kt + 4); LOAD_J(rj2, kt + 4); }
+      __syncthreads();
+    }
+    return;
+  }
+  for (int kt = 0; kt < nkt; kt += 2) {
+    MMA_KTILE(Is0, Js0);
+    __syncthreads();
+    if (kt + 1 >= nkt) break;
+    MMA_KTILE(Is1, Js1);
+    __syncthreads();
+  }
+#elif PF == 2
   // Two K-tiles in flight: while tile t is multiplied out of LDS, tile t+1 sits in one register set (its loads were issued a
   // whole step earlier) and the loads of tile t+2 are issued into the other.  For workgroups that are alone on their CU
   // (tile-starved shapes: one ~0.5 us MFMA phase per K step against ~1 us of HBM latency) this roughly doubles the bytes in flight.

@@ -72,18 +72,18 @@ void native_kernels_t::set_tune(string const &key, string const &val) {
 
 // "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF]]]]"
 static bool parse_tile(string const &s, tile_cfg_t &c) {
-  int v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; int n = 0; string cur;
+  int v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int n = 0; string cur;
   for (size_t i = 0; i <= s.size(); ++i) {
-    if (i == s.size() || s[i] == 'x' || s[i] == ':') { if (cur.empty() || n >= 9) return false; v[n++] = atoi(cur.c_str()); cur.clear(); }
+    if (i == s.size() || s[i] == 'x' || s[i] == ':') { if (cur.empty() || n >= 10) return false; v[n++] = atoi(cur.c_str()); cur.clear(); }
     else if (s[i] >= '0' && s[i] <= '9') cur.push_back(s[i]); else return false;
   }
   if (n < 5) return false;
-  c.BI = v[0]; c.BJ = v[1]; c.BK = v[2]; c.WI = v[3]; c.WJ = v[4]; c.MINW = (n >= 6) ? v[5] : 1; c.SPLITK = (n >= 7) ? v[6] : 1; c.MT = (n >= 8) ? v[7] : 32; c.PF = (n >= 9) ? v[8] : 1;
+  c.BI = v[0]; c.BJ = v[1]; c.BK = v[2]; c.WI = v[3]; c.WJ = v[4]; c.MINW = (n >= 6) ? v[5] : 1; c.SPLITK = (n >= 7) ? v[6] : 1; c.MT = (n >= 8) ? v[7] : 32; c.PF = (n >= 9) ? v[8] : 1; c.SW = (n >= 10) ? v[9] : 0;
   return true;
 }
 // the static_asserts of the kernel, checked on the host so that a bad tune is an unsup_err, not a compile failure
 static void check_cfg(tile_cfg_t const &c, bool gather) {
-  int const nt = c.threads();
+  int const nt = c.WI * c.WJ * 64;   // multiplying threads (= staging threads)
   bool ok = c.BI > 0 && c.BJ > 0 && c.BK > 0 && c.WI > 0 && c.WJ > 0 && nt <= 1024 && (c.MT == 32 || c.MT == 16) && (c.BI % (c.WI * c.MT) == 0) && (c.BJ % (c.WJ * c.MT) == 0) &&
             (c.BK % 2 == 0) && (c.MT == 32 || c.BK % 4 == 0) && (c.BI % 4 == 0) && (c.BJ % 4 == 0);
   if (gather) ok = ok && ((c.BK * c.BJ) % nt == 0); // the gathers give every thread whole elements / rows
@@ -151,12 +151,12 @@ static int pf_for(tile_cfg_t const &c) { return (c.BI == 64 && c.BJ == 64 && c.W
 static vect_string cfg_defs(tile_cfg_t const &c) {
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { // experiment hook: extra -D options for the native kernels
     vect_string r = {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI),
-                     "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW), "-DMT=" + std::to_string(c.MT), "-DPF=" + std::to_string(c.PF)};
+                     "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW), "-DMT=" + std::to_string(c.MT), "-DPF=" + std::to_string(c.PF), "-DSPECW=" + std::to_string(c.SW)};
     std::istringstream is(e); string tok; while (is >> tok) r.push_back(tok);
     return r;
   }
   return {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI),
-          "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW), "-DMT=" + std::to_string(c.MT), "-DPF=" + std::to_string(c.PF)};
+          "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW), "-DMT=" + std::to_string(c.MT), "-DPF=" + std::to_string(c.PF), "-DSPECW=" + std::to_string(c.SW)};
 }
 struct plan_t;
 static kernel_t &get_kernel(native_kernels_t::impl_t *impl, native_host_t *host, plan_t const &p);
@@ -593,10 +593,10 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   p.rows = 0;
   int rg_min_kw = 6; if (char const *e = getenv("BODAHIP_ROW_GATHER_MIN_KW")) rg_min_kw = std::max(2, atoi(e));
   if (!bf16 && !p.ipconv && g.KW >= rg_min_kw && g.KW <= 16 && getenv("BODAHIP_NO_ROW_GATHER") == nullptr) {
-    int const rpp = std::max(1, p.cfg.threads() / p.cfg.BJ);               // row groups per K step
+    int const rpp = std::max(1, p.cfg.WI * p.cfg.WJ * 64 / p.cfg.BJ);               // row groups per K step
     int rows = (g.KW <= 3) ? 8 : (g.KW <= 8 ? 4 : 2);                        // BK = 16..28 (22 for 11x11)
     while (rows % rpp) rows += 2;
-    if ((rows * g.KW) % 2 == 0 && rows % rpp == 0 && p.cfg.threads() % p.cfg.BJ == 0 && p.cfg.BJ % 64 == 0 && p.cfg.MT == 32) { p.rows = rows; p.cfg.BK = rows * g.KW; }
+    if ((rows * g.KW) % 2 == 0 && rows % rpp == 0 && (p.cfg.WI * p.cfg.WJ * 64) % p.cfg.BJ == 0 && p.cfg.BJ % 64 == 0 && p.cfg.MT == 32) { p.rows = rows; p.cfg.BK = rows * g.KW; }
   }
   // 1x1 kernel, no padding (any stride): the reference's k1conv case -- one add per gathered element, no table
   p.k1 = !p.ipconv && g.KH == 1 && g.KW == 1 && g.PY == 0 && g.PX == 0;
@@ -616,7 +616,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
       int const rows_max = (c.BJ - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
       long const cs = (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp;
       long const lds = 2l * 4 * ((long)bk * (c.BI + 4) + cb * cs);
-      return bk <= 128 && lds <= lds_max && cs <= 16l * c.threads();
+      return bk <= 128 && lds <= lds_max && cs <= 16l * (c.WI * c.WJ * 64);
     };
     if (!tile.empty()) { if (fits(p.cfg, 160 * 1024)) { p.patch = true; p.cfg.BK = bk; } }
     else {
@@ -648,19 +648,25 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   if (!bf16 && !exact && tile.empty() && allow_splitk) tolerance_splitk(p, g, num_cus, Nj, Kt);
   // fully-connected layers on 64x64 tiles (one accumulator per wave, usually one workgroup per CU): kernels/fc_f32.hip -- x-major LDS images written with ds_write_b128 and
   // read four k at a time, the staging slotted between the MFMAs.  BODAHIP_FC = off | BKFxPF.  Measured (MI355X, AlexNet at 256 images, isolated launches, us): see the kernel header
-  char const *fc_env = getenv("BODAHIP_FC");   // (an explicit BKFxPF forces the kernel onto every layer it covers: tests)
-  if (!bf16 && p.ipconv && tile.empty() && Kt % 4 == 0 && p.cfg.SPLITK == 1 && ((p.cfg.BI == 64 && p.cfg.BJ == 64 && p.cfg.MT == 32) || (fc_env && *fc_env && string(fc_env) != "off"))) {
-    char const *e = fc_env;
-    if (!(e && string(e) == "off")) {
-      int bkf = 64, pf = 2, spec = 2;   // spec: 0 = four waves that stage and multiply | 1 = four multiplying + four staging waves, two LDS stages | 2 = the same with three stages
-      if (e && *e) { int const n = sscanf(e, "%dx%dx%d", &bkf, &pf, &spec);
-        if (n < 2 || (bkf != 32 && bkf != 64) || pf < 2 || pf > 8 || (pf & 1) || spec < 0 || spec > 2) rt_err(string("bad BODAHIP_FC '") + e + "' (off | BKFxPF[xV]: 32|64 x 2|4|6|8 [x 0|1|2])"); }
-      // (cfg.WJ = 4 with SPEC: eight waves, four of them staging)
-      p.fc = true; p.kname = "bodahip_fc_f32"; p.cfg.BI = 64; p.cfg.BJ = 64; p.cfg.MT = 32; p.cfg.BK = bkf; p.cfg.PF = pf; p.cfg.MINW = 1; p.cfg.WI = 2; p.cfg.WJ = spec ? 4 : 2;
-      p.defs = {"-DBKF=" + std::to_string(bkf), "-DPF=" + std::to_string(pf), "-DSPEC=" + std::to_string(spec ? 1 : 0), "-DNS3=" + std::to_string(spec == 2 ? 1 : 0), string("-DRELU=") + (g.relu ? "1" : "0")};
-      if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
-      return p;
+  // fully-connected layers (whole-input windows, both operands k-contiguous): kernels/fc_f32.hip -- four multiplying + four staging waves, three LDS stages, 16x16x4
+  // MFMA chains.  Tile TM images x TN out_chans: the largest of 64x64 / 64x32 / 32x32 that still gives (nearly) every CU a workgroup.  BODAHIP_FC = off | TMxTNxBKFxPF
+  // (an explicit spec forces the kernel onto every layer it covers: tests).  Measured (MI355X, AlexNet at 256 images, layer sequence, us): fc6 223 -> 170, fc7 104 -> 82.
+  char const *fc_env = getenv("BODAHIP_FC");
+  bool const fc_forced = fc_env && *fc_env && string(fc_env) != "off";
+  if (!bf16 && p.ipconv && tile.empty() && Kt % 4 == 0 && p.cfg.SPLITK == 1 && !(fc_env && string(fc_env) == "off") &&
+      (fc_forced || (Kt >= 512 && (long)g.OC * Nj >= 65536))) {
+    int tm = 64, tn = 64, bkf = 64, pf = 2;
+    if (fc_forced) {
+      if (sscanf(fc_env, "%dx%dx%dx%d", &tm, &tn, &bkf, &pf) != 4 || (tm != 32 && tm != 64) || (tn != 32 && tn != 64) || (bkf != 32 && bkf != 64) || (pf != 2 && pf != 4))
+        rt_err(string("bad BODAHIP_FC '") + fc_env + "' (off | TMxTNxBKFxPF: 32|64 x 32|64 x 32|64 x 2|4)");
+    } else {
+      auto tiles = [&](int m, int n) { return (long)((Nj + m - 1) / m) * ((g.OC + n - 1) / n); };
+      if (tiles(64, 64) * 4 < (long)num_cus * 3) { tn = 32; if (tiles(64, 32) * 4 < (long)num_cus * 3) tm = 32; }
     }
+    p.fc = true; p.kname = "bodahip_fc_f32"; p.cfg.BI = tn; p.cfg.BJ = tm; p.cfg.MT = 16; p.cfg.BK = bkf; p.cfg.PF = pf; p.cfg.MINW = 1; p.cfg.WI = 2; p.cfg.WJ = 4;   // (eight waves)
+    p.defs = {"-DTM=" + std::to_string(tm), "-DTN=" + std::to_string(tn), "-DBKF=" + std::to_string(bkf), "-DPF=" + std::to_string(pf), string("-DRELU=") + (g.relu ? "1" : "0")};
+    if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
+    return p;
   }
   if (bf16) bf16_cfg(p.cfg, !p.ipconv, g.OC, Nj, Kt, allow_splitk ? num_cus : 0, !tile.empty());
   else check_cfg(p.cfg, !p.ipconv && !p.patch);

@@ -95,8 +95,12 @@ def test_planner_picks_the_documented_kernel_and_operand_mode_per_shape():
     p = ex(_conv(256, 256, 27, 256, 1))                           # NiN cccp3: 1x1, tiled kernel (K = 256 is not "short")
     assert p.startswith("bodahip_conv_f32 ") and mode(p, "J_MODE") == "5"
     p = ex(_conv(256, 256, 6, 4096, 6))                           # AlexNet fc6: 256 tiles of 64 x 64 -> the fully-connected kernel (round 4): eight waves, three LDS stages
-    assert p.startswith("bodahip_fc_f32 64x64x64_w2x4_p2") and "-DSPEC=1" in p and "-DNS3=1" in p
-    p = ex(_conv(20, 256, 6, 4096, 6))                            # ... at 20 images (64 tiles): tile-starved, thin 16x16-MFMA tiles of the tiled kernel, contiguous images
+    assert p.startswith("bodahip_fc_f32 64x64x64_w2x4_m16_p2") and "-DTM=64" in p and "-DTN=64" in p
+    p = ex(_conv(256, 4096, 1, 1000, 1))                          # AlexNet fc8: 64 tiles of 64 x 64 would starve the chip -> 256 tiles of 32 x 32
+    assert p.startswith("bodahip_fc_f32 32x32x64_w2x4_m16_p2") and "-DTM=32" in p and "-DTN=32" in p
+    p = ex(_conv(128, 256, 6, 4096, 6))                           # fc6 at 128 images: 64 images x 32 out_chans
+    assert "-DTM=64" in p and "-DTN=32" in p
+    p = ex(_conv(5, 256, 6, 4096, 6))                             # ... at 5 images: the tiled kernel's thin 16x16-MFMA tiles, contiguous images
     assert p.startswith("bodahip_conv_f32 ") and mode(p, "J_MODE") in ("3", "4")
     p = ex(_conv(256, 96, 27, 256, 3, 2, 1))                      # stride 2 in x: per-element table gather
     assert mode(p, "J_MODE") == "2"

@@ -777,13 +777,14 @@ def test_k1_stream_auto_choice_matches_tiled_kernel(be, shape, kernel):
         rtc.release_func("k1s_auto"); rtc.release_per_call_id_data()
 
 
-FC_CASES = [  # (B, C, H, W, OC, BODAHIP_FC): ragged images / out_chans (one and several tiles each way), K tails (K % BKF != 0, fewer K tiles than the ring holds),
-    (5, 4, 3, 3, 7, "64x4x0"),            # both K steps and both ring depths, a 1x1 window (AlexNet fc7 form) and a real window (fc6 form)
-    (70, 8, 2, 2, 130, "32x2x1"),
-    (64, 256, 1, 1, 64, "64x8"),
-    (3, 31, 4, 4, 65, "32x6"),
-    (129, 12, 5, 5, 200, "64x2"),
-    (20, 256, 6, 6, 96, "64x4"),
+FC_CASES = [  # (B, C, H, W, OC, BODAHIP_FC = TMxTNxBKFxPF): ragged images / out_chans (one and several tiles each way), K tails (K % BKF != 0, fewer K tiles than the
+    (5, 4, 3, 3, 7, "64x64x64x4"),      # ring and the stages hold), every tile shape, both K steps and ring depths, a 1x1 window (AlexNet fc7 form) and a real window (fc6 form)
+    (70, 8, 2, 2, 130, "64x64x32x2"),
+    (64, 256, 1, 1, 64, "64x64x64x2"),
+    (3, 31, 4, 4, 65, "32x32x32x4"),
+    (129, 12, 5, 5, 200, "64x32x64x2"),
+    (20, 256, 6, 6, 96, "32x64x64x4"),
+    (33, 64, 2, 2, 100, "32x32x64x2"),
 ]
 
 
@@ -826,9 +827,9 @@ def test_fc_kernel_bit_exact(be, case, relu, monkeypatch):
 
 
 def test_fc_kernel_is_the_planners_choice_for_alexnet_fc6_fc7(be, monkeypatch):
-    """AlexNet fc6 / fc7 at 256 images (256 tiles of 64 x 64) take the fc kernel by themselves; its output is bit-identical to the tiled kernel's."""
+    """AlexNet fc6 / fc7 / fc8 at 256 images (256 tiles of 64 x 64; fc8: of 32 x 32) take the fc kernel by themselves; its output is bit-identical to the tiled kernel's."""
     rtc = be.rtc
-    for (C, H, OC) in ((256, 6, 4096), (4096, 1, 4096)):
+    for (C, H, OC) in ((256, 6, 4096), (4096, 1, 4096), (4096, 1, 1000)):
         op = _conv_op(256, C, H, H, OC, H, H, 1, 0)
         anno = add_codegen_annotations(op, OpTune()); fn = anno.get_func_name()
         rtc.compile([RtcFuncInfo("fc_auto", "", [a for a, _ in NATIVE_ARGS[fn]], anno)])

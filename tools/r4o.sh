@@ -1,9 +1,4 @@
 mkdir -p gpurun_out/s5
-python -m pytest tests/test_gpu_parity.py -x -q -k "fc_kernel or k1_stream" 2>&1 | tail -3
-python bench.py --workload alexnet --no-cpu-baseline > gpurun_out/s5/alexnet.json 2>gpurun_out/s5/alexnet.err; python bench.py --workload nin --no-cpu-baseline > gpurun_out/s5/nin.json 2>/dev/null
-python - <<'PY'
-import json
-for w in ('alexnet','nin'):
-    d=json.loads(open(f'gpurun_out/s5/{w}.json').read().strip().splitlines()[-1])
-    print(w, d['value'], d['ms_per_step'], d['roofline']['frac'], [round(o['ms']*1e3,1) for o in d['per_op']])
-PY
+python -m pytest tests/test_gpu_parity.py -x -q -k "fc_kernel" 2>&1 | tail -3
+for fc in off "" 32x32x64x2 32x32x64x4 32x32x32x4 32x64x64x2 64x32x64x2; do echo "FC=$fc"; BODAHIP_FC=$fc python tools/tile_sweep.py --workload alexnet --ops 5,6,7 --iters 30 2>&1 | grep auto; done
+for w in googlenet resnet50; do python tools/tile_sweep.py --workload $w --batch 64 --ops $( [ $w = googlenet ] && echo 63 || echo 53 ) --iters 30 2>&1 | grep auto; BODAHIP_FC=off python tools/tile_sweep.py --workload $w --batch 64 --ops $( [ $w = googlenet ] && echo 63 || echo 53 ) --iters 30 2>&1 | grep auto; done
