@@ -22,7 +22,7 @@ res = {"_fetch_size_calibration": {"known_bytes": known, "FETCH_SIZE_KB": cal, "
                                    "note": "16 B/lane coalesced stream; FETCH_SIZE under-reports by this factor on gfx950 (guide: exactly 2)"}}
 hash_fn = os.path.join(src, "kernel_src_hash.txt")
 khash = open(hash_fn).read().strip() if os.path.exists(hash_fn) else ""
-WORK = {"sgemm-ops-full": ("--workload sgemm-ops-full", "bodahip_sgemm_f32"), "alexnet": ("--workload alexnet", "bodahip_conv_f32"), "nin": ("--workload nin", "bodahip_conv_f32"),
+WORK = {"sgemm-ops-full": ("--workload sgemm-ops-full", "bodahip_sgemm%f32"), "alexnet": ("--workload alexnet", "bodahip_%f32"), "nin": ("--workload nin", "bodahip_%f32"),   # (LIKE patterns: sgemm_f32 + sgemm_big_f32; conv_f32 + fc_f32 + k1_quad_f32)
         "googlenet-bf16-nhwc": ("--workload googlenet --dtype bf16 --layout nhwc", "bodahip_conv_nhwc%bf16"),      # (SQL LIKE pattern: the implicit-GEMM and the input-patch kernel)
         "resnet50-bf16-nhwc": ("--workload resnet50 --dtype bf16 --layout nhwc", "bodahip_conv_nhwc%bf16")}
 for w, (cmdargs, kern) in WORK.items():
