@@ -189,7 +189,7 @@ static bool plan_k1_stream(conv_geom_t const &g, int num_cus, string const &spec
       while (i < spec.size() && n < 4) { size_t j = spec.find('x', i); if (j == string::npos) j = spec.size(); v[n++] = atoi(spec.substr(i, j - i).c_str()); i = j + 1; }
       if (n < 3) rt_err("bad k1_stream spec '" + spec + "' (qWJxOCBxRING[xMINW])");
       QWJ = v[0]; QOCB = v[1]; QRING = v[2]; QMINW = v[3];
-      if (QWJ < 1 || QWJ > 16 || QOCB < 1 || QOCB > 3 || QRING < 1 || QRING > 16 || ksteps % QRING || g.OH * g.OW < 4 || lds(1, QOCB) > 160 * 1024)
+      if (QWJ < 1 || QWJ > 16 || QOCB < 1 || QOCB > 4 || QRING < 1 || QRING > 16 || ksteps % QRING || g.OH * g.OW < 4 || lds(1, QOCB) > 160 * 1024)
         unsup_err("k1_stream: unsupported configuration '" + spec + "' for this shape");
     } else if (spec.empty() && !getenv("BODAHIP_NO_K1_QUAD") && g.OC > 64 && g.OC <= 96 && g.C <= 128 && g.OH * g.OW >= 512 && Nj >= 150000) {
       // measured (MI355X, tools/k1s_probe.py, NiN cccp1 at 256 / 128 images, us): tiled kernel 159.5 / 88.6; q4x3x8 two workgroups per CU 156.5 / 95.7; q8x3x8 153.5 / 93.7;

@@ -202,12 +202,15 @@ def test_sgemm_vs_oracle_bit_exact(be, M, N, K):
 
 
 @pytest.mark.parametrize("tile", ["64x64x16x1x1", "128x64x16x2x1", "64x128x16x1x2", "32x128x16x1x2", "96x128x16x1x2", "128x128x32x2x2", "256x128x16x4x2",
-                                  "32x32x32x2x2x1x1x16", "64x64x64x4x4x1x1x16", "64x64x16x2x2x2x1x16", "64x64x16x2x2x2x1x32x2", "128x128x16x2x2x1x1x32x2"])
+                                  "32x32x32x2x2x1x1x16", "64x64x64x4x4x1x1x16", "64x64x16x2x2x2x1x16", "64x64x16x2x2x2x1x32x2", "128x128x16x2x2x1x1x32x2",
+                                  "128x128x16x2x2x2x1x32x1x1", "64x64x32x2x2x2x1x16x1x1",   # tenth field 1: as many staging waves as multiplying waves (round 4)
+                                  "256x256x16x2x4x1x1x32x2"])                               # the 256x256 tile = kernels/sgemm_big_f32.hip (ragged edges, K tail, fewer K tiles than its rounds)
 def test_sgemm_tiles_agree(be, tile):
     op = _sgemm_op(320, 448, 200)
     ref, _ = _run(be, op, 5)
     got, prc = _run(be, op, 5, tune=OpTune(hip_tile=tile))
-    assert prc.launch["cfg"].startswith("x".join(tile.split("x")[:3]))
+    assert prc.launch["cfg"].startswith("x".join(tile.split("x")[:2]))
+    assert (prc.launch["kernel"] == "bodahip_sgemm_big_f32") == tile.startswith("256x256") and prc.launch["cfg"].endswith("_sw") == (len(tile.split("x")) == 10)
     assert np.array_equal(ref["c"], got["c"])  # incl. the 16x16x4-MFMA tiles (suffix x16): same ascending-k fma chain
 
 
@@ -373,7 +376,8 @@ def test_conv_without_relu_and_alias(be):
 
 
 @pytest.mark.parametrize("tile", ["64x64x16x1x1", "128x64x16x2x1", "32x128x16x1x2", "96x128x16x1x2", "128x128x32x2x2", "128x256x16x2x4",
-                                  "64x64x16x2x2x2x1x16", "32x64x32x2x2x1x1x16", "64x64x16x2x2x2x1x32x2", "128x128x32x2x2x1x1x32x2", "64x256x16x1x4x2"])
+                                  "64x64x16x2x2x2x1x16", "32x64x32x2x2x1x1x16", "64x64x16x2x2x2x1x32x2", "128x128x32x2x2x1x1x32x2", "64x256x16x1x4x2",
+                                  "64x256x16x1x4x2x1x32x1x1", "64x64x16x2x2x2x1x32x1x1"])   # staging waves (LDS input patch staged by waves of their own)
 def test_conv_tiles_agree(be, tile):
     op = _conv_op(3, 24, 15, 15, 100, 3, 3, 1, 1)
     ref, _ = _run(be, op, 5)
