@@ -154,6 +154,11 @@ static_assert(vec_w(I_MODE) == 1 || BK % vec_w(I_MODE) == 0, "vector staging of 
 //   element J(k=(c,ky,kx), j) = patch[c][ slot(j) + ky ][ ox(j)*SX + kx ]  =  lds[ bj(j) + koff(k) ]
 // -> the MFMA B operand is read straight from the patch (per-lane base + per-k constant); staging a channel costs
 //    kCS/kNT coalesced loads per thread instead of KH*KW*BJ/kNT gathered ones, and needs no per-element index arithmetic.
+#ifndef RDEC
+#define RDEC 0 // 1: ROW-DECIMATED patch for strided convolutions without padding (conv1 layers: 11x11 / 4).  The convolution is presented as C0*KH0 "channels" -- row set
+#endif         // (in_chan, kernel row) -- of KH = 1 x KW kernels with stride 1 in y over a plane of COH rows: row r of row set (c, ky) is input row r * SY0 + ky.  k = (c, ky, kx)
+               // keeps its order, a K step is kCB whole row sets, the LDS holds ONE input row per output row and row set (coalesced row loads instead of a gather of
+               // KW-tap windows that overlap (KW - SX) / KW), the MFMA B operand is read in place at lane stride SX.  Needs -DC0 -DH0 -DKH0 -DSY0; p.C = C0 * KH0.
 #if !defined(CH) || !defined(CW) || !defined(COH) || !defined(COW)
 #error "J_MODE 7 needs -DCH -DCW -DCOH -DCOW (input / output plane sizes are compile-time)"
 #endif
@@ -371,7 +376,12 @@ __device__ __forceinline__ void load_gather(float (&r)[kNJ], rsrc_t in, gather_t
 #pragma unroll
   for (int cc = 0; cc < kCB; ++cc) {
     // channels past the end (K tail) meet zero filter values: any finite data will do -> re-read the last channel of the image
+#if RDEC
+    int const cq = min(c0 + cc, p.C - 1);                           // "channel" = row set (in_chan cq / KH0, kernel row cq % KH0) of the strided convolution
+    int const coff = ((cq / KH0) * H0 + cq % KH0) * (CW * 4);
+#else
     int const coff = min(c0 + cc, p.C - 1) * (CH * CW * 4); // scalar; goff + coff < 2^32 and stays >= 2^31 for kOOB entries
+#endif
 #pragma unroll
     for (int e = 0; e < kEPT; ++e) r[cc * kEPT + e] = bload1(in, g.goff[e] + coff);
   }
@@ -566,7 +576,11 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
       int const img = (s < seg0) ? img0 : (img0 + 1 + im2);
       int const iy = (s < seg0) ? (oy0 * SY - PY + s) : (s2 - im2 * kSegFull - PY);
       bool const ok = (el < kCS) && (img < n_img) && ((unsigned)iy < (unsigned)CH) && ((unsigned)ix < (unsigned)CW);
+#if RDEC
+      g.goff[e] = ok ? (((img * (C0 * H0) + iy * SY0) * CW + ix) * 4) : kOOB;   // row iy of the decimated plane is input row iy * SY0 (+ the row set's kernel row, in coff)
+#else
       g.goff[e] = ok ? (((img * p.C * CH + iy) * CW + ix) * 4) : kOOB;
+#endif
     }
 #pragma unroll
     for (int t = 0; t < kTJ; ++t) { // MFMA B operand: this lane's output positions

@@ -166,7 +166,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(host->nh_launch(k.func, grid, 1, (uint32_t)c.threads(), params), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, fc = false, big = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false; int rows = 0, cg = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, fc = false, big = false, rdec = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false; int rows = 0, cg = 0; };
 
 // Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
 //   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
@@ -577,11 +577,52 @@ static void tolerance_splitk(plan_t &p, conv_geom_t const &g, int num_cus, long 
   if (sk < 2) return;
   c.SPLITK = sk; p.cfg = c;
 }
+// Strided convolutions without padding and with wide kernels (conv1 layers: 11x11 / 4): the row-decimated LDS patch of gemm_conv_f32.hip (-DRDEC=1, J_MODE 7 presented with
+// C*KH row sets of 1 x KW kernels).  BODAHIP_RDEC = off | BIxBJxWIxWJxMINW.  In the returned plan cfg.BK = row sets per K step x KW.
+static bool plan_rdec(conv_geom_t const &g, int num_cus, plan_t &p) {
+  char const *e = getenv("BODAHIP_RDEC");
+  if (e && string(e) == "off") return false;
+  if (!(g.PY == 0 && g.PX == 0 && g.SY > 1 && g.KH >= 2 && g.KW >= 6 && g.KW <= 16 && g.OH > 1)) return false;
+  int cb = 1; while (cb * g.KW < 20 || ((cb * g.KW) & 1)) ++cb;
+  int const bk = cb * g.KW; if (bk > 128) return false;
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  auto fits = [&](tile_cfg_t const &c) {
+    int const rows_max = (c.BJ - 2) / g.OW + 2; long const cs = (long)rows_max * g.W;
+    return 2l * 4 * ((long)bk * (c.BI + 4) + cb * cs) <= 64 * 1024 && cs <= 16l * (c.WI * c.WJ * 64);
+  };
+  struct cand_t { int bi, bj, wi, wj, minw; double base; };
+  // measured (MI355X, AlexNet conv1 at 256 images, isolated, us): row gather 96x256 531 | row-decimated patch 32x256 508, 96x256 546, 96x128 549-562, 64x256 (padded out_chans) 628
+  static cand_t const cands[] = {{32, 256, 1, 4, 2, 1.00}, {96, 256, 1, 4, 2, 0.93}, {64, 256, 1, 4, 2, 0.93}, {128, 256, 2, 4, 1, 0.90}};
+  tile_cfg_t best_c; double best = -1;
+  if (e && *e) { int v[5]; if (sscanf(e, "%dx%dx%dx%dx%d", &v[0], &v[1], &v[2], &v[3], &v[4]) != 5) rt_err(string("bad BODAHIP_RDEC '") + e + "' (off | BIxBJxWIxWJxMINW)");
+    best_c.BI = v[0]; best_c.BJ = v[1]; best_c.WI = v[2]; best_c.WJ = v[3]; best_c.MINW = v[4]; best_c.BK = bk; best_c.MT = 32; best_c.SPLITK = 1; best_c.PF = 1;
+    if (!fits(best_c)) unsup_err(string("BODAHIP_RDEC '") + e + "': the tile does not fit"); best = 1; }
+  else for (cand_t const &cd : cands) {
+    tile_cfg_t c; c.BI = cd.bi; c.BJ = cd.bj; c.WI = cd.wi; c.WJ = cd.wj; c.MINW = cd.minw; c.BK = bk; c.MT = 32; c.SPLITK = 1; c.PF = 1;
+    if (!fits(c)) continue;
+    long const ti = (g.OC + c.BI - 1) / c.BI, tj = (Nj + c.BJ - 1) / c.BJ, tiles = ti * tj;
+    double const pad = ((double)g.OC / (double)(ti * c.BI)) * ((double)Nj / (double)(tj * c.BJ));
+    double const bal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
+    double const score = cd.base * pad * bal;
+    if (score > best) { best = score; best_c = c; }
+  }
+  if (best < 0) return false;
+  check_cfg(best_c, false);
+  p = plan_t(); p.kname = "bodahip_conv_f32"; p.patch = true; p.rdec = true; p.cfg = best_c;
+  p.defs = cfg_defs(p.cfg);
+  p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0 && bk % 4 == 0) ? "2" : ((Kt % 2 == 0) ? "4" : "3")));
+  for (string const &d : {string("-DJ_MODE=7"), string("-DRDEC=1"), "-DC0=" + std::to_string(g.C), "-DH0=" + std::to_string(g.H), "-DKH0=" + std::to_string(g.KH), "-DSY0=" + std::to_string(g.SY),
+                          "-DCH=" + std::to_string(g.OH), "-DCW=" + std::to_string(g.W), "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW), string("-DEPI=1"),
+                          string("-DKH=1"), "-DKW=" + std::to_string(g.KW), string("-DSY=1"), "-DSX=" + std::to_string(g.SX), string("-DPY=0"), string("-DPX=0"),
+                          string("-DRELU=") + (g.relu ? "1" : "0")}) p.defs.push_back(d);
+  return true;
+}
 static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false, string const &k1s = string(), bool allow_splitk = true, bool exact = true) {
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   plan_t p;
   if (!bf16 && tile.empty() && plan_ipconv_dma(g, num_cus, p)) return p;
   if (!bf16 && tile.empty() && plan_k1_stream(g, num_cus, k1s, p)) return p;
+  if (!bf16 && tile.empty() && plan_rdec(g, num_cus, p)) return p;
   if (bf16 && tile.empty() && plan_patch_bf16(g, num_cus, p)) return p; p.kname = bf16 ? "bodahip_conv_bf16" : "bodahip_conv_f32"; p.bf16 = bf16;
   // output 1x1, no padding, kernel == whole input ("ipconv" case): the im2col row of image j is the contiguous image
   p.ipconv = (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W);
@@ -646,8 +687,6 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   }
   if (p.patch && tile.empty()) p.cfg.PF = pf_for(p.cfg);
   if (!bf16 && !exact && tile.empty() && allow_splitk) tolerance_splitk(p, g, num_cus, Nj, Kt);
-  // fully-connected layers on 64x64 tiles (one accumulator per wave, usually one workgroup per CU): kernels/fc_f32.hip -- x-major LDS images written with ds_write_b128 and
-  // read four k at a time, the staging slotted between the MFMAs.  BODAHIP_FC = off | BKFxPF.  Measured (MI355X, AlexNet at 256 images, isolated launches, us): see the kernel header
   // fully-connected layers (whole-input windows, both operands k-contiguous): kernels/fc_f32.hip -- four multiplying + four staging waves, three LDS stages, 16x16x4
   // MFMA chains.  Tile TM images x TN out_chans: the largest of 64x64 / 64x32 / 32x32 that still gives (nearly) every CU a workgroup.  BODAHIP_FC = off | TMxTNxBKFxPF
   // (an explicit spec forces the kernel onto every layer it covers: tests).  Measured (MI355X, AlexNet at 256 images, layer sequence, us): fc6 223 -> 170, fc7 104 -> 82.
@@ -791,12 +830,13 @@ static double launch_model(long n, double a, int s, double r, int cus) {
   return t;
 }
 static char const *const kBigTile = "256x256x16x2x4x1x1x32x2";
+static char const *const kTail64 = getenv("BODAHIP_SGEMM_TAIL64") ? getenv("BODAHIP_SGEMM_TAIL64") : "64x64x32x2x2x2x1x32x2";
 static sgemm_split_t plan_sgemm_split(uint32_t M, uint32_t N, uint32_t K, int num_cus) {
   sgemm_split_t sp;
   if (getenv("BODAHIP_NO_SGEMM_SPLIT") || M % 4 || N % 4 || K < 512 || M < 1024 || N < 1024) return sp;
   long const ti = (M + 255) / 256, tj = (N + 255) / 256;
   if (ti * tj < num_cus) return sp;
-  double const r_big = 1.04, r_mid = 1.0, r_small = 0.93;
+  double const r_big = getenv("BODAHIP_SGEMM_RBIG") ? atof(getenv("BODAHIP_SGEMM_RBIG")) : 1.04, r_mid = 1.0, r_small = 0.93;
   auto small_n = [&](uint32_t rows, int b) { return (long)((rows + b - 1) / b) * (long)((N + b - 1) / b); };
   sp.t_single = std::min(launch_model(ti * tj, 1.0, 1, r_big, num_cus), launch_model(small_n(M, 128), 0.25, 2, r_mid, num_cus));
   double best = sp.t_single * 0.975;   // (a split must buy at least 2.5 %)
@@ -807,9 +847,9 @@ static sgemm_split_t plan_sgemm_split(uint32_t M, uint32_t N, uint32_t K, int nu
     double const t64 = tm + launch_model(small_n(rows, 64), 0.0625, 2, r_small, num_cus) + 0.004;
     char const *const force = getenv("BODAHIP_SGEMM_SPLIT_TAIL");   // (experiments: "128" | "64")
     if (force && atoi(force) == 128) { if (t128 < best) { best = t128; sp.m_main = m_main; sp.tail_tile = "128x128x16x2x2x2"; } continue; }
-    if (force && atoi(force) == 64) { if (t64 < best) { best = t64; sp.m_main = m_main; sp.tail_tile = "64x64x32x2x2x2x1x32x2"; } continue; }
+    if (force && atoi(force) == 64) { if (t64 < best) { best = t64; sp.m_main = m_main; sp.tail_tile = kTail64; } continue; }
     if (t128 < best) { best = t128; sp.m_main = m_main; sp.tail_tile = "128x128x16x2x2x2"; }
-    if (t64 < best) { best = t64; sp.m_main = m_main; sp.tail_tile = "64x64x32x2x2x2x1x32x2"; }
+    if (t64 < best) { best = t64; sp.m_main = m_main; sp.tail_tile = kTail64; }
   }
   sp.t_split = best;
   return sp;
@@ -1088,7 +1128,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   if (in_bytes >= 0x7ffffff0ull || f_bytes >= 0x7ffffff0ull) unsup_err("hip_conv: in / filts of 2 GiB or more are not supported (32-bit buffer offsets)");
   ga.I = filts; ga.J = in; ga.D = out; ga.bias = biases;
   ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.ldI = (int)Kt; ga.ldJ = p.ipconv ? (int)Kt : 0; ga.ldD = g.OH * g.OW;
-  ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
+  ga.C = p.rdec ? g.C * g.KH : g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;   // (row-decimated patch: the kernel's "channels" are the C * KH row sets)
   ga.I_bytes = (unsigned)f_bytes; ga.J_bytes = (unsigned)in_bytes;
   uint64_t const out_bytes = (uint64_t)Nj * out_ctot * 4;
   if (cfg.SPLITK > 1 && out_ctot != g.OC) unsup_err("hip_conv: split-K tiles cannot write a channel slice of a wider output");

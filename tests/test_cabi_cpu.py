@@ -90,7 +90,9 @@ def test_planner_picks_the_documented_kernel_and_operand_mode_per_shape():
     def mode(plan, key): return re.search(rf"-D{key}=(\d+)", plan).group(1)
     p = ex(_conv(256, 96, 27, 256, 5, 1, 2))                      # AlexNet conv2: LDS input patch
     assert p.startswith("bodahip_conv_f32 ") and mode(p, "J_MODE") == "7" and "-DCH=27" in p and "-DRELU=1" in p
-    p = ex(_conv(256, 3, 227, 96, 11, 4, 0))                      # AlexNet conv1: row gather (KW >= 6)
+    p = ex(_conv(256, 3, 227, 96, 11, 4, 0))                      # AlexNet conv1 (strided, unpadded, wide): row-decimated LDS patch (round 4), 33 row sets of 1 x 11 kernels
+    assert p.startswith("bodahip_conv_f32 32x256x22_w1x4") and mode(p, "J_MODE") == "7" and "-DRDEC=1" in p and "-DKH0=11" in p and "-DSY0=4" in p and "-DCH=55" in p
+    p = ex(_conv(64, 3, 224, 64, 7, 2, 3))                        # GoogLeNet / ResNet conv1 (padded): row gather (KW >= 6)
     assert mode(p, "J_MODE") == "6" and "-DJROWS=" in p
     p = ex(_conv(256, 256, 27, 256, 1))                           # NiN cccp3: 1x1, tiled kernel (K = 256 is not "short")
     assert p.startswith("bodahip_conv_f32 ") and mode(p, "J_MODE") == "5"

@@ -781,6 +781,37 @@ def test_k1_stream_auto_choice_matches_tiled_kernel(be, shape, kernel):
         rtc.release_func("k1s_auto"); rtc.release_per_call_id_data()
 
 
+RDEC_CASES = [  # (B, C, H, W, OC, K, S): strided, unpadded, wide kernels -> the row-decimated LDS patch (gemm_conv_f32.hip -DRDEC=1): AlexNet / NiN conv1 form, tiles spanning
+    (3, 3, 39, 39, 96, 11, 4),       # several images, one output row per image, ragged out_chans, odd / even K (row sets per step x KW), non-square planes, stride 2 and 3
+    (20, 3, 227, 227, 96, 11, 4),
+    (7, 5, 20, 33, 40, 7, 3),
+    (2, 4, 16, 64, 33, 6, 2),
+    (9, 1, 11, 11, 7, 11, 4),
+    (5, 2, 30, 19, 130, 8, 2),
+]
+
+
+@pytest.mark.parametrize("case", RDEC_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_row_decimated_patch_bit_exact(be, case, monkeypatch):
+    """Strided convolutions without padding (conv1 layers) through the row-decimated patch: same bits as the oracle and as the row-gather kernel it replaces."""
+    B, C, H, W, OC, K, S = case
+    op = _conv_op(B, C, H, W, OC, K, K, S, 0)
+    monkeypatch.delenv("BODAHIP_RDEC", raising=False)
+    outs, prc = _run(be, op, 5, include_ins=True)
+    assert "_w" in prc.launch["cfg"] and prc.launch["kernel"] == "bodahip_conv_f32"
+    from boda_amd.rtc import explain_plan
+    assert ("-DRDEC=1" in explain_plan(add_codegen_annotations(op, OpTune()))) == ((H - K) // S + 1 > 1)   # (a single output row stays on the row gather)
+    want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (S, S), (0, 0), True)
+    assert np.array_equal(want, outs["out"]), SsdsDiff.of(want, outs["out"]).basic_str()
+    monkeypatch.setenv("BODAHIP_RDEC", "off")
+    ref, _ = _run(be, op, 5)
+    assert np.array_equal(ref["out"], outs["out"])
+    for t in ("96x256x1x4x2", "64x256x1x4x2", "128x256x2x4x1"):
+        monkeypatch.setenv("BODAHIP_RDEC", t)
+        got, _ = _run(be, op, 5)
+        assert np.array_equal(ref["out"], got["out"]), t
+
+
 FC_CASES = [  # (B, C, H, W, OC, BODAHIP_FC = TMxTNxBKFxPF): ragged images / out_chans (one and several tiles each way), K tails (K % BKF != 0, fewer K tiles than the
     (5, 4, 3, 3, 7, "64x64x64x4"),      # ring and the stages hold), every tile shape, both K steps and ring depths, a 1x1 window (AlexNet fc7 form) and a real window (fc6 form)
     (70, 8, 2, 2, 130, "64x64x32x2"),
