@@ -82,7 +82,7 @@ static bool parse_tile(string const &s, tile_cfg_t &c) {
   return true;
 }
 // the static_asserts of the kernel, checked on the host so that a bad tune is an unsup_err, not a compile failure
-static void check_cfg(tile_cfg_t const &c, bool gather) {
+static void check_cfg(tile_cfg_t const &c, bool gather, bool patch = false) {   // patch: the J image is an input patch sized (and checked) by the patch planner, not BK x BJ
   int const nt = c.WI * c.WJ * 64;   // multiplying threads (= staging threads)
   bool ok = c.BI > 0 && c.BJ > 0 && c.BK > 0 && c.WI > 0 && c.WJ > 0 && nt <= 1024 && (c.MT == 32 || c.MT == 16) && (c.BI % (c.WI * c.MT) == 0) && (c.BJ % (c.WJ * c.MT) == 0) &&
             (c.BK % 2 == 0) && (c.MT == 32 || c.BK % 4 == 0) && (c.BI % 4 == 0) && (c.BJ % 4 == 0);
@@ -92,7 +92,7 @@ static void check_cfg(tile_cfg_t const &c, bool gather) {
   if (c.PF > 2) ok = ok && ((long)c.PF * c.BK * (c.BI + c.BJ) / nt <= 192);   // (the ring of register sets: PF x staged elements per thread)
   int const accs = (c.BI / (c.WI * c.MT)) * (c.BJ / (c.WJ * c.MT));
   ok = ok && accs * (c.MT == 32 ? 16 : 4) <= 256;
-  uint64_t const lds = 2ull * c.BK * (c.BI + 4 + c.BJ + 4) * 4;
+  uint64_t const lds = 2ull * c.BK * (c.BI + 4 + (patch ? 0 : c.BJ + 4)) * 4;
   ok = ok && lds <= 160 * 1024;
   if (!ok) unsup_err("native kernel: unsupported tile configuration " + c.str());
 }
@@ -607,7 +607,7 @@ static bool plan_rdec(conv_geom_t const &g, int num_cus, plan_t &p) {
     if (score > best) { best = score; best_c = c; }
   }
   if (best < 0) return false;
-  check_cfg(best_c, false);
+  check_cfg(best_c, false, true);
   p = plan_t(); p.kname = "bodahip_conv_f32"; p.patch = true; p.rdec = true; p.cfg = best_c;
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0 && bk % 4 == 0) ? "2" : ((Kt % 2 == 0) ? "4" : "3")));
@@ -708,7 +708,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
     return p;
   }
   if (bf16) bf16_cfg(p.cfg, !p.ipconv, g.OC, Nj, Kt, allow_splitk ? num_cus : 0, !tile.empty());
-  else check_cfg(p.cfg, !p.ipconv && !p.patch);
+  else check_cfg(p.cfg, !p.ipconv && !p.patch, p.patch);
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0 && p.cfg.BK % 4 == 0) ? "2" : ((p.patch && Kt % 2 == 0) ? "4" : "3")));
   p.defs.push_back(p.ipconv ? (string("-DJ_MODE=") + ((Kt % 4 == 0) ? "3" : "4")) : string(p.k1 ? "-DJ_MODE=5" : (p.patch ? "-DJ_MODE=7" : (p.rows ? "-DJ_MODE=6" : "-DJ_MODE=2"))));

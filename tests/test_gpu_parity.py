@@ -323,6 +323,9 @@ EDGE_CONVS = [  # B, C, H, W, OC, KH, KW, S, P   (incl. 1x1 stride 1/2 -> k1 pat
     (1, 1, 5, 5, 1, 5, 5, 1, 2), (4, 20, 8, 8, 100, 3, 3, 1, 1),
     # multi-tile with padding: the first / last row windows of the tensor sit in different workgroups than the bulk
     (2, 3, 40, 40, 16, 7, 7, 2, 3), (3, 4, 33, 31, 20, 5, 5, 1, 2), (2, 3, 64, 64, 24, 11, 11, 4, 5), (1, 3, 150, 150, 64, 7, 7, 2, 3),
+    # many-tap windows at a batch where the planner takes 256-pel tiles: K steps of 70 / 98 (two whole channels) -- the patch planner's own LDS bound applies, not the
+    # BK x BJ image's (found by tools/fuzz_conv.py big in round 4: "unsupported tile configuration 32x256x70")
+    (64, 2, 19, 54, 100, 7, 5, 1, 0), (64, 16, 42, 49, 24, 7, 7, 1, 0),
 ]
 
 
