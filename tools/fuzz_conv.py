@@ -75,7 +75,11 @@ def main():
             ocb = int(rng.integers(1, 5)); cb = int(rng.integers(1, 3))
             if (sh[1] + 1) // 2 * cb + 32 * ocb * cb + 30 > 256: cb = 1
             if (sh[1] + 1) // 2 * cb + 32 * ocb * cb + 30 > 256: ocb = 1
-            spec = f"{wi}x{wj}x{ocb}x{cb}"; rtc.set_tune("k1_stream", spec)
+            spec = f"{wi}x{wj}x{ocb}x{cb}"
+            if rng.random() < 0.5:   # the 16-bytes-per-lane kernel (k1_quad_f32.hip): qWJxOCBxRING, RING a divisor of the K step count; planes of >= 4 pels
+                ks = (sh[1] + 1) // 2; divs = [d for d in range(1, 17) if ks % d == 0]
+                spec = f"q{int(rng.choice([1, 2, 4, 8]))}x{int(rng.integers(1, 4))}x{int(rng.choice(divs))}" + (f"x{int(rng.integers(1, 3))}" if rng.random() < 0.5 else "")
+            rtc.set_tune("k1_stream", spec)
         try:
             outs, prc = _run(be, op, 5, tune=OpTune(hip_tile=tile, hip_dtype="bf16" if mode == "bf16" else ""), include_ins=True)
         except Exception as e:
@@ -92,7 +96,7 @@ def main():
         else:
             sd = SsdsDiff.of(want, outs["out"]); worst = max(worst, sd.mrd); K = sh[1] * sh[5] * sh[6]   # fp32 accumulation-order noise on near-zero outputs grows like K (eps x partial-sum magnitude, K times): the stated bf16 bound is 1e-3 up to K = 2400
             ok = (not sd.has_nan()) and sd.mrd < (1e-3 * max(1.0, K / 2400.0) if mode == "bf16" else 2e-3)
-        if mode == "k1s" and prc.launch["kernel"] != "bodahip_k1_stream_f32": ok = False
+        if mode == "k1s" and prc.launch["kernel"] != ("bodahip_k1_quad_f32" if spec.startswith("q") else "bodahip_k1_stream_f32"): ok = False
         if not ok:
             bad += 1; print("MISMATCH", sh, cfg, spec, int((want != outs["out"]).sum()), "of", want.size, flush=True)
     print(f"MODE={mode}: {n} cases, {bad} mismatches" + (f", worst mrd {worst:.2e}" if worst else "") + "; kernels / tile configs used:", dict(sorted(modes.items(), key=lambda kv: -kv[1])))
