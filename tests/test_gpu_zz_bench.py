@@ -74,7 +74,7 @@ def test_default_line_carries_conv_ops():
     assert set(tol) == {"alexnet", "nin"} and all(0 < v["frac"] <= 1 and v["value"] > 0 for v in tol.values())
     cf = out["configs"]                                                     # BASELINE configs[3] / [4] as legs of the same line
     assert set(cf) >= {"config4_nin-net_b128_f32", "config5_googlenet_b64_bf16_nhwc", "config5_resnet50_b64_bf16_nhwc", "config5_googlenet_b64_bf16_nhwc_independent",
-                       "config5_resnet50_b64_bf16_nhwc_independent"}
+                       "config5_resnet50_b64_bf16_nhwc_independent", "config5_googlenet_b64_bf16_nhwc_independent_multi"}
     for nm in ("googlenet", "resnet50"):     # the edge-free graph replays the same kernels: never slower than the chain by more than noise, and it says what it is
         ind, ch = cf[f"config5_{nm}_b64_bf16_nhwc_independent"], cf[f"config5_{nm}_b64_bf16_nhwc"]
         assert "no edges" in ind["launch"] and "chain" in ch["launch"] and ind["ms_per_step"] < 1.15 * ch["ms_per_step"]

@@ -18,6 +18,8 @@ rows.append(f"| NiN full net @128 (config 4's per-GPU shard), bit-exact / tolera
 for net, key in (("GoogLeNet", "googlenet"), ("ResNet-50", "resnet50")):
     c, i = cf[f"config5_{key}_b64_bf16_nhwc"], cf[f"config5_{key}_b64_bf16_nhwc_independent"]
     rows.append(f"| {net} list bf16 channels-last @64 (config 5 per GPU): chained graph / edge-free graph | {c['value']:.0f} / **{i['value']:.0f} TF/s** ({c['ms_per_step']:.3f} / {i['ms_per_step']:.3f} ms) | kernel time {c['roofline']['frac']:.3f}; wall {c['roofline']['timed_region']['frac']:.3f} / **{i['roofline']['timed_region']['frac']:.3f}** | bf16 parity unpinned (§4) |")
+m = cf.get("config5_googlenet_b64_bf16_nhwc_independent_multi")
+if m: rows.append(f"| … GoogLeNet list, edge-free graph + its implicit-GEMM members as one multi-problem launch | **{m['value']:.0f} TF/s** ({m['ms_per_step']:.3f} ms) | wall **{m['roofline']['timed_region']['frac']:.3f}** | `hip_conv_nhwc_multi` |")
 g = cf["config5_googlenet-net_b64_bf16_nhwc"]
 rows.append(f"| GoogLeNet full net bf16 channels-last @64 (level sets, fused poolings) | {g['images_per_s']/1e3:.1f} k img/s ({g['ms_per_step']:.3f} ms) | {g['roofline']['frac']:.3f} on the conv calls | `non_conv_ms` {g['roofline']['non_conv_ms']:.3f} |")
 cb = d["cpu_baseline"]
