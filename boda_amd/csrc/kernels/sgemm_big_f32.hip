@@ -96,9 +96,9 @@ extern "C" __global__ __launch_bounds__(768, 1) void KNAME(gemm_args_t const p) 
       goffJ[n] = (j0 + x < p.Nj) ? ((kr * p.ldJ + j0 + x) * 4) : kOOB;
     }
     // (K tail: rows past K must read zeros -- the range check only covers the end of the tensor, so the row index is tested; the per-tile part of the offset,
-    //  kt * BKS rows, goes through the scalar offset operand)
-    auto gloadI = [&](int n, int kt) -> f32x4 { return bload4(rI, (kt * BKS + krow[n] < p.K) ? goffI[n] : kOOB, kt * (BKS * 4) * p.ldI); };
-    auto gloadJ = [&](int n, int kt) -> f32x4 { return bload4(rJ, (kt * BKS + krow[n] < p.K) ? goffJ[n] : kOOB, kt * (BKS * 4) * p.ldJ); };
+    //  kt * BKS rows, goes through the scalar offset operand -- clamped to the last real tile, so that it stays inside the tensor (< 2^31) for the padded steps too)
+    auto gloadI = [&](int n, int kt) -> f32x4 { return bload4(rI, (kt * BKS + krow[n] < p.K) ? goffI[n] : kOOB, min(kt, nkt - 1) * (BKS * 4) * p.ldI); };
+    auto gloadJ = [&](int n, int kt) -> f32x4 { return bload4(rJ, (kt * BKS + krow[n] < p.K) ? goffJ[n] : kOOB, min(kt, nkt - 1) * (BKS * 4) * p.ldJ); };
     auto lstore = [&](int op, int n, int stage, f32x4 const &v) { *reinterpret_cast<f32x4 *>(sm + (stage * 2 + op) * kImg + loff[n]) = v; };
     f32x4 ringI[PF][kNL], ringJ[PF][kNL];
 #pragma unroll
