@@ -4,7 +4,7 @@
 //   (the reference's ipconv case: src/cnn_op.cc:104-117, test/rtc/ipconv.cucl; epilogue src/cnn_codegen.cc:35-42)
 //
 // Why a kernel of its own.  AlexNet fc6 / fc7 at 256 images are 4096 x 256 outputs with K = 9216 / 4096: 256 tiles of 64 x 64, one workgroup per CU, one 32 x 32
-// accumulator per wave -- nothing hides anything.  gemm_conv_f32.hip runs them at 235 / 108 us (82 / 79 TF/s).  What was measured on the way here (tools/r4o.sh,
+// accumulator per wave -- nothing hides anything.  gemm_conv_f32.hip runs them at 235 / 108 us (82 / 79 TF/s).  What was measured on the way here (profiles/r04_probe_fc_chain.txt,
 // tools/pmc_fc.sh; fc6, isolated launches):
 //   * a lone chain of dependent v_mfma_f32_32x32x2_f32 issues every 71 cycles, not 64 (no LDS traffic at all: 132 us = the floor of ANY one-chain-per-wave layout),
 //     and every ~100 cycles once operand reads and lane-half selects sit between the links (PMC: 61 % MFMA-busy, no LDS bank conflicts, LDS 23 % busy);
