@@ -403,7 +403,7 @@ class ConvPipeFwd:
     mode = "rtc"
 
     def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False, fuse_siblings: bool = True, fuse_levels: bool = True, fuse_pools: bool = True, sets_take_groups: bool = True,
-                 spec_fwd: bool = True):
+                 spec_fwd: bool = True, fuse_pool_lrn: bool = True):
         self.rtc, self.op_tune = rtc, op_tune or OpTune()
         self.spec_fwd = spec_fwd     # channels-last nets: pool / LRN kernels specialised per geometry (False: the generic kernels with run-time geometry)
         # channels-last bf16 nets: convolutions that read the SAME node with the same kernel geometry (an inception module's 1x1 / 3x3-reduce / 5x5-reduce
@@ -417,6 +417,10 @@ class ConvPipeFwd:
         # reads + 32 packed max per B fragment) makes the convolution a 12-24 us launch of its own at the module's first level: 78.9 -> 75.1 k img/s.  Together with
         # sets_take_groups -- the pool projection then shares ONE launch with the module's sibling group, both read the module's input -- it wins: 79.8 -> 83.0 k img/s
         self.fused_pools: Dict[str, str] = {}  # pooling tag -> the convolution that took it
+        # channels-last nets: a max pooling and an across-channel LRN that follow each other (either order, the first one's output read by nothing else) run as ONE pass
+        # over the tensor (nhwc.POOL_LRN_SPEC_SRC): each of them runs at the HBM roof by itself, the fused call saves the intermediate's write + read.  Bit-identical.
+        self.fuse_pool_lrn = fuse_pool_lrn
+        self.fused_pool_lrn: Dict[str, Tuple[str, bool]] = {}   # tag of the FIRST op of a pair -> (tag of the second, lrn_first)
         self._lazy: Dict[str, FwdCall] = {}    # nodes no call of the forward pass writes any more (a fused pooling's output): the call that materialises one when it is asked for
         self.groups: List[Tuple[str, ...]] = []      # tags of the members of each fused call
         self.per_call_fn, self.enable_double_run = per_call_fn, enable_double_run
@@ -525,6 +529,24 @@ class ConvPipeFwd:
                     continue
                 _nhwc.fuse_pool(annos[q.tag], pin, tuple(o.kern_sz), tuple(o.in_pad))
                 self.fused_pools[o.tag] = q.tag; conv_in[q.tag] = o.bot
+        # pooling <-> LRN pairs (channels-last nets, specialised kernels): see fuse_pool_lrn
+        pl_second: Dict[str, str] = {}     # tag of the second op of a pair -> tag of the first
+        if self.nhwc and self.spec_fwd and self.fuse_pool_lrn:
+            rd_all: Dict[str, List[PipeOp]] = {}
+            for o in cp.ops:
+                if o.tag not in fused:
+                    for b in (o.bots or (o.bot,)):
+                        rd_all.setdefault(b, []).append(o)
+            for a in cp.ops:
+                rd = rd_all.get(a.top, [])
+                if a.tag in fused or a.tag in self.fused_pools or a.tag in pl_second or a.in_place or len(rd) != 1 or a.top in self.slices:
+                    continue
+                b = rd[0]
+                if b.in_place or b.tag in self.fused_pools or {a.type, b.type} != {"Pooling", "LRN"}:
+                    continue
+                pool, lrn = (a, b) if a.type == "Pooling" else (b, a)
+                if pool.bot != cp.in_node and _nhwc.pool_lrn_fusable(_nhwc.nhwc_dims(cp.nodes[pool.bot]), _nhwc.nhwc_dims(cp.nodes[pool.top]), pool.kern_sz, pool.stride, pool.in_pad, int(pool.avg_pool), lrn.lrn[0], lrn.lrn[1], lrn.lrn[3]):
+                    self.fused_pool_lrn[a.tag] = (b.tag, a.type == "LRN"); pl_second[b.tag] = a.tag
         # sibling convolutions (channels-last nets): same bottom node, same kernel / stride / padding / fused ReLU, plain hip_conv_nhwc members
         group_of: Dict[str, List[PipeOp]] = {}     # tag of a member -> its group (list of ops, definition order)
         if self.nhwc and self.fuse_siblings:
@@ -611,6 +633,15 @@ class ConvPipeFwd:
                 elif self.nhwc and vd(op.top).dsz("chan") != op.out_chans:
                     am["out_chan_off"] = _u32(0)     # (the var carries zero pad channels: the conv writes the first out_chans of each row)
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(gen_fn, am), fn, cop.flops()))
+            elif self.nhwc and op.tag in self.fused_pool_lrn:       # first op of a pooling <-> LRN pair: its node is only materialised when somebody asks for it
+                if op.type == "Pooling":
+                    self._lazy[op.top] = FwdCall(op.tag, _nhwc.pool_call(vn(op.bot), op.top, vd(op.bot), vd(op.top), op.kern_sz, op.stride, op.in_pad, int(op.avg_pool), rtc), "nhwc_pool")
+                else:
+                    self._lazy[op.top] = FwdCall(op.tag, _nhwc.lrn_call(vn(op.bot), op.top, vd(op.bot), *op.lrn, rtc=rtc), "nhwc_lrn")
+            elif self.nhwc and op.tag in pl_second:                 # second op of the pair: ONE call from the first op's input to this op's output
+                first = next(o for o in cp.ops if o.tag == pl_second[op.tag]); pool, lrn = (first, op) if first.type == "Pooling" else (op, first)
+                self.fwd_calls.append(FwdCall(first.tag + "+" + op.tag, _nhwc.pool_lrn_call(vn(first.bot), op.top, vd(first.bot), vd(op.top), pool.kern_sz, pool.stride, pool.in_pad,
+                                                                                       *lrn.lrn, lrn_first=(first.type == "LRN"), rtc=rtc), "nhwc_pool_lrn"))
             elif self.nhwc and op.type == "Pooling" and op.tag in self.fused_pools:     # taken into its convolution: only materialised when somebody asks for the node
                 self._lazy[op.top] = FwdCall(op.tag, _nhwc.pool_call(vn(op.bot), op.top, vd(op.bot), vd(op.top), op.kern_sz, op.stride, op.in_pad, int(op.avg_pool),
                                                                       rtc if self.spec_fwd else None), "nhwc_pool")

@@ -635,6 +635,114 @@ CUCL_GLOBAL_KERNEL void @NAME@( GASQ bf16x8_t const * const in, GASQ bf16x8_t * 
 """
 
 
+# Max pooling and across-channel LRN as ONE pass over the tensor (round 4b): GoogLeNet's pool1 -> norm1 and norm2 -> pool2, AlexNet's norm1 -> pool1 and norm2 -> pool2
+# all run at the HBM roof by themselves (5.0-5.5 TB/s), so the only thing left to save is the intermediate tensor's write + read.  One thread = XT consecutive outputs
+# along x of one (img, oy, 8-channel chunk), as in the pooling kernel; for every window position it loads its own chunk AND the two neighbouring chunks (the LRN window
+# reaches HALF channels into each: L1 hits, the neighbouring threads load them as their own).  @LRN_FIRST@ = 1: LRN of every window position (rounded to bf16 as the LRN
+# kernel stores it), then the maximum; 0: maximum of the 8 + 2 HALF channels (rounded to bf16 as the pooling kernel stores it), then LRN.  Same expressions, same order of
+# additions, same roundings as the two kernels run apart: bit-identical output.  Window positions outside the plane are clamped onto it (maximum: duplicates are harmless).
+POOL_LRN_SPEC_SRC = """
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+CUCL_GLOBAL_KERNEL __launch_bounds__(256) void @NAME@( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n, float const alpha, float const beta, float const k ) {
+  // CUCL IX GLOB_ID_1D out n=n
+  uint32_t const i = GLOB_ID_1D;
+  if( i >= n ) { return; }
+  uint32_t const c = i % @C8@u, p = i / @C8@u, xg = p % @OWG@u, q = p / @OWG@u, oy = q % @OH@u, img = q / @OH@u;
+  int32_t const y0 = (int32_t)( oy*@SY@u ) - @PY@, xs = (int32_t)( xg*( @XT@u*@SX@u ) ) - @PX@;
+  int32_t const ya = ( y0 < 0 ) ? 0 : y0, yb = ( y0 + @KH@ > @H@ ) ? @H@ : y0 + @KH@;
+  GASQ bf16x8_t const * const base = in + (size_t)img*( @H@u*@W@u*@C8@u ) + c;
+  bool const has_lo = c > 0, has_hi = c + 1 < @C8@u;
+  int32_t const dlo = has_lo ? -1 : 0, dhi = has_hi ? 1 : 0;      // (a missing neighbour re-reads the chunk itself: in range, and its values are zeroed below)
+  float const per_elem = alpha / @LOCAL_SIZE@.0f;
+  float acc[@XT@][8 + 2*@HALF@];       // running maxima: channels [-HALF, 8 + HALF) of this chunk (LRN first: only [HALF, HALF + 8) are used)
+  for( int32_t t = 0; t != @XT@; ++t ) { for( int32_t e = 0; e != 8 + 2*@HALF@; ++e ) { acc[t][e] = -FLT_MAX; } }
+  // one window COLUMN at a time: its KH x 3 chunks are loaded while the previous column is worked on (all of a thread's window at once does not fit the registers)
+  bf16x8_t cur[@KH@][3], nxt[@KH@][3];
+#define PL_LOAD( DST, J ) { int32_t const x = xs + (J), xc = ( x < 0 ) ? 0 : ( ( x >= @W@ ) ? @W@ - 1 : x ); \
+  _Pragma("unroll") for( int32_t ky = 0; ky != @KH@; ++ky ) { int32_t const y = y0 + ky, yc = ( y < ya ) ? ya : ( ( y >= yb ) ? yb - 1 : y ); \
+    GASQ bf16x8_t const * const at = base + ( yc*@W@ + xc )*@C8@; DST[ky][0] = at[dlo]; DST[ky][1] = at[0]; DST[ky][2] = at[dhi]; } }
+  PL_LOAD( cur, 0 );
+#pragma unroll
+  for( int32_t j = 0; j != @NCOL@; ++j ) {
+    if( j + 1 != @NCOL@ ) { PL_LOAD( nxt, j + 1 ); }
+    __builtin_amdgcn_sched_barrier( 0 );
+#pragma unroll
+    for( int32_t ky = 0; ky != @KH@; ++ky ) {
+      float w[8 + 2*@HALF@];           // the position's channels [-HALF, 8 + HALF): zeros past the tensor's channels (their squares add nothing; as maxima they are never used)
+      for( int32_t e = 0; e != @HALF@; ++e ) { w[e] = has_lo ? (float)cur[ky][0][8 - @HALF@ + e] : 0.0f; w[@HALF@ + 8 + e] = has_hi ? (float)cur[ky][2][e] : 0.0f; }
+      for( int32_t e = 0; e != 8; ++e ) { w[@HALF@ + e] = (float)cur[ky][1][e]; }
+#if @LRN_FIRST@
+      float sq[8 + 2*@HALF@], r8[8];
+      for( int32_t e = 0; e != 8 + 2*@HALF@; ++e ) { sq[e] = w[e]*w[e]; }
+      for( int32_t e = 0; e != 8; ++e ) {
+        float sumsq = 0.0f;
+        for( int32_t d = 0; d != 2*@HALF@ + 1; ++d ) { sumsq += sq[e + d]; }        // ascending channel order, as the LRN kernels
+        r8[e] = (float)(__bf16)( w[@HALF@ + e] * __builtin_amdgcn_exp2f( -beta * __builtin_amdgcn_logf( k + sumsq * per_elem ) ) );
+      }
+      for( int32_t e = 0; e != 8; ++e ) { w[@HALF@ + e] = r8[e]; }
+#endif
+#pragma unroll
+      for( int32_t t = 0; t != @XT@; ++t ) {
+        if( ( j >= t*@SX@ ) && ( j < t*@SX@ + @KW@ ) ) {
+          for( int32_t e = ( @LRN_FIRST@ ? @HALF@ : 0 ); e != ( @LRN_FIRST@ ? @HALF@ + 8 : 8 + 2*@HALF@ ); ++e ) { acc[t][e] = ( w[e] > acc[t][e] ) ? w[e] : acc[t][e]; }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier( 0 );
+#pragma unroll
+    for( int32_t ky = 0; ky != @KH@; ++ky ) { cur[ky][0] = nxt[ky][0]; cur[ky][1] = nxt[ky][1]; cur[ky][2] = nxt[ky][2]; }
+  }
+#pragma unroll
+  for( int32_t t = 0; t != @XT@; ++t ) {
+    uint32_t const ox = xg*@XT@u + t;
+    bf16x8_t r;
+#if @LRN_FIRST@
+    for( int32_t e = 0; e != 8; ++e ) { r[e] = (__bf16)acc[t][@HALF@ + e]; }
+#else
+    float pv[8 + 2*@HALF@], sq[8 + 2*@HALF@];
+    for( int32_t e = 0; e != 8 + 2*@HALF@; ++e ) {
+      bool const real = ( e >= @HALF@ || has_lo ) && ( e < @HALF@ + 8 || has_hi );
+      pv[e] = real ? (float)(__bf16)acc[t][e] : 0.0f; sq[e] = pv[e]*pv[e];       // the pooled value as the pooling kernel stores it
+    }
+    for( int32_t e = 0; e != 8; ++e ) {
+      float sumsq = 0.0f;
+      for( int32_t d = 0; d != 2*@HALF@ + 1; ++d ) { sumsq += sq[e + d]; }
+      r[e] = (__bf16)( pv[@HALF@ + e] * __builtin_amdgcn_exp2f( -beta * __builtin_amdgcn_logf( k + sumsq * per_elem ) ) );
+    }
+#endif
+    if( ( @OW@ % @XT@ == 0 ) || ( ox < @OW@u ) ) { out[( ( img*@OH@u + oy )*@OW@u + ox )*@C8@u + c] = r; }
+  }
+#undef PL_LOAD
+}
+"""
+
+
+def pool_lrn_fusable(i: Dims, o: Dims, kern, stride, pad, avg: int, local_size: int, alpha: float, k: float) -> bool:
+    """Can a max pooling (input dims i, output dims o, channels-last) and an across-channel LRN run as one kernel?  The conditions of the two specialised kernels."""
+    H, W, OH, OW = i.dsz("y"), i.dsz("x"), o.dsz("y"), o.dsz("x")
+    nonempty = all(min(H, oy * stride[0] - pad[0] + kern[0]) > max(0, oy * stride[0] - pad[0]) for oy in (0, OH - 1)) and \
+        all(min(W, ox * stride[1] - pad[1] + kern[1]) > max(0, ox * stride[1] - pad[1]) for ox in (0, OW - 1))
+    return (not avg) and nonempty and kern[0] * kern[1] <= 25 and i.dims_prod() * 2 < (1 << 31) and i.dsz("chan") % 8 == 0 and \
+        local_size % 2 == 1 and 1 <= local_size // 2 <= 4 and k > 0.0 and alpha >= 0.0
+
+
+def pool_lrn_call(in_vn: str, out_vn: str, i: Dims, o: Dims, kern, stride, pad, local_size: int, alpha: float, beta: float, k: float, lrn_first: bool, rtc) -> RtcFuncCall:
+    """One call for Pooling(max) -> LRN (lrn_first False) or LRN -> Pooling(max) (True).  i: the dims of the first op's input, o: of the second op's output."""
+    c8 = i.dsz("chan") // 8
+    H, W, OH, OW = i.dsz("y"), i.dsz("x"), o.dsz("y"), o.dsz("x")
+    xt = 4 if OW >= 8 else (2 if OW >= 4 else 1)
+    while xt > 1 and ((xt - 1) * stride[1] + kern[1]) * kern[0] > 36:
+        xt //= 2
+    ncol, owg = (xt - 1) * stride[1] + kern[1], (OW + xt - 1) // xt
+    nt = o.dsz("img") * OH * owg * c8
+    name = f"nhwc_{'lrn_pool' if lrn_first else 'pool_lrn'}_c{c8}_{H}x{W}_{OH}x{OW}_k{kern[0]}x{kern[1]}_s{stride[0]}x{stride[1]}_p{pad[0]}x{pad[1]}_n{local_size}_t{xt}"
+    _spec_compile(rtc, name, POOL_LRN_SPEC_SRC, {"C8": c8, "H": H, "W": W, "OH": OH, "OW": OW, "KH": kern[0], "KW": kern[1], "SY": stride[0], "SX": stride[1], "PY": pad[0], "PX": pad[1],
+                                                  "XT": xt, "NCOL": ncol, "OWG": owg, "HALF": local_size // 2, "LOCAL_SIZE": local_size, "LRN_FIRST": int(bool(lrn_first))},
+                  ["in", "out", "n", "alpha", "beta", "k"])
+    return RtcFuncCall(name, {"in": RtcArg.var(in_vn), "out": RtcArg.var(out_vn), "n": _u32(nt), "alpha": _f32(alpha), "beta": _f32(beta), "k": _f32(k)},
+                       tpb=_TPB, blks=(nt + _TPB - 1) // _TPB)
+
+
 def pool_call(in_vn: str, out_vn: str, i: Dims, o: Dims, kern, stride, pad, avg: int, rtc=None) -> RtcFuncCall:
     """i / o: the channels-last dims of the vars (img:y:x:chan, chan a multiple of 8).  With `rtc`: the geometry-specialised kernel (compiled on first use) where
     every window meets the plane and is small enough to unroll; the generic kernel otherwise."""

@@ -529,6 +529,53 @@ def test_pool_fused_into_its_1x1_convolution_is_bit_identical(rtc, monkeypatch):
             assert np.array_equal(res[0][n], res[1][n]), (cp.name, n)
 
 
+def test_pool_and_lrn_next_to_each_other_run_as_one_kernel_bit_identical(rtc):
+    """A max pooling and an across-channel LRN that follow each other (either order; the first one's output read by nothing else) run as ONE pass over the tensor
+    (nhwc.POOL_LRN_SPEC_SRC).  Every node -- the first op's own output, materialised on demand, included -- equals the two kernels run apart bit for bit: windows cut by
+    the edges, ceil-mode last windows, padding, one / several / non-power-of-two channel chunks, LRN windows of 3 / 5 / 7; pairs that must NOT fuse stay apart."""
+    from boda_amd.cnn_op import OpTune
+    def small():
+        p = ConvPipe("pl", "data", Dims.make("float", img=3, chan=3, y=23, x=21))
+        p.add(PipeOp("c0", "Convolution", "data", "c0", out_chans=40, kern_sz=(3, 3), in_pad=(1, 1)))                                          # signed values: no ReLU
+        p.add(PipeOp("pa", "Pooling", "c0", "pa", kern_sz=(3, 3), stride=(2, 2))); p.add(PipeOp("na", "LRN", "pa", "na", lrn=(5, 1e-4, 0.75, 1.0)))       # pool -> LRN (GoogLeNet pool1 / norm1)
+        p.add(PipeOp("nb", "LRN", "c0", "nb", lrn=(5, 1e-2, 0.75, 2.0))); p.add(PipeOp("pb", "Pooling", "nb", "pb", kern_sz=(3, 3), stride=(2, 2)))     # LRN -> pool (norm2 / pool2)
+        p.add(PipeOp("c1", "Convolution", "na", "c1", out_chans=8, kern_sz=(1, 1)))                                                              # one chunk: no neighbours
+        p.add(PipeOp("nc", "LRN", "c1", "nc", lrn=(3, 5e-3, 0.5, 1.0))); p.add(PipeOp("pc", "Pooling", "nc", "pc", kern_sz=(2, 2), stride=(2, 2), in_pad=(1, 1)))
+        p.add(PipeOp("c2", "Convolution", "pb", "c2", out_chans=72, kern_sz=(1, 1))); p.add(PipeOp("relu_c2", "ReLU", "c2", "c2"))
+        p.add(PipeOp("pd", "Pooling", "c2", "pd", kern_sz=(5, 5), stride=(3, 3), in_pad=(2, 2))); p.add(PipeOp("nd", "LRN", "pd", "nd", lrn=(7, 2e-3, 0.75, 1.0)))
+        # not fusable: an average pooling; a pooling whose output a second op reads
+        p.add(PipeOp("pe", "Pooling", "c2", "pe", kern_sz=(3, 3), stride=(2, 2), avg_pool=1)); p.add(PipeOp("ne", "LRN", "pe", "ne", lrn=(5, 1e-4, 0.75, 1.0)))
+        p.add(PipeOp("pf", "Pooling", "c2", "pf", kern_sz=(3, 3), stride=(2, 2))); p.add(PipeOp("nf", "LRN", "pf", "nf", lrn=(5, 1e-4, 0.75, 1.0)))
+        p.add(PipeOp("cf", "Convolution", "pf", "cf", out_chans=8, kern_sz=(1, 1)))
+        return p
+    for cp, want in ((small(), {"pa": ("na", False), "nb": ("pb", True), "pd": ("nd", False)}),     # (nc -> pc: the padded ceil-mode pooling has an empty last window: stays apart)
+                     (googlenet_conv(3), {"pool1": ("norm1", False), "norm2": ("pool2", True)}), (alexnet_ng_conv(2), {"norm1": ("pool1", True), "norm2": ("pool2", True)})):
+        params = _params(cp)
+        data = bo.gen_conv_in(*cp.nodes["data"].sizes)
+        nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
+        res = []
+        for fuse in (True, False):
+            fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc"), fuse_pool_lrn=fuse)
+            fwd.init(cp, op_params=params)
+            try:
+                io = {"data": data}
+                fwd.run_fwd(["data"], io, nodes)
+                res.append(io)
+                if fuse:
+                    assert fwd.fused_pool_lrn == want, fwd.fused_pool_lrn
+                    assert not any(c.tag in want or c.tag in {v[0] for v in want.values()} for c in fwd.fwd_calls)     # both ops of a pair are gone from the pass ...
+                    assert sum(c.func == "nhwc_pool_lrn" for c in fwd.fwd_calls) == len(want)                            # ... one call each stands for them
+                    fwd.capture_graph(); out = cp.out_node()
+                    rtc.set_var_to_zero(fwd.var_of(out)); fwd.run_graph()
+                    assert np.array_equal(fwd._fetch(out), io[out])
+                else:
+                    assert not fwd.fused_pool_lrn
+            finally:
+                fwd.release()
+        for n in nodes:
+            assert np.array_equal(res[0][n], res[1][n]), (cp.name, n, int((res[0][n] != res[1][n]).sum()))
+
+
 def test_channels_last_pool_lrn_specialised_kernels(rtc):
     """The geometry-specialised channels-last pool / LRN kernels (boda_amd/nhwc.py POOL_SPEC_SRC / LRN_SPEC_SRC: literal window / stride / padding / plane
     sizes, taps as independent loads, x^-beta through exp2 / log2) against the generic kernels with run-time geometry and against the oracle on the values the
