@@ -166,7 +166,43 @@ NATIVE_ARGS: Dict[str, tuple] = {
     "cudnn_conv": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
     "hip_conv_winograd": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
     "hip_conv_nhwc": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
+    "hip_conv_k1_chain": (("filts", "IN"), ("biases", "IN"), ("filts2", "IN"), ("biases2", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
 }
+
+
+K1_CHAIN_FUNC = "hip_conv_k1_chain"
+
+
+def k1_chain_applies(a: Op, b: Op) -> bool:
+    """Can the fp32 convolutions a -> b (b reads a's output) run as one hip_conv_k1_chain launch?  Mirrors plan_k1_chain (csrc/native_kernels.cc): both 1x1 /
+    stride 1 / unpadded, at most 96 intermediate channels, at most 128 out_chans, both filter images (k-major, odd pitch) within the LDS."""
+    ga, gb = a.conv_geom(), b.conv_geom()
+    for g in (ga, gb):
+        if (g["KH"], g["KW"], g["SY"], g["SX"], g["PY"], g["PX"]) != (1, 1, 1, 1, 0, 0):
+            return False
+    if gb["C"] != ga["OC"] or (gb["H"], gb["W"], gb["B"]) != (ga["OH"], ga["OW"], ga["B"]) or ga["OH"] * ga["OW"] < 4:
+        return False
+    if not (1 <= ga["OC"] <= 96 and 1 <= gb["OC"] <= 128):
+        return False
+    ocb, ocb2 = -(-ga["OC"] // 32), -(-gb["OC"] // 32)
+    kp, kp2 = (ga["C"] + 1) // 2 * 2, (ga["OC"] + 1) // 2 * 2
+    return 4 * (kp * ((ocb * 32) | 1) + ocb * 32 + kp2 * ((ocb2 * 32) | 1) + ocb2 * 32) <= 160 * 1024
+
+
+def annotate_k1_chain(a: Op, b: Op, relu_a: int, relu_b: int) -> Op:
+    """The function op of hip_conv_k1_chain for the annotated hip_conv ops a -> b: a's in / filts / biases / stride / in_pad, b's filts / biases as filts2 /
+    biases2, b's out; conv_has_relu / conv_has_relu2 the two fused ReLUs."""
+    if not k1_chain_applies(a, b):
+        raise UnsupErr("hip_conv_k1_chain: two chained 1x1 / stride-1 / unpadded convolutions with <= 96 intermediate channels and <= 128 out_chans")
+    c = a.copy()
+    c.nda_vals["filts2"] = b.nda_vals["filts"]; c.nda_vals["biases2"] = b.nda_vals["biases"]; c.nda_vals["out"] = b.nda_vals["out"]
+    if "out_chans" in b.nda_vals:
+        c.nda_vals["out_chans"] = b.nda_vals["out_chans"]
+    from .op import Nda
+    c.nda_vals["conv_has_relu"] = Nda(None, "uint32_t", (int(relu_a),)); c.nda_vals["conv_has_relu2"] = Nda(None, "uint32_t", (int(relu_b),))
+    c.str_vals["func_name"] = K1_CHAIN_FUNC
+    c.str_vals.pop("hip_tile", None)
+    return c
 
 
 import os as _os

@@ -18,10 +18,12 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 
 from . import gen_data as gd
-from .cnn_op import NATIVE_ARGS, OpTune, add_codegen_annotations
+from .cnn_op import K1_CHAIN_FUNC, NATIVE_ARGS, OpTune, add_codegen_annotations, annotate_k1_chain, k1_chain_applies
 from .cucl_template import instantiate, parse_template
 from .op import Dims, Nda, Op, RtErr, UnsupErr
 from .rtc import HipCompute, RtcArg, RtcCompileOpts, RtcFuncCall, RtcFuncInfo
@@ -403,8 +405,13 @@ class ConvPipeFwd:
     mode = "rtc"
 
     def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False, fuse_siblings: bool = True, fuse_levels: bool = True, fuse_pools: bool = True, sets_take_groups: bool = True,
-                 spec_fwd: bool = True, fuse_pool_lrn: bool = True):
+                 spec_fwd: bool = True, fuse_pool_lrn: bool = True, fuse_k1_chains: bool = True):
         self.rtc, self.op_tune = rtc, op_tune or OpTune()
+        # fp32 nets: a 1x1 convolution whose output is read by ONE other 1x1 convolution only (NiN's cccp1 -> cccp2) runs with it as one hip_conv_k1_chain launch: the
+        # intermediate tensor stays in the accumulator registers (kernels/k1_quad_f32.hip -DCHAIN=1), its write + read are gone.  Bit-identical; the first
+        # convolution's node is materialised on demand.  The reference chains them through memory (src/rtc_fwd.cc:495-503)
+        self.fuse_k1_chains = fuse_k1_chains
+        self.k1_chains: List[Tuple[str, str]] = []     # (first conv tag, second conv tag) of each fused pair
         self.spec_fwd = spec_fwd     # channels-last nets: pool / LRN kernels specialised per geometry (False: the generic kernels with run-time geometry)
         # channels-last bf16 nets: convolutions that read the SAME node with the same kernel geometry (an inception module's 1x1 / 3x3-reduce / 5x5-reduce
         # convs) run as one hip_conv_nhwc_grp launch -- input read once, the members' tiles in one grid, two launches fewer per module; same bits
@@ -500,6 +507,28 @@ class ConvPipeFwd:
                 s2d_ok = self.nhwc and len(in_readers) == 1 and in_readers[0] is o
                 annos[o.tag] = add_codegen_annotations(cp.conv_op(o), dataclasses.replace(self.op_tune, hip_s2d=int(s2d_ok)) if self.nhwc else self.op_tune)
         in_anno = annos[in_readers[0].tag] if (self.nhwc and len(in_readers) == 1 and in_readers[0].type == "Convolution") else None
+        # 1x1 -> 1x1 chains (fp32 nets; see fuse_k1_chains): first conv's output (after its fused ReLU) read by the second conv and nothing else, both plain hip_conv
+        # functions without a tile of their own, the pair covered by the chain kernel, and a layer the streaming kernels are measured ahead on (long pel axis)
+        chain_first: Dict[str, PipeOp] = {}    # tag of the second conv -> the first conv
+        chain_lazy = set()                      # tags of first convs
+        if (not self.nhwc) and self.fuse_k1_chains and os.environ.get("BODAHIP_NO_K1_CHAIN") is None:
+            rd_k1: Dict[str, List[PipeOp]] = {}
+            for o in cp.ops:
+                if o.tag not in fused:
+                    for b in (o.bots or (o.bot,)):
+                        rd_k1.setdefault(b, []).append(o)
+            busy_tops = {o.top for o in cp.ops if o.in_place and o.tag not in fused and o.type != "Dropout"}
+            for a_ in cp.ops:
+                rd = rd_k1.get(a_.top, [])
+                if a_.type != "Convolution" or a_.tag in chain_first or len(rd) != 1 or rd[0].type != "Convolution" or rd[0].tag in chain_first or a_.top in self.slices or a_.top in busy_tops or a_.bot in busy_tops:
+                    continue
+                b_ = rd[0]; aa, ab = annos[a_.tag], annos[b_.tag]
+                if aa.get_func_name() != "hip_conv" or ab.get_func_name() != "hip_conv" or "hip_tile" in aa.str_vals or "hip_tile" in ab.str_vals or not k1_chain_applies(aa, ab):
+                    continue
+                ga = aa.conv_geom()
+                if self.fuse_k1_chains != "all" and (ga["OH"] * ga["OW"] < 512 or ga["B"] * ga["OH"] * ga["OW"] < 150000):   # ("all": every pair the kernel covers -- tests)
+                    continue
+                chain_first[b_.tag] = a_; chain_lazy.add(a_.tag); self.k1_chains.append((a_.tag, b_.tag))
         # pooling -> 1x1 convolution pairs (channels-last nets; an inception module's pool -> pool projection): the pooling is taken into the convolution where that is
         # legal -- max, stride 1, the convolution its only reader, and a NON-NEGATIVE input (the kernel pads the window with zeros and orders bf16 patterns as integers:
         # right exactly for values >= 0).  Non-negative nodes: outputs of a conv with fused ReLU / a ReLU / a pooling, LRN or Dropout of such / a Concat of such.
@@ -632,6 +661,20 @@ class ConvPipeFwd:
                     am["out"] = RtcArg.var(cat); am["out_chan_off"] = _u32(c_off)
                 elif self.nhwc and vd(op.top).dsz("chan") != op.out_chans:
                     am["out_chan_off"] = _u32(0)     # (the var carries zero pad channels: the conv writes the first out_chans of each row)
+                if op.tag in chain_lazy:         # first conv of a 1x1 chain: no call of the pass writes its node; this call materialises it when somebody asks
+                    self._lazy[op.top] = FwdCall(op.tag, RtcFuncCall(gen_fn, am), fn, cop.flops())
+                    continue
+                if op.tag in chain_first:        # second conv of the chain: ONE call from the first conv's input to this conv's output
+                    first = chain_first[op.tag]; fa = annos[first.tag]
+                    canno = annotate_k1_chain(fa, anno, has_relu[first.tag], has_relu[op.tag]); annos[first.tag + "+" + op.tag] = canno
+                    cfn = f"{K1_CHAIN_FUNC}__{cp.name}_{first.tag}"
+                    rtc.compile([RtcFuncInfo(cfn, "", [a for a, _ in NATIVE_ARGS[K1_CHAIN_FUNC]], canno)]); self._funcs.append(cfn)
+                    cam = {"filts": RtcArg.var(first.tag + "_filts"), "biases": RtcArg.var(first.tag + "_biases"), "filts2": am["filts"], "biases2": am["biases"],
+                           "in": RtcArg.var(vn(first.bot)), "stride": RtcArg.ref(fa.get_dims("stride")), "in_pad": RtcArg.ref(fa.get_dims("in_pad")), "out": am["out"]}
+                    if "out_chan_off" in am:
+                        cam["out_chan_off"] = am["out_chan_off"]
+                    self.fwd_calls.append(FwdCall(first.tag + "+" + op.tag, RtcFuncCall(cfn, cam), K1_CHAIN_FUNC, cp.conv_op(first).flops() + cop.flops()))
+                    continue
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(gen_fn, am), fn, cop.flops()))
             elif self.nhwc and op.tag in self.fused_pool_lrn:       # first op of a pooling <-> LRN pair: its node is only materialised when somebody asks for it
                 if op.type == "Pooling":

@@ -28,6 +28,7 @@
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef ABLATE
 #define ABLATE 0 // experiment hook (BODAHIP_EXTRA_DEFS): 1 no stores | 2 no input loads | 4 no MFMAs
 #endif
@@ -61,6 +62,33 @@ constexpr int kOOB = (int)0x80000000;
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(float const *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)bytes, 0x00020000); }
 __device__ __forceinline__ float bload1(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
+__device__ __forceinline__ f32x4 bload4(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
+// Resident filter image Fs[k][oc] = filts[row0 + oc][k] (ROWS x KCC, k-major with pitch LD; rows past the tensor and the pad row of an odd KCC are zero).  The filter
+// block is one contiguous run of floats: every thread issues ALL its 16-byte loads first, branch-free, and transposes into LDS afterwards -- one memory round trip for
+// the whole image.  (The first form -- one dword load, wait, one LDS store per element -- was a serial chain of 36-72 round trips per thread: 25-50 us at the head of
+// an 85-150 us kernel; a branch per vector serialises the same way, the compiler drains vmcnt at every join.)  A vector is wholly inside the valid run or not loaded;
+// the up to three floats behind the last whole vector go dword by dword: nothing relies on per-dword range checks.
+template <int ROWS, int KCC, int LD, int NT>
+__device__ __forceinline__ void stage_filters(float *Fs, rsrc_t const rI, int const row0, int const rows_valid, int const tid) {
+  constexpr int kN4 = (ROWS * KCC + 3) / 4, kNB = (kN4 + NT - 1) / NT;
+  int const nvalid = ((rows_valid < 0) ? 0 : ((rows_valid > ROWS) ? ROWS : rows_valid)) * KCC, t0 = nvalid & ~3;
+  f32x4 fv[kNB];
+#pragma unroll
+  for (int b = 0; b < kNB; ++b) {
+    int const e0 = 4 * (tid + b * NT);
+    fv[b] = bload4(rI, (e0 + 4 <= nvalid) ? ((row0 * KCC + e0) * 4) : kOOB, 0);
+  }
+  float const tail = bload1(rI, (t0 + tid < nvalid) ? ((row0 * KCC + t0 + tid) * 4) : kOOB, 0);
+  if (KCC & 1) for (int e = tid; e < ROWS; e += NT) Fs[KCC * LD + e] = 0.f;
+#pragma unroll
+  for (int b = 0; b < kNB; ++b)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int const e = 4 * (tid + b * NT) + j, oc = e / KCC, k = e - oc * KCC;
+      if ((e < ROWS * KCC) && !((e >= t0) && (e < nvalid))) Fs[k * LD + oc] = fv[b][j];
+    }
+  if (t0 + tid < nvalid) { int const e = t0 + tid, oc = e / KCC, k = e - oc * KCC; Fs[k * LD + oc] = tail; }
+}
 } // namespace
 
 extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p) {
@@ -75,10 +103,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   // ---- resident filter image: Fs[k][oc] = filts[oc0 + oc][k] (zero rows / columns past the tensor), Bs[oc] = bias
   {
     rsrc_t const rI = make_rsrc(p.I, p.I_bytes), rB = make_rsrc(p.bias, (unsigned)p.Mi * 4u);
-    for (int e = tid; e < kOCT * kKP; e += kNT) {
-      int const oc = e / kKP, k = e - oc * kKP;
-      Fs[k * kLD + oc] = bload1(rI, ((oc0 + oc < p.Mi) && (k < KC)) ? (((oc0 + oc) * KC + k) * 4) : kOOB, 0);
-    }
+    stage_filters<kOCT, KC, kLD, kNT>(Fs, rI, oc0, p.Mi - oc0, tid);
     for (int e = tid; e < kOCT; e += kNT) Bs[e] = bload1(rB, (oc0 + e) * 4, 0); // rows past out_chan read 0 (range-checked)
   }
   __syncthreads();

@@ -23,6 +23,9 @@ struct gemm_args_t { // must match kernels/gemm_conv_f32.hip
   int out_ctot, out_coff;
   void const *ktab; int ktab_n;
   long bsI, bsJ, bsD;
+  // kernels/k1_quad_f32.hip -DCHAIN=1 only (the other kernels declare the struct up to here): the second convolution of a 1x1 chain
+  float const *I2; float const *bias2; float *Dmid;
+  int M2; unsigned I2_bytes, Dmid_bytes;
 };
 
 struct kernel_t { hipModule_t mod = nullptr; hipFunction_t func = nullptr; };
@@ -61,6 +64,7 @@ void native_kernels_t::check_compile_time(rtc_func_info_t const &fi) {
   string const &fn = fi.op.get_func_name();
   if (fn == "hip_sgemm" || fn == "cublas_sgemm" || fn == "hip_sgemm_bf16") return;
   if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd" || fn == "hip_conv_nhwc" || fn == "hip_conv_nhwc_grp" || fn == "hip_conv_nhwc_multi" || fn == "hip_conv_nhwc_set") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
+  if (fn == "hip_conv_k1_chain") { (void)fi.op.get_u32("conv_has_relu"); (void)fi.op.get_u32("conv_has_relu2"); return; }
   rt_err("unknown/unhandled native hip function: " + fn);
 }
 void native_kernels_t::set_tune(string const &key, string const &val) {
@@ -1176,6 +1180,57 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
 }
 
 
+// ---- hip_conv_k1_chain: two 1x1 / stride-1 / unpadded fp32 convolutions back to back as ONE launch (kernels/k1_quad_f32.hip -DCHAIN=1): the first one's output
+// tile stays in the accumulator registers and becomes the second one's MFMA operand after a half exchange; both filter images are resident in LDS.  NiN's
+// cccp1 -> cccp2 (96 -> 96 -> 96 on 55 x 55): the 24 flop/B layers of the net become one 48 flop/B pass, the intermediate tensor's write + read are gone.
+// g = the FIRST convolution's geometry (g.OC = the intermediate channels, g.relu its ReLU); oc2 / relu2 = the second one's.  Covered: at most 96 intermediate
+// channels (one accumulator set of three 32-row blocks: 192 registers + 64 for the second convolution's block), at most 128 out_chans, both filter images in LDS.
+static bool plan_k1_chain(conv_geom_t const &g, int oc2, bool relu2, plan_t &p) {
+  if (!(g.KH == 1 && g.KW == 1 && g.SY == 1 && g.SX == 1 && g.PY == 0 && g.PX == 0)) return false;
+  if (g.OC < 1 || g.OC > 96 || oc2 < 1 || oc2 > 128 || g.C < 1 || g.OH * g.OW < 4) return false;
+  int const OCB = (g.OC + 31) / 32, OCB2 = (oc2 + 31) / 32, ksteps = (g.C + 1) / 2;
+  long const kp = (long)ksteps * 2, kp2 = (long)(g.OC + 1) / 2 * 2;
+  long const lds = 4 * (kp * ((OCB * 32) | 1) + OCB * 32 + kp2 * ((OCB2 * 32) | 1) + OCB2 * 32);
+  if (lds > 160 * 1024) return false;
+  int RING = 8; while (ksteps % RING) --RING;
+  p = plan_t(); p.stream = true; p.quad = true; p.kname = "bodahip_k1_chain_f32";
+  p.cfg.BI = OCB * 32; p.cfg.BJ = 4 * 128; p.cfg.BK = g.C; p.cfg.WI = 1; p.cfg.WJ = 4; p.cfg.MINW = 1; p.cfg.SPLITK = 1; p.cfg.MT = 32; p.cfg.PF = RING;
+  p.defs = {"-DKC=" + std::to_string(g.C), "-DHW=" + std::to_string(g.OH * g.OW), "-DWJ=4", "-DOCB=" + std::to_string(OCB), "-DRING=" + std::to_string(RING), "-DMINW=1",
+            string("-DRELU=") + (g.relu ? "1" : "0"), "-DEDGE_OC=1", "-DCHAIN=1", "-DMID=" + std::to_string(g.OC), "-DOCB2=" + std::to_string(OCB2),
+            string("-DRELU2=") + (relu2 ? "1" : "0"), string("-DEDGE_OC2=") + ((oc2 % 32) ? "1" : "0")};
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return true;
+}
+
+void native_kernels_t::conv_k1_chain(float const *filts, float const *biases, float const *filts2, float const *biases2, float const *in, float *out, float *mid,
+                                     conv_geom_t const &g, int oc2, bool relu2, int out_ctot, int out_coff) {
+  if (out_ctot <= 0) { out_ctot = oc2; out_coff = 0; }
+  long const Nj = (long)g.B * g.OH * g.OW;
+  if (!Nj || !g.OC || !oc2) return;
+  plan_t p;
+  if (!plan_k1_chain(g, oc2, relu2, p)) unsup_err("hip_conv_k1_chain: two 1x1 / stride-1 / unpadded convolutions with at most 96 intermediate channels, at most 128 out_chans and filters that fit the LDS");
+  uint64_t const in_bytes = (uint64_t)g.B * g.C * g.H * g.W * 4, mid_bytes = (uint64_t)Nj * g.OC * 4, out_bytes = (uint64_t)Nj * out_ctot * 4;
+  if (in_bytes >= 0x7ffffff0ull || mid_bytes >= 0x7ffffff0ull || out_bytes >= 0x7ffffff0ull) unsup_err("hip_conv_k1_chain: tensors of 2 GiB or more are not supported (32-bit buffer offsets)");
+  kernel_t &k = get_kernel(impl, host, p);
+  tile_cfg_t const &cfg = p.cfg;
+  gemm_args_t ga; memset(&ga, 0, sizeof(ga));
+  ga.I = filts; ga.J = in; ga.D = out; ga.bias = biases; ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = g.C; ga.ldI = g.C; ga.ldD = g.OH * g.OW;
+  ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
+  ga.I_bytes = (unsigned)((uint64_t)g.OC * g.C * 4); ga.J_bytes = (unsigned)in_bytes; ga.D_bytes = (unsigned)out_bytes; ga.out_ctot = out_ctot; ga.out_coff = out_coff;
+  ga.I2 = filts2; ga.bias2 = biases2; ga.Dmid = mid; ga.M2 = oc2; ga.I2_bytes = (unsigned)((uint64_t)oc2 * g.OC * 4); ga.Dmid_bytes = mid ? (unsigned)mid_bytes : 0u;
+  // persistent workgroups, one per CU (four waves, one per SIMD), an even deal of super-blocks (four 128-pel blocks of one image each), XCD-contiguous ranges
+  ga.tiles_i = 1; ga.tiles_j = (int)(((long)g.B * ((g.OH * g.OW + 127) / 128) + cfg.WJ - 1) / cfg.WJ);
+  long const slots = std::max(1l, (long)host->nh_num_cus());
+  long const per = (ga.tiles_j + slots - 1) / slots;
+  ga.kt_per = (int)((ga.tiles_j + per - 1) / per); ga.splitk = 1;
+  if (ga.kt_per >= 8) ga.kt_per = (ga.kt_per + 7) / 8 * 8;
+  void *params[] = {&ga};
+  hip_err_chk(host->nh_launch(k.func, (uint32_t)ga.kt_per, 1, (uint32_t)cfg.threads(), params), "hipModuleLaunchKernel(k1_chain)");
+  last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)ga.kt_per; last_launch.block = cfg.threads();
+  last_launch.flops = 2.0 * Nj * ((double)g.OC * g.C + (double)oc2 * g.OC);
+  last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * oc2 + (double)g.OC * g.C + g.OC + (double)oc2 * g.OC + oc2);
+}
+
 struct grp_args_t { // must match kernels/conv_nhwc_bf16.hip
   int n; int oc0[4]; int noc[4];
   void *D[4]; unsigned D_bytes[4]; int ctot[4]; int coff[4];
@@ -1598,6 +1653,9 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
       }
       p = plan_conv_nhwc_patch(gp, num_cus, tile, op.get_dims("out").tn == "float", pool);
     }
+    else if (op.has_func_name() && op.get_func_name() == "hip_conv_k1_chain") {
+      if (!plan_k1_chain(g, (int)op.get_dims("filts2").dsz("out_chan"), op.get_u32("conv_has_relu2") != 0, p)) unsup_err("prebuild: hip_conv_k1_chain does not cover this pair of convolutions");
+    }
     else if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc") p = plan_conv_nhwc(g, num_cus, tile, op.get_dims("out").tn == "float");
     else if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc_grp") { dims_t const &grp = op.get_dims("grp"); p = plan_conv_nhwc(g, num_cus, tile, op.get_dims("out_0").tn == "float", (int)grp.dims(grp.sz() - 1)); }
     else if (bf16 && tile.empty() && s2d_geom(g, g2, pry, prx) && plan_patch_bf16(g2, num_cus, p)) { // conv1-type layers: space-to-depth front end (see conv())
@@ -1868,6 +1926,42 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW) rt_err("hip_conv_nhwc: out dims do not match in/filts/stride/in_pad");
     tile_override_t const tov(impl, "conv_tile", fi.op);
     conv_nhwc(host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), host->nh_var_ptr(inm), host->nh_var_ptr(onm), g, out.tn == "float", out_ctot, out_coff, patch_filts, pool);
+    return;
+  }
+  if (fn == "hip_conv_k1_chain") {
+    // two chained 1x1 convolutions (see conv_k1_chain): vars filts / biases (first conv), filts2 / biases2 (second), in, out, optionally mid (the first conv's output,
+    // written as well); REFs stride / in_pad (of both: 1x1 / stride 1 / no padding); uint32 conv_has_relu / conv_has_relu2; optional by-value out_chan_off
+    string const fnm = var_of(am, "filts"), bnm = var_of(am, "biases"), f2nm = var_of(am, "filts2"), b2nm = var_of(am, "biases2"), inm = var_of(am, "in"), onm = var_of(am, "out");
+    dims_t const f = host->nh_var_dims(fnm), bi = host->nh_var_dims(bnm), f2 = host->nh_var_dims(f2nm), b2 = host->nh_var_dims(b2nm), in = host->nh_var_dims(inm), out = host->nh_var_dims(onm);
+    need_float(f, "filts"); need_float(bi, "biases"); need_float(f2, "filts2"); need_float(b2, "biases2"); need_float(in, "in"); need_float(out, "out");
+    auto si = am.find("stride"), pi = am.find("in_pad");
+    if (si == am.end() || pi == am.end()) rt_err("hip_conv_k1_chain: 'stride' and 'in_pad' REF args are required");
+    dims_t const stride = si->second.get_dims(host->nh_rtc()), in_pad = pi->second.get_dims(host->nh_rtc());
+    assert_st(stride.sz() == 2); assert_st(in_pad.sz() == 2);
+    assert_st(f.sz() == 4 && f2.sz() == 4 && in.sz() == 4 && out.sz() == 4 && bi.sz() == 1 && b2.sz() == 1);
+    conv_geom_t g = geom_from_dims(f, in, out, stride, in_pad, fi.op.get_u32("conv_has_relu") != 0);
+    bool const relu2 = fi.op.get_u32("conv_has_relu2") != 0;
+    int const oc2 = (int)f2.dsz("out_chan");
+    if (f.dsz("in_chan") != (uint32_t)g.C || f2.dsz("in_chan") != (uint32_t)g.OC) rt_err("hip_conv_k1_chain: filts.in_chan != in.chan or filts2.in_chan != filts.out_chan");
+    if (f2.dsz("y") != 1 || f2.dsz("x") != 1 || g.KH != 1 || g.KW != 1 || g.SY != 1 || g.SX != 1 || g.PY || g.PX) unsup_err("hip_conv_k1_chain: both convolutions must be 1x1 / stride 1 / unpadded");
+    int out_ctot = 0, out_coff = 0;
+    auto oi = am.find("out_chan_off");
+    if (oi != am.end()) {
+      if (oi->second.is_var() || !oi->second.v || !oi->second.v->rp_elems()) rt_err("hip_conv_k1_chain: out_chan_off must be a by-value uint32");
+      out_coff = (int)*(uint32_t const *)oi->second.v->rp_elems(); out_ctot = (int)out.dsz("chan");
+      if (out_coff < 0 || out_coff + oc2 > out_ctot) rt_err("hip_conv_k1_chain: out_chan_off + out_chan exceeds the channels of out");
+    }
+    if (bi.dsz("out_chan") != (uint32_t)g.OC || b2.dsz("out_chan") != (uint32_t)oc2 || (!out_ctot && out.dsz("chan") != (uint32_t)oc2) || out.dsz("img") != (uint32_t)g.B) rt_err("hip_conv_k1_chain: inconsistent biases / out dims");
+    if (g.OH != g.H || g.OW != g.W) rt_err("hip_conv_k1_chain: out dims do not match in");
+    float *mid = nullptr;
+    auto mi = am.find("mid");
+    if (mi != am.end()) {
+      string const mnm = var_of(am, "mid"); dims_t const md = host->nh_var_dims(mnm); need_float(md, "mid");
+      if (md.sz() != 4 || md.dsz("img") != (uint32_t)g.B || md.dsz("chan") != (uint32_t)g.OC || md.dsz("y") != (uint32_t)g.OH || md.dsz("x") != (uint32_t)g.OW) rt_err("hip_conv_k1_chain: mid must be img:chan:y:x of the first convolution's output");
+      mid = (float *)host->nh_var_ptr(mnm);
+    }
+    conv_k1_chain((float const *)host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), (float const *)host->nh_var_ptr(f2nm), (float const *)host->nh_var_ptr(b2nm),
+                  (float const *)host->nh_var_ptr(inm), (float *)host->nh_var_ptr(onm), mid, g, oc2, relu2, out_ctot, out_coff);
     return;
   }
   if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd") {

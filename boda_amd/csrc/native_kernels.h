@@ -84,6 +84,10 @@ struct native_kernels_t {
   void conv_nhwc_multi(int n, multi_member_t const *members, bool out_f32);
   // a few independent channels-last convolutions, each on its own specialised kernel code (implicit-GEMM or input-patch form), as one launch (wrapper kernel built at run time)
   void conv_nhwc_set(int n, multi_member_t const *members, bool const *patch_filts, bool out_f32);
+  // two 1x1 / stride-1 / unpadded fp32 convolutions back to back as one launch, the intermediate tensor in registers (kernels/k1_quad_f32.hip -DCHAIN=1); g = the first
+  // convolution's geometry, mid (optional) also receives its output
+  void conv_k1_chain(float const *filts, float const *biases, float const *filts2, float const *biases2, float const *in, float *out, float *mid, conv_geom_t const &g, int oc2,
+                     bool relu2, int out_ctot, int out_coff);
   void conv_winograd(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, int out_ctot, int out_coff);
 
   // tuning overrides ("" clears): key "sgemm_tile" / "conv_tile" -> "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT]]]"; key "k1_stream" -> "off" | "WIxWJxOCBxCB[xMINW]";

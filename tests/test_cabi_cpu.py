@@ -125,6 +125,28 @@ def test_planner_picks_the_documented_kernel_and_operand_mode_per_shape():
     assert "-DSPLITK" not in ex(_conv(64, 1024, 14, 256, 1, func="hip_conv_bf16"))
 
 
+def test_planner_k1_chain_and_the_net_driver_fuses_nin_block_one():
+    """hip_conv_k1_chain (round 4c): two chained 1x1 convolutions plan onto the chain form of the 16-bytes-per-lane streaming kernel (both filter images in LDS, the
+    intermediate channels = the rows of one accumulator set), and ConvPipeFwd fuses exactly NiN's cccp1 -> cccp2 at the bench batches (dry init, no device)."""
+    from boda_amd.cnn_op import OpTune, add_codegen_annotations as _aca, annotate_k1_chain, k1_chain_applies
+    def add_codegen_annotations(op, tune):   # (_conv() ops arrive annotated: strip, annotate again)
+        op = op.copy(); op.str_vals.pop("func_name"); op.nda_vals.pop("conv_has_relu"); return _aca(op, tune)
+    a = add_codegen_annotations(_conv(128, 96, 55, 96, 1), OpTune()); b = add_codegen_annotations(_conv(128, 96, 55, 96, 1), OpTune())
+    ch = annotate_k1_chain(a, b, 1, 0)
+    p = R.explain_plan(ch)
+    assert p.startswith("bodahip_k1_chain_f32 96x512x96_w1x4") and "-DCHAIN=1" in p and "-DMID=96" in p and "-DOCB2=3" in p and "-DRELU=1" in p and "-DRELU2=0" in p and "-DRING=8" in p
+    ch2 = annotate_k1_chain(add_codegen_annotations(_conv(4, 33, 20, 64, 1), OpTune()), add_codegen_annotations(_conv(4, 64, 20, 100, 1), OpTune()), 1, 1)
+    p2 = R.explain_plan(ch2)
+    assert "-DKC=33" in p2 and "-DMID=64" in p2 and "-DOCB=2" in p2 and "-DOCB2=4" in p2 and "-DEDGE_OC2=1" in p2 and "-DRING=1" in p2     # 17 K steps: a ring of one
+    assert not k1_chain_applies(add_codegen_annotations(_conv(4, 256, 27, 256, 1), OpTune()), add_codegen_annotations(_conv(4, 256, 27, 256, 1), OpTune()))   # cccp3 -> cccp4
+    from boda_amd.conv_pipe import ConvPipeFwd, DryRtc, alexnet_ng_conv, nin_imagenet
+    for batch, want in ((128, [("cccp1", "cccp2")]), (2, [])):
+        f = ConvPipeFwd(DryRtc()); f.init(nin_imagenet(batch))
+        assert f.k1_chains == want and (not want or [c.tag for c in f.fwd_calls][:3] == ["conv1", "cccp1+cccp2", "pool0"]) and list(f._lazy) == [a_ for a_, _ in want]
+    f = ConvPipeFwd(DryRtc(), fuse_k1_chains=False); f.init(nin_imagenet(128)); assert not f.k1_chains
+    f = ConvPipeFwd(DryRtc()); f.init(alexnet_ng_conv(256)); assert not f.k1_chains       # fc6 -> fc7 -> fc8 are whole-input windows / too wide
+
+
 def test_planner_sgemm_tiles_follow_problem_size():
     from boda_amd.op import parse_op
     def sg(M, N, K, fn="hip_sgemm"):

@@ -107,6 +107,37 @@ def test_full_net_forward_matches_oracle(rtc, net, batch, tmp_path):
         fwd.release()
 
 
+def test_k1_chains_are_bit_identical_to_separate_launches(rtc):
+    """fp32 nets: a 1x1 convolution read by one other 1x1 convolution only runs with it as ONE hip_conv_k1_chain launch (NiN: cccp1+cccp2, cccp3+cccp4 is too wide;
+    fuse_k1_chains="all" lifts the size gate so that a batch the oracle finishes covers it).  Every node equals the unfused pass bit for bit -- including the first
+    convolution's node, which no call of the pass writes any more and which is materialised when asked for -- and the fused pair equals the oracle's two layers."""
+    cp = nin_imagenet(3); params = _params(cp); data = bo.gen_conv_in(*cp.nodes["data"].sizes)
+    nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
+    res = {}
+    for fuse in (False, "all"):
+        fwd = ConvPipeFwd(rtc, fuse_k1_chains=fuse); fwd.init(cp, op_params=params)
+        try:
+            funcs = [c.func for c in fwd.fwd_calls]
+            if fuse:
+                chains = fwd.k1_chains
+                assert ("cccp1", "cccp2") in chains and all(a in fwd._lazy for a, _ in chains)
+                assert funcs.count("hip_conv_k1_chain") == len(chains) and funcs.count("hip_conv") == sum(o.type == "Convolution" for o in cp.ops) - 2 * len(chains)
+            else:
+                assert "hip_conv_k1_chain" not in funcs and not fwd.k1_chains
+            io = {"data": data}
+            fwd.run_fwd(["data"], io, nodes)
+            res[bool(fuse)] = io
+            if fuse:   # graph replay of the fused list writes the same bits
+                fwd.capture_graph(); rtc.set_var_to_zero(fwd.var_of(cp.out_node())); fwd.run_graph()
+                assert np.array_equal(rtc.copy_var_to_nda(fwd.var_of(cp.out_node())), io[cp.out_node()])
+        finally:
+            fwd.release()
+    for n in nodes:
+        assert np.array_equal(res[False][n], res[True][n]), n
+    mid = bo.conv_fwd(res[True]["conv1"], params["cccp1_filts"], params["cccp1_biases"], (1, 1), (0, 0), True)
+    assert np.array_equal(mid, res[True]["cccp1"]) and np.array_equal(bo.conv_fwd(mid, params["cccp2_filts"], params["cccp2_biases"], (1, 1), (0, 0), True), res[True]["cccp2"])
+
+
 def test_graph_replay_equals_call_by_call(rtc):
     """hipGraph capture of a whole forward call list (GoogLeNet: 82 launches): the replay writes the same bits as the
     call-by-call run, can be relaunched, and captured calls have no per-call timing."""

@@ -756,6 +756,74 @@ def test_k1_stream_kernel_bit_exact(be, case, relu):
         rtc.release_func("k1s_conv"); rtc.release_per_call_id_data()
 
 
+K1_CHAIN_CASES = [  # (B, C, H, W, MID, OC2): odd in_chan / intermediate / out_chan counts (padded K steps of both convolutions, ragged row blocks), planes shorter than a
+    (2, 5, 9, 9, 7, 13),            # 128-pel block and planes with tail blocks, more blocks than workgroup slots, one to three row blocks either side, 128 out_chans
+    (3, 96, 11, 9, 96, 96),
+    (2, 33, 20, 20, 64, 100),
+    (1, 2, 2, 2, 1, 3),
+    (5, 48, 13, 13, 33, 128),
+    (9, 96, 55, 55, 96, 96),
+    (2, 128, 23, 23, 95, 32),
+]
+
+
+@pytest.mark.parametrize("case", K1_CHAIN_CASES, ids=lambda c: "x".join(str(v) for v in c))
+@pytest.mark.parametrize("relus", [(1, 1), (0, 1), (1, 0)], ids=["relu_relu", "lin_relu", "relu_lin"])
+def test_k1_chain_bit_exact(be, case, relus):
+    """hip_conv_k1_chain (kernels/k1_quad_f32.hip -DCHAIN=1): two 1x1 convolutions as one launch, the intermediate tensor in the accumulator registers -- the same bits
+    as the oracle's two convolutions run one after the other (the intermediate rounded to fp32, bias and ReLU in between), into a channel slice of a wider tensor with
+    an untouched guard band; with `mid` given, the intermediate tensor too."""
+    from boda_amd.cnn_op import annotate_k1_chain, k1_chain_applies
+    rtc = be.rtc
+    B, C, H, W, MID, OC2 = case
+    a = add_codegen_annotations(_conv_op(B, C, H, W, MID, 1, 1, 1, 0), OpTune()); b = add_codegen_annotations(_conv_op(B, MID, H, W, OC2, 1, 1, 1, 0), OpTune())
+    assert k1_chain_applies(a, b)
+    ch = annotate_k1_chain(a, b, *relus)
+    args = [x for x, _ in NATIVE_ARGS["hip_conv_k1_chain"]]
+    rtc.compile([RtcFuncInfo("k1c", "", args, ch), RtcFuncInfo("k1c_mid", "", args + ["mid"], ch)])
+    x = bo.gen_conv_in(B, C, H, W); f1 = bo.gen_conv_filts(MID, C, 1, 1); b1 = bo.gen_conv_biases(MID)
+    f2 = (bo.gen_conv_filts(OC2, MID, 1, 1) * np.float32(0.25)).astype(np.float32); b2 = bo.gen_conv_biases(OC2)
+    wide = Dims.make("float", img=B, chan=OC2 + 5, y=H, x=W)
+    names = {"in": ("k1c_in", a.get_dims("in"), x), "filts": ("k1c_f1", a.get_dims("filts"), f1), "biases": ("k1c_b1", a.get_dims("biases"), b1),
+             "filts2": ("k1c_f2", b.get_dims("filts"), f2), "biases2": ("k1c_b2", b.get_dims("biases"), b2), "out": ("k1c_out", wide, np.full(wide.sizes, 7.0, np.float32)),
+             "mid": ("k1c_mid_v", a.get_dims("out"), np.full(a.get_dims("out").sizes, 3.0, np.float32))}
+    for vn, d, arr in names.values():
+        rtc.create_var_with_dims(vn, d); rtc.copy_nda_to_var(vn, arr)
+    try:
+        am = {an: RtcArg.var(names[an][0]) for an in names if an != "mid"}
+        am["stride"] = RtcArg.ref(a.get_dims("stride")); am["in_pad"] = RtcArg.ref(a.get_dims("in_pad")); am["out_chan_off"] = RtcArg.scalar(2, "uint32_t")
+        mid_w = bo.conv_fwd(x, f1, b1, (1, 1), (0, 0), bool(relus[0])); want = bo.conv_fwd(mid_w, f2, b2, (1, 1), (0, 0), bool(relus[1]))
+        rtc.run(RtcFuncCall("k1c", am)); rtc.finish_and_sync()
+        assert rtc.last_launch()["kernel"] == "bodahip_k1_chain_f32"
+        got = rtc.copy_var_to_nda("k1c_out")
+        assert np.array_equal(got[:, 2:2 + OC2], want), SsdsDiff.of(want, got[:, 2:2 + OC2]).basic_str()
+        assert (got[:, :2] == 7).all() and (got[:, 2 + OC2:] == 7).all()
+        assert (rtc.copy_var_to_nda("k1c_mid_v") == 3).all()       # (not asked for: not written)
+        rtc.copy_nda_to_var("k1c_out", np.full(wide.sizes, 7.0, np.float32))
+        rtc.run(RtcFuncCall("k1c_mid", dict(am, mid=RtcArg.var("k1c_mid_v")))); rtc.finish_and_sync()
+        got = rtc.copy_var_to_nda("k1c_out")
+        assert np.array_equal(got[:, 2:2 + OC2], want) and (got[:, :2] == 7).all() and (got[:, 2 + OC2:] == 7).all()
+        assert np.array_equal(rtc.copy_var_to_nda("k1c_mid_v"), mid_w)
+    finally:
+        for vn, _, _ in names.values():
+            rtc.release_var(vn)
+        rtc.release_func("k1c"); rtc.release_func("k1c_mid"); rtc.release_per_call_id_data()
+
+
+def test_k1_chain_refuses_what_it_does_not_cover(be):
+    """More than 96 intermediate channels, a padded or strided member: the annotation refuses (UnsupErr), nothing is launched."""
+    from boda_amd.cnn_op import annotate_k1_chain, k1_chain_applies
+    from boda_amd.op import UnsupErr
+    mk = lambda *a_: add_codegen_annotations(_conv_op(*a_), OpTune())
+    assert not k1_chain_applies(mk(2, 8, 9, 9, 97, 1, 1, 1, 0), mk(2, 97, 9, 9, 8, 1, 1, 1, 0))
+    assert not k1_chain_applies(mk(2, 8, 9, 9, 16, 1, 1, 1, 0), mk(2, 16, 9, 9, 129, 1, 1, 1, 0))
+    assert not k1_chain_applies(mk(2, 8, 9, 9, 16, 3, 3, 1, 1), mk(2, 16, 9, 9, 8, 1, 1, 1, 0))
+    assert not k1_chain_applies(mk(2, 8, 9, 9, 16, 1, 1, 1, 0), mk(2, 16, 9, 9, 8, 3, 3, 1, 1))
+    assert not k1_chain_applies(mk(2, 8, 9, 9, 16, 1, 1, 1, 0), mk(2, 24, 9, 9, 8, 1, 1, 1, 0))
+    with pytest.raises(UnsupErr):
+        annotate_k1_chain(mk(2, 8, 9, 9, 97, 1, 1, 1, 0), mk(2, 97, 9, 9, 8, 1, 1, 1, 0), 1, 1)
+
+
 @pytest.mark.parametrize("shape,kernel", [((64, 64, 56, 56, 256), "bodahip_k1_stream_f32"), ((52, 96, 55, 55, 96), "bodahip_k1_quad_f32")], ids=["res2_64to256", "nin_cccp1"])
 def test_k1_stream_auto_choice_matches_tiled_kernel(be, shape, kernel):
     """At the sizes where the planner picks a streaming kernel by itself (ResNet-50 res2 at B=64: 64 -> 256 chans on 56x56; NiN cccp1 / cccp2: 96 -> 96 on 55x55 planes, the
