@@ -201,6 +201,12 @@ static bool plan_k1_stream(conv_geom_t const &g, int num_cus, string const &spec
       // they overflow the 6-bit vmcnt and every wait becomes a drain)
       QWJ = 4; QOCB = (g.OC + 31) / 32; QRING = 8; QMINW = 1; while (ksteps % QRING) --QRING;
       if (lds(1, QOCB) > 80 * 1024) QWJ = 0;
+    } else if (spec.empty() && !getenv("BODAHIP_NO_K1_QUAD") && g.OC > 96 && g.OC <= 256 && g.OC % 64 == 0 && g.C > 128 && g.C <= 256 && g.OH * g.OW >= 512 && Nj >= 180000) {
+      // NiN cccp3 / cccp4 class (256 -> 256 on 27 x 27) at 256 images, once the filter image was staged with all its loads in flight (round 4c; before, 64 serial round
+      // trips cost this kernel 40 us per launch): eight waves, 64 out_chans per workgroup (four passes over the input, from L2), two workgroups per CU.  Measured
+      // (tools/k1s_probe.py, us): tiled 128x128 219.1 | q8x2x8x2 203.6 | q4x2x8x1 210.5 | q4x4x8x1 211.9 | q4x3x8x1 242.1; at 128 images the tiled kernel leads (116 vs 126)
+      QWJ = 8; QOCB = 2; QRING = 8; QMINW = 2; while (ksteps % QRING) --QRING;
+      if (lds(1, QOCB) > 80 * 1024) QWJ = 0;
     }
     if (QWJ) {
       if (!QMINW) QMINW = (QOCB == 3) ? 2 : ((QOCB == 2) ? 3 : 4);   // registers: OCB*64 accumulators + 4*RING operands + ~30

@@ -94,8 +94,10 @@ def test_planner_picks_the_documented_kernel_and_operand_mode_per_shape():
     assert p.startswith("bodahip_conv_f32 32x256x22_w1x4") and mode(p, "J_MODE") == "7" and "-DRDEC=1" in p and "-DKH0=11" in p and "-DSY0=4" in p and "-DCH=55" in p
     p = ex(_conv(64, 3, 224, 64, 7, 2, 3))                        # GoogLeNet / ResNet conv1 (padded): row gather (KW >= 6)
     assert mode(p, "J_MODE") == "6" and "-DJROWS=" in p
-    p = ex(_conv(256, 256, 27, 256, 1))                           # NiN cccp3: 1x1, tiled kernel (K = 256 is not "short")
+    p = ex(_conv(128, 256, 27, 256, 1))                           # NiN cccp3 at 128 images: 1x1, tiled kernel (K = 256 is not "short")
     assert p.startswith("bodahip_conv_f32 ") and mode(p, "J_MODE") == "5"
+    p = ex(_conv(256, 256, 27, 256, 1))                           # ... at 256 images (round 4c): the 16-bytes-per-lane streaming kernel, eight waves x 64 out_chans
+    assert p.startswith("bodahip_k1_quad_f32 64x1024x256_w1x8") and "-DOCB=2" in p and "-DMINW=2" in p
     p = ex(_conv(256, 256, 6, 4096, 6))                           # AlexNet fc6: 256 tiles of 64 x 64 -> the fully-connected kernel (round 4): eight waves, three LDS stages
     assert p.startswith("bodahip_fc_f32 64x64x64_w2x4_m16_p2") and "-DTM=64" in p and "-DTN=64" in p
     p = ex(_conv(256, 4096, 1, 1000, 1))                          # AlexNet fc8: 64 tiles of 64 x 64 would starve the chip -> 256 tiles of 32 x 32
