@@ -51,7 +51,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define CHAIN 0
 #endif
 #ifndef ABLATE
-#define ABLATE 0 // experiment hook (BODAHIP_EXTRA_DEFS): 1 no stores | 2 no input loads | 4 no MFMAs
+#define ABLATE 0 // experiment hook (BODAHIP_EXTRA_DEFS): 1 no stores | 2 no input loads | 4 no MFMAs | 8 (CHAIN) nothing between the two convolutions
 #endif
 
 struct gemm_args_t { // same layout as gemm_conv_f32.hip (one host-side struct serves all fp32 kernels)
@@ -223,6 +223,7 @@ extern "C" __global__ __launch_bounds__(WJ * 64, MINW) void KNAME(gemm_args_t co
     }
 #if CHAIN
     // ---- first convolution's bias / ReLU in place; the intermediate rows leave only when somebody wants them
+#if !(ABLATE & 8)   // (8: measurement only -- no bias / ReLU / half exchange between the two convolutions)
     {
       int img; int const q = pel0(u, img);
       int const moff = (p.Dmid && (u < n_units)) ? (int)((((unsigned)img * (unsigned)MID + (hi ? 4u : 0u)) * (unsigned)HW + (unsigned)q) * 4u) : kOOB;
@@ -262,6 +263,7 @@ extern "C" __global__ __launch_bounds__(WJ * 64, MINW) void KNAME(gemm_args_t co
           unsigned const s0 = sw[0], s1 = sw[1];
           acc[rb][cb][2 * t] = __builtin_bit_cast(float, s0); acc[rb][cb][2 * t + 1] = __builtin_bit_cast(float, s1);
         }
+#endif
     // ---- second convolution: K step s2 = 16 rb + 4 g + j reads the (swapped) register 4g + {0, 2, 1, 3}[j] of row block rb
     int const ooff = out_off(u);
     float const *const a2_base = Fs2 + (hi ? kLD2 : 0) + (lane & 31);
@@ -292,6 +294,9 @@ extern "C" __global__ __launch_bounds__(WJ * 64, MINW) void KNAME(gemm_args_t co
 #if RELU2
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (v[i] > 0.f) ? v[i] : 0.f;
+#endif
+#if ABLATE & 1
+        if (v[0] == 123.456f)
 #endif
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rD, ooff, (int)((unsigned)rc * S4), 0);
         __builtin_amdgcn_sched_barrier(0);
