@@ -23,10 +23,14 @@ struct gemm_args_t { // must match kernels/gemm_conv_f32.hip
   int out_ctot, out_coff;
   void const *ktab; int ktab_n;
   long bsI, bsJ, bsD;
-  // kernels/k1_quad_f32.hip -DCHAIN=1 only (the other kernels declare the struct up to here): the second convolution of a 1x1 chain
+};
+// kernels/k1_quad_f32.hip -DCHAIN=1: gemm_args_t followed by the second convolution of a 1x1 chain.  (A struct of its own: gemm_args_t is also the element type of the member
+// tables of hip_conv_nhwc_set, whose device-side declaration must keep the size.)
+struct chain_args_t : gemm_args_t {
   float const *I2; float const *bias2; float *Dmid;
   int M2; unsigned I2_bytes, Dmid_bytes;
 };
+static_assert(sizeof(gemm_args_t) == 176, "gemm_args_t is declared with this size by every kernel source (and by set_kernel_source's text)");
 
 struct kernel_t { hipModule_t mod = nullptr; hipFunction_t func = nullptr; };
 
@@ -1219,7 +1223,7 @@ void native_kernels_t::conv_k1_chain(float const *filts, float const *biases, fl
   if (in_bytes >= 0x7ffffff0ull || mid_bytes >= 0x7ffffff0ull || out_bytes >= 0x7ffffff0ull) unsup_err("hip_conv_k1_chain: tensors of 2 GiB or more are not supported (32-bit buffer offsets)");
   kernel_t &k = get_kernel(impl, host, p);
   tile_cfg_t const &cfg = p.cfg;
-  gemm_args_t ga; memset(&ga, 0, sizeof(ga));
+  chain_args_t ga; memset((void *)&ga, 0, sizeof(ga));
   ga.I = filts; ga.J = in; ga.D = out; ga.bias = biases; ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = g.C; ga.ldI = g.C; ga.ldD = g.OH * g.OW;
   ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
   ga.I_bytes = (unsigned)((uint64_t)g.OC * g.C * 4); ga.J_bytes = (unsigned)in_bytes; ga.D_bytes = (unsigned)out_bytes; ga.out_ctot = out_ctot; ga.out_coff = out_coff;
