@@ -156,12 +156,15 @@ def test_gen_data_on_a_sharded_var_gives_the_global_pattern(multi):
         rtc.release_var("gin"); rtc.release_per_call_id_data()
 
 
-@pytest.mark.parametrize("net,batch,ndev", [("nin", 16, 4), ("alexnet", 5, 3)])
+@pytest.mark.parametrize("net,batch,ndev", [("nin", 16, 4), ("alexnet", 5, 3), ("nin-chain", 7, 3)])
 def test_full_net_forward_on_a_multi_device_backend_equals_single_device(single, net, batch, ndev):
     """BASELINE config 4 behind the boundary: the whole net through ConvPipeFwd on (be=hip,devices=0:0:..) -- inputs and weights generated on the
-    devices, hip_conv on every shard, the templated pool / LRN kernels over each shard's ids -- node for node bit-identical to one device."""
+    devices, hip_conv on every shard, the templated pool / LRN kernels over each shard's ids -- node for node bit-identical to one device.
+    nin-chain: with cccp1 -> cccp2 as one hip_conv_k1_chain call per shard (the size gate lifted), against the UNFUSED pass on one device."""
     from boda_amd import gen_data as gd
-    from boda_amd.conv_pipe import ConvPipeFwd, alexnet_ng_conv, nin_imagenet
+    from boda_amd.conv_pipe import ConvPipeFwd as _CPF, alexnet_ng_conv, nin_imagenet
+    chain = net == "nin-chain"; net = net.split("-")[0]
+    ConvPipeFwd = (lambda r: _CPF(r, fuse_k1_chains=("all" if (chain and r is not single) else False))) if chain else _CPF
     cp_of = {"nin": nin_imagenet, "alexnet": alexnet_ng_conv}[net]
     res = []
     for be in ("(be=hip,devices=" + ":".join(["0"] * ndev) + ")", None):
@@ -173,6 +176,9 @@ def test_full_net_forward_on_a_multi_device_backend_equals_single_device(single,
         try:
             rtc.run(gd.gen_call("Convolution", "in", fwd.in_var, cp.nodes["data"], 5, 0.0)); rtc.finish_and_sync()
             nodes = [nn for nn in cp.nodes if nn in {o.top for o in cp.ops if o.type != "Dropout"}]
+            if chain:
+                assert (fwd.k1_chains == [("cccp1", "cccp2")]) == (rtc is not single)
+                nodes = [nn for nn in nodes if nn != "cccp1"]     # (the fused pass does not write it)
             for c in fwd.fwd_calls:
                 c.call_id = rtc.run(c.rfc)
             rtc.finish_and_sync()
