@@ -55,6 +55,7 @@ python bench.py --workload alexnet --exact 0 --no-cpu-baseline > $O/bench_alexne
 python bench.py --workload nin-net --batch 128 --no-cpu-baseline > $O/bench_nin-net_b128.json 2>/dev/null
 python bench.py --workload nin-net --batch 128 --exact 0 --no-cpu-baseline > $O/bench_nin-net_b128_tolerance.json 2>/dev/null
 python bench.py --workload nin --batch 128 --no-cpu-baseline > $O/bench_nin_b128.json 2>/dev/null
+python bench.py --workload nin-net --batch 128 --graph --no-cpu-baseline > $O/bench_nin-net_b128_graph.json 2>/dev/null    # round 4c: config 4's leg of the default line (one hipGraph replay per forward pass)
 python bench.py --workload nin-net --batch 128 --no-fuse-k1-chains --no-cpu-baseline > $O/bench_nin-net_b128_nochain.json 2>/dev/null    # round 4c: cccp1 / cccp2 as two launches (default: one hip_conv_k1_chain call)
 find $O -name "*.db" -size +30M -delete   # keep the merge-back under the 64 MiB cap
 ls $O | head -80
