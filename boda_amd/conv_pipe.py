@@ -980,3 +980,4 @@ class ConvPipeFwd:
         for v in self._vars:
             rtc.release_var(v)
         self._funcs, self._vars, self.fwd_calls, self._grp_params, self.groups = [], [], [], [], []
+        self.k1_chains, self._lazy, self.fused_pools, self.fused_pool_lrn, self.level_sets = [], {}, {}, {}, []   # (a second init() starts from a clean slate)
