@@ -51,6 +51,9 @@ python bench.py --workload googlenet-net --dtype bf16 --layout nhwc --no-cpu-bas
 for w in googlenet-net alexnet-net; do python bench.py --workload $w --dtype bf16 --layout nhwc --no-cpu-baseline --graph --steps 20 --warmup 5 --no-fuse-pool-lrn > $O/bench_${w}_bf16_nhwc_graph_nopoollrnfusion.json 2>/dev/null; done   # round 4b: pooling + LRN as two passes
 python bench.py --workload googlenet-net --dtype bf16 --layout nhwc --no-cpu-baseline --graph --steps 20 --warmup 5 --no-groups-in-sets > $O/bench_googlenet-net_bf16_nhwc_graph_nogroupsinsets.json 2>/dev/null
 cd /tmp; rocprofv3 --kernel-trace --stats -d $O/stats_googlenet-net-bf16-nhwc -o p -- python $R/bench.py --workload googlenet-net --dtype bf16 --layout nhwc --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_googlenet-net.log 2>&1; cd $R
+# round 4c: the fp32 NiN net at config 4's per-GPU batch (hip_conv_k1_chain inside): kernel trace, and the SQ counters per kernel
+cd /tmp; rocprofv3 --kernel-trace --stats -d $O/stats_nin-net-b128 -o p -- python $R/bench.py --workload nin-net --batch 128 --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_nin-net.log 2>&1
+rocprofv3 --kernel-trace --pmc $SQ -d $O/sq_nin-net-b128 -o p -- python $R/bench.py --workload nin-net --batch 128 --steps 1 --warmup 0 --settle-ms 0 --no-cpu-baseline > $O/sq_nin-net.log 2>&1; cd $R
 python bench.py --workload alexnet --exact 0 --no-cpu-baseline > $O/bench_alexnet_tolerance.json 2>/dev/null
 python bench.py --workload nin-net --batch 128 --no-cpu-baseline > $O/bench_nin-net_b128.json 2>/dev/null
 python bench.py --workload nin-net --batch 128 --exact 0 --no-cpu-baseline > $O/bench_nin-net_b128_tolerance.json 2>/dev/null

@@ -61,6 +61,26 @@ for w, (cmdargs, kern) in WORK.items():
             f.write(line + "\n")
         f.write(f"# total per step: fetch {tot_f/1e9:.3f} GB (corrected), write {tot_w/1e9:.3f} GB\n")
     res[w] = {"hbm_bytes_per_step": int(tot_f + tot_w), "fetch_bytes_corrected": int(tot_f), "write_bytes": int(tot_w), "kernel_src_hash": khash, "file": f"{tag}_{w}_pmc.txt"}
+# whole-net runs: kernel trace (and, where collected, the SQ counters per kernel name) -- no HBM-byte entry in pmc_summary.json
+NETS = {"googlenet-net-bf16-nhwc": "--workload googlenet-net --dtype bf16 --layout nhwc", "nin-net-b128": "--workload nin-net --batch 128"}
+for w, cmdargs in NETS.items():
+    sdb = os.path.join(src, f"stats_{w}", "p_results.db")
+    if os.path.exists(sdb):
+        with open(os.path.join(out, f"{tag}_{w}_kernel_stats.txt"), "w") as f:
+            f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py {cmdargs} --steps 5 --warmup 2 --no-cpu-baseline\n")
+            f.write(subprocess.check_output([sys.executable, summ, sdb, "--by-grid"], text=True))
+    qdb = os.path.join(src, f"sq_{w}", "p_results.db")
+    if os.path.exists(qdb):
+        per = {}
+        for kn, cn, v, dur, nn in q(qdb, "select kernel_name, counter_name, sum(value), sum(end-start), count(*) from counters_collection group by kernel_name, counter_name"):
+            per.setdefault(kn, {})[cn] = v; per[kn]["_dur_ns"] = dur; per[kn]["_n"] = nn
+        with open(os.path.join(out, f"{tag}_{w}_pmc.txt"), "w") as f:
+            f.write(f"# rocprofv3 --kernel-trace --pmc <SQ set> -- python bench.py {cmdargs} --steps 1 --warmup 0 --settle-ms 0; kernel sources {khash}\n")
+            f.write("# kernel  launches  avg_us(under the counters)  | mfma_busy% against the kernel's own duration at the nominal 2.4 GHz (a lower bound)  wave_cycles: wait_inst% wait_any% active%\n")
+            for kn in sorted(per, key=lambda k: -per[k]["_dur_ns"]):
+                s_ = per[kn]; wc = s_.get("SQ_WAVE_CYCLES", 0) or 1
+                f.write(f"{kn[:48]:48s} {s_['_n']:5d} {s_['_dur_ns']/s_['_n']/1e3:9.1f}  | {100*s_.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/1024/(s_['_dur_ns']*2.4):6.1f}  "
+                        f"{100*s_.get('SQ_WAIT_INST_ANY',0)/wc:6.1f} {100*s_.get('SQ_WAIT_ANY',0)/wc:6.1f} {100*s_.get('SQ_ACTIVE_INST_ANY',0)/wc:6.1f}\n")
 import glob, shutil
 for fn in glob.glob(os.path.join(src, "bench_*.json")):   # the bench lines of the same box
     if os.path.getsize(fn) > 10:
