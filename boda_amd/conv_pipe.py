@@ -405,7 +405,7 @@ class ConvPipeFwd:
     mode = "rtc"
 
     def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False, fuse_siblings: bool = True, fuse_levels: bool = True, fuse_pools: bool = True, sets_take_groups: bool = True,
-                 spec_fwd: bool = True, fuse_pool_lrn: bool = True, fuse_k1_chains: bool = True):
+                 spec_fwd: bool = True, fuse_pool_lrn="pool_first", fuse_k1_chains: bool = True):
         self.rtc, self.op_tune = rtc, op_tune or OpTune()
         # fp32 nets: a 1x1 convolution whose output is read by ONE other 1x1 convolution only (NiN's cccp1 -> cccp2) runs with it as one hip_conv_k1_chain launch: the
         # intermediate tensor stays in the accumulator registers (kernels/k1_quad_f32.hip -DCHAIN=1), its write + read are gone.  Bit-identical; the first
@@ -426,6 +426,9 @@ class ConvPipeFwd:
         self.fused_pools: Dict[str, str] = {}  # pooling tag -> the convolution that took it
         # channels-last nets: a max pooling and an across-channel LRN that follow each other (either order, the first one's output read by nothing else) run as ONE pass
         # over the tensor (nhwc.POOL_LRN_SPEC_SRC): each of them runs at the HBM roof by itself, the fused call saves the intermediate's write + read.  Bit-identical.
+        # "pool_first" (default since round 4c): only Pooling -> LRN pairs -- a pure saving of the intermediate's write + read; True: LRN -> Pooling pairs too (their fused kernel evaluates the
+        # LRN once per window position and is compute-bound: whether it still pays differs BY BOX -- same-box A/Bs on four MI355X boxes, AlexNet-net at 256 images with / without its two
+        # LRN-first pairs fused: 309 / 325 k img/s, 328 / 319 k, 338 / 324 k, 296 / 311 k, 310 / 322 k; GoogLeNet-net 83.3 / 84.0, 82.9 / 81.4, 85.8 / 82.8, 81.0 / 81.6, 83.1 / 83.5 k); False: none
         self.fuse_pool_lrn = fuse_pool_lrn
         self.fused_pool_lrn: Dict[str, Tuple[str, bool]] = {}   # tag of the FIRST op of a pair -> (tag of the second, lrn_first)
         self._lazy: Dict[str, FwdCall] = {}    # nodes no call of the forward pass writes any more (a fused pooling's output): the call that materialises one when it is asked for
@@ -574,6 +577,8 @@ class ConvPipeFwd:
                 if b.in_place or b.tag in self.fused_pools or {a.type, b.type} != {"Pooling", "LRN"}:
                     continue
                 pool, lrn = (a, b) if a.type == "Pooling" else (b, a)
+                if a.type == "LRN" and self.fuse_pool_lrn == "pool_first":     # (LRN first: the fused kernel evaluates the LRN per window position -- compute-bound, level with or behind the two kernels)
+                    continue
                 if pool.bot != cp.in_node and _nhwc.pool_lrn_fusable(_nhwc.nhwc_dims(cp.nodes[pool.bot]), _nhwc.nhwc_dims(cp.nodes[pool.top]), pool.kern_sz, pool.stride, pool.in_pad, int(pool.avg_pool), lrn.lrn[0], lrn.lrn[1], lrn.lrn[3]):
                     self.fused_pool_lrn[a.tag] = (b.tag, a.type == "LRN"); pl_second[b.tag] = a.tag
         # sibling convolutions (channels-last nets): same bottom node, same kernel / stride / padding / fused ReLU, plain hip_conv_nhwc members
