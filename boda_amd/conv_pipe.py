@@ -431,6 +431,7 @@ class ConvPipeFwd:
         # LRN-first pairs fused: 309 / 325 k img/s, 328 / 319 k, 338 / 324 k, 296 / 311 k, 310 / 322 k; GoogLeNet-net 83.3 / 84.0, 82.9 / 81.4, 85.8 / 82.8, 81.0 / 81.6, 83.1 / 83.5 k); False: none
         self.fuse_pool_lrn = fuse_pool_lrn
         self.fused_pool_lrn: Dict[str, Tuple[str, bool]] = {}   # tag of the FIRST op of a pair -> (tag of the second, lrn_first)
+        self.lds_pool_lrn = set()    # tags of the first op (an LRN) of the pairs that run through the LDS kernel (nhwc.LRN_POOL_LDS_SRC)
         self._lazy: Dict[str, FwdCall] = {}    # nodes no call of the forward pass writes any more (a fused pooling's output): the call that materialises one when it is asked for
         self.groups: List[Tuple[str, ...]] = []      # tags of the members of each fused call
         self.per_call_fn, self.enable_double_run = per_call_fn, enable_double_run
@@ -576,11 +577,17 @@ class ConvPipeFwd:
                 b = rd[0]
                 if b.in_place or b.tag in self.fused_pools or {a.type, b.type} != {"Pooling", "LRN"}:
                     continue
-                pool, lrn = (a, b) if a.type == "Pooling" else (b, a)
-                if a.type == "LRN" and self.fuse_pool_lrn == "pool_first":     # (LRN first: the fused kernel evaluates the LRN per window position -- compute-bound, level with or behind the two kernels)
-                    continue
+                pool, lrn = (a, b) if a.type == "Pooling" else (b, a); lds_pair = False
+                if a.type == "LRN" and self.fuse_pool_lrn == "pool_first":     # LRN first: through LDS (the LRN evaluated once per input chunk) where that kernel applies; the thread-per-
+                    # output kernel evaluates it per window position -- compute-bound, level with or behind the two kernels -- and is only taken on request (fuse_pool_lrn=True)
+                    single = (getattr(rtc, "num_devices", None) is None) or ((rtc.num_devices() or 1) == 1)      # (a workgroup kernel: the multi-device backend shards per-element functions only)
+                    if not (single and os.environ.get("BODAHIP_NO_LRN_POOL_LDS") is None and _nhwc.lrn_pool_lds_rows(_nhwc.nhwc_dims(cp.nodes[lrn.bot]), _nhwc.nhwc_dims(cp.nodes[pool.top]), pool.kern_sz, pool.stride)):
+                        continue
+                    lds_pair = True
                 if pool.bot != cp.in_node and _nhwc.pool_lrn_fusable(_nhwc.nhwc_dims(cp.nodes[pool.bot]), _nhwc.nhwc_dims(cp.nodes[pool.top]), pool.kern_sz, pool.stride, pool.in_pad, int(pool.avg_pool), lrn.lrn[0], lrn.lrn[1], lrn.lrn[3]):
                     self.fused_pool_lrn[a.tag] = (b.tag, a.type == "LRN"); pl_second[b.tag] = a.tag
+                    if lds_pair:
+                        self.lds_pool_lrn.add(a.tag)
         # sibling convolutions (channels-last nets): same bottom node, same kernel / stride / padding / fused ReLU, plain hip_conv_nhwc members
         group_of: Dict[str, List[PipeOp]] = {}     # tag of a member -> its group (list of ops, definition order)
         if self.nhwc and self.fuse_siblings:
@@ -688,6 +695,10 @@ class ConvPipeFwd:
                     self._lazy[op.top] = FwdCall(op.tag, _nhwc.lrn_call(vn(op.bot), op.top, vd(op.bot), *op.lrn, rtc=rtc), "nhwc_lrn")
             elif self.nhwc and op.tag in pl_second:                 # second op of the pair: ONE call from the first op's input to this op's output
                 first = next(o for o in cp.ops if o.tag == pl_second[op.tag]); pool, lrn = (first, op) if first.type == "Pooling" else (op, first)
+                if first.tag in self.lds_pool_lrn:
+                    self.fwd_calls.append(FwdCall(first.tag + "+" + op.tag, _nhwc.lrn_pool_lds_call(vn(first.bot), op.top, vd(first.bot), vd(op.top), pool.kern_sz, pool.stride, pool.in_pad,
+                                                                                                   *lrn.lrn, rtc=rtc), "nhwc_lrn_pool_lds"))
+                    continue
                 self.fwd_calls.append(FwdCall(first.tag + "+" + op.tag, _nhwc.pool_lrn_call(vn(first.bot), op.top, vd(first.bot), vd(op.top), pool.kern_sz, pool.stride, pool.in_pad,
                                                                                        *lrn.lrn, lrn_first=(first.type == "LRN"), rtc=rtc), "nhwc_pool_lrn"))
             elif self.nhwc and op.type == "Pooling" and op.tag in self.fused_pools:     # taken into its convolution: only materialised when somebody asks for the node
@@ -985,4 +996,4 @@ class ConvPipeFwd:
         for v in self._vars:
             rtc.release_var(v)
         self._funcs, self._vars, self.fwd_calls, self._grp_params, self.groups = [], [], [], [], []
-        self.k1_chains, self._lazy, self.fused_pools, self.fused_pool_lrn, self.level_sets = [], {}, {}, {}, []   # (a second init() starts from a clean slate)
+        self.k1_chains, self._lazy, self.fused_pools, self.fused_pool_lrn, self.level_sets, self.lds_pool_lrn = [], {}, {}, {}, [], set()   # (a second init() starts from a clean slate)

@@ -717,6 +717,113 @@ CUCL_GLOBAL_KERNEL __launch_bounds__(256) void @NAME@( GASQ bf16x8_t const * con
 """
 
 
+# LRN -> max pooling through LDS (round 4c): the thread-per-output kernel above evaluates the LRN once per WINDOW POSITION (3x3 / stride 2, four outputs per thread: 6.75
+# evaluations per output where the LRN kernel does 4) and is compute-bound behind v_log_f32 / v_exp_f32.  Here a workgroup owns TY output rows of one image: it normalises
+# the (TY - 1) SY + KH input rows they need ONCE into LDS -- the LRN kernel's own code, chunk by chunk, halo squares from the neighbouring lanes -- and pools from LDS.
+# 1 + (KH - SY) / (TY SY) of the LRN kernel's arithmetic (1.5 for the TY = 1 the planner takes: see lrn_pool_lds_rows), one read of the input, one write of the pooled output.  Same expressions, same order, same
+# bf16 rounding between the two ops as the two kernels run apart: bit-identical.  A workgroup kernel: single-device backends only (the multi-device backend shards
+# per-element functions), ConvPipeFwd keeps the pair apart elsewhere.
+LRN_POOL_LDS_SRC = """
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+CUCL_GLOBAL_KERNEL __launch_bounds__(@TPB@) void @NAME@( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n, float const alpha, float const beta, float const k ) {
+  LOCSHAR_MEM bf16x8_t lds[@NROWS@*@W@*@C8@];
+  uint32_t const blk = GRP_ID_1D, tid = LOC_ID_1D;
+  if( blk*@TPB@u >= n ) { return; }
+  uint32_t const img = blk / @RG@u, rg = blk % @RG@u, oy0 = rg*@TY@u;
+  int32_t const oy_end = ( oy0 + @TY@u < @OH@u ) ? (int32_t)oy0 + @TY@ : @OH@;      // (exclusive)
+  int32_t const y_lo0 = (int32_t)( oy0*@SY@u ) - @PY@, y_lo = ( y_lo0 < 0 ) ? 0 : y_lo0;
+  int32_t const y_hi0 = ( oy_end - 1 )*@SY@ - @PY@ + @KH@, y_hi = ( y_hi0 > @H@ ) ? @H@ : y_hi0;
+  uint32_t const nch = (uint32_t)( y_hi - y_lo )*( @W@u*@C8@u );                    // chunks to normalise: whole input rows y_lo .. y_hi - 1, contiguous in memory
+  GASQ bf16x8_t const * const src = in + ( (size_t)img*@H@u + (uint32_t)y_lo )*( @W@u*@C8@u );
+  float const per_elem = alpha / @LOCAL_SIZE@.0f;
+  int32_t const lane = tid & 63;
+  for( uint32_t i0 = 0; i0 < nch; i0 += @TPB@u ) {      // (uniform trip count: every lane of a wave takes part in the shuffles; i0 and TPB are multiples of 64: lane <-> chunk as in the LRN kernel)
+    uint32_t const i = i0 + tid;
+    bool const live = i < nch;
+    int32_t const q = live ? (int32_t)( i % @C8@u ) : 0;
+    float v[8], sq[8 + 2*@HALF@];
+    bf16x8_t const mid = live ? src[i] : (bf16x8_t)0;
+    for( int32_t e = 0; e != 8; ++e ) { v[e] = (float)mid[e]; sq[@HALF@ + e] = v[e]*v[e]; }
+    for( int32_t e = 0; e != @HALF@; ++e ) {
+      sq[e] = __shfl_up( sq[@HALF@ + 8 - @HALF@ + e], 1, 64 );
+      sq[@HALF@ + 8 + e] = __shfl_down( sq[@HALF@ + e], 1, 64 );
+    }
+    bool const has_lo = q > 0, has_hi = q + 1 < @C8@;
+    if( has_lo && live && lane == 0 ) { bf16x8_t const lo = src[i - 1]; for( int32_t e = 0; e != @HALF@; ++e ) { float const f = (float)lo[8 - @HALF@ + e]; sq[e] = f*f; } }
+    if( has_hi && live && ( lane == 63 || i + 1 >= nch ) ) { bf16x8_t const hi = src[i + 1]; for( int32_t e = 0; e != @HALF@; ++e ) { float const f = (float)hi[e]; sq[@HALF@ + 8 + e] = f*f; } }
+    if( !has_lo ) { for( int32_t e = 0; e != @HALF@; ++e ) { sq[e] = 0.0f; } }
+    if( !has_hi ) { for( int32_t e = 0; e != @HALF@; ++e ) { sq[@HALF@ + 8 + e] = 0.0f; } }
+    if( live ) {
+      bf16x8_t r;
+      for( int32_t e = 0; e != 8; ++e ) {
+        float sumsq = 0.0f;
+        for( int32_t d = 0; d != 2*@HALF@ + 1; ++d ) { sumsq += sq[e + d]; }        // ascending channel order, as the LRN kernels
+        r[e] = (__bf16)( v[e] * __builtin_amdgcn_exp2f( -beta * __builtin_amdgcn_logf( k + sumsq * per_elem ) ) );
+      }
+      lds[i] = r;
+    }
+  }
+  BARRIER_SYNC;
+  uint32_t const nout = (uint32_t)( oy_end - (int32_t)oy0 )*( @OW@u*@C8@u );
+  for( uint32_t o = tid; o < nout; o += @TPB@u ) {
+    uint32_t const c = o % @C8@u, p = o / @C8@u, ox = p % @OW@u, oy = oy0 + p / @OW@u;
+    int32_t const y0 = (int32_t)( oy*@SY@u ) - @PY@, x0 = (int32_t)( ox*@SX@u ) - @PX@;
+    int32_t const ya = ( y0 < 0 ) ? 0 : y0, yb = ( y0 + @KH@ > @H@ ) ? @H@ : y0 + @KH@, xa = ( x0 < 0 ) ? 0 : x0, xb = ( x0 + @KW@ > @W@ ) ? @W@ : x0 + @KW@;
+    float acc[8];
+    for( int32_t e = 0; e != 8; ++e ) { acc[e] = -FLT_MAX; }
+#pragma unroll
+    for( int32_t ky = 0; ky != @KH@; ++ky ) {
+#pragma unroll
+      for( int32_t kx = 0; kx != @KW@; ++kx ) {      // window positions outside the plane are clamped onto it (a maximum: duplicates are harmless)
+        int32_t const y = y0 + ky, x = x0 + kx;
+        int32_t const yc = ( y < ya ) ? ya : ( ( y >= yb ) ? yb - 1 : y ), xc = ( x < xa ) ? xa : ( ( x >= xb ) ? xb - 1 : x );
+        bf16x8_t const w = lds[( ( yc - y_lo )*@W@ + xc )*@C8@ + c];
+        for( int32_t e = 0; e != 8; ++e ) { float const f = (float)w[e]; acc[e] = ( f > acc[e] ) ? f : acc[e]; }
+      }
+    }
+    bf16x8_t r;
+    for( int32_t e = 0; e != 8; ++e ) { r[e] = (__bf16)acc[e]; }
+    out[( ( img*@OH@u + oy )*@OW@u + ox )*@C8@u + c] = r;
+  }
+}
+"""
+_LRN_POOL_LDS_MAX = 112 * 1024     # bytes of LDS a workgroup may take (one workgroup of 1024 threads per CU)
+
+
+def lrn_pool_lds_rows(i: Dims, o: Dims, kern, stride) -> int:
+    """Output rows per workgroup (TY) of the LDS form of LRN -> Pooling: the largest of 4 / 2 / 1 whose normalised input rows fit the LDS budget; 0: none fits."""
+    W, c8, OH = i.dsz("x"), i.dsz("chan") // 8, o.dsz("y")
+    import os
+    lim = int(os.environ.get("BODAHIP_LRN_POOL_LDS_MAX", _LRN_POOL_LDS_MAX))      # (experiments: a smaller budget gives fewer rows per workgroup, more workgroups per CU)
+    # measured (MI355X, bench.py *-net at 64 / 256 images, us for the pair; apart: LRN + pooling kernels): GoogLeNet norm2 -> pool2 (56 x 56 x 192) apart 52 | TY 1 / 2: 41 / 50;
+    # AlexNet norm1 -> pool1 (55 x 55 x 96) apart 96 | TY 1 / 2 / 4: 69 / 73 / 84; norm2 -> pool2 (27 x 27 x 256) apart 57 | 39 / 47 / 51 -- one output row per workgroup: more, smaller
+    # workgroups per CU overlap each other's load, LRN and pooling phases, which is worth more than the rows a taller tile would not normalise twice
+    forced = int(os.environ.get("BODAHIP_LRN_POOL_TY", "0"))
+    for ty in ((forced,) if forced else (1,)):
+        if ty <= max(1, OH) and ((ty - 1) * stride[0] + kern[0]) * W * c8 * 16 <= lim:
+            return ty
+    return 0
+
+
+def lrn_pool_lds_call(in_vn: str, out_vn: str, i: Dims, o: Dims, kern, stride, pad, local_size: int, alpha: float, beta: float, k: float, rtc) -> RtcFuncCall:
+    """LRN -> Pooling(max) through LDS (LRN_POOL_LDS_SRC).  i: the LRN's input dims, o: the pooling's output dims (channels-last)."""
+    c8 = i.dsz("chan") // 8
+    H, W, OH, OW = i.dsz("y"), i.dsz("x"), o.dsz("y"), o.dsz("x")
+    ty = lrn_pool_lds_rows(i, o, kern, stride)
+    if not ty:
+        raise UnsupErr("channels-last LRN -> Pooling through LDS: the input rows of one output row do not fit the LDS")
+    import os
+    nrows, rg = (ty - 1) * stride[0] + kern[0], (OH + ty - 1) // ty
+    tpb = 1024 if nrows * W * c8 >= 3072 else 512      # (threads per workgroup by the chunks it normalises: GoogLeNet norm2 4032 chunks 41 us on 1024 threads, 50 on 512; AlexNet norm1 1980 chunks 76 / 69)
+    if os.environ.get("BODAHIP_LRN_POOL_TPB"):
+        tpb = int(os.environ["BODAHIP_LRN_POOL_TPB"])
+    blks = o.dsz("img") * rg
+    name = f"nhwc_lrn_pool_lds_c{c8}_{H}x{W}_{OH}x{OW}_k{kern[0]}x{kern[1]}_s{stride[0]}x{stride[1]}_p{pad[0]}x{pad[1]}_n{local_size}_y{ty}_t{tpb}"
+    _spec_compile(rtc, name, LRN_POOL_LDS_SRC, {"C8": c8, "H": H, "W": W, "OH": OH, "OW": OW, "KH": kern[0], "KW": kern[1], "SY": stride[0], "SX": stride[1], "PY": pad[0], "PX": pad[1],
+                                                 "TY": ty, "NROWS": nrows, "RG": rg, "TPB": tpb, "HALF": local_size // 2, "LOCAL_SIZE": local_size}, ["in", "out", "n", "alpha", "beta", "k"])
+    return RtcFuncCall(name, {"in": RtcArg.var(in_vn), "out": RtcArg.var(out_vn), "n": _u32(blks * tpb), "alpha": _f32(alpha), "beta": _f32(beta), "k": _f32(k)}, tpb=tpb, blks=blks)
+
+
 def pool_lrn_fusable(i: Dims, o: Dims, kern, stride, pad, avg: int, local_size: int, alpha: float, k: float) -> bool:
     """Can a max pooling (input dims i, output dims o, channels-last) and an across-channel LRN run as one kernel?  The conditions of the two specialised kernels."""
     H, W, OH, OW = i.dsz("y"), i.dsz("x"), o.dsz("y"), o.dsz("x")

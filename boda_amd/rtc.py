@@ -205,6 +205,12 @@ class HipCompute:
         _chk(_lib.bodahip_get_plat_tag(self._ctx, buf, 512))
         return buf.value.decode()
 
+    def num_devices(self) -> int:
+        """Devices behind this backend (1 for `(be=hip)` / `(be=cpu)`, N for `(be=hip,devices=...)`)."""
+        n = C.c_uint32(0)
+        _chk(_lib.bodahip_num_devices(self._ctx, C.byref(n)))
+        return int(n.value)
+
     def create_var_with_dims(self, vn: str, dims: Dims) -> None:
         cd, ka = _cdims(dims)
         _chk(_lib.bodahip_create_var(self._ctx, vn.encode(), C.byref(cd)))

@@ -585,7 +585,7 @@ def test_pool_and_lrn_next_to_each_other_run_as_one_kernel_bit_identical(rtc):
         data = bo.gen_conv_in(*cp.nodes["data"].sizes)
         nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
         res = []
-        for fuse in (True, False):
+        for fuse in (True, False, "pool_first"):     # True: every pair on the thread-per-output kernel; "pool_first" (the default): LRN -> Pooling pairs through LDS (nhwc.LRN_POOL_LDS_SRC)
             fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc"), fuse_pool_lrn=fuse)
             fwd.init(cp, op_params=params)
             try:
@@ -595,7 +595,9 @@ def test_pool_and_lrn_next_to_each_other_run_as_one_kernel_bit_identical(rtc):
                 if fuse:
                     assert fwd.fused_pool_lrn == want, fwd.fused_pool_lrn
                     assert not any(c.tag in want or c.tag in {v[0] for v in want.values()} for c in fwd.fwd_calls)     # both ops of a pair are gone from the pass ...
-                    assert sum(c.func == "nhwc_pool_lrn" for c in fwd.fwd_calls) == len(want)                            # ... one call each stands for them
+                    n_lds = sum(1 for v in want.values() if v[1]) if fuse == "pool_first" else 0
+                    assert fwd.lds_pool_lrn == ({t for t, v in want.items() if v[1]} if fuse == "pool_first" else set())
+                    assert sum(c.func == "nhwc_pool_lrn" for c in fwd.fwd_calls) == len(want) - n_lds and sum(c.func == "nhwc_lrn_pool_lds" for c in fwd.fwd_calls) == n_lds   # ... one call each stands for them
                     fwd.capture_graph(); out = cp.out_node()
                     rtc.set_var_to_zero(fwd.var_of(out)); fwd.run_graph()
                     assert np.array_equal(fwd._fetch(out), io[out])
@@ -605,6 +607,7 @@ def test_pool_and_lrn_next_to_each_other_run_as_one_kernel_bit_identical(rtc):
                 fwd.release()
         for n in nodes:
             assert np.array_equal(res[0][n], res[1][n]), (cp.name, n, int((res[0][n] != res[1][n]).sum()))
+            assert np.array_equal(res[2][n], res[1][n]), (cp.name, "lds", n, int((res[2][n] != res[1][n]).sum()))
 
 
 def test_channels_last_pool_lrn_specialised_kernels(rtc):
