@@ -50,6 +50,7 @@ done
 python bench.py --workload googlenet-net --dtype bf16 --layout nhwc --no-cpu-baseline --graph --steps 20 --warmup 5 --no-fuse-pools > $O/bench_googlenet-net_bf16_nhwc_graph_nopoolfusion.json 2>/dev/null
 for w in googlenet-net alexnet-net; do python bench.py --workload $w --dtype bf16 --layout nhwc --no-cpu-baseline --graph --steps 20 --warmup 5 --no-fuse-pool-lrn > $O/bench_${w}_bf16_nhwc_graph_nopoollrnfusion.json 2>/dev/null; done   # round 4b: pooling + LRN as two passes
 for w in googlenet-net alexnet-net; do BENCH_FUSE_POOL_LRN=all python bench.py --workload $w --dtype bf16 --layout nhwc --no-cpu-baseline --graph --steps 20 --warmup 5 > $O/bench_${w}_bf16_nhwc_graph_lrnfirstfused.json 2>/dev/null; done   # round 4c: LRN -> Pooling pairs fused too (the default fuses Pooling -> LRN pairs only)
+for w in googlenet-net alexnet-net; do BODAHIP_NO_LRN_POOL_LDS=1 python bench.py --workload $w --dtype bf16 --layout nhwc --no-cpu-baseline --graph --steps 20 --warmup 5 > $O/bench_${w}_bf16_nhwc_graph_nolrnpoollds.json 2>/dev/null; done   # round 4c: LRN -> Pooling pairs apart (default: through LDS)
 python bench.py --workload googlenet-net --dtype bf16 --layout nhwc --no-cpu-baseline --graph --steps 20 --warmup 5 --no-groups-in-sets > $O/bench_googlenet-net_bf16_nhwc_graph_nogroupsinsets.json 2>/dev/null
 cd /tmp; rocprofv3 --kernel-trace --stats -d $O/stats_googlenet-net-bf16-nhwc -o p -- python $R/bench.py --workload googlenet-net --dtype bf16 --layout nhwc --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_googlenet-net.log 2>&1; cd $R
 # round 4c: the fp32 NiN net at config 4's per-GPU batch (hip_conv_k1_chain inside): kernel trace, and the SQ counters per kernel
