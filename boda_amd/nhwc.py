@@ -16,6 +16,7 @@ func_name `hip_conv_nhwc` (kernels/conv_nhwc_bf16.hip); the layout passes below 
 generic hiprtc path like the reference's own `xpose_*` kernels.
 """
 from __future__ import annotations
+import os
 from typing import Dict, List, Tuple
 
 from .op import Dims, Nda, Op, UnsupErr
@@ -793,7 +794,6 @@ _LRN_POOL_LDS_MAX = 112 * 1024     # bytes of LDS a workgroup may take (one work
 def lrn_pool_lds_rows(i: Dims, o: Dims, kern, stride) -> int:
     """Output rows per workgroup (TY) of the LDS form of LRN -> Pooling: the largest of 4 / 2 / 1 whose normalised input rows fit the LDS budget; 0: none fits."""
     W, c8, OH = i.dsz("x"), i.dsz("chan") // 8, o.dsz("y")
-    import os
     lim = int(os.environ.get("BODAHIP_LRN_POOL_LDS_MAX", _LRN_POOL_LDS_MAX))      # (experiments: a smaller budget gives fewer rows per workgroup, more workgroups per CU)
     # measured (MI355X, bench.py *-net at 64 / 256 images, us for the pair; apart: LRN + pooling kernels): GoogLeNet norm2 -> pool2 (56 x 56 x 192) apart 52 | TY 1 / 2: 41 / 50;
     # AlexNet norm1 -> pool1 (55 x 55 x 96) apart 96 | TY 1 / 2 / 4: 69 / 73 / 84; norm2 -> pool2 (27 x 27 x 256) apart 57 | 39 / 47 / 51 -- one output row per workgroup: more, smaller
@@ -812,7 +812,6 @@ def lrn_pool_lds_call(in_vn: str, out_vn: str, i: Dims, o: Dims, kern, stride, p
     ty = lrn_pool_lds_rows(i, o, kern, stride)
     if not ty:
         raise UnsupErr("channels-last LRN -> Pooling through LDS: the input rows of one output row do not fit the LDS")
-    import os
     nrows, rg = (ty - 1) * stride[0] + kern[0], (OH + ty - 1) // ty
     tpb = 1024 if nrows * W * c8 >= 3072 else 512      # (threads per workgroup by the chunks it normalises: GoogLeNet norm2 4032 chunks 41 us on 1024 threads, 50 on 512; AlexNet norm1 1980 chunks 76 / 69)
     if os.environ.get("BODAHIP_LRN_POOL_TPB"):
