@@ -453,6 +453,11 @@ class ConvPipeFwd:
     def init(self, cp: ConvPipe, op_params: Optional[Dict[str, np.ndarray]] = None, gen_mode: int = 5) -> None:
         rtc = self.rtc
         self.cp = cp
+        try:    # the device's CU count for the planner questions asked below (a recording backend has none: the MI355X's 256)
+            info = rtc.get_device_info()
+            self._num_cus = int(info["num_cus"]) if isinstance(info, dict) and info.get("num_cus") else 256
+        except Exception:
+            self._num_cus = 256
         if not getattr(rtc, "_gen_data_compiled", False):
             rtc.compile(gd.func_infos()); rtc._gen_data_compiled = True
         if not getattr(rtc, "_fwd_funcs_compiled", False):
@@ -538,16 +543,25 @@ class ConvPipeFwd:
         # right exactly for values >= 0).  Non-negative nodes: outputs of a conv with fused ReLU / a ReLU / a pooling, LRN or Dropout of such / a Concat of such.
         conv_in: Dict[str, str] = {}    # convolution tag -> the node it reads instead of its bottom
         if self.nhwc and self.fuse_pools:
-            nonneg = set()
+            # decided IN OP ORDER: a pooling is fusable when its input is non-negative at the pooling's own position (a node rectified by a LATER in-place ReLU does not
+            # count), and every writer redefines its top's state (a convolution without ReLU makes it unknown again)
+            state: Dict[str, bool] = {}
+            pool_in_nonneg = set()      # tags of poolings whose input was non-negative when they read it
             for o in cp.ops:
+                if o.type == "Pooling" and state.get(o.bot, False):
+                    pool_in_nonneg.add(o.tag)
                 if (o.type == "Convolution" and has_relu[o.tag]) or o.type == "ReLU":
-                    nonneg.add(o.top)
-                elif o.type in ("Pooling", "Dropout") and o.bot in nonneg:
-                    nonneg.add(o.top)
-                elif o.type == "LRN" and o.bot in nonneg and o.lrn[3] > 0 and o.lrn[1] >= 0:
-                    nonneg.add(o.top)
-                elif o.type == "Concat" and all(b in nonneg for b in o.bots):
-                    nonneg.add(o.top)
+                    nn = True
+                elif o.type in ("Pooling", "Dropout"):
+                    nn = state.get(o.bot, False)
+                elif o.type == "LRN":
+                    nn = state.get(o.bot, False) and o.lrn[3] > 0 and o.lrn[1] >= 0
+                elif o.type == "Concat":
+                    nn = all(state.get(b, False) for b in o.bots)
+                else:
+                    nn = False
+                state[o.top] = nn
+            op_index = {o.tag: i for i, o in enumerate(cp.ops)}
             n_readers: Dict[str, List[PipeOp]] = {}
             for o in cp.ops:
                 if o.tag not in fused:
@@ -555,9 +569,12 @@ class ConvPipeFwd:
                         n_readers.setdefault(b, []).append(o)
             for o in cp.ops:
                 rd = n_readers.get(o.top, [])
-                if not (o.type == "Pooling" and not o.in_place and o.bot in nonneg and len(rd) == 1 and rd[0].type == "Convolution" and _nhwc.multi_eligible(annos[rd[0].tag])):
+                if not (o.type == "Pooling" and not o.in_place and o.tag in pool_in_nonneg and len(rd) == 1 and rd[0].type == "Convolution" and _nhwc.multi_eligible(annos[rd[0].tag])):
                     continue
                 q = rd[0]; pin = cp.nodes[o.bot]
+                # the fused kernel reads the pooling's input at the CONVOLUTION's position: nobody may rewrite it in between
+                if any(w.top == o.bot and w.tag not in fused for w in cp.ops[op_index[o.tag] + 1:op_index[q.tag]]):
+                    continue
                 if pin.dsz("chan") % 8 or not _nhwc.pool_fusable(cp.conv_op(q).conv_geom(), (pin.dsz("y"), pin.dsz("x")), o.kern_sz, o.stride, o.in_pad, bool(o.avg_pool)):
                     continue
                 _nhwc.fuse_pool(annos[q.tag], pin, tuple(o.kern_sz), tuple(o.in_pad))
@@ -812,13 +829,15 @@ class ConvPipeFwd:
         flops_of = {o.tag: cp.conv_op(o).flops() for o in cp.ops if o.type == "Convolution"}
         for l in sorted(by_level):
             idxs = by_level[l]
-            def joins(i: int) -> bool:   # a plain convolution whose own plan does not slice K (a sliced member would run unsliced in a set and set its pace:
-                c = self.fwd_calls[i]    # GoogLeNet's 4x4 auxiliary-head conv, K = 2048 on 8 tiles, 12 us sliced on its own against 44 us as a member)
+            def joins(i: int) -> bool:   # a plain convolution (round 4: one whose own plan does not slice K -- unsliced in a set GoogLeNet's 4x4 auxiliary-head conv,
+                c = self.fwd_calls[i]    # K = 2048 on 8 tiles, set the set's pace: 44 us against 12 sliced on its own)
                 if c.func == _nhwc.GRP_FUNC:
                     return self.sets_take_groups   # (a sibling group as a member: the GROUPS form of the implicit-GEMM kernel inside the wrapper)
                 if c.func != _nhwc.FUNC or not _nhwc.set_eligible(self._annos[c.tag]):
                     return False
-                from .rtc import explain_plan
+                if os.environ.get("BODAHIP_NHWC_SPLITK2") is None:
+                    return True     # (round 5: K slices are reduced INSIDE the launch -- a sliced member is one kernel like any other and brings its slices along)
+                from .rtc import explain_plan   # the two-kernel form of the slices (slabs in the shared scratch + a reduce pass): such a member stays a call of its own
                 return "_s" not in explain_plan(self._annos[c.tag], getattr(self, "_num_cus", 256)).split()[1]
             elig = [i for i in idxs if joins(i)]
             out_tn = {(self._annos[self.fwd_calls[i].tag].get_dims("out_0") if self.fwd_calls[i].func == _nhwc.GRP_FUNC else self._annos[self.fwd_calls[i].tag].get_dims("out")).tn for i in elig}

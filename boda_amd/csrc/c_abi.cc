@@ -204,4 +204,8 @@ int bodahip_explain_plan(const char *op_lexp, int num_cus, const char *tile, cha
   native_kernels_t::prebuild(parse_op_lexp(S(op_lexp, "op")), "", num_cus > 0 ? num_cus : 256, tile ? tile : "", &plan);
   put_str(plan_buf, plan_buf_sz, plan, "plan");
   ABI_CATCH }
+int bodahip_compile_stats(uint64_t *cache_hits_out, uint64_t *compiled_out, double *compile_ms_out) {
+  ABI_TRY
+  hiprtc_compile_stats(cache_hits_out, compiled_out, compile_ms_out);
+  ABI_CATCH }
 } // extern "C"

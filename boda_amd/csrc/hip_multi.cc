@@ -130,14 +130,22 @@ struct hip_multi_compute_t : public rtc_compute_t {
     mgraph_t g; g.live = true;
     bool const with_deps = dep_ptr != nullptr;
     string err;
-    for (auto &s : subs) {   // every device's capture is closed whatever happens on another
+    std::vector<std::pair<size_t, uint32_t>> made;   // (device, graph id) of every graph instantiated so far: destroyed again if any device fails
+    for (size_t d = 0; d < n(); ++d) {   // every device's capture is closed whatever happens on another
+      rtc_compute_t *const s = subs[d].get();
       try {
-        if (with_deps && cap_skipped) { (void)hip_compute_graph_end(s.get()); err = "graph_end_deps: a captured call launched nothing on some device (a batch smaller than the device count): dependencies cannot be attributed"; continue; }
-        g.ids.push_back(with_deps ? hip_compute_graph_end_deps(s.get(), n_calls, dep_ptr, dep_idx) : hip_compute_graph_end(s.get()));
+        uint32_t id;
+        if (with_deps && cap_skipped) { id = hip_compute_graph_end(s); made.emplace_back(d, id); err = "graph_end_deps: a captured call launched nothing on some device (a batch smaller than the device count): dependencies cannot be attributed"; continue; }
+        id = with_deps ? hip_compute_graph_end_deps(s, n_calls, dep_ptr, dep_idx) : hip_compute_graph_end(s);
+        made.emplace_back(d, id); g.ids.push_back(id);
       } catch (std::exception const &e) { err = e.what(); }
     }
-    if (!err.empty()) rt_err(err);
-    g.n_calls = hip_compute_graph_num_calls(subs[0].get(), g.ids[0]);
+    if (!err.empty()) {
+      for (auto const &m : made) { try { hip_compute_graph_destroy(subs[m.first].get(), m.second); } catch (...) {} }
+      rt_err(err);
+    }
+    g.n_calls = 0;   // devices with an empty shard capture fewer calls: report the largest count
+    for (size_t d = 0; d < n(); ++d) g.n_calls = std::max(g.n_calls, hip_compute_graph_num_calls(subs[d].get(), g.ids[d]));
     mgraphs.push_back(g);
     return (uint32_t)mgraphs.size() - 1;
   }

@@ -29,7 +29,7 @@
 // Numerics: bf16 products are exact in fp32; the MFMA sums 16 of them per instruction in an order of its own, so results are NOT
 // bit-comparable with a CPU loop; parity is stated against the oracle fed the same bf16 operands (tests), unpinned by construction.
 //
-// -D parameters: KNAME BI BJ BK(32|64; f32: 16|32) WI WJ MINW CIN KH KW SY SX PY PX CH CW COH COW RELU OUT_F32 NBUF(2..8) [IN_F32 SPLITK]
+// -D parameters: KNAME BI BJ BK(32|64; f32: 16|32) WI WJ MINW CIN KH KW SY SX PY PX CH CW COH COW RELU OUT_F32 NBUF(2..8) [IN_F32 SPLITK KSL]
 
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
@@ -61,6 +61,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define SPLITK 0 // 1: the grid is tiles x p.splitk; slice s runs K steps [s*kt_per, (s+1)*kt_per) and stores its raw fp32 partial tile to slab s of p.ws
 #endif           // ([pel][oc], row pitch Mi); bodahip_nhwc_splitk_reduce (REDUCE_ONLY) sums the slabs and applies bias / ReLU / the output type.  For
                  // tile-starved layers with a long K (7x7-map layers at 64 images, fully-connected layers): this path has no summation order to keep.
+#ifndef KSL
+#define KSL 1    // > 1: K SLICES REDUCED INSIDE THE LAUNCH (round 5).  The grid is tiles x KSL; workgroup bid runs tile bid / KSL, K steps [s * kt_per, (s + 1) * kt_per) with
+#endif           // s = bid % KSL, stores its raw fp32 accumulators to its slab of the call's slice workspace (p.ws: tile tickets first, slabs from p.ws + p.ws_slab on; a
+                 // slab is the accumulator registers thread by thread -- 16-byte stores, fully coalesced, no layout change), publishes them (release fence, agent scope:
+                 // the slices of a tile run on different XCDs, i.e. behind different L2s) and takes a ticket (one atomic add per workgroup).  The workgroup that draws the
+                 // LAST ticket of its tile acquires, sums the KSL slabs in slice order -- the same order whoever arrives last: run-to-run deterministic --, resets the
+                 // ticket for the next launch / graph replay, and runs the ordinary epilogue.  One kernel, no second launch, no shared scratch: legal for members of a
+                 // hip_conv_nhwc_set and for calls that overlap in an edge-free graph.  For tile-starved layers with a long K (7x7 / 14x14 maps at 64 images).
 #ifndef ABLATE
 #define ABLATE 0   // measurement only (wrong results): 1 = no operand loads, 2 = no fragment reads / MFMAs, 3 = fragment reads but no MFMAs,
                    // 4 = no K loop at all (prologue + epilogue), 5 = return at once (launch floor), 6 = K loop but no epilogue
@@ -154,7 +162,8 @@ constexpr int kEB = IN_F32 ? 4 : 2;           // bytes per element
 constexpr int kCK = 16 / kEB;                 // k per 16-byte chunk
 static_assert(IN_F32 ? (BK == 16 || BK == 32) : (BK == 32 || BK == 64), "BK: 32 | 64 (bf16), 16 | 32 (f32)");
 static_assert(CIN % kCK == 0, "channels-last tensors carry a whole number of 16-byte chunks per position");
-static_assert(!IN_F32 || (OUT_F32 && !SPLITK), "the exact fp32 variant writes float and never splits K");
+static_assert(!IN_F32 || (OUT_F32 && !SPLITK && KSL == 1), "the exact fp32 variant writes float and never splits K");
+static_assert(KSL >= 1 && KSL <= 32 && !(SPLITK && KSL > 1), "K slices: 1..32, one mechanism at a time");
 constexpr int kRowB = BK * kEB;               // bytes per LDS row
 constexpr int kCPR = kRowB / 16;              // 16-byte chunks per LDS row
 constexpr int kRP = 256 / kRowB;              // LDS rows per 256 bytes (one pass over the 64 banks)
@@ -183,11 +192,11 @@ __device__ __forceinline__ constexpr int swz(int row) { return (row / kRP) & (kC
 } // namespace
 
 #ifdef BODAHIP_AS_MEMBER
-static_assert(!SPLITK && !IN_F32, "a member of a set: one kernel, no K slices");
+static_assert(!SPLITK && !IN_F32, "a member of a set: one kernel (K slices only in their in-launch form, KSL)");
 constexpr int member_smem_bytes = kSmem, member_threads = WI * WJ * 64, member_minw = MINW;
 __device__ __forceinline__ void KNAME(gemm_args_t const &p, grp_args_t const &q, int const member_bid, char *const smem) {   // (q: read by the GROUPS form only)
 #elif GROUPS
-static_assert(!SPLITK && !IN_F32, "fused convolutions: no K slices, bf16 tensors");
+static_assert(!SPLITK && !IN_F32, "fused convolutions: bf16 tensors, K slices only in their in-launch form (KSL)");
 extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args_t const p, grp_args_t const q) {
   __shared__ __attribute__((aligned(1024))) char smem[kSmem];
 #else
@@ -203,6 +212,8 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   {
 #if SPLITK
     int const bid = BODAHIP_BID / p.splitk;
+#elif KSL > 1
+    int const bid = BODAHIP_BID / KSL;
 #else
     int const bid = BODAHIP_BID;
 #endif
@@ -322,6 +333,8 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };   // (the step's last MFMAs, which the compiler may sink below it, only read registers)
 #if SPLITK
   int const k_begin = (int)(BODAHIP_BID % p.splitk) * p.kt_per, nk = max(0, min(kNK, k_begin + p.kt_per) - k_begin);   // this slice's K steps
+#elif KSL > 1
+  int const k_begin = (int)(BODAHIP_BID % KSL) * p.kt_per, nk = max(0, min(kNK, k_begin + p.kt_per) - k_begin);
 #else
   constexpr int k_begin = 0, nk = (ABLATE == 4) ? 0 : kNK;
 #endif
@@ -396,6 +409,49 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
     cur = (cur + 1 == NBUF) ? 0 : cur + 1;
   }
   if (ABLATE == 6) { if (acc[0][0][0] == 123.456f) p.D[0] = 1.f; return; }
+#if KSL > 1
+  {   // ---- in-launch reduction of the K slices (see KSL at the top of conv_nhwc_bf16.hip).  Publish / combine as /opt/skills/guides/cdna_hip_programming.md prescribes for a
+      // split-K seam on gfx950: write-through (sc1) 16-byte slab stores, every wave drains vmcnt, barrier, ONE relaxed agent-scope ticket per workgroup; the last
+      // arriver reads the slabs with sc1 loads (L1-bypassing: the per-XCD L2s are not coherent with each other, a slab written write-through is read from the fabric).
+    int const tile_id = (int)BODAHIP_BID / KSL, slice = (int)BODAHIP_BID % KSL;
+    constexpr int kQ = kTI * kTJ * 4;                                  // accumulator quads per thread
+    constexpr int kSlabB = kQ * kNT * 16;                           // bytes per slab: the accumulator registers, thread by thread (fully coalesced 16-byte accesses)
+    rsrc_t const rW = make_rsrc(p.ws + p.ws_slab + (long)tile_id * (long)(KSL * (kSlabB / 4)), (unsigned)(KSL * kSlabB));
+    unsigned *const ticket = reinterpret_cast<unsigned *>(p.ws) + tile_id;
+#pragma unroll
+    for (int a = 0; a < kTI; ++a)
+#pragma unroll
+      for (int b = 0; b < kTJ; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float const x0 = acc[a][b][4 * g], x1 = acc[a][b][4 * g + 1], x2 = acc[a][b][4 * g + 2], x3 = acc[a][b][4 * g + 3];
+          f32x4 v; v[0] = x0; v[1] = x1; v[2] = x2; v[3] = x3;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rW, slice * kSlabB + (((a * kTJ + b) * 4 + g) * kNT + tid) * 16, 0, 16);
+        }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_barrier" ::: "memory");       // every wave's share of the slab has left (write-through: acknowledged by the fabric)
+    unsigned *const flag = reinterpret_cast<unsigned *>(smem);                     // (the operand images are dead: every wave is past the K loop's last barrier)
+    if (tid == 0) *flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_barrier" ::: "memory");
+    bool const last = (*flag == (unsigned)(KSL - 1));
+    asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");                 // (the flag is read before the epilogue reuses the LDS)
+    if (!last) return;
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch / graph replay
+    // the sum runs over the slabs in slice order whoever arrived last (this workgroup's own slab is read back like the others): run-to-run deterministic
+#pragma unroll
+    for (int a = 0; a < kTI; ++a)
+#pragma unroll
+      for (int b = 0; b < kTJ; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          int const o = (((a * kTJ + b) * 4 + g) * kNT + tid) * 16;
+          f32x4 sum = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 16));
+#pragma unroll
+          for (int s = 1; s < KSL; ++s) sum += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, s * kSlabB + o, 0, 16));
+          float const y0 = sum[0], y1 = sum[1], y2 = sum[2], y3 = sum[3];
+          acc[a][b][4 * g] = y0; acc[a][b][4 * g + 1] = y1; acc[a][b][4 * g + 2] = y2; acc[a][b][4 * g + 3] = y3;
+        }
+  }
+#endif
   // ---- epilogue.  C/D layout of the 32x32 MFMA family: column j = lane & 31, rows i = 8*g + 4*(lane >> 5) + e for register 4*g + e:
   // a lane holds 4 consecutive out_chans of one pel per register quad
 #if SPLITK

@@ -18,7 +18,7 @@
 //
 // Numerics: as conv_nhwc_bf16.hip (fp32 accumulate in the MFMA's own order; parity stated against the oracle on bf16-rounded operands).
 //
-// -D parameters: KNAME BI BJ WI WJ MINW CG CIN KH KW SY PY PX CH CW COH COW RELU OUT_F32 [ADIRECT PF BPF WPITCH DBUF ABLATE POOL]       (SX == 1)
+// -D parameters: KNAME BI BJ WI WJ MINW CG CIN KH KW SY PY PX CH CW COH COW RELU OUT_F32 [ADIRECT PF BPF WPITCH DBUF ABLATE POOL KSL]       (SX == 1)
 
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
@@ -57,6 +57,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef ABLATE
 #define ABLATE 0   // measurement only (wrong results): 1 = no operand loads, 2 = no fragment reads / MFMAs, 3 = no LDS stores of the staged operands, 4 = no K loop at all
+#endif
+#ifndef KSL
+#define KSL 1      // > 1: K slices reduced inside the launch -- see conv_nhwc_bf16.hip (same protocol, same workspace layout); ADIRECT form only
 #endif
 #ifndef POOL
 #define POOL 0     // 1: MAX POOLING FUSED INTO THE CONSUMING 1x1 CONVOLUTION (an inception module's pool -> pool-projection pair, test/rtc/pool.cucl + a k1conv in the
@@ -110,6 +113,7 @@ constexpr int kWp = WPITCH ? wpitch() : kWr;
 constexpr int kNCG = CIN / 8;                                      // channel groups of the tensor
 constexpr int kNKT = (kNCG + CG - 1) / CG;                         // K steps
 static_assert(!POOL || ADIRECT, "the fused-pooling form reads its filter fragments directly");
+static_assert(KSL == 1 || (ADIRECT && KSL <= 32), "K slices: the direct-filter form, at most 32");
 constexpr int kNPr = POOL ? CG : CG * kTaps;                       // k-slots (of 8 channels) per K step (POOL: one per channel group -- the window is reduced before the MFMA) ...
 constexpr int kNP = kNPr + (kNPr & 1);                             // ... padded to whole MFMAs (two slots each): an odd count gets one all-zero filter slot
 static_assert(KH >= SY, "patch slots assume overlapping or abutting windows in y");
@@ -163,7 +167,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
 
   int tile_i, tile_j; // XCD-aware workgroup -> tile map (as gemm_conv_f32.hip)
   {
-    int const bid = BODAHIP_BID, nb = p.tiles_i * p.tiles_j;
+    int const bid = (int)BODAHIP_BID / KSL, nb = p.tiles_i * p.tiles_j;
     int const q = nb >> 3, rr = nb & 7, xcd = bid & 7, idx = bid >> 3;
     int const nid = ((xcd < rr) ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
     int const group_sz = GROUP_I * p.tiles_j, gid = nid / group_sz, first_i = gid * GROUP_I;
@@ -265,14 +269,19 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
       for (int e = 0; e < kPE; ++e) if (((e + 1) * kNT <= kLoadN) || (tid + e * kNT < kLoadN)) Js[pdst[e]] = rp[e];
     };
     u32x4 cur[kN][kTI], nxt[kPF][kTI];
-    load_patch(0);
+#if KSL > 1
+    int const kt0 = ((int)BODAHIP_BID % KSL) * p.kt_per, kt1 = min(kNKT, kt0 + p.kt_per);   // this slice's K steps
+#else
+    constexpr int kt0 = 0, kt1 = (ABLATE == 4) ? 0 : kNKT;
+#endif
+    load_patch(kt0);
 #pragma unroll
-    for (int s = 0; s < kPF; ++s) load_a(0, s, cur[s]);
+    for (int s = 0; s < kPF; ++s) load_a(kt0, s, cur[s]);
     store_patch(0);
     __syncthreads();
-    for (int kt = 0; kt < ((ABLATE == 4) ? 0 : kNKT); ++kt) {
-      u32x4 const *const Js = Js0 + (kt & 1) * kImgC;
-      if (kt + 1 < kNKT) load_patch(kt + 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      u32x4 const *const Js = Js0 + ((kt - kt0) & 1) * kImgC;
+      if (kt + 1 < kt1) load_patch(kt + 1);
       constexpr int kBD = (BPF < kN) ? BPF : kN, kBR = kBD + 1;   // patch fragments are read kBD k-iterations ahead, through a ring of kBR sets
       bf16x8 b[kBR][kTJ];
 #pragma unroll
@@ -296,7 +305,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
         } else asm volatile("" ::"v"(cur[s][0]), "v"(b[s % kBR][0]));
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (kt + 1 < kNKT) store_patch((kt & 1) ^ 1);
+      if (kt + 1 < kt1) store_patch(((kt - kt0) & 1) ^ 1);
 #pragma unroll
       for (int s = 0; s < kPF; ++s)
 #pragma unroll
@@ -341,6 +350,49 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64, MINW) void KNAME(gemm_args
   }
 #endif // ADIRECT
 
+#if KSL > 1
+  {   // ---- in-launch reduction of the K slices (see KSL at the top of conv_nhwc_bf16.hip).  Publish / combine as /opt/skills/guides/cdna_hip_programming.md prescribes for a
+      // split-K seam on gfx950: write-through (sc1) 16-byte slab stores, every wave drains vmcnt, barrier, ONE relaxed agent-scope ticket per workgroup; the last
+      // arriver reads the slabs with sc1 loads (L1-bypassing: the per-XCD L2s are not coherent with each other, a slab written write-through is read from the fabric).
+    int const tile_id = (int)BODAHIP_BID / KSL, slice = (int)BODAHIP_BID % KSL;
+    constexpr int kQ = kTI * kTJ * 4;                                  // accumulator quads per thread
+    constexpr int kSlabB = kQ * kNT * 16;                           // bytes per slab: the accumulator registers, thread by thread (fully coalesced 16-byte accesses)
+    rsrc_t const rW = make_rsrc(p.ws + p.ws_slab + (long)tile_id * (long)(KSL * (kSlabB / 4)), (unsigned)(KSL * kSlabB));
+    unsigned *const ticket = reinterpret_cast<unsigned *>(p.ws) + tile_id;
+#pragma unroll
+    for (int a = 0; a < kTI; ++a)
+#pragma unroll
+      for (int b = 0; b < kTJ; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float const x0 = acc[a][b][4 * g], x1 = acc[a][b][4 * g + 1], x2 = acc[a][b][4 * g + 2], x3 = acc[a][b][4 * g + 3];
+          f32x4 v; v[0] = x0; v[1] = x1; v[2] = x2; v[3] = x3;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rW, slice * kSlabB + (((a * kTJ + b) * 4 + g) * kNT + tid) * 16, 0, 16);
+        }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_barrier" ::: "memory");       // every wave's share of the slab has left (write-through: acknowledged by the fabric)
+    unsigned *const flag = reinterpret_cast<unsigned *>(smem);                     // (the operand images are dead: every wave is past the K loop's last barrier)
+    if (tid == 0) *flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_barrier" ::: "memory");
+    bool const last = (*flag == (unsigned)(KSL - 1));
+    asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");                 // (the flag is read before the epilogue reuses the LDS)
+    if (!last) return;
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch / graph replay
+    // the sum runs over the slabs in slice order whoever arrived last (this workgroup's own slab is read back like the others): run-to-run deterministic
+#pragma unroll
+    for (int a = 0; a < kTI; ++a)
+#pragma unroll
+      for (int b = 0; b < kTJ; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          int const o = (((a * kTJ + b) * 4 + g) * kNT + tid) * 16;
+          f32x4 sum = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 16));
+#pragma unroll
+          for (int s = 1; s < KSL; ++s) sum += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, s * kSlabB + o, 0, 16));
+          float const y0 = sum[0], y1 = sum[1], y2 = sum[2], y3 = sum[3];
+          acc[a][b][4 * g] = y0; acc[a][b][4 * g + 1] = y1; acc[a][b][4 * g + 2] = y2; acc[a][b][4 * g + 3] = y3;
+        }
+  }
+#endif
   // ---- epilogue (as conv_nhwc_bf16.hip).  C/D layout of the 32x32 MFMA family: column j = lane & 31, rows i = 8*g + 4*(lane >> 5) + e for register 4*g + e
   int const h = lane >> 5;
   rsrc_t const rD = make_rsrc(p.D, p.D_bytes), rB = make_rsrc(p.bias, (unsigned)p.Mi * 4u);

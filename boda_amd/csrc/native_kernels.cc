@@ -92,7 +92,7 @@ static bool parse_tile(string const &s, tile_cfg_t &c) {
 // the static_asserts of the kernel, checked on the host so that a bad tune is an unsup_err, not a compile failure
 static void check_cfg(tile_cfg_t const &c, bool gather, bool patch = false) {   // patch: the J image is an input patch sized (and checked) by the patch planner, not BK x BJ
   int const nt = c.WI * c.WJ * 64;   // multiplying threads (= staging threads)
-  bool ok = c.BI > 0 && c.BJ > 0 && c.BK > 0 && c.WI > 0 && c.WJ > 0 && nt <= 1024 && (c.MT == 32 || c.MT == 16) && (c.BI % (c.WI * c.MT) == 0) && (c.BJ % (c.WJ * c.MT) == 0) &&
+  bool ok = c.BI > 0 && c.BJ > 0 && c.BK > 0 && c.WI > 0 && c.WJ > 0 && nt <= 1024 && c.threads() <= 1024 && (c.MT == 32 || c.MT == 16) && (c.BI % (c.WI * c.MT) == 0) && (c.BJ % (c.WJ * c.MT) == 0) &&
             (c.BK % 2 == 0) && (c.MT == 32 || c.BK % 4 == 0) && (c.BI % 4 == 0) && (c.BJ % 4 == 0);
   if (gather) ok = ok && ((c.BK * c.BJ) % nt == 0); // the gathers give every thread whole elements / rows
   if (gather) ok = ok && (nt % c.BJ == 0) && (c.BJ % 64 == 0);
@@ -174,7 +174,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(host->nh_launch(k.func, grid, 1, (uint32_t)c.threads(), params), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, fc = false, big = false, rdec = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false; int rows = 0, cg = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, fc = false, big = false, rdec = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false, ksl = false; int rows = 0, cg = 0; };
 
 // Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
 //   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
@@ -358,6 +358,13 @@ static bool plan_patch_bf16(conv_geom_t const &g, int num_cus, plan_t &p) {
 // (buffer_load ... lds), 32x32x16 bf16 MFMA.  g.C is the STORED channel count (a multiple of 8).  tile: "BIxBJxBKxWIxWJ[xMINW]" or "".
 // grp_pad > 0: horizontally fused convolutions (-DGROUPS=1): g.OC is the stacked, padded out_chan count, every member starts at a multiple of grp_pad -> tiles
 // may not be taller than grp_pad and must divide it; no K slices.
+// In-launch K slices (KSL of kernels/conv_nhwc_bf16.hip, conv_nhwc_patch_bf16.hip): the count is a compile-time constant of the kernel, every slice runs
+// ceil(nk / slices) K steps -- so the count is lowered until no slice is empty (32 at most).
+static int ksl_normalise(int want, long nk) {
+  int s = (int)std::max<long>(1, std::min<long>(std::min(want, 32), nk));
+  while (s > 1) { long const per = (nk + s - 1) / s; if ((nk + per - 1) / per == s) break; --s; }
+  return s;
+}
 static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &tile, bool out_f32, int grp_pad = 0, bool allow_split = true) {
   if (g.C % 8) unsup_err("hip_conv_nhwc: in_chan of a channels-last bf16 tensor must be a multiple of 8 (the layout pass pads)");
   if (g.H >= 32768 || g.W >= 32768) unsup_err("hip_conv_nhwc: planes of 32768 rows / columns or more are not supported");
@@ -366,18 +373,22 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
   plan_t p; p.nhwc = true; p.bf16 = true; p.kname = "bodahip_conv_nhwc_bf16";
   tile_cfg_t c; c.MT = 32; c.SPLITK = 1; c.PF = 1;
   // K step: 64 (8 chunks) when a tap's chunks divide into it -- or when K is long anyway; 32 otherwise
-  c.BK = (cg % 8 == 0) ? 64 : ((cg % 4 == 0) ? 32 : (kc >= 32 ? 64 : 32));
-  // short K (<= 512): a 32-deep step -- half the LDS per ring slot, so a deeper ring and more workgroups per CU for what are HBM-bound
-  // launches (measured at 64 images: 1x1 layers with 64-512 input channels 5-10 % faster, the 7x7 / 2 conv1 on 8 stored channels 93 -> 75 us;
+  // Round 5 (tools/ksl_sweep.py, every 1x1 layer of GoogLeNet at 64 images under ten tiles): on SMALL maps (14 x 14 and 7 x 7 at 64 images: 3-12 k pels, 100-600
+  // tiles) the launches are latency-bound, not HBM-bound, and the 64-deep step with half as many barriers wins by 15-25 % (512 -> 128 channels at 14 x 14: 64x128x32
+  // ring 4 10.5 us, 64x64x64 ring 3 7.9; 480 -> 96: 10.3 -> 8.6), ragged taps included (480 channels = 7.5 steps); the 32-deep rules stay for the large maps.
+  bool const big_map = Nj >= 32768;
+  c.BK = (cg % 8 == 0) ? 64 : ((cg % 4 == 0 && big_map) ? 32 : (kc >= 32 ? 64 : 32));
+  // short K (<= 512) on large maps: a 32-deep step -- half the LDS per ring slot, so a deeper ring and more workgroups per CU for what are HBM-bound
+  // launches (measured at 64 images: 1x1 layers with 64-512 input channels at 28 x 28 / 56 x 56 5-10 % faster, the 7x7 / 2 conv1 on 8 stored channels 93 -> 75 us;
   // from 1024 channels up and on 3x3 layers the 64-deep step wins)
-  if (kc <= 64) c.BK = 32;
+  if (kc <= 64 && (big_map || kc <= 32)) c.BK = 32;
   int nbuf = 0;   // LDS ring depth (the tile string's 9th field; 0 = choose below)
   if (!tile.empty()) {
     if (!parse_tile(tile, c)) rt_err("bad conv_tile '" + tile + "'");
     { int nf = 1; for (char ch : tile) if (ch == 'x' || ch == ':') ++nf; if (nf >= 9) nbuf = c.PF; }
     c.MT = 32; c.PF = 1;
     if (c.SPLITK < 1 || c.SPLITK > 64) unsup_err("hip_conv_nhwc: unsupported K split " + std::to_string(c.SPLITK));
-    if (grp_pad && (c.SPLITK != 1 || c.BI > grp_pad || grp_pad % c.BI)) unsup_err("hip_conv_nhwc_grp: tile " + c.str() + " does not fit the members' padding of " + std::to_string(grp_pad) + " out_chans");
+    if (grp_pad && (c.BI > grp_pad || grp_pad % c.BI)) unsup_err("hip_conv_nhwc_grp: tile " + c.str() + " does not fit the members' padding of " + std::to_string(grp_pad) + " out_chans");
   } else {
     // score = base rate of the tile x fraction of the padded tile grid that is real work x how evenly the tiles deal out over the CUs
     // (the rule of choose_cfg); base rates are first MI355X measurements of this kernel relative to 128x128
@@ -390,9 +401,12 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
     struct cand_t { int bi, bj, wi, wj, minw; };
     //   * large tiles (8 / 16 waves) move fewer operand bytes per flop but then meet the matrix pipes: a K step is never faster than its flops at
     //     ~45 % of the CU's bf16 MFMA rate (AlexNet / NiN conv2, 5x5 96->256 at 256 images: 128x128 305, 128x256 254, 256x256 243 us).
-    static cand_t const cands[] = {{128, 128, 2, 2, 2}, {64, 128, 1, 4, 2}, {64, 64, 2, 2, 2}, {32, 128, 1, 4, 2}, {32, 64, 1, 2, 2}, {128, 256, 2, 4, 1}, {256, 256, 4, 4, 1}};
+    //   * (round 5) the two-wave 32 x 64 tile is gone from the list: never ahead of 64 x 64 x 64 / 32 x 128 x 64 in the sweep of GoogLeNet's 1x1 layers (16-32 out_chans at
+    //     14 x 14: 8.2-8.5 us against 6.6-7.4), and a 128-thread member cannot share a level set's wrapper kernel
+    static cand_t const cands[] = {{128, 128, 2, 2, 2}, {64, 128, 1, 4, 2}, {64, 64, 2, 2, 2}, {32, 128, 1, 4, 2}, {128, 256, 2, 4, 1}, {256, 256, 4, 4, 1}};
     long const nk = (kc + c.BK / 8 - 1) / (c.BK / 8);
-    bool const may_split = getenv("BODAHIP_NO_NHWC_SPLITK") == nullptr && !grp_pad && allow_split;
+    bool const two_kernel = getenv("BODAHIP_NHWC_SPLITK2") != nullptr && !grp_pad;
+    bool const may_split = getenv("BODAHIP_NO_NHWC_SPLITK") == nullptr && allow_split && !(grp_pad && two_kernel);
     double best = 1e30;
     for (cand_t const &cd : cands) {
       if (grp_pad && (cd.bi > grp_pad || grp_pad % cd.bi)) continue;
@@ -404,8 +418,11 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
       for (int sk = 1; sk <= 16; sk *= 2) {
         if (sk > 1 && (!may_split || nk / sk < 4)) break;
         long const wgs = tiles * sk, steps = (nk + sk - 1) / sk;
-        double t = (double)((wgs + num_cus - 1) / num_cus) * (double)steps * tau + 4.0;
-        if (sk > 1) t += 3.0 + 2.0 * sk * (double)Nj * g.OC * 4.0 / 5e6;
+        // (two workgroups share a CU without slowing each other at these sizes -- the launches are latency-bound: 392 tiles of 64 x 64 run like 196 --, so a round is 2 x CUs)
+        double t = (double)((wgs + 2 * num_cus - 1) / (2 * num_cus)) * (double)steps * tau + 4.0;
+        // K slices reduced inside the launch (KSL): no second launch, but the slabs leave write-through and are read back by the last arriver -- measured (tools/ksl_sweep.py,
+        // GoogLeNet's 14 x 14 / 7 x 7 layers at 64 images): ~1.5 us + ~1 us per MB of slabs (slices x out_chans x pels x 4 bytes), whatever the tile
+        if (sk > 1) t += two_kernel ? (3.0 + 2.0 * sk * (double)Nj * g.OC * 4.0 / 5e6) : (1.5 + sk * (double)Nj * g.OC * 4.0 / 1e6);
         if (t < best) { best = t; c.BI = cd.bi; c.BJ = cd.bj; c.WI = cd.wi; c.WJ = cd.wj; c.MINW = cd.minw; c.SPLITK = sk; }
       }
     }
@@ -416,7 +433,9 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
     // workgroups still fit a CU's LDS; 2 otherwise
     bool const even = c.WI > 0 && c.WJ > 0 && ((c.BI * cpr / 64) % (c.WI * c.WJ) == 0) && ((c.BJ * cpr / 64) % (c.WI * c.WJ) == 0);
     long const per_buf = (long)(c.BI + c.BJ) * c.BK * 2;
-    if (!nbuf) nbuf = (even && c.BK == 32 && 4 * per_buf <= 48 * 1024) ? 4 : ((even && 3 * per_buf <= 80 * 1024) ? 3 : 2);
+    // (64-deep steps: a third slot only for the small tiles -- 64 x 128 x 64 and 128 x 128 x 64 measured level or FASTER on a ring of two at 28 x 28 / 14 x 14 / 7 x 7:
+    //  832 -> 384 at 7 x 7 11.3 -> 9.4 us, 192 -> 96 at 28 x 28 on 128 x 128 12.9 -> 10.4)
+    if (!nbuf) nbuf = (even && c.BK == 32 && 4 * per_buf <= 48 * 1024) ? 4 : ((even && 3 * per_buf <= 80 * 1024 && (c.BK == 32 || per_buf <= 20 * 1024)) ? 3 : 2);
     if (nbuf < 2 || nbuf > 4 || (nbuf > 2 && !even)) unsup_err("hip_conv_nhwc: unsupported LDS ring depth " + std::to_string(nbuf) + " for tile " + c.str());
     c.PF = nbuf;   // (reported as _pN in the launch info)
   }
@@ -431,7 +450,11 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
             "-DSY=" + std::to_string(g.SY), "-DSX=" + std::to_string(g.SX), "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX),
             "-DCH=" + std::to_string(g.H), "-DCW=" + std::to_string(g.W), "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW),
             string("-DRELU=") + (g.relu ? "1" : "0"), string("-DOUT_F32=") + (out_f32 ? "1" : "0"), "-DNBUF=" + std::to_string(nbuf)};
-  if (c.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
+  if (c.SPLITK > 1) {   // K slices: reduced inside the launch (KSL, round 5) unless the two-kernel form is asked for (BODAHIP_NHWC_SPLITK2=1: slabs in the shared scratch + bodahip_nhwc_splitk_reduce)
+    long const nk2 = ((long)kc + c.BK / 8 - 1) / (c.BK / 8);
+    if (getenv("BODAHIP_NHWC_SPLITK2") && !grp_pad) p.defs.push_back("-DSPLITK=1");
+    else { c.SPLITK = ksl_normalise(c.SPLITK, nk2); p.cfg = c; if (c.SPLITK > 1) { p.defs.push_back("-DKSL=" + std::to_string(c.SPLITK)); p.ksl = true; } }
+  }
   if (grp_pad) p.defs.push_back("-DGROUPS=1");
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
   return p;
@@ -439,8 +462,10 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
 // Channels-last bf16 convolution from an LDS input patch (kernels/conv_nhwc_patch_bf16.hip): KH x KW kernels with more than one tap, stride 1 in x; filters in the
 // F'[in_grp][ky][kx][out_chan][8] form.  A K step is CG groups of 8 channels x all taps.  tile: "BIxBJx0xWIxWJ[xMINW]" or "".
 // pool: g.KH x g.KW / g.PY, g.PX describe a MAX-POOLING window fused in front of a 1x1 convolution (-DPOOL=1: the filters hold one k-slot per channel group).
-static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string const &tile, bool out_f32, bool pool = false) {
+static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string const &tile_arg, bool out_f32, bool pool = false) {
   if (g.C % 8) unsup_err("hip_conv_nhwc: in_chan of a channels-last bf16 tensor must be a multiple of 8");
+  string tile = tile_arg;
+  if (pool && tile.empty()) { if (char const *e = getenv("BODAHIP_NHWC_POOL_TILE")) tile = e; }   // (experiments: the tile of the fused-pooling form)
   int const taps = g.KH * g.KW, ncg = g.C / 8;
   if (!(g.SX == 1 && taps >= 2 && g.KH >= g.SY)) unsup_err("hip_conv_nhwc (patch form of filts): needs stride 1 in x and more than one tap");
   long const Nj = (long)g.B * g.OH * g.OW;
@@ -455,7 +480,8 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
       long const slots = (long)((ncg + c - 1) / c) * (c * taps + ((c * taps) & 1));
       if (best < 0 || slots < best) { best = slots; cg = c; }
     } }
-  if (pool) { if (!adirect) unsup_err("hip_conv_nhwc (fused pooling): needs the direct filter path"); cg = std::min(ncg, 4); }   // (one k-slot per group: four groups = two MFMA k-iterations per step)
+  if (pool) { if (!adirect) unsup_err("hip_conv_nhwc (fused pooling): needs the direct filter path"); cg = std::min(ncg, 4);    // (one k-slot per group: four groups = two MFMA k-iterations per step)
+    if (char const *e = getenv("BODAHIP_NHWC_POOL_CG")) { if (atoi(e) > 0) cg = std::min(ncg, atoi(e)); } }
   if (char const *e = getenv("BODAHIP_NHWC_PATCH_CG")) { if (atoi(e) > 0) cg = std::min(ncg, atoi(e)); }   // (experiments)
   int wp = g.W + 2 * g.PX;                                              // slot pitch: as the kernel's wpitch()
   for (int p2 = wp; p2 < wp + 16; ++p2) if ((g.SY * p2 - g.OW) % 16 == 0) { wp = p2; break; }
@@ -479,7 +505,8 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
   int pick_pf = 0;
   if (!tile.empty()) {
     if (!parse_tile(tile, c)) rt_err("bad conv_tile '" + tile + "'");
-    c.MT = 32; c.SPLITK = 1; c.PF = 1;
+    c.MT = 32; c.PF = 1;
+    if (c.SPLITK < 1 || c.SPLITK > 32 || (c.SPLITK > 1 && !adirect)) unsup_err("hip_conv_nhwc (patch form of filts): unsupported K slices " + std::to_string(c.SPLITK));
   } else if (!adirect) {
     // Narrow in out_chan, wide in pels: the filter tile -- the larger operand stream here -- is staged once per BJ pels.  score = padding efficiency x share of
     // the CUs that get a workgroup / operand bytes per flop (filter stream ~ 1/BJ, patch stream ~ 1/(4 BI)).  Measured on MI355X (tools/patch_sweep.sh, 64
@@ -539,6 +566,7 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
             "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW), string("-DRELU=") + (g.relu ? "1" : "0"), string("-DOUT_F32=") + (out_f32 ? "1" : "0")};
   if (adirect) p.defs.push_back("-DADIRECT=1");
   if (pool) p.defs.push_back("-DPOOL=1");
+  if (c.SPLITK > 1) { c.SPLITK = ksl_normalise(c.SPLITK, (ncg + cg - 1) / cg); p.cfg = c; if (c.SPLITK > 1) { p.defs.push_back("-DKSL=" + std::to_string(c.SPLITK)); p.ksl = true; } }
   if (adirect && (pick_pf || (tile.empty() ? 0 : ((c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) >= 8)))) p.defs.push_back("-DPF=4");   // (128 accumulators: four fragments in flight)
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
   return p;
@@ -765,6 +793,29 @@ static void setup_splitk(native_kernels_t::impl_t *impl, native_host_t *host, ge
   size_t const need = slab * (size_t)cfg.SPLITK * sizeof(float);
   ensure_ws(impl, host, need);
   ga.ws = (float *)impl->ws; ga.ws_slab = (long)slab;
+}
+
+// The workspace of a call whose K slices are reduced inside the launch (KSL): one ticket word per tile (zero between launches: the last arriver of a tile resets
+// its ticket), then one slab of raw fp32 accumulators per (tile, slice).  It belongs to the CALL (key: its operands and plan), not to the backend's shared scratch:
+// calls of an edge-free graph and members of a level set run at the same time.  Allocated and zeroed on the call's first run (not inside a capture), kept until the
+// backend goes; `key_ptr` tells calls on the same tensors' shapes apart.
+static void setup_ksl(native_kernels_t::impl_t *impl, native_host_t *host, gemm_args_t &ga, tile_cfg_t const &cfg, long nk, void const *key_ptr, char const *what) {
+  long const tiles = (long)ga.tiles_i * ga.tiles_j;
+  size_t const tick_b = ((size_t)tiles * 4 + 255) & ~size_t(255);
+  size_t const slab_b = (size_t)cfg.BI * cfg.BJ * 4;   // (kTI * kTJ * 16 floats x threads = BI x BJ floats)
+  size_t const total = tick_b + (size_t)tiles * cfg.SPLITK * slab_b;
+  if ((size_t)cfg.SPLITK * slab_b >= 0x7ffffff0ull || total >= (size_t(1) << 32)) unsup_err(string(what) + ": K-slice workspace too large");
+  string const key = "ksl:" + std::to_string((uintptr_t)key_ptr) + ":" + std::to_string((uintptr_t)ga.J) + ":" + std::to_string((uintptr_t)ga.I) + ":" + std::to_string(ga.out_coff) + ":" +
+                     std::to_string(total) + ":" + cfg.str();
+  auto it = impl->ktabs.find(key);
+  if (it == impl->ktabs.end()) {
+    if (host->nh_capturing()) rt_err("graph capture: the K-slice workspace of this call is not allocated yet -- run the call list once before capturing it");
+    void *dev = nullptr;
+    hip_err_chk(hipMalloc(&dev, total), "hipMalloc(K-slice workspace)");
+    hip_err_chk(hipMemsetAsync(dev, 0, tick_b, host->nh_stream()), "hipMemsetAsync(K-slice tickets)");
+    it = impl->ktabs.emplace(key, dev).first;
+  }
+  ga.splitk = cfg.SPLITK; ga.kt_per = (int)((nk + cfg.SPLITK - 1) / cfg.SPLITK); ga.ws = (float *)it->second; ga.ws_slab = (long)(tick_b / 4);
 }
 
 static kernel_t &get_reduce_kernel(native_kernels_t::impl_t *impl, native_host_t *host, bool epi, bool relu) {
@@ -1352,7 +1403,7 @@ void native_kernels_t::conv_nhwc_multi(int n, multi_member_t const *ms, bool out
 // member's own launch.  Members that cannot join (another workgroup size, K slices) are launched on their own by the same call.
 struct set_member_plan_t { plan_t p; gemm_args_t ga; grp_args_t q; long tiles; int variant; double tile_cost; };
 static char const *const k_set_macros[] = {"BI", "BJ", "BK", "WI", "WJ", "MINW", "CIN", "KH", "KW", "SY", "SX", "PY", "PX", "CH", "CW", "COH", "COW", "RELU", "OUT_F32", "NBUF", "CG",
-                                           "ADIRECT", "PF", "BPF", "WPITCH", "DBUF", "ABLATE", "POOL", "GROUP_I", "IN_F32", "SPLITK", "INTERLEAVE", "GROUPS", "KNAME", "BODAHIP_BID"};
+                                           "ADIRECT", "PF", "BPF", "WPITCH", "DBUF", "ABLATE", "POOL", "GROUP_I", "IN_F32", "SPLITK", "KSL", "INTERLEAVE", "GROUPS", "KNAME", "BODAHIP_BID"};
 static string set_kernel_source(std::vector<plan_t const *> const &variants, int threads, int minw) {
   std::ostringstream o;
   o << "// generated by native_kernels.cc (conv_nhwc_set): " << variants.size() << " member specialisations in one kernel\n";
@@ -1406,18 +1457,47 @@ static gemm_args_t nhwc_member_args(native_kernels_t::multi_member_t const &mm, 
   return ga;
 }
 
+// What decides a set member's plan and the wrapper kernel -- ONE routine for run() and prebuild(), so that the ahead-of-time build compiles exactly the translation unit
+// the first run would: a member's plan (its own launch's plan; K slices only in their in-launch form), then the members that share the wrapper (256 threads) longest
+// tile first, variants numbered in that order, a lone 256-thread member launched on its own kernel instead.
+struct set_member_in_t { conv_geom_t g; bool patch_filts, pool; int grp_pad; };
+static plan_t plan_set_member(set_member_in_t const &mi, int num_cus, bool out_f32) {
+  if (mi.grp_pad > 0) return plan_conv_nhwc(mi.g, num_cus, string(), out_f32, mi.grp_pad);
+  return mi.patch_filts ? plan_conv_nhwc_patch(mi.g, num_cus, string(), out_f32, mi.pool) : plan_conv_nhwc(mi.g, num_cus, string(), out_f32, 0, /*allow_split=*/getenv("BODAHIP_NHWC_SPLITK2") == nullptr);
+}
+static double set_tile_cost(set_member_in_t const &mi, plan_t const &p) {
+  return (double)p.cfg.BI * p.cfg.BJ * (double)mi.g.C * (mi.pool ? 2 : mi.g.KH * mi.g.KW) / std::max(1, p.ksl ? p.cfg.SPLITK : 1);
+}
+struct set_layout_t { std::vector<int> in_set, alone, variant_of; std::vector<plan_t const *> variants; std::vector<string> vkeys; int minw = 8; string skey; };
+static set_layout_t layout_set(std::vector<plan_t> const &plans, std::vector<double> const &tile_cost) {
+  set_layout_t L; L.variant_of.assign(plans.size(), -1);
+  for (size_t m = 0; m < plans.size(); ++m) (plans[m].cfg.threads() == 256 ? L.in_set : L.alone).push_back((int)m);
+  if (L.in_set.size() < 2) { L.alone.insert(L.alone.end(), L.in_set.begin(), L.in_set.end()); L.in_set.clear(); }
+  // longest tiles first: the dispatcher hands workgroups out in grid order
+  std::stable_sort(L.in_set.begin(), L.in_set.end(), [&](int x, int y) { return tile_cost[(size_t)x] > tile_cost[(size_t)y]; });
+  for (int m : L.in_set) {
+    string key = plans[(size_t)m].kname; for (auto const &d : plans[(size_t)m].defs) key += " " + d;
+    size_t v = 0; while (v < L.vkeys.size() && L.vkeys[v] != key) ++v;
+    if (v == L.vkeys.size()) { L.vkeys.push_back(key); L.variants.push_back(&plans[(size_t)m]); }
+    L.variant_of[(size_t)m] = (int)v; L.minw = std::min(L.minw, plans[(size_t)m].cfg.MINW);
+  }
+  L.skey = "set:"; for (auto const &vk : L.vkeys) L.skey += "[" + vk + "]";
+  return L;
+}
+
 void native_kernels_t::conv_nhwc_set(int n, multi_member_t const *ms, bool const *patch_filts, bool out_f32) {
   if (n < 1 || n > 16) unsup_err("hip_conv_nhwc_set: 1..16 members");
   std::vector<set_member_plan_t> mp((size_t)n);
-  std::vector<int> in_set, alone;
+  std::vector<plan_t> plans((size_t)n); std::vector<double> costs((size_t)n);
   for (int m = 0; m < n; ++m) {
     conv_geom_t const &g = ms[m].g;
     if (!((long)g.B * g.OH * g.OW) || !g.OC) rt_err("hip_conv_nhwc_set: empty member");
     set_member_plan_t &q = mp[(size_t)m];
     memset(&q.q, 0, sizeof(q.q));
+    set_member_in_t const mi{g, patch_filts[m], ms[m].pool, ms[m].grp_n > 0 ? ms[m].grp_pad : 0};
     if (ms[m].grp_n > 0) {   // a horizontally fused member: the GROUPS form of the implicit-GEMM kernel, its members' destinations in q
       if (patch_filts[m] || ms[m].pool) rt_err("hip_conv_nhwc_set: a fused (grp) member takes out_chan:y:x:in_chan filters");
-      q.p = plan_conv_nhwc(g, host->nh_num_cus(), string(), out_f32, ms[m].grp_pad);
+      q.p = plan_set_member(mi, host->nh_num_cus(), out_f32);
       multi_member_t mm = ms[m]; mm.out_ctot = 0; mm.out_coff = 0;
       q.ga = nhwc_member_args(mm, q.p.cfg, out_f32, "hip_conv_nhwc_set"); q.ga.D = nullptr; q.ga.D_bytes = 0;
       long const Njg = (long)g.B * g.OH * g.OW; int tot = 0;
@@ -1430,39 +1510,36 @@ void native_kernels_t::conv_nhwc_set(int n, multi_member_t const *ms, bool const
       }
       if (tot != g.OC) rt_err("hip_conv_nhwc_set: a fused member's filts hold " + std::to_string(g.OC) + " out_chans, its members need " + std::to_string(tot));
     } else {
-    q.p = patch_filts[m] ? plan_conv_nhwc_patch(g, host->nh_num_cus(), string(), out_f32, ms[m].pool) : plan_conv_nhwc(g, host->nh_num_cus(), string(), out_f32, 0, /*allow_split=*/false);
-    q.ga = nhwc_member_args(ms[m], q.p.cfg, out_f32, "hip_conv_nhwc_set");
+      q.p = plan_set_member(mi, host->nh_num_cus(), out_f32);
+      q.ga = nhwc_member_args(ms[m], q.p.cfg, out_f32, "hip_conv_nhwc_set");
     }
-    q.tiles = (long)q.ga.tiles_i * q.ga.tiles_j;
-    q.tile_cost = (double)q.p.cfg.BI * q.p.cfg.BJ * (double)g.C * (ms[m].pool ? 2 : g.KH * g.KW);
-    (q.p.cfg.threads() == 256 ? in_set : alone).push_back(m);
+    if (q.p.ksl) {   // K slices reduced inside the launch: the member's grid is tiles x slices, its workspace its own
+      long const nk = q.p.nhwc_patch ? ((long)(g.C / 8) + q.p.cg - 1) / q.p.cg : ((long)(g.C / 8) * g.KH * g.KW + q.p.cfg.BK / 8 - 1) / (q.p.cfg.BK / 8);
+      setup_ksl(impl, host, q.ga, q.p.cfg, nk, ms[m].grp_n > 0 ? ms[m].grp_out[0] : ms[m].out, "hip_conv_nhwc_set");
+    }
+    q.tiles = (long)q.ga.tiles_i * q.ga.tiles_j * std::max(1, q.ga.splitk);
+    q.tile_cost = set_tile_cost(mi, q.p);
+    plans[(size_t)m] = q.p; costs[(size_t)m] = q.tile_cost;
   }
-  if (in_set.size() < 2) { alone.insert(alone.end(), in_set.begin(), in_set.end()); in_set.clear(); }
+  set_layout_t const L = layout_set(plans, costs);
+  std::vector<int> const &in_set = L.in_set, &alone = L.alone;
+  for (int m = 0; m < n; ++m) mp[(size_t)m].variant = L.variant_of[(size_t)m];
   double flops = 0, bytes = 0;
   for (int m = 0; m < n; ++m) { conv_geom_t g = ms[m].g; double const Nj = (double)g.B * g.OH * g.OW, Kt = ms[m].pool ? (double)g.C : (double)g.C * g.KH * g.KW;
     if (ms[m].grp_n > 0) { int roc = 0; for (int j = 0; j < ms[m].grp_n; ++j) roc += ms[m].grp_noc[j]; g.OC = roc; }   // (a fused member's own out_chans: zero padding rows are not credit)
     flops += 2.0 * Nj * g.OC * Kt; bytes += 2.0 * ((double)g.B * g.C * g.H * g.W + (double)g.OC * Kt) + (out_f32 ? 4.0 : 2.0) * Nj * g.OC + 4.0 * g.OC; }
-  for (int m : alone) {   // members with another workgroup size: their own launch, the plan they would have taken anyway
+  for (int m : alone) {   // members with another workgroup size (or a lone 256-thread member): their own launch, the plan they would have taken anyway
     kernel_t &k = get_kernel(impl, host, mp[(size_t)m].p);
     void *params[] = {&mp[(size_t)m].ga, &mp[(size_t)m].q};     // (the second argument is read by the GROUPS form only)
     hip_err_chk(host->nh_launch(k.func, (uint32_t)mp[(size_t)m].tiles, 1, (uint32_t)mp[(size_t)m].p.cfg.threads(), params), "hipModuleLaunchKernel(conv_nhwc_set, lone member)");
   }
   if (!in_set.empty()) {
-    // longest tiles first: the dispatcher hands workgroups out in grid order
-    std::stable_sort(in_set.begin(), in_set.end(), [&](int x, int y) { return mp[(size_t)x].tile_cost > mp[(size_t)y].tile_cost; });
-    std::vector<plan_t const *> variants; std::vector<string> vkeys; int minw = 8;
-    for (int m : in_set) {
-      string key = mp[(size_t)m].p.kname; for (auto const &d : mp[(size_t)m].p.defs) key += " " + d;
-      size_t v = 0; while (v < vkeys.size() && vkeys[v] != key) ++v;
-      if (v == vkeys.size()) { vkeys.push_back(key); variants.push_back(&mp[(size_t)m].p); }
-      mp[(size_t)m].variant = (int)v; minw = std::min(minw, mp[(size_t)m].p.cfg.MINW);
-    }
-    string skey = "set:"; for (auto const &vk : vkeys) skey += "[" + vk + "]";
+    string const &skey = L.skey;
     auto kit = impl->kernels.find(skey);
     if (kit == impl->kernels.end()) {
       if (host->nh_capturing()) rt_err("graph capture: this hip_conv_nhwc_set kernel is not compiled yet -- run the call list once before capturing it");
       string log;
-      std::vector<char> code = hiprtc_compile(set_kernel_source(variants, 256, std::max(1, minw)), "bodahip_conv_nhwc_set", host->nh_arch(), vect_string(), &log, true);
+      std::vector<char> code = hiprtc_compile(set_kernel_source(L.variants, 256, std::max(1, L.minw)), "bodahip_conv_nhwc_set", host->nh_arch(), vect_string(), &log, true);
       kernel_t k;
       hip_err_chk(hipModuleLoadData(&k.mod, code.data()), "hipModuleLoadData(conv_nhwc_set)");
       hip_err_chk(hipModuleGetFunction(&k.func, k.mod, "bodahip_conv_nhwc_set"), "hipModuleGetFunction(conv_nhwc_set)");
@@ -1528,9 +1605,10 @@ void native_kernels_t::conv_nhwc_grp(void const *filts, float const *biases, voi
   ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.C = g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;
   ga.I_bytes = (unsigned)f_bytes; ga.J_bytes = (unsigned)in_bytes; ga.splitk = 1;
   ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
+  if (p.ksl) setup_ksl(impl, host, ga, cfg, ((long)(g.C / 8) * g.KH * g.KW + cfg.BK / 8 - 1) / (cfg.BK / 8), outs[0], "hip_conv_nhwc_grp");
   void *params[] = {&ga, &q};
-  hip_err_chk(host->nh_launch(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j), 1, (uint32_t)cfg.threads(), params), "hipModuleLaunchKernel(conv_nhwc_bf16, fused)");
-  last_launch.kernel = p.kname + "(x" + std::to_string(n) + ")"; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(ga.tiles_i * ga.tiles_j); last_launch.block = cfg.threads();
+  hip_err_chk(host->nh_launch(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j * ga.splitk), 1, (uint32_t)cfg.threads(), params), "hipModuleLaunchKernel(conv_nhwc_bf16, fused)");
+  last_launch.kernel = p.kname + "(x" + std::to_string(n) + ")"; last_launch.cfg = cfg; last_launch.grid = (uint32_t)(ga.tiles_i * ga.tiles_j * ga.splitk); last_launch.block = cfg.threads();
   last_launch.flops = 2.0 * Nj * real_oc * Kt;   // (the members' own out_chans: zero padding rows are work done, not credit)
   last_launch.algo_bytes = 2.0 * ((double)g.B * g.C * g.H * g.W + real_oc * Kt) + (out_f32 ? 4.0 : 2.0) * (double)Nj * real_oc + 4.0 * real_oc;
 }
@@ -1552,7 +1630,10 @@ void native_kernels_t::conv_nhwc(void const *filts, float const *biases, void co
   ga.I_bytes = (unsigned)f_bytes; ga.J_bytes = (unsigned)in_bytes; ga.D_bytes = (unsigned)out_bytes;
   ga.out_ctot = out_ctot; ga.out_coff = out_coff; ga.splitk = 1;
   ga.tiles_i = (g.OC + cfg.BI - 1) / cfg.BI; ga.tiles_j = (int)((Nj + cfg.BJ - 1) / cfg.BJ);
-  if (cfg.SPLITK > 1) {
+  if (p.ksl) {
+    long const nk = p.nhwc_patch ? ((long)(g.C / 8) + p.cg - 1) / p.cg : ((long)(g.C / 8) * g.KH * g.KW + cfg.BK / 8 - 1) / (cfg.BK / 8);
+    setup_ksl(impl, host, ga, cfg, nk, out, "hip_conv_nhwc");
+  } else if (cfg.SPLITK > 1) {
     long const nk = ((long)(g.C / 8) * g.KH * g.KW + cfg.BK / 8 - 1) / (cfg.BK / 8);
     size_t const slab = ((size_t)Nj * g.OC + 3) & ~size_t(3);
     if (slab * 4 >= 0x7ffffff0ull) unsup_err("hip_conv_nhwc: split-K slab of 2 GiB or more");
@@ -1561,7 +1642,7 @@ void native_kernels_t::conv_nhwc(void const *filts, float const *biases, void co
   }
   void *params[] = {&ga};
   hip_err_chk(host->nh_launch(k.func, (uint32_t)(ga.tiles_i * ga.tiles_j * ga.splitk), 1, (uint32_t)cfg.threads(), params), "hipModuleLaunchKernel(conv_nhwc_bf16)");
-  if (cfg.SPLITK > 1) {
+  if (cfg.SPLITK > 1 && !p.ksl) {
     plan_t rp; rp.nhwc = true; rp.bf16 = true; rp.kname = "bodahip_nhwc_splitk_reduce";
     rp.defs = {"-DREDUCE_ONLY=1", string("-DRELU=") + (g.relu ? "1" : "0"), string("-DOUT_F32=") + (out_f32 ? "1" : "0")};
     kernel_t &rk = get_kernel(impl, host, rp);
@@ -1620,28 +1701,27 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
     bool const multi = op.has_func_name() && op.get_func_name() == "hip_conv_nhwc_multi";
     if (op.has_func_name() && op.get_func_name() == "hip_conv_nhwc_set") {   // the wrapper kernel of the members' specialisations (and the kernels of members that stay alone)
       int const n = (int)op.get_dims("multi").dsz("n"); bool const out_f32 = op.get_dims(op.has("out_0") ? "out_0" : "out_0_0").tn == "float";
-      std::vector<plan_t> plans; std::vector<plan_t const *> variants; std::vector<string> vkeys; int minw = 8; size_t bytes = 0; string desc;
+      std::vector<plan_t> plans; std::vector<double> costs; size_t bytes = 0; string desc;
       for (int m = 0; m < n; ++m) { string const sfx = "_" + std::to_string(m);
+        bool const relu_m = op.has("relu_mask") ? (((op.get_u32("relu_mask") >> m) & 1u) != 0) : relu;   // (per member, fused members included)
+        set_member_in_t mi; memset(&mi, 0, sizeof(mi));
         if (op.has("grp" + sfx)) {   // a horizontally fused member
           dims_t const &grp = op.get_dims("grp" + sfx);
-          conv_geom_t const gg = geom_from_dims(op.get_dims("filts" + sfx), op.get_dims("in" + sfx), op.get_dims("out_0" + sfx), op.get_dims("stride" + sfx), op.get_dims("in_pad" + sfx), relu);
-          plans.push_back(plan_conv_nhwc(gg, num_cus, string(), out_f32, (int)grp.dims(grp.sz() - 1))); continue;
+          mi.g = geom_from_dims(op.get_dims("filts" + sfx), op.get_dims("in" + sfx), op.get_dims("out_0" + sfx), op.get_dims("stride" + sfx), op.get_dims("in_pad" + sfx), relu_m);
+          mi.grp_pad = (int)grp.dims(grp.sz() - 1);
+        } else {
+          dims_t f = op.get_dims("filts" + sfx); mi.patch_filts = f.sz() == 5;
+          if (mi.patch_filts) f = dims_t({f.dims(3), f.dims(1), f.dims(2), f.dims(0) * 8}, {"out_chan", "y", "x", "in_chan"}, f.tn);
+          mi.g = geom_from_dims(f, op.get_dims("in" + sfx), op.get_dims("out" + sfx), op.get_dims("stride" + sfx), op.get_dims("in_pad" + sfx), relu_m);
+          mi.pool = apply_pool_window(op, sfx, mi.g, "hip_conv_nhwc_set");
         }
-        dims_t f = op.get_dims("filts" + sfx); bool const pf = f.sz() == 5;
-        if (pf) f = dims_t({f.dims(3), f.dims(1), f.dims(2), f.dims(0) * 8}, {"out_chan", "y", "x", "in_chan"}, f.tn);
-        bool const relu_m = op.has("relu_mask") ? (((op.get_u32("relu_mask") >> m) & 1u) != 0) : relu;
-        conv_geom_t g = geom_from_dims(f, op.get_dims("in" + sfx), op.get_dims("out" + sfx), op.get_dims("stride" + sfx), op.get_dims("in_pad" + sfx), relu_m);
-        bool const pool_m = apply_pool_window(op, sfx, g, "hip_conv_nhwc_set");
-        plans.push_back(pf ? plan_conv_nhwc_patch(g, num_cus, string(), out_f32, pool_m) : plan_conv_nhwc(g, num_cus, string(), out_f32, 0, false)); }
-      for (plan_t const &q : plans) {
-        if (q.cfg.threads() != 256) { if (!arch.empty()) bytes += compile_plan(q, arch, &log).size(); desc += " alone:" + q.kname + ":" + q.cfg.str(); continue; }
-        string key = q.kname; for (auto const &d : q.defs) key += " " + d;
-        if (std::find(vkeys.begin(), vkeys.end(), key) == vkeys.end()) { vkeys.push_back(key); variants.push_back(&q); desc += " " + q.kname + ":" + q.cfg.str(); }
-        minw = std::min(minw, q.cfg.MINW);
-      }
-      if (plan_out) *plan_out = "bodahip_conv_nhwc_set variants=" + std::to_string(variants.size()) + desc;
+        plans.push_back(plan_set_member(mi, num_cus, out_f32)); costs.push_back(set_tile_cost(mi, plans.back())); }
+      set_layout_t const L = layout_set(plans, costs);   // (the ordering, variant numbering and lone-member rule of conv_nhwc_set)
+      for (int m : L.alone) { plan_t const &q = plans[(size_t)m]; if (!arch.empty()) bytes += compile_plan(q, arch, &log).size(); desc += " alone:" + q.kname + ":" + q.cfg.str(); }
+      for (plan_t const *q : L.variants) desc += " " + q->kname + ":" + q->cfg.str();
+      if (plan_out) *plan_out = "bodahip_conv_nhwc_set variants=" + std::to_string(L.variants.size()) + desc;
       if (arch.empty()) return 0;
-      if (variants.size() >= 1) bytes += hiprtc_compile(set_kernel_source(variants, 256, std::max(1, minw)), "bodahip_conv_nhwc_set", arch, vect_string(), &log, true).size();
+      if (L.variants.size() >= 1) bytes += hiprtc_compile(set_kernel_source(L.variants, 256, std::max(1, L.minw)), "bodahip_conv_nhwc_set", arch, vect_string(), &log, true).size();
       return bytes;
     }
     conv_geom_t g; memset(&g, 0, sizeof(g));
@@ -1689,7 +1769,8 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
   if (arch.empty()) return 0;
   size_t const n = compile_plan(p, arch, &log).size();
   if (p.patch16) { plan_t fp; fp.patch16 = true; fp.bf16 = true; fp.kname = "bodahip_filt_bf16"; fp.defs = {"-DFILT_ONLY=1"}; compile_plan(fp, arch, &log); }
-  if (p.cfg.SPLITK > 1 && p.nhwc) {
+  if (p.ksl) {   // (K slices reduced inside the launch: no second kernel)
+  } else if (p.cfg.SPLITK > 1 && p.nhwc) {
     plan_t rp; rp.nhwc = true; rp.bf16 = true; rp.kname = "bodahip_nhwc_splitk_reduce";
     bool const relu = op.has("conv_has_relu") ? (op.get_u32("conv_has_relu") != 0) : true;
     rp.defs = {"-DREDUCE_ONLY=1", string("-DRELU=") + (relu ? "1" : "0"), string("-DOUT_F32=") + ((op.get_dims("out").tn == "float") ? "1" : "0")};

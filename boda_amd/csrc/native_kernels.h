@@ -26,6 +26,7 @@ namespace bodahip {
 
 void hip_err_chk(hipError_t e, char const *what);
 std::vector<char> hiprtc_compile(string const &src, string const &name, string const &arch, vect_string const &opts, string *log_out, bool use_cache);
+void hiprtc_compile_stats(uint64_t *hits, uint64_t *misses, double *compile_ms);   // process-wide: code objects from the on-disk cache / compiled, time spent compiling
 string cucl_prelude();
 string default_cache_dir();
 

@@ -83,6 +83,7 @@ ABI = {  # symbol -> (restype, argtypes); every symbol include/bodahip.h declare
     "bodahip_graph_end_deps": (C.c_int, [_ctxp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "bodahip_graph_destroy": (C.c_int, [_ctxp, C.c_uint32]),
     "bodahip_get_stream": (C.c_int, [_ctxp, C.POINTER(C.c_void_p)]),
+    "bodahip_compile_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "bodahip_get_device_info": (C.c_int, [_ctxp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bodahip_set_tune": (C.c_int, [_ctxp, C.c_char_p, C.c_char_p]),
     "bodahip_last_launch": (C.c_int, [_ctxp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
@@ -417,6 +418,13 @@ def explain_plan(op: Op, num_cus: int = 256, tile: str = "") -> str:
     buf = C.create_string_buffer(1 << 14)
     _chk(_lib.bodahip_explain_plan(op.to_str().encode(), num_cus, tile.encode(), buf, 1 << 14))
     return buf.value.decode()
+
+
+def compile_stats() -> dict:
+    """What run-time compilation cost this process so far: code objects served from the on-disk cache, compiled by hiprtc, and the time that took."""
+    h = C.c_uint64(); m = C.c_uint64(); ms = C.c_double()
+    _chk(_lib.bodahip_compile_stats(C.byref(h), C.byref(m), C.byref(ms)))
+    return {"cache_hits": int(h.value), "compiled": int(m.value), "compile_ms": float(ms.value)}
 
 
 def parse_op_native(line: str) -> str:

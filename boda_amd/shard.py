@@ -59,6 +59,39 @@ def broadcast_weights(tensors: Sequence, src: int = 0) -> None:
         dist.broadcast(t, src=src)
 
 
+def tensor_digest(t) -> int:
+    """A 64-bit position-sensitive digest of a torch tensor's BYTES (any dtype / device): sum over its bytes, taken as little-endian 16-bit words w_i, of
+    w_i * (i mod 65521 + 1), wrapped to int64.  Not cryptographic -- it tells a replicated weight tensor from one that was not replicated (zeros, another rank's
+    pattern, a shifted copy)."""
+    import torch
+    b = t.contiguous().view(torch.uint8).reshape(-1)
+    if b.numel() % 2:
+        b = torch.cat([b, torch.zeros(1, dtype=torch.uint8, device=b.device)])
+    w = b.view(torch.int16).to(torch.int64) & 0xffff
+    idx = torch.arange(w.numel(), dtype=torch.int64, device=w.device) % 65521 + 1
+    return int((w * idx).sum().item())
+
+
+def verify_replicated(tensors: Sequence, what: str = "weights") -> bool:
+    """After broadcast_weights: every rank digests every tensor, the digests are all-gathered (8 bytes per tensor and rank) and compared ON EVERY RANK.  A mismatch
+    raises RtErr naming the first tensor that differs and the ranks that disagree with rank 0; -> True when all ranks hold the same bytes (also with one rank)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return True
+    mine = torch.tensor([tensor_digest(t) for t in tensors], dtype=torch.int64)
+    dev = tensors[0].device if (len(tensors) and dist.get_backend() == "nccl") else torch.device("cpu")
+    mine = mine.to(dev)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    ref = parts[0].cpu()
+    for r, p_ in enumerate(parts):
+        bad = (p_.cpu() != ref).nonzero().reshape(-1)
+        if bad.numel():
+            raise RtErr(f"verify_replicated: {what} tensor #{int(bad[0])} on rank {r} differs from rank 0 after the broadcast (digest {int(p_.cpu()[bad[0]])} vs {int(ref[bad[0]])})")
+    return True
+
+
 def gather_outputs(local: np.ndarray, op_type: str, arg: str, dst: int = 0):
     """Host-side gather of per-rank output arrays into the global tensor on rank `dst` (None elsewhere)."""
     import torch

@@ -153,6 +153,9 @@ int bodahip_prebuild(const char *op_lexp, const char *arch, int num_cus, const c
 /* the planner's decision for an annotated op, without compiling or touching a device: "<kernel> <tile> <-D options ...>"
  * (variant / blocking selection is host logic: the counterpart of add_codegen_annotations' choice, src/cnn_op.cc:16-378) */
 int bodahip_explain_plan(const char *op_lexp, int num_cus, const char *tile, char *plan_buf, size_t plan_buf_sz);
+/* what run-time compilation cost this process so far (the reference publishes it per run: doc/ops-prof-and-wis-ana-usage-notes.txt:9-10, INSTALL.md:283; its compile is
+ * nvrtc_compute_t::compile, src/nvrtc_util.cc:216-238): code objects served from the on-disk cache, code objects hiprtc had to compile, milliseconds spent compiling */
+int bodahip_compile_stats(uint64_t *cache_hits_out, uint64_t *compiled_out, double *compile_ms_out);
 
 #ifdef __cplusplus
 }

@@ -65,9 +65,12 @@ def test_planner_choices():
     assert "-DCG=2" in plan((64, 112, 14, 14, 224, 3, 3, 1, 1))                              # 14 groups: 7 x 18 slots rather than 4 x 36
     assert plan((64, 256, 56, 56, 64, 1, 1, 1, 0))[0] == plan((64, 128, 28, 28, 128, 3, 3, 2, 1))[0] == "bodahip_conv_nhwc_bf16"   # 1x1, and stride 2 in x: implicit GEMM
     assert plan((64, 128, 4, 4, 1024, 4, 4, 1, 0))[0] == "bodahip_conv_nhwc_bf16"            # whole-input kernel (an fc layer): implicit GEMM + K slices
-    fc = plan((64, 2048, 1, 1, 1000, 1, 1, 1, 0))                                # 64 output rows, K = 2048: K slices + reduce pass
-    assert "-DSPLITK=1" in fc and "_s" in fc[1]
-    assert "-DSPLITK=1" not in plan((64, 1024, 14, 14, 256, 1, 1, 1, 0))        # 3.2 M outputs: the fp32 partial tiles would cost more than they save
+    fc = plan((64, 2048, 1, 1, 1000, 1, 1, 1, 0))                                # 64 output rows, K = 2048: K slices, reduced inside the launch (round 5: KSL)
+    assert any(o.startswith("-DKSL=") for o in fc) and "-DSPLITK=1" not in fc and "_s" in fc[1]
+    big = plan((64, 1024, 14, 14, 256, 1, 1, 1, 0))
+    assert "-DSPLITK=1" not in big and not any(o.startswith("-DKSL=") for o in big)        # 3.2 M outputs: the fp32 partial tiles would cost more than they save
+    # small maps (14 x 14 / 7 x 7 at 64 images) are latency-bound: 64-deep K steps, ragged taps included (480 channels = 7.5 steps); large maps keep the 32-deep rules
+    assert "-DBK=64" in plan((64, 512, 14, 14, 128, 1, 1, 1, 0)) and "-DBK=64" in plan((64, 480, 14, 14, 96, 1, 1, 1, 0)) and "-DBK=32" in plan((64, 192, 28, 28, 96, 1, 1, 1, 0))
     assert "-DOUT_F32=1" in plan((2, 64, 8, 8, 64, 3, 3, 1, 1), hip_out="f32")
     t = plan((2, 64, 8, 8, 64, 3, 3, 1, 1), hip_tile="64x64x32x2x2x2x2x32x3", hip_patch=0)
     assert t[1].startswith("64x64x32_w2x2_s2") and "-DNBUF=3" in t
@@ -192,8 +195,8 @@ def test_level_set_annotation_and_wrapper_kernel():
     assert rtc.parse_op_native(m.to_str()) == m.to_str()
     plan = rtc.explain_plan(m)
     assert plan.startswith("bodahip_conv_nhwc_set variants=3 ") and plan.count("bodahip_conv_nhwc_patch_bf16:") == 2 and plan.count("bodahip_conv_nhwc_bf16:") == 1
-    for a, part in zip(annos, plan.split()[2:]):      # every member's plan is the one its own launch takes (K slices apart)
-        assert rtc.explain_plan(a).split()[1] == part.split(":")[1] or "_s" in rtc.explain_plan(a).split()[1]
+    # every member's plan is the one its own launch takes; the wrapper lists them longest tile first (the order the run builds it in: one code object for both)
+    assert sorted(part.split(":")[1] for part in plan.split()[2:]) == sorted(rtc.explain_plan(a).split()[1] for a in annos)
     assert rtc.prebuild(m) > 20000
     # two members on the same plan share one instantiation
     twin = nhwc.annotate_set([annos[2], add_codegen_annotations(_conv_op(*shapes[2]), T)])

@@ -52,7 +52,15 @@ def _worker(rank, world, port, q):
         else:  # garbage until the broadcast
             filts = np.full((g["OC"], g["C"], g["KH"], g["KW"]), 1e9, np.float32); biases = np.full((g["OC"],), -1e9, np.float32)
         tf, tb = torch.from_numpy(filts), torch.from_numpy(biases)
+        from boda_amd.shard import verify_replicated, tensor_digest
+        from boda_amd.op import RtErr
+        try:   # before the broadcast the ranks hold different bytes: the check must say so, on every rank
+            verify_replicated([tf, tb]); res["caught_unequal"] = False
+        except RtErr:
+            res["caught_unequal"] = True
         broadcast_weights([tf, tb], src=0)
+        res["verified"] = verify_replicated([tf, tb])          # ... and after it the same bytes everywhere
+        res["digest_position_sensitive"] = tensor_digest(torch.tensor([1.0, 2.0])) != tensor_digest(torch.tensor([2.0, 1.0]))
         out = bo.conv_fwd(loc_in, tf.numpy(), tb.numpy(), (1, 1), (1, 1), True)
         full = gather_outputs(out, "Convolution", "out")
         if rank == 0:
@@ -91,4 +99,6 @@ def test_two_rank_gloo_sharded_equals_unsharded():
     for rank, res, err in got:
         assert err is None, err
     r0 = [res for rank, res, err in got if rank == 0][0]
-    assert r0 == {"conv_equal": True, "sgemm_equal": True}
+    assert r0 == {"conv_equal": True, "sgemm_equal": True, "caught_unequal": True, "verified": True, "digest_position_sensitive": True}
+    r1 = [res for rank, res, err in got if rank == 1][0]
+    assert r1["caught_unequal"] and r1["verified"]      # (the comparison runs on every rank)
