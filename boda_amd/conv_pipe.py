@@ -597,8 +597,8 @@ class ConvPipeFwd:
                 pool, lrn = (a, b) if a.type == "Pooling" else (b, a); lds_pair = False
                 if a.type == "LRN" and self.fuse_pool_lrn == "pool_first":     # LRN first: through LDS (the LRN evaluated once per input chunk) where that kernel applies; the thread-per-
                     # output kernel evaluates it per window position -- compute-bound, level with or behind the two kernels -- and is only taken on request (fuse_pool_lrn=True)
-                    single = (getattr(rtc, "num_devices", None) is None) or ((rtc.num_devices() or 1) == 1)      # (a workgroup kernel: the multi-device backend shards per-element functions only)
-                    if not (single and os.environ.get("BODAHIP_NO_LRN_POOL_LDS") is None and _nhwc.lrn_pool_lds_rows(_nhwc.nhwc_dims(cp.nodes[lrn.bot]), _nhwc.nhwc_dims(cp.nodes[pool.top]), pool.kern_sz, pool.stride)):
+                    # (a workgroup kernel; since round 5 the multi-device backend shards it by img like the per-element functions: it declares its group index)
+                    if not (os.environ.get("BODAHIP_NO_LRN_POOL_LDS") is None and _nhwc.lrn_pool_lds_rows(_nhwc.nhwc_dims(cp.nodes[lrn.bot]), _nhwc.nhwc_dims(cp.nodes[pool.top]), pool.kern_sz, pool.stride)):
                         continue
                     lds_pair = True
                 if pool.bot != cp.in_node and _nhwc.pool_lrn_fusable(_nhwc.nhwc_dims(cp.nodes[pool.bot]), _nhwc.nhwc_dims(cp.nodes[pool.top]), pool.kern_sz, pool.stride, pool.in_pad, int(pool.avg_pool), lrn.lrn[0], lrn.lrn[1], lrn.lrn[3]):

@@ -130,7 +130,9 @@ std::vector<char> hiprtc_compile(string const &src, string const &name, string c
 // A backend that is one device of a multi-device backend (hip_multi.cc) runs generated functions over a SHARD of their 1-D index space:
 // GLOB_ID_1D then starts at the shard's first id, and threads past the shard's last id see U32_MAX -- which the function's own range test
 // (`if( GLOB_ID_1D >= %(..._dims_prod) ) { return; }`, present in every per-element template of the reference: blks*tpb overshoots) sends
-// home.  Both bounds are read from a module global that the launch sets on the stream.  {0, U32_MAX} = the whole index space.
+// home.  Both bounds are read from a module global that the launch sets on the stream.  {0, U32_MAX} = the whole index space.  A WORKGROUP function whose
+// groups enumerate (img, ...) batch-major (`// CUCL IX GRP_ID_1D <arg> n=<threads>`) shards the same way: its first id is a multiple of the workgroup size, and
+// GRP_ID_1D starts at the shard's first group.
 static char const *const hip_shard_gid_decls = R"rstr(
 #undef GLOB_ID_1D
 __device__ uint32_t bodahip_gid[2] = { 0u, 0xffffffffU };
@@ -139,6 +141,8 @@ static __device__ __forceinline__ uint32_t bodahip_glob_id( void ) {
   return ( i <= bodahip_gid[1] ) ? i : 0xffffffffU;
 }
 #define GLOB_ID_1D (bodahip_glob_id())
+#undef GRP_ID_1D
+#define GRP_ID_1D (blockIdx.x + bodahip_gid[0] / blockDim.x)
 )rstr";
 
 string cucl_prelude() { return hip_base_decls; }

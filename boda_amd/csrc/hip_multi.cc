@@ -54,6 +54,11 @@ struct gen_func_t {
   string n_arg;            // `n=<arg>`: the ids enumerate <by-value uint32 arg> items in all, batch-major over <ix_arg>'s leading `img` (kernels that walk 16-byte chunks or
                            // several outputs per thread: ids per image = that count / images -- the dims of <ix_arg> alone cannot say it)
   bool wave_local = false; // `wave_local`: LOC_ID_1D is used only as the lane number, for shuffles between consecutive ids (a shard's first id need not start a wave)
+  bool grp_ix = false;     // `// CUCL IX GRP_ID_1D <arg> n=<threads>`: a WORKGROUP function (LDS, barriers) whose groups enumerate (img, ...) batch-major -- n / tpb groups in
+                           // all, the same number per image: a shard is a contiguous run of whole workgroups (the LRN -> Pooling pass through LDS, boda_amd/nhwc.py)
+  // `// CUCL SHARD2 <var arg> size=<by-value arg> off=<by-value arg>`: the function walks a tensor sharded along its SECOND dim (sgemm a, K:M -- every device holds
+  // K x M_i packed); per device the two by-value uint32 arguments become the shard's size and first index (gen_data_sgemm_a: M, m_off; its M_glob stays)
+  string s2_arg, s2_size, s2_off;
 };
 static bool ident_char(char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_'; }
 static bool has_token(string const &s, char const *tok) {
@@ -81,15 +86,27 @@ static gen_func_t scan_gen_func(string const &all_src, string const &func_name) 
     size_t const eol = body.find('\n', p);
     std::istringstream is(body.substr(p + strlen(key), (eol == string::npos) ? string::npos : eol - p - strlen(key)));
     string ix, arg, opt; is >> ix >> arg;
-    if (ix != "GLOB_ID_1D") { g.uses_group = true; continue; }
-    if (g.has_ix) { g.has_ix = false; g.uses_group = true; return g; }   // (two declarations of the same index: not a form we know)
-    g.has_ix = !arg.empty(); g.ix_arg = arg;
+    if (ix != "GLOB_ID_1D" && ix != "GRP_ID_1D") { g.uses_group = true; continue; }
+    if (g.has_ix) { g.has_ix = false; g.uses_group = true; g.grp_ix = false; return g; }   // (two declarations of the same index: not a form we know)
+    g.has_ix = !arg.empty(); g.ix_arg = arg; g.grp_ix = (ix == "GRP_ID_1D");
     while (is >> opt) {
       if (startswith(opt, "use_dims=")) {
         string cur; for (char c : opt.substr(9)) { if (c == ':') { if (!cur.empty()) g.use_dims.push_back(cur); cur.clear(); } else cur.push_back(c); }
         if (!cur.empty()) g.use_dims.push_back(cur);
       } else if (startswith(opt, "n=")) g.n_arg = opt.substr(2);
       else if (opt == "wave_local") g.wave_local = true;
+    }
+  }
+  if (g.grp_ix && g.n_arg.empty()) { g.has_ix = false; g.grp_ix = false; }   // (a group index needs its count)
+  {
+    char const *const k2 = "// CUCL SHARD2 ";
+    size_t const p2 = body.find(k2);
+    if (p2 != string::npos) {
+      size_t const eol = body.find('\n', p2);
+      std::istringstream is(body.substr(p2 + strlen(k2), (eol == string::npos) ? string::npos : eol - p2 - strlen(k2)));
+      string opt; is >> g.s2_arg;
+      while (is >> opt) { if (startswith(opt, "size=")) g.s2_size = opt.substr(5); else if (startswith(opt, "off=")) g.s2_off = opt.substr(4); }
+      if (g.s2_size.empty() || g.s2_off.empty()) g.s2_arg.clear();
     }
   }
   if (g.wave_local && g.has_ix) {   // only LOC_ID_1D (the lane number) is excused; real workgroup cooperation is not
@@ -344,7 +361,11 @@ struct hip_multi_compute_t : public rtc_compute_t {
     string const &fn = rfc.rtc_func_name;
     gen_func_t const &g = must_find(func_gen, fn);
     string const why = "multi-device backend: generated function '" + fn + "' takes sharded vars but ";
-    if (g.uses_group) unsup_err(why + "uses the workgroup (LOC_ID_1D / GRP_ID_1D / LOCSHAR_MEM / BARRIER_SYNC): only per-element functions run on shards");
+    if (!g.s2_arg.empty()) {   // a tensor sharded along its second dim, walked by a function that takes the shard's size and first index by value
+      auto vi = rfc.arg_map.find(g.s2_arg);
+      if (vi != rfc.arg_map.end() && vi->second.is_valid() && vi->second.is_var() && must_find(vis, vi->second.n).shard_dim == 1) return run_generated_on_dim2_shards(rfc, g);
+    }
+    if (g.uses_group && !g.grp_ix) unsup_err(why + "uses the workgroup (LOC_ID_1D / GRP_ID_1D / LOCSHAR_MEM / BARRIER_SYNC) without declaring a group index (`// CUCL IX GRP_ID_1D <arg> n=<threads>`): only per-element functions and such workgroup functions run on shards");
     if (!g.has_ix) unsup_err(why + "its source declares no `// CUCL IX GLOB_ID_1D <arg>` index: the backend cannot tell which ids belong to which image");
     uint32_t T = 0;
     for (auto const &kv : rfc.arg_map) {
@@ -376,6 +397,7 @@ struct hip_multi_compute_t : public rtc_compute_t {
     if (!lead_ok) unsup_err(why + "its index over '" + g.ix_arg + "' " + ixd.pretty_str() + " does not lead with the sharded batch dim img=" + std::to_string(T));
     if (W * T >= 0xffffffffull || !W) unsup_err(why + "its index space does not fit 32 bits");
     if (!rfc.tpb) rt_err("boda/rtc: can't launch kernel; tpb is zero: rtc_func_name=" + fn);
+    if (g.grp_ix && (W % rfc.tpb)) unsup_err(why + "its " + std::to_string(W) + " ids per image are not whole workgroups of " + std::to_string(rfc.tpb));
     std::vector<uint32_t> ids;
     for (size_t i = 0; i < n(); ++i) {
       uint32_t const b = chunk_begin(T, i), e = chunk_begin(T, i + 1);
@@ -387,7 +409,37 @@ struct hip_multi_compute_t : public rtc_compute_t {
         if (v.shard_dim == 0) bias[kv.second.n] = -(int64_t)((uint64_t)b * (v.dims.dims_prod() / T) * v.dims.tsz());
       }
       uint64_t const work = (uint64_t)(e - b) * W;
-      ids.push_back(hip_compute_run_shard(subs[i].get(), rfc, (uint32_t)((work + rfc.tpb - 1) / rfc.tpb), (uint32_t)(b * W), (uint32_t)(e * W - 1), bias));
+      // (a workgroup function: whole groups only, so nothing is cut at the shard's end -- and its threads must not see U32_MAX ids before their barriers)
+      ids.push_back(hip_compute_run_shard(subs[i].get(), rfc, (uint32_t)((work + rfc.tpb - 1) / rfc.tpb), (uint32_t)(b * W), g.grp_ix ? 0xffffffffu : (uint32_t)(e * W - 1), bias));
+    }
+    if (capturing) return kCapturedCallId;
+    calls.push_back(ids);
+    return (uint32_t)calls.size() - 1;
+  }
+  // sgemm `a` (K:M, split along M: device i holds K x M_i packed) filled by a function that takes the extent and the first index of what it walks by value
+  uint32_t run_generated_on_dim2_shards(rtc_func_call_t const &rfc, gen_func_t const &g) {
+    string const &fn = rfc.rtc_func_name;
+    string const why = "multi-device backend: generated function '" + fn + "' (second-dim shards of '" + g.s2_arg + "') ";
+    for (auto const &kv : rfc.arg_map)
+      if (kv.first != g.s2_arg && kv.second.is_valid() && kv.second.is_var() && must_find(vis, kv.second.n).shard_dim >= 0) unsup_err(why + "takes another sharded var '" + kv.second.n + "'");
+    auto si = rfc.arg_map.find(g.s2_size), oi = rfc.arg_map.find(g.s2_off);
+    auto u32_ok = [](std::map<string, rtc_arg_t>::const_iterator it, std::map<string, rtc_arg_t> const &m) { return it != m.end() && it->second.is_valid() && !it->second.is_var() && it->second.v->rp_elems() && it->second.v->dims.tsz() == 4; };
+    if (!u32_ok(si, rfc.arg_map) || !u32_ok(oi, rfc.arg_map)) rt_err(why + "binds no by-value 32-bit '" + g.s2_size + "' / '" + g.s2_off + "'");
+    multi_var_t const &v = must_find(vis, rfc.arg_map.find(g.s2_arg)->second.n);
+    uint32_t const M = v.dims.dims(1), K = v.dims.dims(0);
+    if (*(uint32_t const *)si->second.v->rp_elems() != M) rt_err(why + "was called with " + g.s2_size + " = " + std::to_string(*(uint32_t const *)si->second.v->rp_elems()) + " for a var of " + std::to_string(M) + " columns");
+    uint32_t const off0 = *(uint32_t const *)oi->second.v->rp_elems();
+    if (!rfc.tpb) rt_err("boda/rtc: can't launch kernel; tpb is zero: rtc_func_name=" + fn);
+    std::vector<uint32_t> ids;
+    for (size_t i = 0; i < n(); ++i) {
+      uint32_t const b = chunk_begin(M, i), e = chunk_begin(M, i + 1);
+      if (e == b) { ids.push_back(kNoCall); if (capturing) cap_skipped = true; continue; }
+      rtc_func_call_t sub = rfc;
+      auto put = [&](string const &an, uint32_t val) { sub.arg_map[an] = rtc_arg_t(make_scalar_nda<uint32_t>(val)); };   // (a fresh by-value nda: the caller's is shared)
+      put(g.s2_size, e - b); put(g.s2_off, off0 + b);
+      uint64_t const work = (uint64_t)K * (e - b);
+      sub.blks = (uint32_t)((work + rfc.tpb - 1) / rfc.tpb);
+      ids.push_back(subs[i]->run(sub));
     }
     if (capturing) return kCapturedCallId;
     calls.push_back(ids);

@@ -406,7 +406,8 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
     static cand_t const cands[] = {{128, 128, 2, 2, 2}, {64, 128, 1, 4, 2}, {64, 64, 2, 2, 2}, {32, 128, 1, 4, 2}, {128, 256, 2, 4, 1}, {256, 256, 4, 4, 1}};
     long const nk = (kc + c.BK / 8 - 1) / (c.BK / 8);
     bool const two_kernel = getenv("BODAHIP_NHWC_SPLITK2") != nullptr && !grp_pad;
-    bool const may_split = getenv("BODAHIP_NO_NHWC_SPLITK") == nullptr && allow_split && !(grp_pad && two_kernel);
+    // (no slices for a fused sibling group: its outputs stay bit-identical to its members' own launches, which may slice differently or not at all)
+    bool const may_split = getenv("BODAHIP_NO_NHWC_SPLITK") == nullptr && allow_split && !grp_pad;
     double best = 1e30;
     for (cand_t const &cd : cands) {
       if (grp_pad && (cd.bi > grp_pad || grp_pad % cd.bi)) continue;
@@ -507,6 +508,18 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
     if (!parse_tile(tile, c)) rt_err("bad conv_tile '" + tile + "'");
     c.MT = 32; c.PF = 1;
     if (c.SPLITK < 1 || c.SPLITK > 32 || (c.SPLITK > 1 && !adirect)) unsup_err("hip_conv_nhwc (patch form of filts): unsupported K slices " + std::to_string(c.SPLITK));
+  } else if (pool && getenv("BODAHIP_NHWC_POOL_R4PLAN") == nullptr) {
+    // The fused-pooling form is bound by its LDS reads: a B fragment is KH x KW patch reads + maxima, and a wave forms it for every pel block of its tile -- so waves
+    // must not SHARE pels (WI = 1: the 4 x 1 and 2 x 2 layouts redo the window maxima four / two times per tile) and the wave tile is one pel block wide.  Round 5,
+    // GoogLeNet's nine pool projections at 64 images, us per launch (tools/pool_tile_ab.sh; round-4 plan | 64x128 as 1 x 4 waves): 24.5 | 15.1 (256 -> 64 at 28 x 28),
+    // 26.0 | 17.1 (528 -> 128 at 14 x 14); level elsewhere.  Tile-starved layers with a long K (832 -> 128 at 7 x 7: 50 tiles, 26 steps -- every workgroup pulls 400 KB
+    // through ONE CU's load path) take 64 x 64 tiles and four K slices reduced inside the launch: 27.5 -> 15.6 us.
+    c.BI = (g.OC <= 32) ? 32 : 64; c.BJ = 128; c.WI = 1; c.WJ = 4; c.MINW = 2;
+    long const tiles = (long)((g.OC + c.BI - 1) / c.BI) * ((Nj + c.BJ - 1) / c.BJ), steps = (ncg + 3) / 4;
+    if (tiles * 4 < num_cus && steps >= 16 && getenv("BODAHIP_NO_NHWC_SPLITK") == nullptr) { c.BI = 64; c.BJ = 64; c.WI = 2; c.WJ = 2; c.SPLITK = 4; }
+    cg = std::min(ncg, 4);
+    while (cg > 1 && lds_cg(c.BI, c.BJ, cg) > 80 * 1024) cg = (cg + 1) / 2;
+    if (cg < 4) { cg = std::min(ncg, 4); while (cg > 1 && lds_cg(c.BI, c.BJ, cg) > 160 * 1024) cg = (cg + 1) / 2; }   // (narrow maps with a padded pitch: one workgroup per CU rather than twice the steps)
   } else if (!adirect) {
     // Narrow in out_chan, wide in pels: the filter tile -- the larger operand stream here -- is staged once per BJ pels.  score = padding efficiency x share of
     // the CUs that get a workgroup / operand bytes per flop (filter stream ~ 1/BJ, patch stream ~ 1/(4 BI)).  Measured on MI355X (tools/patch_sweep.sh, 64

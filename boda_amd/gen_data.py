@@ -31,6 +31,8 @@ _SGEMM_T = """
 // m_off / M_glob: this var holds columns [m_off, m_off+M) of a global K:M_glob tensor (batch-axis shard); unsharded: 0 / M
 CUCL_GLOBAL_KERNEL void gen_data_sgemm_a%(SFX)( GASQ %(TN) * const a, uint32_t const mode, float const vi, uint32_t const K, uint32_t const M,
                                           uint32_t const m_off, uint32_t const M_glob ) {
+  // CUCL SHARD2 a size=M off=m_off
+  // (what lets a multi-device backend run the function on an `a` split along M: per device M and m_off become the shard's -- csrc/hip_multi.cc)
   uint32_t fin_mode = mode; if( fin_mode >= 100 ) { fin_mode = fin_mode / 100; }
   if( GLOB_ID_1D >= K*M ) { return; }
   uint32_t const k = GLOB_ID_1D / M; uint32_t const m = GLOB_ID_1D % M + m_off;

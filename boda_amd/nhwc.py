@@ -727,6 +727,8 @@ CUCL_GLOBAL_KERNEL __launch_bounds__(256) void @NAME@( GASQ bf16x8_t const * con
 LRN_POOL_LDS_SRC = """
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 CUCL_GLOBAL_KERNEL __launch_bounds__(@TPB@) void @NAME@( GASQ bf16x8_t const * const in, GASQ bf16x8_t * const out, uint32_t const n, float const alpha, float const beta, float const k ) {
+  // CUCL IX GRP_ID_1D in n=n
+  // (a workgroup = one (img, output-row group): groups enumerate images batch-major, n / TPB of them -- a multi-device backend shards them by img, csrc/hip_multi.cc)
   LOCSHAR_MEM bf16x8_t lds[@NROWS@*@W@*@C8@];
   uint32_t const blk = GRP_ID_1D, tid = LOC_ID_1D;
   if( blk*@TPB@u >= n ) { return; }

@@ -156,6 +156,28 @@ def test_gen_data_on_a_sharded_var_gives_the_global_pattern(multi):
         rtc.release_var("gin"); rtc.release_per_call_id_data()
 
 
+def test_gen_data_sgemm_a_on_a_var_sharded_along_its_second_dim(multi):
+    """sgemm `a` is K:M and shards along M (every device holds K x M_i packed).  gen_data_sgemm_a declares what it walks (`// CUCL SHARD2 a size=M off=m_off`), so the
+    backend runs it per device with the shard's extent and first column: the gathered tensor is the whole-tensor pattern (modes 5 and 600), and an sgemm on the
+    device-generated operands equals the oracle's (test/rtc/gen_data_sgemm_a.cucl; round-4 gap: refused with unsup_err)."""
+    from boda_amd import gen_data as gd
+    rtc, n = multi
+    if not getattr(rtc, "_gen_data_compiled", False):
+        rtc.compile(gd.func_infos()); rtc._gen_data_compiled = True
+    K, M = 37, 4 * n + 3          # (uneven shards; with n devices some hold one column more)
+    d = Dims(("K", "M"), (K, M), "float")
+    rtc.create_var_with_dims("ga", d)
+    try:
+        for mode in (5, 600):
+            rtc.run(gd.gen_call("sgemm", "a", "ga", d, mode, 0.0)); rtc.finish_and_sync()
+            assert np.array_equal(rtc.copy_var_to_nda("ga"), bo.gen_sgemm_a(K, M, mode)), mode
+        # as one rank's M-shard of a larger global problem (bench.py's multi-process form on top of a multi-device backend): offsets add up
+        rtc.run(gd.gen_call("sgemm", "a", "ga", d, 5, 0.0, shard_off=M, shard_glob=3 * M)); rtc.finish_and_sync()
+        assert np.array_equal(rtc.copy_var_to_nda("ga"), bo.gen_sgemm_a(K, 3 * M, 5)[:, M:2 * M])
+    finally:
+        rtc.release_var("ga"); rtc.release_per_call_id_data()
+
+
 @pytest.mark.parametrize("net,batch,ndev", [("nin", 16, 4), ("alexnet", 5, 3), ("nin-chain", 7, 3)])
 def test_full_net_forward_on_a_multi_device_backend_equals_single_device(single, net, batch, ndev):
     """BASELINE config 4 behind the boundary: the whole net through ConvPipeFwd on (be=hip,devices=0:0:..) -- inputs and weights generated on the
@@ -227,6 +249,8 @@ def test_channels_last_net_and_graph_replay_on_a_multi_device_backend(single, ne
                     assert np.array_equal(fwd._fetch(out), io[out])
                 if net == "googlenet":
                     assert len(fwd.level_sets) >= 9 and len(fwd.fused_pools) == 9 and len(fwd.groups) == 9
+                # round 5: the LRN -> Pooling pass through LDS -- a WORKGROUP function -- runs on the shards too (`// CUCL IX GRP_ID_1D in n=n`: whole workgroups per image)
+                assert sum(c.func == "nhwc_lrn_pool_lds" for c in fwd.fwd_calls) == {"googlenet": 1, "alexnet": 2}[net]
         finally:
             fwd.release(); rtc.release_per_call_id_data()
             if be:

@@ -106,12 +106,21 @@ def test_nhwc_conv_bf16_out_vs_oracle(be, shape):
 @pytest.mark.parametrize("tile", ["128x128x64x2x2", "128x128x32x2x2", "64x128x64x1x4", "64x64x32x2x2", "32x128x32x1x4", "32x64x64x1x2", "64x256x32x2x4x1", "256x128x32x4x2x1",
                                   "128x128x64x2x2x2x1x32x3", "64x128x32x1x4x2x1x32x4", "64x64x64x2x2x2x3", "128x128x32x2x2x2x2x32x3", "32x64x32x1x2x2x5"])
 def test_nhwc_conv_tiles_agree_with_oracle(be, tile):
+    from boda_amd import nhwc
     for shape in [(3, 40, 15, 15, 100, 3, 3, 1, 1), (2, 64, 9, 9, 200, 1, 1, 1, 0), (2, 3, 33, 33, 48, 7, 7, 2, 3)]:
         op = _conv_op(*shape)
         outs, prc = _run(be, op, OpTune(hip_tile=tile, hip_patch=0, **NHWC_F32))
         assert prc.launch["cfg"].startswith(tile.split("x")[0] + "x" + tile.split("x")[1] + "x" + tile.split("x")[2]), prc.launch
-        if len(tile.split("x")) >= 7 and int(tile.split("x")[6]) > 1:
-            assert f"_s{tile.split('x')[6]}" in prc.launch["cfg"], prc.launch     # K slices + the reduce pass
+        if len(tile.split("x")) >= 7 and int(tile.split("x")[6]) > 1:     # K slices, reduced inside the launch (round 5): the count is lowered until no slice is empty
+            g = op.conv_geom(); bk = int(tile.split("x")[2]); nk = -(-(g["KH"] * g["KW"] * (-(-g["C"] // 8))) // (bk // 8)); want = min(int(tile.split("x")[6]), nk)
+            while want > 1 and -(-nk // -(-nk // want)) != want:
+                want -= 1
+            import re
+            got = int((re.search(r"_s(\d+)", prc.launch["cfg"]) or [0, "1"])[1])
+            if nhwc.s2d_geom(g) is None:
+                assert got == want, prc.launch
+            else:       # (the space-to-depth form of a conv1-type layer has its own K steps: fewer taps on more channels)
+                assert 1 <= got <= int(tile.split("x")[6]), prc.launch
         _check_f32(op, outs, prc)
         outs, prc = _run(be, op, OpTune(hip_tile=tile, hip_patch=0, **NHWC))
         _check_bf16(op, outs, prc)
@@ -437,3 +446,28 @@ def test_multi_problem_launch_refuses_what_it_cannot_run(be):
         nhwc.annotate_multi([plain, f32])            # one output type per launch
     with pytest.raises(UnsupErr):
         nhwc.annotate_multi([])
+
+
+@pytest.mark.parametrize("shape,tile", [
+    ((4, 832, 7, 7, 128, 1, 1, 1, 0), "64x64x64x2x2x2x4x32x3"), ((4, 832, 7, 7, 130, 1, 1, 1, 0), "32x128x64x1x4x2x8x32x3"), ((2, 1024, 1, 1, 1000, 1, 1, 1, 0), "64x64x64x2x2x2x16x32x3"),
+    ((5, 160, 7, 7, 320, 3, 3, 1, 1), "64x64x0x2x2x2x2"), ((3, 192, 7, 7, 100, 3, 3, 1, 1), "128x64x0x4x1x2x3"), ((2, 48, 7, 7, 128, 5, 5, 1, 2), "64x128x0x2x2x2x2"),
+    ((2, 128, 4, 4, 1024, 4, 4, 1, 0), "64x64x64x2x2x2x8x32x3")], ids=lambda v: v if isinstance(v, str) else "x".join(str(x) for x in v))
+def test_k_slices_reduced_inside_the_launch(be, shape, tile):
+    """Round 5 (KSL of kernels/conv_nhwc_bf16.hip / conv_nhwc_patch_bf16.hip): the grid is tiles x slices, every slice publishes its raw fp32 accumulators write-through,
+    the workgroup that draws a tile's last ticket sums the slabs IN SLICE ORDER and runs the ordinary epilogue -- one kernel, no reduce pass.  Checked: against the oracle
+    (float and bf16 outputs), run-to-run bitwise (the order of the sum does not depend on who arrives last), and launch after launch on the same workspace (the tickets
+    are back at zero: eight launches in a row, the last one compared).  The slices of a tile run on different XCDs -- behind different, mutually incoherent L2s."""
+    from boda_amd import nhwc
+    op = _conv_op(*shape)
+    first = None
+    for rep in range(3):
+        for tune in (OpTune(hip_tile=tile, **NHWC_F32), OpTune(hip_tile=tile, **NHWC)):
+            anno = add_codegen_annotations(op, tune)
+            outs, prc = profile_rcg_call(be, anno, 5, 0.0, 8 if rep == 2 else 1, include_ins=True, tile=tile)
+            assert "_s" in prc.launch["cfg"] and prc.launch["kernel"] in ("bodahip_conv_nhwc_bf16", "bodahip_conv_nhwc_patch_bf16"), prc.launch
+            (_check_f32 if tune.hip_out == "f32" else _check_bf16)(op, outs, prc)
+            key = tune.hip_out
+            if first is None or key not in first:
+                first = dict(first or {}); first[key] = outs["out"].copy()
+            else:
+                assert np.array_equal(first[key], outs["out"]), (rep, key)
