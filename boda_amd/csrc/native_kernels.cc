@@ -290,20 +290,31 @@ static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string
     if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
     return p;
   }
-  check_cfg(p.cfg, false);
-  // 256x256 tiles of plain fp32 operands: kernels/sgemm_big_f32.hip -- eight multiplying waves + four staging waves, three LDS stages (BODAHIP_SGEMM_BIG = off | BKSxPF).
-  // cfg.WI x WJ = 3 x 4 stands for its twelve waves.
-  if (allow_big && batch == 1 && p.cfg.BI == 256 && p.cfg.BJ == 256 && p.cfg.MT == 32 && p.cfg.SPLITK == 1 && M % 4 == 0 && N % 4 == 0) {
+  // Plain fp32 operands on the staging-wave kernel (kernels/sgemm_big_f32.hip: eight multiplying waves + four staging waves, four LDS stages; BODAHIP_SGEMM_BIG = off |
+  // BKSxPF): 256 x 256 tiles where they fill the chip, and -- round 5 -- its 128 x 128 (two workgroups per CU), 256 x 128 and 128 x 256 forms.  cfg.WI x WJ = 3 x 4 stands for
+  // the twelve waves; an explicit tile asks for the kernel that way ("128x128x16x3x4x2").
+  bool const big_tile = (p.cfg.BI == 256 || p.cfg.BI == 128) && (p.cfg.BJ == 256 || p.cfg.BJ == 128);
+  bool const want_big = big_tile && ((p.cfg.WI == 3 && p.cfg.WJ == 4) || (p.cfg.BI == 256 && p.cfg.BJ == 256));
+  if (allow_big && batch == 1 && want_big && p.cfg.MT == 32 && p.cfg.SPLITK == 1 && M % 4 == 0 && N % 4 == 0) {
     char const *e = getenv("BODAHIP_SGEMM_BIG");
     if (!(e && string(e) == "off")) {
       int bks = 8, pf = 2;   // measured (MI355X, 12288^3 / 8192^3 / 6144^3, TF/s): gemm_conv_f32.hip on the same tile 140.2 / 140.4 / 133.6; 16x2 144.7 / 144.5 / 129.0; 8x2 145.1 / 144.8 / 137.7; 8x4 145.1 / 144.8 / 135.4; 16x4 142.0 / 142.2 / 136.5 (four LDS stages)
+      if (!tile.empty() && p.cfg.WI == 3 && p.cfg.BK >= 4 && p.cfg.BK <= 32 && p.cfg.BK % 4 == 0) bks = p.cfg.BK;   // (asked for by its own tile string: the K step too)
       if (e && *e) { if (sscanf(e, "%dx%d", &bks, &pf) != 2 || bks < 4 || bks > 32 || bks % 4 || (pf != 2 && pf != 4)) rt_err(string("bad BODAHIP_SGEMM_BIG '") + e + "' (off | BKSxPF)"); }
-      p.big = true; p.kname = "bodahip_sgemm_big_f32"; p.cfg.BK = bks; p.cfg.PF = pf; p.cfg.WI = 3; p.cfg.WJ = 4; p.cfg.MINW = 1;
+      if (bks * (p.cfg.BI / 4) % 256 || bks * (p.cfg.BJ / 4) % 256) bks = 8;   // (whole float4 units per staging thread: BKS x TB / 4 a multiple of 256)
+      int const minw = (p.cfg.BI == 128 && p.cfg.BJ == 128) ? ((!tile.empty() && p.cfg.MINW >= 1) ? std::min(p.cfg.MINW, 2) : 2) : 1;
+      p.big = true; p.kname = "bodahip_sgemm_big_f32"; p.cfg.BK = bks; p.cfg.PF = pf; p.cfg.WI = 3; p.cfg.WJ = 4; p.cfg.MINW = minw;
       p.defs = {"-DBKS=" + std::to_string(bks), "-DPF=" + std::to_string(pf)};
+      if (!(p.cfg.BI == 256 && p.cfg.BJ == 256)) {   // (the 256 x 256 form keeps its option string: its code objects stay the cached ones)
+        bool const tall = (p.cfg.BI == 256 && p.cfg.BJ == 128);    // 256 x 128: 4 x 2 multiplying waves of 64 x 64; the others 2 x 4 (128 x 128: 64 x 32; 128 x 256: 64 x 64)
+        p.defs.push_back("-DTBI=" + std::to_string(p.cfg.BI)); p.defs.push_back("-DTBJ=" + std::to_string(p.cfg.BJ));
+        p.defs.push_back(string("-DWI=") + (tall ? "4" : "2")); p.defs.push_back(string("-DWJ=") + (tall ? "2" : "4")); p.defs.push_back("-DMINW=" + std::to_string(minw));
+      }
       if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
       return p;
     }
   }
+  check_cfg(p.cfg, false);
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((M % 4 == 0) ? "0" : "1"));
   p.defs.push_back(string("-DJ_MODE=") + ((N % 4 == 0) ? "0" : "1"));
@@ -933,13 +944,31 @@ static sgemm_split_t plan_sgemm_split(uint32_t M, uint32_t N, uint32_t K, int nu
   return sp;
 }
 
+// the 256 x 128 form of the staging-wave kernel where its tiles deal out in (nearly) whole rounds -- see sgemm(); "" = not here
+static string sgemm_wide_tile(uint32_t M, uint32_t N, uint32_t K, long cus) {
+  if (M % 4 || N % 4 || K < 512 || getenv("BODAHIP_NO_SGEMM_256X128")) return string();
+  long const t256 = (long)((M + 255) / 256) * ((N + 255) / 256), t128 = (long)((M + 255) / 256) * ((N + 127) / 128);
+  double const eff = (double)t128 / (double)(((t128 + cus - 1) / cus) * cus);
+  return (t256 >= cus && eff >= 0.95) ? string("256x128x8x3x4x1") : string();
+}
+
 void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16, bool half) {
   if (!M || !N) return;
   size_t const esz = half ? 2 : 4;   // half: a / b / c stored as IEEE half, fp32 math (the reference's 16-bit-storage sgemm, src/cnn_codegen.cc:440-449)
   if (half && bf16) unsup_err("hip_sgemm_bf16: half-typed tensors are not supported (bf16 OPERANDS are made from float tensors)");
   if (!K) { hip_err_chk(hipMemsetAsync(c, 0, (size_t)M * N * esz, host->nh_stream()), "hipMemsetAsync"); return; }
   if (M > 0x7fffffffu || N > 0x7fffffffu || K > 0x7fffffffu) unsup_err("hip_sgemm: dims exceed int32");
-  if (!bf16 && !half && tune_of(impl, "sgemm_tile").empty()) {
+  string tile_for;   // experiments: BODAHIP_SGEMM_TILE_FOR="4096=256x128x8x3x4x1;5120=128x128x8x3x4x1": the tile of the square sgemm of that size (no two-level split)
+  if (char const *e = getenv("BODAHIP_SGEMM_TILE_FOR")) {
+    string const key = std::to_string(M) + "="; string const v = e; size_t const at = (";" + v).find(";" + key);
+    if (M == N && N == K && at != string::npos) { size_t const b = at + key.size(), en = v.find(';', b); tile_for = v.substr(b, en == string::npos ? string::npos : en - b); }
+  }
+  // Round 5: where 256 x 128 tiles of the staging-wave kernel deal out over the CUs in (nearly) whole rounds they run ahead of 256 x 256 -- same kernel, 4 x 2 multiplying
+  // waves of 64 x 64; measured in the layer sequence of sgemm-ops-full, three alternating repetitions on one box (tools/sgemm_policy_ab.sh, TF/s): 4096^3 141.2 -> 142.7,
+  // 8192^3 143.6 -> 144.9, 12288^3 144.2 -> 145.5, and 10240^3 (3200 tiles = 12.5 rounds, against 6 rounds of 256 x 256 + a tail launch) 136.5 -> 139.7; the whole list
+  // 139.6 -> 141.2.  Where the last round is emptier (5120 / 6144 / 7168: 0.78-0.90 full) the two-level split below stays ahead.  Bit-identical either way.
+  if (!bf16 && !half && tune_of(impl, "sgemm_tile").empty() && tile_for.empty()) tile_for = sgemm_wide_tile(M, N, K, host->nh_num_cus());
+  if (!bf16 && !half && tune_of(impl, "sgemm_tile").empty() && tile_for.empty()) {
     sgemm_split_t const sp = plan_sgemm_split(M, N, K, host->nh_num_cus());
     if (sp.m_main) {
       if ((uint64_t)K * M * 4 > 0x80000000ull || (uint64_t)K * N * 4 > 0x80000000ull || (uint64_t)M * N * 4 >= 0x7ffffff0ull) unsup_err("hip_sgemm: operands / c of 2 GiB or more are not supported (32-bit buffer offsets)");
@@ -961,7 +990,7 @@ void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t 
       return;
     }
   }
-  plan_t p = plan_sgemm(M, N, K, host->nh_num_cus(), tune_of(impl, "sgemm_tile"), bf16, 1, !half);
+  plan_t p = plan_sgemm(M, N, K, host->nh_num_cus(), tile_for.empty() ? tune_of(impl, "sgemm_tile") : tile_for, bf16, 1, !half);
   if (half) {
     if (p.cfg.SPLITK > 1) unsup_err("hip_sgemm: split-K tiles are not supported for half-typed tensors");
     p.kname = "bodahip_sgemm_f16s"; p.defs.push_back("-DHALF=1");
@@ -1699,8 +1728,10 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
   bool const bf16 = op.has_func_name() && (op.get_func_name() == "hip_sgemm_bf16" || op.get_func_name() == "hip_conv_bf16");
   if (t == "sgemm") {
     dims_t const &a = op.get_dims("a"), &b = op.get_dims("b");
-    sgemm_split_t sp; if (!bf16 && tile.empty() && a.tn != "half") sp = plan_sgemm_split(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus);
-    if (sp.m_main) {   // two-level tiling: the large tile over the first m_main rows (reported), small tiles over the rest
+    string const wide = (!bf16 && tile.empty() && a.tn != "half") ? sgemm_wide_tile(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus) : string();
+    sgemm_split_t sp; if (!bf16 && tile.empty() && a.tn != "half" && wide.empty()) sp = plan_sgemm_split(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus);
+    if (!wide.empty()) p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, wide, false);
+    else if (sp.m_main) {   // two-level tiling: the large tile over the first m_main rows (reported), small tiles over the rest
       plan_t const tp = plan_sgemm(a.dsz("M") - sp.m_main, b.dsz("N"), a.dsz("K"), num_cus, sp.tail_tile, false);
       p = plan_sgemm(sp.m_main, b.dsz("N"), a.dsz("K"), num_cus, kBigTile, false);
       s2d = "rows<" + std::to_string(sp.m_main) + ":" + p.cfg.str() + "+rest:";

@@ -154,7 +154,14 @@ def test_planner_sgemm_tiles_follow_problem_size():
     def sg(M, N, K, fn="hip_sgemm"):
         return parse_op(f"(str_vals=(type=sgemm,func_name={fn}),nda_vals=(a=(dims=(K={K},M={M})),b=(dims=(K={K},N={N})),c=(dims=(M={M},N={N}))))")
     big, small = R.explain_plan(sg(8192, 8192, 8192)), R.explain_plan(sg(256, 256, 256))
-    assert big.startswith("bodahip_sgemm_big_f32 256x256x8_w3x4_p2") and "-DBKS=8" in big and "-DPF=2" in big     # round 4: eight multiplying + four staging waves
+    # round 4: eight multiplying + four staging waves; round 5: as 256 x 128 tiles (4 x 2 multiplying waves of 64 x 64) where those deal out in whole rounds (2048 tiles = 8 x 256 CUs)
+    assert big.startswith("bodahip_sgemm_big_f32 256x128x8_w3x4_p2") and "-DBKS=8" in big and "-DPF=2" in big and "-DTBJ=128" in big and "-DWI=4" in big
+    os.environ["BODAHIP_NO_SGEMM_256X128"] = "1"
+    try: assert R.explain_plan(sg(8192, 8192, 8192)).startswith("bodahip_sgemm_big_f32 256x256x8_w3x4_p2")
+    finally: del os.environ["BODAHIP_NO_SGEMM_256X128"]
+    # ... and, asked for by their tile strings ("...x3x4": the twelve waves), its 128 x 128 (two workgroups per CU) and 128 x 256 forms
+    assert R.explain_plan(sg(2048, 2048, 2048), tile="128x128x8x3x4x2").startswith("bodahip_sgemm_big_f32 128x128x8_w3x4_p2") and "-DMINW=2" in R.explain_plan(sg(2048, 2048, 2048), tile="128x128x8x3x4x2")
+    assert "-DTBI=128 -DTBJ=256 -DWI=2 -DWJ=4" in R.explain_plan(sg(4096, 4096, 4096), tile="128x256x8x3x4x1")
     assert small.startswith("bodahip_sgemm_f32 ") and small.split()[1] != big.split()[1]
     assert "-DI_MODE=1" in R.explain_plan(sg(130, 64, 50)) and "-DJ_MODE=1" in R.explain_plan(sg(128, 66, 50))     # scalar staging for ragged M / N
     assert R.explain_plan(sg(8192, 8192, 8192), tile="128x128x16x2x2x2x4").count("-DSPLITK=1") == 1           # split-K only as an explicit tune
@@ -163,7 +170,8 @@ def test_planner_sgemm_tiles_follow_problem_size():
     # tiles; 8192^3 (1024 = 4 rounds exactly) is not split; an explicit tile or BODAHIP_NO_SGEMM_SPLIT switches it off
     sp = R.explain_plan(sg(7168, 7168, 7168))
     assert sp.startswith("rows<6912:256x256x8_w3x4_p2+rest:bodahip_sgemm_f32 64x64x32_w2x2_p2"), sp
-    assert R.explain_plan(sg(10240, 10240, 10240)).startswith("rows<9728:") and not R.explain_plan(sg(12288, 12288, 12288)).startswith("rows<")
+    assert R.explain_plan(sg(6144, 6144, 6144)).startswith("rows<5376:") and not R.explain_plan(sg(12288, 12288, 12288)).startswith("rows<")
+    assert R.explain_plan(sg(10240, 10240, 10240)).startswith("bodahip_sgemm_big_f32 256x128x8")     # (round 5: 3200 tiles of 256 x 128 = 12.5 rounds, no tail launch; round 4 split it at row 9728)
     assert R.explain_plan(sg(7168, 7168, 7168), tile="128x128x16x2x2x2").startswith("bodahip_sgemm_f32 128x128")
     assert not R.explain_plan(sg(7168, 7170, 7168)).startswith("rows<")        # ragged N: scalar staging, no split
     os.environ["BODAHIP_NO_SGEMM_SPLIT"] = "1"

@@ -204,13 +204,14 @@ def test_sgemm_vs_oracle_bit_exact(be, M, N, K):
 @pytest.mark.parametrize("tile", ["64x64x16x1x1", "128x64x16x2x1", "64x128x16x1x2", "32x128x16x1x2", "96x128x16x1x2", "128x128x32x2x2", "256x128x16x4x2",
                                   "32x32x32x2x2x1x1x16", "64x64x64x4x4x1x1x16", "64x64x16x2x2x2x1x16", "64x64x16x2x2x2x1x32x2", "128x128x16x2x2x1x1x32x2",
                                   "128x128x16x2x2x2x1x32x1x1", "64x64x32x2x2x2x1x16x1x1",   # tenth field 1: as many staging waves as multiplying waves (round 4)
-                                  "256x256x16x2x4x1x1x32x2"])                               # the 256x256 tile = kernels/sgemm_big_f32.hip (ragged edges, K tail, fewer K tiles than its rounds)
+                                  "256x256x16x2x4x1x1x32x2",                                # the 256x256 tile = kernels/sgemm_big_f32.hip (ragged edges, K tail, fewer K tiles than its rounds)
+                                  "128x128x8x3x4x2", "128x128x16x3x4x1", "256x128x8x3x4x1", "128x256x16x3x4x1"])   # round 5: that kernel's 128 x 128 / 256 x 128 / 128 x 256 forms ("x3x4": its twelve waves)
 def test_sgemm_tiles_agree(be, tile):
     op = _sgemm_op(320, 448, 200)
     ref, _ = _run(be, op, 5)
     got, prc = _run(be, op, 5, tune=OpTune(hip_tile=tile))
     assert prc.launch["cfg"].startswith("x".join(tile.split("x")[:2]))
-    assert (prc.launch["kernel"] == "bodahip_sgemm_big_f32") == tile.startswith("256x256") and prc.launch["cfg"].endswith("_sw") == (len(tile.split("x")) == 10)
+    assert (prc.launch["kernel"] == "bodahip_sgemm_big_f32") == (tile.startswith("256x256") or "x3x4" in tile) and prc.launch["cfg"].endswith("_sw") == (len(tile.split("x")) == 10)
     assert np.array_equal(ref["c"], got["c"])  # incl. the 16x16x4-MFMA tiles (suffix x16): same ascending-k fma chain
 
 

@@ -4,7 +4,7 @@ kernel-source hash it was measured with: bench.py reports roofline.traffic only 
 import json, os, sqlite3, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "final")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
 summ = os.path.join(ROOT, "tools", "rocprof_summary.py")
@@ -42,13 +42,19 @@ for w, (cmdargs, kern) in WORK.items():
     with open(os.path.join(out, f"{tag}_{w}_pmc.txt"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --pmc <set> -- python bench.py {cmdargs} --steps 1 --warmup 0   (separate passes: FETCH_SIZE | WRITE_SIZE | SQ set); kernel {kern}; kernel sources {khash}\n")
         f.write(f"# HBM bytes = FETCH_SIZE_KB*1024*{factor:.3f} (calibrated, see pmc_summary.json) + WRITE_SIZE_KB*1024 ; summed over launches of the same grid size\n")
-        f.write("# grid(threads)  fetch_MB(corrected)  write_MB  | mfma_busy%  clock_GHz  waves  wave_cycles: wait_inst% wait_any% active%\n")
+        f.write("# grid(threads)  workgroups/launch  launches  fetch_MB(corrected)  write_MB  | mfma_busy%  clock_GHz  waves  wave_cycles: wait_inst% wait_any% active%\n")
+        wgs = {}
+        try:   # workgroups per launch and launches per grid size (round 5: how full the chip is, launch by launch -- 256 CUs)
+            for g, wsz, nn in q(os.path.join(src, f"fetch_{w}", "p_results.db"), f"select grid_size, max(workgroup_size), count(*) from counters_collection where counter_name='FETCH_SIZE' and kernel_name like '{kern}' group by grid_size"):
+                wgs[g] = (int(g // max(1, wsz)), int(nn))
+        except Exception:
+            pass
         tot_f = tot_w = 0.0
         for g in sorted(rows):
             fb = rows[g].get("FETCH_SIZE", 0) * 1024 * factor; wb = rows[g].get("WRITE_SIZE", 0) * 1024
             tot_f += fb; tot_w += wb
             s = sq.get(g, {})
-            line = f"{g:12d}  {fb/1e6:14.1f}  {wb/1e6:10.1f}"
+            line = f"{g:12d}  {wgs.get(g, (0, 0))[0]:8d}  {wgs.get(g, (0, 0))[1]:6d}  {fb/1e6:14.1f}  {wb/1e6:10.1f}"
             if s.get("GRBM_GUI_ACTIVE"):
                 cyc = s["GRBM_GUI_ACTIVE"] / 8.0
                 wc = s.get("SQ_WAVE_CYCLES", 0) or 1
@@ -69,6 +75,14 @@ for w, cmdargs in NETS.items():
         with open(os.path.join(out, f"{tag}_{w}_kernel_stats.txt"), "w") as f:
             f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py {cmdargs} --steps 5 --warmup 2 --no-cpu-baseline\n")
             f.write(subprocess.check_output([sys.executable, summ, sdb, "--by-grid"], text=True))
+    fdb, wdb = os.path.join(src, f"fetch_{w}", "p_results.db"), os.path.join(src, f"write_{w}", "p_results.db")
+    if os.path.exists(fdb) and os.path.exists(wdb):   # round 5: HBM bytes of ONE forward pass, every kernel of it (convs, pool / LRN / layout passes): the config legs' roofline.traffic
+        not_setup = "kernel_name not like 'gen_data%' and kernel_name not like '%xpose_filts%' and kernel_name not like '__amd_rocclr%'"
+        fb = (q(fdb, f"select sum(value) from counters_collection where counter_name='FETCH_SIZE' and {not_setup}")[0][0] or 0) * 1024 * factor
+        wb = (q(wdb, f"select sum(value) from counters_collection where counter_name='WRITE_SIZE' and {not_setup}")[0][0] or 0) * 1024
+        passes = max(1, int(open(os.path.join(src, f"passes_{w}.txt")).read().strip())) if os.path.exists(os.path.join(src, f"passes_{w}.txt")) else 1
+        res[w] = {"hbm_bytes_per_step": int((fb + wb) / passes), "fetch_bytes_corrected": int(fb / passes), "write_bytes": int(wb / passes), "kernel_src_hash": khash, "file": f"{tag}_{w}_pmc.txt",
+                  "passes_profiled": passes, "scope": "every kernel of a forward pass except data generation and the one-time filter layout passes"}
     qdb = os.path.join(src, f"sq_{w}", "p_results.db")
     if os.path.exists(qdb):
         per = {}
