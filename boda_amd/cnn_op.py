@@ -205,6 +205,32 @@ def annotate_k1_chain(a: Op, b: Op, relu_a: int, relu_b: int) -> Op:
     return c
 
 
+def f32_pool_fusable(conv: Op, pool_in, kern, stride, in_pad, avg_pool) -> bool:
+    """Can a max pooling (input dims pool_in, window kern, stride, padding in_pad) be taken into the annotated fp32 hip_conv function that alone reads its output?
+    Mirrors apply_f32_pool / plan_conv (csrc/native_kernels.cc): max, no pooling pad, windows of at most 3 x 3 that tile the plane exactly (no clipped last window),
+    and a convolution that takes the LDS-patch form (stride 1 in x, more than one tap, not output 1 x 1)."""
+    if avg_pool or tuple(in_pad) != (0, 0) or conv.get_func_name() != "hip_conv" or "hip_tile" in conv.str_vals or conv.has("hip_pool"):
+        return False
+    kh, kw = kern; sy, sx = stride; H, W = pool_in.dsz("y"), pool_in.dsz("x")
+    if not (1 <= kh <= 3 and 1 <= kw <= 3 and kh * kw >= 2 and sy >= 1 and sx >= 1 and H >= kh and W >= kw and (H - kh) % sy == 0 and (W - kw) % sx == 0):
+        return False
+    g = conv.conv_geom()
+    if (g["H"], g["W"]) != ((H - kh) // sy + 1, (W - kw) // sx + 1) or pool_in.dsz("chan") != g["C"] or pool_in.dsz("img") != g["B"]:
+        return False
+    return g["SX"] == 1 and g["KH"] * g["KW"] >= 2 and g["KH"] >= g["SY"] and not (g["OH"] == 1 and g["OW"] == 1)
+
+
+def fuse_f32_pool(conv: Op, pool_in, kern, stride) -> None:
+    """In place: the annotated fp32 hip_conv function takes the max pooling in front of it (f32_pool_fusable).  Its `in` becomes the POOLING's input and the window travels
+    with the function: uint32 hip_pool, dims pool_sz / pool_stride.  The reference runs two functions (test/rtc/pool.cucl, then the conv: src/rtc_fwd.cc:545-549); here a
+    patch element of the convolution's LDS input patch is the window maximum, formed while the patch is staged (kernels/gemm_conv_f32.hip, PKH).  Bit-identical."""
+    from .op import Dims, Nda
+    none = lambda y, x: Nda(Dims(("y", "x"), (y, x), "none"), "none")
+    conv.nda_vals["in"] = Nda(dims=pool_in, tn=pool_in.tn)
+    conv.set_u32("hip_pool", 1)
+    conv.nda_vals["pool_sz"] = none(*kern); conv.nda_vals["pool_stride"] = none(*stride)
+
+
 import os as _os
 if _os.environ.get("BODAHIP_TILE_WISDOM"):
     set_tile_wisdom(_os.environ["BODAHIP_TILE_WISDOM"])

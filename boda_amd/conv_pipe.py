@@ -23,7 +23,7 @@ import os
 import numpy as np
 
 from . import gen_data as gd
-from .cnn_op import K1_CHAIN_FUNC, NATIVE_ARGS, OpTune, add_codegen_annotations, annotate_k1_chain, k1_chain_applies
+from .cnn_op import K1_CHAIN_FUNC, NATIVE_ARGS, OpTune, add_codegen_annotations, annotate_k1_chain, f32_pool_fusable, fuse_f32_pool, k1_chain_applies
 from .cucl_template import instantiate, parse_template
 from .op import Dims, Nda, Op, RtErr, UnsupErr
 from .rtc import HipCompute, RtcArg, RtcCompileOpts, RtcFuncCall, RtcFuncInfo
@@ -405,8 +405,17 @@ class ConvPipeFwd:
     mode = "rtc"
 
     def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False, fuse_siblings: bool = True, fuse_levels: bool = True, fuse_pools: bool = True, sets_take_groups: bool = True,
-                 spec_fwd: bool = True, fuse_pool_lrn="pool_first", fuse_k1_chains: bool = True):
+                 spec_fwd: bool = True, fuse_pool_lrn="pool_first", fuse_k1_chains: bool = True, fuse_f32_pools: Optional[bool] = None, fuse_post: bool = True):
         self.rtc, self.op_tune = rtc, op_tune or OpTune()
+        # channels-last bf16 nets (round 5): a convolution on the rolling-rows kernel (csrc/kernels/conv_nhwc_rows_bf16.hip: the 7x7/2 stems) takes the max pooling that alone
+        # reads it, and the LRN that alone reads that, into its launch -- its rows are pooled out of an LDS ring, its own output (four times the pooled tensor) is never
+        # written or read.  GoogLeNet: conv1 + pool1 + norm1 = one call.  Bit-identical to the calls run apart; the skipped nodes are materialised on demand.
+        self.fuse_post = fuse_post and os.environ.get("BODAHIP_NO_NHWC_POST_FUSION") is None
+        self.fused_post: Dict[str, Tuple[str, Optional[str]]] = {}     # convolution tag -> (pooling tag, LRN tag or None)
+        self._lazy_pre: Dict[str, List[str]] = {}                        # lazy node -> the lazy nodes its call reads (materialised first)
+        # fp32 nets: a max pooling read by one LDS-patch convolution is formed inside that convolution's patch loads (see init()).  Built and exact, but OFF by default: it
+        # measured slower (same-box A/B, profiles/r05_probe_f32_pool_fusion.txt).  None: the env switch BODAHIP_F32_POOL_FUSION=1 decides
+        self.fuse_f32_pools = (os.environ.get("BODAHIP_F32_POOL_FUSION") == "1") if fuse_f32_pools is None else bool(fuse_f32_pools)
         # fp32 nets: a 1x1 convolution whose output is read by ONE other 1x1 convolution only (NiN's cccp1 -> cccp2) runs with it as one hip_conv_k1_chain launch: the
         # intermediate tensor stays in the accumulator registers (kernels/k1_quad_f32.hip -DCHAIN=1), its write + read are gone.  Bit-identical; the first
         # convolution's node is materialised on demand.  The reference chains them through memory (src/rtc_fwd.cc:495-503)
@@ -579,6 +588,71 @@ class ConvPipeFwd:
                     continue
                 _nhwc.fuse_pool(annos[q.tag], pin, tuple(o.kern_sz), tuple(o.in_pad))
                 self.fused_pools[o.tag] = q.tag; conv_in[q.tag] = o.bot
+        # fp32 nets (round 5; the fusion clause of SURVEY section 8 F2 on the path config 4 runs): a max pooling whose only reader is a convolution that takes the LDS-patch
+        # form is taken INTO that convolution -- a patch element becomes the window maximum, formed while the patch is staged (kernels/gemm_conv_f32.hip, PKH): the pooled
+        # tensor's write + read and a launch are gone.  Exact (a true float maximum, the convolution's own fma chains): no condition on the values.  NiN: pool0 -> conv2,
+        # pool2 -> conv3 (conv4's 64 x 64 tile keeps two K tiles in flight, which the fused form does not have: pool3 stays).  The pooling's node is materialised on demand.
+        # MEASURED SLOWER, hence opt-in (fuse_f32_pools): every one of the convolution's OC tiles forms the window maxima of its patch again (9 loads per element, x OC/BI
+        # tiles), which costs the convolutions more than the pooling launches took -- NiN-net at 128 images 113.0 -> 112.2 TF/s, AlexNet-net at 128 111.7 -> 110.3 TF/s
+        if (not self.nhwc) and self.fuse_f32_pools and self.op_tune.hip_dtype == "":
+            from .rtc import explain_plan
+            rd_p: Dict[str, List[PipeOp]] = {}
+            for o in cp.ops:
+                if o.tag not in fused:
+                    for b in (o.bots or (o.bot,)):
+                        rd_p.setdefault(b, []).append(o)
+            op_index = {o.tag: i for i, o in enumerate(cp.ops)}
+            for o in cp.ops:
+                rd = rd_p.get(o.top, [])
+                if not (o.type == "Pooling" and not o.in_place and len(rd) == 1 and rd[0].type == "Convolution" and o.top not in self.slices):
+                    continue
+                q = rd[0]; qa = annos[q.tag]
+                if q.tag in chain_first or q.tag in chain_lazy or not f32_pool_fusable(qa, cp.nodes[o.bot], tuple(o.kern_sz), tuple(o.stride), tuple(o.in_pad), bool(o.avg_pool)):
+                    continue
+                if any(w.top == o.bot and w.tag not in fused for w in cp.ops[op_index[o.tag] + 1:op_index[q.tag]]):
+                    continue      # (the fused kernel reads the pooling's input at the convolution's position: nobody may rewrite it in between)
+                plan0 = explain_plan(qa, getattr(self, "_num_cus", 256)).split()
+                if "-DJ_MODE=7" not in plan0 or (("_p" in plan0[1]) and os.environ.get("BODAHIP_F32_POOL_ALL") is None) or "-DRDEC=1" in plan0:
+                    continue      # (not the patch form / a plan with several K tiles in flight)
+                fa = qa.copy(); fuse_f32_pool(fa, cp.nodes[o.bot], tuple(o.kern_sz), tuple(o.stride))
+                try:
+                    explain_plan(fa, getattr(self, "_num_cus", 256))
+                except UnsupErr:
+                    continue
+                annos[q.tag] = fa; self.fused_pools[o.tag] = q.tag; conv_in[q.tag] = o.bot
+        # convolution -> pooling [-> LRN] inside the convolution's launch (channels-last bf16 nets): see fuse_post
+        post_of: Dict[str, str] = {}       # tag of a pooling / LRN taken into a convolution -> that convolution's tag
+        if self.nhwc and self.fuse_post and self.op_tune.hip_dtype == "bf16":
+            from .rtc import explain_plan
+            rd_q: Dict[str, List[PipeOp]] = {}
+            for o in cp.ops:
+                if o.tag not in fused:
+                    for b in (o.bots or (o.bot,)):
+                        rd_q.setdefault(b, []).append(o)
+            for q in cp.ops:
+                if not (q.type == "Convolution" and has_relu[q.tag] and q.top not in self.slices and q.tag not in self.fused_pools.values()):
+                    continue
+                rd = rd_q.get(q.top, [])
+                if len(rd) != 1 or rd[0].type != "Pooling" or rd[0].in_place or rd[0].top in self.slices or rd[0].tag in self.fused_pools or q.top == cp.out_node():
+                    continue
+                pool = rd[0]; rd2 = rd_q.get(pool.top, [])
+                lrn = rd2[0] if (len(rd2) == 1 and rd2[0].type == "LRN" and not rd2[0].in_place and pool.top != cp.out_node()) else None
+                for with_lrn in ((lrn, None) if lrn is not None else (None,)):
+                    lp = tuple(with_lrn.lrn) if with_lrn is not None else None
+                    if not _nhwc.post_fusable(annos[q.tag], pool.kern_sz, pool.stride, pool.in_pad, bool(pool.avg_pool), lp):
+                        continue
+                    fa = annos[q.tag].copy(); fa.nda_vals["conv_has_relu"].v = (1,)
+                    _nhwc.fuse_post(fa, cp.nodes[pool.top], tuple(pool.kern_sz), tuple(pool.stride), tuple(pool.in_pad), lp)
+                    try:
+                        explain_plan(fa, getattr(self, "_num_cus", 256))
+                    except (UnsupErr, RtErr):
+                        continue
+                    self._post_plain = getattr(self, "_post_plain", {}); self._post_plain[q.tag] = annos[q.tag]
+                    annos[q.tag] = fa; self.fused_post[q.tag] = (pool.tag, with_lrn.tag if with_lrn is not None else None)
+                    post_of[pool.tag] = q.tag
+                    if with_lrn is not None:
+                        post_of[with_lrn.tag] = q.tag
+                    break
         # pooling <-> LRN pairs (channels-last nets, specialised kernels): see fuse_pool_lrn
         pl_second: Dict[str, str] = {}     # tag of the second op of a pair -> tag of the first
         if self.nhwc and self.spec_fwd and self.fuse_pool_lrn:
@@ -589,10 +663,10 @@ class ConvPipeFwd:
                         rd_all.setdefault(b, []).append(o)
             for a in cp.ops:
                 rd = rd_all.get(a.top, [])
-                if a.tag in fused or a.tag in self.fused_pools or a.tag in pl_second or a.in_place or len(rd) != 1 or a.top in self.slices:
+                if a.tag in fused or a.tag in self.fused_pools or a.tag in pl_second or a.in_place or len(rd) != 1 or a.top in self.slices or a.tag in post_of:
                     continue
                 b = rd[0]
-                if b.in_place or b.tag in self.fused_pools or {a.type, b.type} != {"Pooling", "LRN"}:
+                if b.in_place or b.tag in self.fused_pools or b.tag in post_of or {a.type, b.type} != {"Pooling", "LRN"}:
                     continue
                 pool, lrn = (a, b) if a.type == "Pooling" else (b, a); lds_pair = False
                 if a.type == "LRN" and self.fuse_pool_lrn == "pool_first":     # LRN first: through LDS (the LRN evaluated once per input chunk) where that kernel applies; the thread-per-
@@ -693,6 +767,20 @@ class ConvPipeFwd:
                 if op.tag in chain_lazy:         # first conv of a 1x1 chain: no call of the pass writes its node; this call materialises it when somebody asks
                     self._lazy[op.top] = FwdCall(op.tag, RtcFuncCall(gen_fn, am), fn, cop.flops())
                     continue
+                if op.tag in self.fused_post:    # conv + pooling [+ LRN] as one call: it writes the LAST op's node; the convolution's own node is materialised (by the plain function) on demand
+                    ptag, ltag = self.fused_post[op.tag]; last = next(o for o in cp.ops if o.tag == (ltag or ptag))
+                    if last.top not in made and last.top not in self._vars:
+                        rtc.create_var_with_dims(last.top, vd(last.top)); self._vars.append(last.top); made.add(last.top)
+                    pam = dict(am); am["out"] = RtcArg.var(last.top)
+                    if vd(last.top).dsz("chan") != op.out_chans:
+                        am["out_chan_off"] = _u32(0)
+                    plain = self._post_plain[op.tag]; plain.nda_vals["conv_has_relu"].v = (has_relu[op.tag],)
+                    pfn = gen_fn + "_plain"
+                    rtc.compile([RtcFuncInfo(pfn, "", [a for a, _ in NATIVE_ARGS[fn]], plain)]); self._funcs.append(pfn)
+                    self._lazy[op.top] = FwdCall(op.tag, RtcFuncCall(pfn, pam), fn, cop.flops())
+                    ftag = "+".join(t for t in (op.tag, ptag, ltag) if t); annos[ftag] = anno
+                    self.fwd_calls.append(FwdCall(ftag, RtcFuncCall(gen_fn, am), fn, cop.flops()))
+                    continue
                 if op.tag in chain_first:        # second conv of the chain: ONE call from the first conv's input to this conv's output
                     first = chain_first[op.tag]; fa = annos[first.tag]
                     canno = annotate_k1_chain(fa, anno, has_relu[first.tag], has_relu[op.tag]); annos[first.tag + "+" + op.tag] = canno
@@ -705,6 +793,10 @@ class ConvPipeFwd:
                     self.fwd_calls.append(FwdCall(first.tag + "+" + op.tag, RtcFuncCall(cfn, cam), K1_CHAIN_FUNC, cp.conv_op(first).flops() + cop.flops()))
                     continue
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(gen_fn, am), fn, cop.flops()))
+            elif self.nhwc and op.tag in post_of:                   # taken into its convolution's launch (fuse_post): the pooling's node on demand (from the convolution's, on demand too); the LRN's is what that launch writes
+                if op.type == "Pooling":
+                    self._lazy[op.top] = FwdCall(op.tag, _nhwc.pool_call(vn(op.bot), op.top, vd(op.bot), vd(op.top), op.kern_sz, op.stride, op.in_pad, int(op.avg_pool), rtc if self.spec_fwd else None), "nhwc_pool")
+                    self._lazy_pre[op.top] = [op.bot]
             elif self.nhwc and op.tag in self.fused_pool_lrn:       # first op of a pooling <-> LRN pair: its node is only materialised when somebody asks for it
                 if op.type == "Pooling":
                     self._lazy[op.top] = FwdCall(op.tag, _nhwc.pool_call(vn(op.bot), op.top, vd(op.bot), vd(op.top), op.kern_sz, op.stride, op.in_pad, int(op.avg_pool), rtc), "nhwc_pool")
@@ -755,7 +847,11 @@ class ConvPipeFwd:
                 inst = cache[sig]
                 am = {"in": RtcArg.var(vn(op.bot)), "out": RtcArg.var(op.top), "avg_pool": _u32(op.avg_pool), "kern_sz": RtcArg.ref(pop.get_dims("kern_sz")),
                       "stride": RtcArg.ref(pop.get_dims("stride")), "in_pad": RtcArg.ref(pop.get_dims("in_pad"))}
-                self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(inst.func_name, am, tpb=inst.tpb, blks=inst.blks), "fwd_pool"))
+                pcall = FwdCall(op.tag, RtcFuncCall(inst.func_name, am, tpb=inst.tpb, blks=inst.blks), "fwd_pool")
+                if op.tag in self.fused_pools:     # taken into its convolution (fp32 nets, round 5): only materialised when somebody asks for the node
+                    self._lazy[op.top] = pcall
+                else:
+                    self.fwd_calls.append(pcall)
             elif op.type == "Concat":
                 o = cp.nodes[op.top]; hw = o.dsz("y") * o.dsz("x"); chw_out = o.dsz("chan") * hw
                 c_done = 0
@@ -893,7 +989,7 @@ class ConvPipeFwd:
         rtc.finish_and_sync()
         for v in to_get_vns:
             if v in self._lazy:      # (a fused pooling's output: no call of the pass writes it)
-                rtc.run(self._lazy[v].rfc); rtc.finish_and_sync()
+                self._materialise(v)
             if v in self.slices:     # a conv output that only exists as a channel range of its Concat output
                 cat, c_off, ch = self.slices[v]
                 fwd[v] = np.ascontiguousarray(self._fetch(cat)[:, c_off:c_off + ch])
@@ -907,6 +1003,13 @@ class ConvPipeFwd:
                 for tag, func, ms, _ in self.per_call_ms:
                     f.write(f"per_layer_time['{tag}']=per_layer_time.get('{tag}',0.0) + {ms / 1000.0} # {func} \n")
         rtc.release_per_call_id_data()
+
+    def _materialise(self, v: str) -> None:
+        """Run the call that writes a node no call of the pass writes any more (after the lazy nodes it reads)."""
+        for d in self._lazy_pre.get(v, ()):
+            if d in self._lazy:
+                self._materialise(d)
+        self.rtc.run(self._lazy[v].rfc); self.rtc.finish_and_sync()
 
     def _fetch(self, node: str) -> np.ndarray:
         """A node's value in the reference layout (img:chan:y:x float)."""
@@ -1015,4 +1118,5 @@ class ConvPipeFwd:
         for v in self._vars:
             rtc.release_var(v)
         self._funcs, self._vars, self.fwd_calls, self._grp_params, self.groups = [], [], [], [], []
+        self.fused_post, self._lazy_pre = {}, {}
         self.k1_chains, self._lazy, self.fused_pools, self.fused_pool_lrn, self.level_sets, self.lds_pool_lrn = [], {}, {}, {}, [], set()   # (a second init() starts from a clean slate)

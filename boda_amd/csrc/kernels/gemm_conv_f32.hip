@@ -159,9 +159,18 @@ static_assert(vec_w(I_MODE) == 1 || BK % vec_w(I_MODE) == 0, "vector staging of 
 #endif         // (in_chan, kernel row) -- of KH = 1 x KW kernels with stride 1 in y over a plane of COH rows: row r of row set (c, ky) is input row r * SY0 + ky.  k = (c, ky, kx)
                // keeps its order, a K step is kCB whole row sets, the LDS holds ONE input row per output row and row set (coalesced row loads instead of a gather of
                // KW-tap windows that overlap (KW - SX) / KW), the MFMA B operand is read in place at lane stride SX.  Needs -DC0 -DH0 -DKH0 -DSY0; p.C = C0 * KH0.
+#ifndef PKH
+#define PKH 1  // PKH x PKW > 1 (round 5): a MAX POOLING fused in front of the convolution (the reference runs two functions: test/rtc/pool.cucl, then the conv -- src/rtc_fwd.cc:545-549).
+#define PKW 1  // The convolution's "input plane" CH x CW is then the POOLED plane; the tensor behind p.J is the pooling's input, planes of UH x UW, and patch element
+#define PSY 1  // (c, iy, ix) is max_{dy < PKH, dx < PKW} in[img][c][iy * PSY + dy][ix * PSX + dx] -- formed in registers while the patch is staged (PKH * PKW loads per element instead
+#define PSX 1  // of one: a K step of the patch is a few hundred elements per workgroup against ~100 MFMAs of 64 cycles per wave).  Only windows that never leave the plane
+#define UH CH  // ((CH - 1) * PSY + PKH <= UH, no pooling pad: NiN's and AlexNet's 3x3 / 2 pools); the maximum is exact, the convolution's fma chains are its own: bit-identical to
+#define UW CW  // pooling and convolution run apart.  The loads of window row r fly under a third of the K step's MFMAs (PF == 1 only).
+#endif
 #if !defined(CH) || !defined(CW) || !defined(COH) || !defined(COW)
 #error "J_MODE 7 needs -DCH -DCW -DCOH -DCOW (input / output plane sizes are compile-time)"
 #endif
+static_assert(PKH >= 1 && PKH <= 3 && PKW >= 1 && PKW <= 3 && (PKH * PKW == 1 || (!RDEC && !SPECW && (PF == 1) && (CH - 1) * PSY + PKH <= UH && (CW - 1) * PSX + PKW <= UW)), "fused pooling: windows of up to 3 x 3 that stay inside the plane, plain patch mode, one K tile in flight");
 constexpr int kTaps = KH * KW, kCB = BK / kTaps, kWp = CW + 2 * PX;
 static_assert(BK % kTaps == 0 && KH >= SY && MT == 32, "patch mode geometry");
 constexpr int kRowsMax = (BJ - 2) / COW + 2;                     // output rows a BJ-pel tile can touch
@@ -380,12 +389,43 @@ __device__ __forceinline__ void load_gather(float (&r)[kNJ], rsrc_t in, gather_t
     int const cq = min(c0 + cc, p.C - 1);                           // "channel" = row set (in_chan cq / KH0, kernel row cq % KH0) of the strided convolution
     int const coff = ((cq / KH0) * H0 + cq % KH0) * (CW * 4);
 #else
-    int const coff = min(c0 + cc, p.C - 1) * (CH * CW * 4); // scalar; goff + coff < 2^32 and stays >= 2^31 for kOOB entries
+    int const coff = min(c0 + cc, p.C - 1) * (UH * UW * 4); // scalar; goff + coff < 2^32 and stays >= 2^31 for kOOB entries
 #endif
 #pragma unroll
-    for (int e = 0; e < kEPT; ++e) r[cc * kEPT + e] = bload1(in, g.goff[e] + coff);
+    for (int e = 0; e < kEPT; ++e) {
+      float v = bload1(in, g.goff[e] + coff);
+#if PKH * PKW > 1
+#pragma unroll
+      for (int t = 1; t < PKH * PKW; ++t) v = fmaxf(v, bload1(in, g.goff[e] + coff + ((t / PKW) * UW + (t % PKW)) * 4));   // (a padding element's offsets all stay out of range: max of zeros)
+#endif
+      r[cc * kEPT + e] = v;
+    }
   }
 }
+#if PKH * PKW > 1
+// fused pooling, one window ROW at a time: the PKW loads of row `wr` of every patch element of the K step (issued before a third of the step's MFMAs) ...
+__device__ __forceinline__ void load_pool_row(float (&raw)[PKW * kNJ], rsrc_t in, gather_t const &g, gemm_args_t const &p, int k0, int const wr) {
+  int const c0 = k0 / kTaps;
+#pragma unroll
+  for (int cc = 0; cc < kCB; ++cc) {
+    int const coff = min(c0 + cc, p.C - 1) * (UH * UW * 4) + wr * (UW * 4);
+#pragma unroll
+    for (int e = 0; e < kEPT; ++e)
+#pragma unroll
+      for (int x = 0; x < PKW; ++x) raw[(cc * kEPT + e) * PKW + x] = bload1(in, g.goff[e] + coff + x * 4);
+  }
+}
+// ... and their maximum folded into the element's running maximum (after those MFMAs)
+__device__ __forceinline__ void fold_pool_row(float (&r)[kNJ], float const (&raw)[PKW * kNJ], bool const first) {
+#pragma unroll
+  for (int n = 0; n < kNJ; ++n) {
+    float v = raw[n * PKW];
+#pragma unroll
+    for (int x = 1; x < PKW; ++x) v = fmaxf(v, raw[n * PKW + x]);
+    r[n] = first ? v : fmaxf(r[n], v);
+  }
+}
+#endif
 __device__ __forceinline__ void store_gather(float const (&r)[kNJ], float *__restrict__ S, int tid) {
 #pragma unroll
   for (int cc = 0; cc < kCB; ++cc)
@@ -478,7 +518,8 @@ __device__ __forceinline__ void store_J(float const (&rj)[kNJ], float *__restric
   store_tile<J_MODE, BJ, kLDJ, kNJ>(rj, S, tid);
 #endif
 }
-// one K-tile of MFMAs out of LDS: Ic / Jc point at this lane's first A / B element of the tile
+// one K-tile of MFMAs out of LDS (or its k pairs [KK0, KK1)): Ic / Jc point at this lane's first A / B element of the tile
+template <int KK0 = 0, int KK1 = -1>
 __device__ __forceinline__ void mma_ktile(acc_t (&acc)[kTI][kTJ], float const *__restrict__ Ic, float const *__restrict__ Jc
 #if J_MODE == 7
                                           , int const (&bj)[kTJ][3]
@@ -488,7 +529,7 @@ __device__ __forceinline__ void mma_ktile(acc_t (&acc)[kTI][kTJ], float const *_
   __builtin_amdgcn_s_setprio(1); // co-resident waves of other workgroups are in their load phase: favour the MFMA issuer
 #endif
 #pragma unroll
-  for (int kk = 0; kk < BK / kKS; ++kk) {
+  for (int kk = KK0; kk < ((KK1 < 0) ? (BK / kKS) : KK1); ++kk) {
     float a[kTI], b[kTJ];
 #pragma unroll
     for (int t = 0; t < kTI; ++t) a[t] = Ic[kk * kKS * kLDI + t * MT];
@@ -579,7 +620,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
 #if RDEC
       g.goff[e] = ok ? (((img * (C0 * H0) + iy * SY0) * CW + ix) * 4) : kOOB;   // row iy of the decimated plane is input row iy * SY0 (+ the row set's kernel row, in coff)
 #else
-      g.goff[e] = ok ? (((img * p.C * CH + iy) * CW + ix) * 4) : kOOB;
+      g.goff[e] = ok ? (((img * p.C * UH + iy * PSY) * UW + ix * PSX) * 4) : kOOB;   // (fused pooling: the window's first element in the pooling's input)
 #endif
     }
 #pragma unroll
@@ -742,6 +783,25 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
         __syncthreads();
       }
     }
+  }
+#elif J_MODE == 7 && (PKH * PKW > 1)
+  // Fused pooling: the next K tile's patch elements are window maxima.  Window row r's loads are issued before the r-th part of this step's MFMAs and folded into the running
+  // maxima after it: PKW x kNJ loads in flight at a time instead of PKH x PKW x kNJ, nothing waits for memory in front of an MFMA.
+  constexpr int kKKn = BK / kKS, kP1 = (PKH >= 2) ? (kKKn / PKH) : kKKn, kP2 = (PKH >= 3) ? (2 * kKKn / PKH) : kKKn;
+  for (int kt = 0; kt < nkt; ++kt) {
+    bool const more = (kt + 1) < nkt;
+    float const *const Ic = ((kt & 1) ? Is1 : Is0) + a_off, *const Jc = ((kt & 1) ? Js1 : Js0) + b_off;
+    int const k0n = (kt_begin + kt + 1) * BK;
+    float raw[PKW * kNJ];
+    if (more) { LOAD_I(ri, kt + 1); load_pool_row(raw, rJ, g, p, k0n, 0); }
+    mma_ktile<0, kP1>(acc, Ic, Jc, bj);
+    if (more) { fold_pool_row(rj, raw, true); if (PKH >= 2) load_pool_row(raw, rJ, g, p, k0n, 1); }
+    if (PKH >= 2) mma_ktile<kP1, kP2>(acc, Ic, Jc, bj);
+    if (more && PKH >= 2) { fold_pool_row(rj, raw, false); if (PKH >= 3) load_pool_row(raw, rJ, g, p, k0n, 2); }
+    if (PKH >= 3) mma_ktile<kP2, kKKn>(acc, Ic, Jc, bj);
+    if (more && PKH >= 3) fold_pool_row(rj, raw, false);
+    if (more) STORE_IJ(ri, rj, (kt & 1) ? Is0 : Is1, (kt & 1) ? Js0 : Js1);
+    __syncthreads();
   }
 #else
   for (int kt = 0; kt < nkt; ++kt) {

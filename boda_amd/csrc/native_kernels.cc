@@ -174,7 +174,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(host->nh_launch(k.func, grid, 1, (uint32_t)c.threads(), params), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, fc = false, big = false, rdec = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false, ksl = false; int rows = 0, cg = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, fc = false, big = false, rdec = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false, nhwc_rows = false, ksl = false; int rows = 0, cg = 0; };
 
 // Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
 //   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
@@ -474,6 +474,16 @@ static plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &ti
 // Channels-last bf16 convolution from an LDS input patch (kernels/conv_nhwc_patch_bf16.hip): KH x KW kernels with more than one tap, stride 1 in x; filters in the
 // F'[in_grp][ky][kx][out_chan][8] form.  A K step is CG groups of 8 channels x all taps.  tile: "BIxBJx0xWIxWJ[xMINW]" or "".
 // pool: g.KH x g.KW / g.PY, g.PX describe a MAX-POOLING window fused in front of a 1x1 convolution (-DPOOL=1: the filters hold one k-slot per channel group).
+// channel groups per K step of the input-patch forms (shared by the patch kernel and the rolling-rows kernel: same k-slot order, same MFMA chain, same bits)
+static int patch_cg(int ncg, int taps) {
+  int cg = 1; long best = -1;
+  for (int c = std::min(ncg, 4); c >= 1; --c) {
+    if (c > 1 && c * taps > 50) continue;
+    long const slots = (long)((ncg + c - 1) / c) * (c * taps + ((c * taps) & 1));
+    if (best < 0 || slots < best) { best = slots; cg = c; }
+  }
+  return cg;
+}
 static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string const &tile_arg, bool out_f32, bool pool = false) {
   if (g.C % 8) unsup_err("hip_conv_nhwc: in_chan of a channels-last bf16 tensor must be a multiple of 8");
   string tile = tile_arg;
@@ -486,12 +496,7 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
   // Channel groups per K step: at most 4, at most 50 k-slots, the count that wastes the fewest zero k-slots over the layer (a ragged last step and the zero slot
   // of an odd step are MFMAs on zeros: 6 groups of a 3x3 as 4 + 2 cost 72 slots, as 2 + 2 + 2 54 -- AlexNet's space-to-depth conv1 at 256 images 128.7 -> 111.9 us;
   // 5x5 on 12 groups as 6 x 50 instead of 12 x 26: 209 -> 200 us); ties go to the larger step (fewer barriers).
-  int cg = 1; { long best = -1;
-    for (int c = std::min(ncg, 4); c >= 1; --c) {
-      if (c > 1 && c * taps > 50) continue;
-      long const slots = (long)((ncg + c - 1) / c) * (c * taps + ((c * taps) & 1));
-      if (best < 0 || slots < best) { best = slots; cg = c; }
-    } }
+  int cg = patch_cg(ncg, taps);
   if (pool) { if (!adirect) unsup_err("hip_conv_nhwc (fused pooling): needs the direct filter path"); cg = std::min(ncg, 4);    // (one k-slot per group: four groups = two MFMA k-iterations per step)
     if (char const *e = getenv("BODAHIP_NHWC_POOL_CG")) { if (atoi(e) > 0) cg = std::min(ncg, atoi(e)); } }
   if (char const *e = getenv("BODAHIP_NHWC_PATCH_CG")) { if (atoi(e) > 0) cg = std::min(ncg, atoi(e)); }   // (experiments)
@@ -595,6 +600,113 @@ static plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string con
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
   return p;
 }
+// Rolling-rows form of the channels-last bf16 convolution (kernels/conv_nhwc_rows_bf16.hip): short-K layers of at most 64 out_chans whose time is their output --
+// the 7x7/2 stems after space-to-depth.  A workgroup of eight waves walks down a run of output rows of one image with the filters in registers; the rows land in an LDS
+// ring from which they are stored -- or pooled (+ LRN'd) without ever reaching memory (post).  Same k-slot order as the patch kernel (patch_cg): with an even tap count
+// the MFMA chains are the same for every CG, i.e. the same bits as bodahip_conv_nhwc_patch_bf16 whatever that one's plan.
+// Returns false (why = the reason) where the form does not apply.  cfg: BI x BJ = 64 x 256 positions per tile, BK = K of the layer, WJ waves.
+struct rows_args_t { // must match kernels/conv_nhwc_rows_bf16.hip
+  void const *filts; void const *in; void *out; float const *bias;
+  int n_img, oc; unsigned filts_bytes, in_bytes, out_bytes; int out_ctot, out_coff; int n_chunks, rows_per_chunk; float lrn_alpha, lrn_beta, lrn_k;
+};
+static bool plan_conv_nhwc_rows(conv_geom_t const &g, post_ops_t const &post, int num_cus, plan_t &p, string *why = nullptr) {
+  auto no = [&](char const *w) { if (why) *why = w; return false; };
+  (void)num_cus;
+  int const taps = g.KH * g.KW, ncg = g.C / 8;
+  if (g.C % 8) return no("in_chan must be a multiple of 8");
+  if (!(g.SX == 1 && g.SY == 1 && taps >= 2)) return no("needs stride 1 and more than one tap");
+  if (g.OC > 64) return no("at most 64 out_chans (every wave multiplies all of them)");
+  if (g.OW > 256 || g.OW < 1) return no("output rows of at most 256 positions");
+  int cg = patch_cg(ncg, taps);
+  if (char const *e = getenv("BODAHIP_NHWC_PATCH_CG")) { if (atoi(e) > 0) cg = std::min(ncg, atoi(e)); }
+  int const nkt = (ncg + cg - 1) / cg, npr = cg * taps, kn = (npr + (npr & 1)) / 2, nit = nkt * kn;
+  if (nit * 2 * 4 > 160) return no("the filters do not fit the registers (K too long)");
+  if (post.pooled() && !g.relu) return no("the fused pooling needs the convolution's ReLU (non-negative values)");
+  if (post.LRN_N && !(post.pooled() && (post.LRN_N & 1) && post.LRN_N <= 9)) return no("the fused LRN follows a fused pooling; odd local sizes up to 9");
+  int wj = 8; if (char const *e = getenv("BODAHIP_NHWC_ROWS_WJ")) { int const v = atoi(e); if (v == 2 || v == 4 || v == 8) wj = v; }
+  int tr = std::max(1, std::min(256 / g.OW, 8)); if (char const *e = getenv("BODAHIP_NHWC_ROWS_TR")) { int const v = atoi(e); if (v >= 1 && v * g.OW <= 256) tr = v; }
+  auto lds = [&](int trx) {
+    int const wr = g.W + 2 * g.PX; int wp = wr; for (int q = wr; q < wr + 16; ++q) if ((q - g.OW) % 16 == 0) { wp = q; break; }
+    long const cs = (long)(trx + g.KH - 1) * wp, csp = cs + ((2 - cs % 16) + 16) % 16;
+    return 2l * 16l * ncg * csp + (long)(post.pooled() ? trx + post.PKH - 1 : trx) * g.OW * (64 * 2 + 16) + (post.pooled() ? (long)post.POW * 160 : 0l) + 256l;
+  };
+  while (tr > 1 && lds(tr) > 160 * 1024) --tr;
+  if (lds(tr) > 160 * 1024) return no("the input rows of one output row do not fit the LDS");
+  p = plan_t(); p.nhwc = true; p.nhwc_rows = true; p.bf16 = true; p.kname = "bodahip_conv_nhwc_rows_bf16"; p.cg = cg; p.rows = tr;
+  tile_cfg_t c; c.MT = 32; c.SPLITK = 1; c.PF = 1; c.BI = 64; c.BJ = 256; c.BK = g.C * taps; c.WI = 1; c.WJ = wj; c.MINW = 1;
+  p.cfg = c;
+  p.defs = {"-DCIN=" + std::to_string(g.C), "-DCG=" + std::to_string(cg), "-DKH=" + std::to_string(g.KH), "-DKW=" + std::to_string(g.KW), "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX),
+            "-DCH=" + std::to_string(g.H), "-DCW=" + std::to_string(g.W), "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW), string("-DRELU=") + (g.relu ? "1" : "0"),
+            "-DWJ=" + std::to_string(wj), "-DTR=" + std::to_string(tr)};
+  if (post.pooled()) for (auto const &kv : std::vector<std::pair<char const *, int>>{{"PKH", post.PKH}, {"PKW", post.PKW}, {"PSY", post.PSY}, {"PSX", post.PSX}, {"PPY", post.PPY}, {"PPX", post.PPX}, {"POH", post.POH}, {"POW", post.POW}})
+    p.defs.push_back(string("-D") + kv.first + "=" + std::to_string(kv.second));
+  if (post.LRN_N) { p.defs.push_back("-DLRN_N=" + std::to_string(post.LRN_N)); p.defs.push_back("-ffast-math"); }   // (the LRN expression under the flags of the generated LRN functions: see the kernel)
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return true;
+}
+// Plain convolutions (no post ops) that take the rolling-rows kernel by themselves: output-bound stems -- a short K (the filters in registers), few out_chans, a large
+// output.  BODAHIP_NHWC_ROWS=0: never (the patch kernel, as before round 5); =1: wherever the form applies.
+static bool rows_auto(conv_geom_t const &g, int num_cus, string const &tile) {
+  char const *e = getenv("BODAHIP_NHWC_ROWS");
+  if ((e && atoi(e) == 0) || !tile.empty()) return false;
+  plan_t p;
+  if (!plan_conv_nhwc_rows(g, post_ops_t(), num_cus, p)) return false;
+  if (e && atoi(e) == 1) return true;
+  return (long)g.C * g.KH * g.KW <= 512 && (double)g.B * g.OH * g.OW * g.OC * 2.0 >= 32e6 && g.B * 2 >= num_cus / 4;
+}
+
+void native_kernels_t::conv_nhwc_rows(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, post_ops_t const &post, int out_ctot, int out_coff) {
+  if (out_ctot <= 0) { out_ctot = g.OC; out_coff = 0; }
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  if (!Nj || !g.OC) return;
+  plan_t p; string why;
+  if (!plan_conv_nhwc_rows(g, post, host->nh_num_cus(), p, &why)) unsup_err("hip_conv_nhwc (rolling-rows form): " + why);
+  kernel_t &k = get_kernel(impl, host, p);
+  long const out_pels = post.pooled() ? (long)g.B * post.POH * post.POW : Nj;
+  uint64_t const in_bytes = (uint64_t)g.B * g.C * g.H * g.W * 2, f_bytes = (uint64_t)g.OC * Kt * 2, out_bytes = (uint64_t)out_pels * out_ctot * 2;
+  if (in_bytes >= 0x7ffffff0ull || f_bytes >= 0x7ffffff0ull || out_bytes >= 0x7ffffff0ull) unsup_err("hip_conv_nhwc: tensors of 2 GiB or more are not supported (32-bit buffer offsets)");
+  rows_args_t ra; memset(&ra, 0, sizeof(ra));
+  ra.filts = filts; ra.in = in; ra.out = out; ra.bias = biases; ra.n_img = g.B; ra.oc = g.OC;
+  ra.filts_bytes = (unsigned)f_bytes; ra.in_bytes = (unsigned)in_bytes; ra.out_bytes = (unsigned)out_bytes; ra.out_ctot = out_ctot; ra.out_coff = out_coff;
+  // one workgroup per CU: the chunks of an image each redo the rows they share with the next one (overlapping pooling windows), so no more of them than fill the chip
+  int const rows = post.pooled() ? post.POH : g.OH, cus = host->nh_num_cus();
+  int nch = std::max(1, std::min(rows, (cus + g.B - 1) / g.B));
+  if (char const *e = getenv("BODAHIP_NHWC_ROWS_CHUNKS")) { int const v = atoi(e); if (v >= 1) nch = std::min(rows, v); }
+  ra.rows_per_chunk = (rows + nch - 1) / nch; ra.n_chunks = (rows + ra.rows_per_chunk - 1) / ra.rows_per_chunk;
+  ra.lrn_alpha = post.alpha; ra.lrn_beta = post.beta; ra.lrn_k = post.k;
+  void *params[] = {&ra};
+  uint32_t const grid = (uint32_t)(g.B * ra.n_chunks);
+  hip_err_chk(host->nh_launch(k.func, grid, 1, (uint32_t)p.cfg.threads(), params), "hipModuleLaunchKernel(conv_nhwc_rows_bf16)");
+  last_launch.kernel = p.kname; last_launch.cfg = p.cfg; last_launch.grid = grid; last_launch.block = p.cfg.threads();
+  last_launch.flops = 2.0 * Nj * g.OC * Kt;
+  last_launch.algo_bytes = 2.0 * ((double)g.B * g.C * g.H * g.W + (double)g.OC * Kt) + 2.0 * (double)out_pels * g.OC + 4.0 * g.OC;
+}
+
+// What follows the convolution inside the rolling-rows launch (annotations of the function's op, boda_amd/nhwc.py fuse_post): uint32 nhwc_post_pool = 1 with dims
+// post_pool_sz / post_pool_stride / post_pool_pad (y, x); uint32 nhwc_post_lrn = local size with floats post_lrn_alpha / post_lrn_beta / post_lrn_k.  The function's
+// `out` is then the POOLED tensor: g arrives with OH x OW read from it; they become post's planes and g gets the convolution's own.
+static float op_f32(op_base_t const &op, string const &an) {
+  p_nda_t const &n = op.get(an); if (n->dims.tn != "float" || n->dims.sz() != 0 || !n->rp) rt_err("op: '" + an + "' is not a float scalar");
+  return *static_cast<float const *>(n->rp);
+}
+static bool apply_post_ops(op_base_t const &op, conv_geom_t &g, post_ops_t &post, char const *what) {
+  post = post_ops_t();
+  if (!op.has("nhwc_post_pool") || !op.get_u32("nhwc_post_pool")) return false;
+  dims_t const &ks = op.get_dims("post_pool_sz"), &st = op.get_dims("post_pool_stride"), &pp = op.get_dims("post_pool_pad");
+  post.PKH = (int)ks.dsz("y"); post.PKW = (int)ks.dsz("x"); post.PSY = (int)st.dsz("y"); post.PSX = (int)st.dsz("x"); post.PPY = (int)pp.dsz("y"); post.PPX = (int)pp.dsz("x");
+  post.POH = g.OH; post.POW = g.OW;
+  if (!g.SY || !g.SX) rt_err(string(what) + ": zero stride");
+  g.OH = (g.H + 2 * g.PY - g.KH) / g.SY + 1; g.OW = (g.W + 2 * g.PX - g.KW) / g.SX + 1;
+  if (post.PKH < 1 || post.PKW < 1 || post.PKH > 7 || post.PKW > 7 || post.PSY < 1 || post.PSX < 1 || post.PPY < 0 || post.PPX < 0 || post.PPY >= post.PKH || post.PPX >= post.PKW)
+    unsup_err(string(what) + ": fused pooling behind the convolution takes windows of at most 7 x 7 with a padding smaller than the window");
+  if (post.POH < 1 || post.POW < 1 || (post.POH - 1) * post.PSY - post.PPY >= g.OH || (post.POW - 1) * post.PSX - post.PPX >= g.OW)
+    rt_err(string(what) + ": the pooled planes of `out` have windows outside the convolution's output");
+  if (op.has("nhwc_post_lrn") && op.get_u32("nhwc_post_lrn")) {
+    post.LRN_N = (int)op.get_u32("nhwc_post_lrn"); post.alpha = op_f32(op, "post_lrn_alpha"); post.beta = op_f32(op, "post_lrn_beta"); post.k = op_f32(op, "post_lrn_k");
+  }
+  return true;
+}
+
 // Exact fp32 convolutions whose operands are k-contiguous in the REFERENCE layout -- output 1x1, no padding, kernel == whole input (AlexNet
 // fc6-fc8: in[img][K], filts[out_chan][K]) -- through the LDS-DMA kernel's IN_F32 variant (kernels/conv_nhwc_bf16.hip): 64x64 tiles of four
 // waves, 32-deep K steps, an 8-slot LDS ring (six K steps of loads in flight).  Same ascending-k fma chain: bit-exact (tested).  MEASURED SLOWER
@@ -688,7 +800,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   plan_t p;
   if (!bf16 && tile.empty() && plan_ipconv_dma(g, num_cus, p)) return p;
   if (!bf16 && tile.empty() && plan_k1_stream(g, num_cus, k1s, p)) return p;
-  if (!bf16 && tile.empty() && plan_rdec(g, num_cus, p)) return p;
+  if (!bf16 && tile.empty() && !g.pooled() && plan_rdec(g, num_cus, p)) return p;
   if (bf16 && tile.empty() && plan_patch_bf16(g, num_cus, p)) return p; p.kname = bf16 ? "bodahip_conv_bf16" : "bodahip_conv_f32"; p.bf16 = bf16;
   // output 1x1, no padding, kernel == whole input ("ipconv" case): the im2col row of image j is the contiguous image
   p.ipconv = (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W);
@@ -752,7 +864,11 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
     }
   }
   if (p.patch && tile.empty()) p.cfg.PF = pf_for(p.cfg);
-  if (!bf16 && !exact && tile.empty() && allow_splitk) tolerance_splitk(p, g, num_cus, Nj, Kt);
+  if (g.pooled()) {   // a max pooling fused in front (round 5): the LDS-patch form only, one K tile in flight (the window rows are gathered under thirds of a step's MFMAs)
+    if (bf16 || !p.patch || p.rdec) unsup_err("hip_conv: fused pooling (hip_pool) needs an fp32 convolution that takes the LDS-patch form (stride 1 in x, more than one tap)");
+    p.cfg.PF = 1; p.cfg.SW = 0; p.cfg.SPLITK = 1;
+  }
+  if (!bf16 && !exact && tile.empty() && allow_splitk && !g.pooled()) tolerance_splitk(p, g, num_cus, Nj, Kt);
   // fully-connected layers (whole-input windows, both operands k-contiguous): kernels/fc_f32.hip -- four multiplying + four staging waves, three LDS stages, 16x16x4
   // MFMA chains.  Tile TM images x TN out_chans: the largest of 64x64 / 64x32 / 32x32 that still gives (nearly) every CU a workgroup.  BODAHIP_FC = off | TMxTNxBKFxPF
   // (an explicit spec forces the kernel onto every layer it covers: tests).  Measured (MI355X, AlexNet at 256 images, layer sequence, us): fc6 223 -> 170, fc7 104 -> 82.
@@ -781,6 +897,8 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   if (p.rows) p.defs.push_back("-DJROWS=" + std::to_string(p.rows));
   if (p.patch) { p.defs.push_back("-DCH=" + std::to_string(g.H)); p.defs.push_back("-DCW=" + std::to_string(g.W));
                  p.defs.push_back("-DCOH=" + std::to_string(g.OH)); p.defs.push_back("-DCOW=" + std::to_string(g.OW)); }
+  if (g.pooled()) for (auto const &kv : {std::make_pair("PKH", g.PKH), std::make_pair("PKW", g.PKW), std::make_pair("PSY", g.PSY), std::make_pair("PSX", g.PSX), std::make_pair("UH", g.UH), std::make_pair("UW", g.UW)})
+    p.defs.push_back(string("-D") + kv.first + "=" + std::to_string(kv.second));
   p.defs.push_back("-DEPI=1");
   if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
   p.defs.push_back("-DKH=" + std::to_string(g.KH)); p.defs.push_back("-DKW=" + std::to_string(g.KW));
@@ -791,7 +909,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
 }
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
-  return hiprtc_compile(p.nhwc_multi ? k_src_conv_nhwc_multi_bf16 : p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.big ? k_src_sgemm_big_f32 : p.fc ? k_src_fc_f32 : p.stream ? (p.quad ? k_src_k1_quad_f32 : k_src_k1_stream_f32) : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
+  return hiprtc_compile(p.nhwc_rows ? k_src_conv_nhwc_rows_bf16 : p.nhwc_multi ? k_src_conv_nhwc_multi_bf16 : p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.big ? k_src_sgemm_big_f32 : p.fc ? k_src_fc_f32 : p.stream ? (p.quad ? k_src_k1_quad_f32 : k_src_k1_stream_f32) : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
 }
 
 // grow-only scratch shared by the split-K slabs and the Winograd-domain tensors (like the reference's cudnn scratch var)
@@ -1169,9 +1287,10 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   // tolerance mode: 3x3 / stride-1 layers take the F(2x2,3x3) path where it measured ahead of the direct kernel unless conv_algo says otherwise
   // (the reference holds Winograd results to mrd < 2e-3, src/rtc_prof.cc:317-319,436)
   string const conv_algo = algo ? string(algo) : (tune_of(impl, "conv_algo").empty() && !exact ? string("winograd") : tune_of(impl, "conv_algo"));
-  if (!bf16 && winograd_applies(g, conv_algo) && tune_of(impl, "conv_tile").empty()) {
+  if (!bf16 && !g.pooled() && winograd_applies(g, conv_algo) && tune_of(impl, "conv_tile").empty()) {
     conv_winograd(filts, biases, in, out, g, out_ctot, out_coff); return;
   }
+  if (g.pooled() && bf16) unsup_err("hip_conv: fused pooling is an fp32 form");
   if (bf16 && tune_of(impl, "conv_tile").empty()) {
     conv_geom_t g2; int pry = 0, prx = 0; plan_t p2;
     if (s2d_geom(g, g2, pry, prx) && plan_patch_bf16(g2, host->nh_num_cus(), p2)) {
@@ -1231,8 +1350,9 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
     return;
   }
   gemm_args_t ga; memset(&ga, 0, sizeof(ga));
-  uint64_t const in_bytes = (uint64_t)g.B * g.C * g.H * g.W * 4, f_bytes = (uint64_t)g.OC * Kt * 4;
+  uint64_t const in_bytes = (uint64_t)g.B * g.C * (g.pooled() ? (uint64_t)g.UH * g.UW : (uint64_t)g.H * g.W) * 4, f_bytes = (uint64_t)g.OC * Kt * 4;   // (fused pooling: the tensor read is the pooling's input)
   if (in_bytes >= 0x7ffffff0ull || f_bytes >= 0x7ffffff0ull) unsup_err("hip_conv: in / filts of 2 GiB or more are not supported (32-bit buffer offsets)");
+  if (g.pooled() && !(p.patch && !p.rdec && cfg.PF == 1 && cfg.SW == 0 && cfg.SPLITK == 1)) unsup_err("hip_conv: fused pooling needs the LDS-patch form of the kernel with one K tile in flight (plan: " + cfg.str() + ")");
   ga.I = filts; ga.J = in; ga.D = out; ga.bias = biases;
   ga.Mi = g.OC; ga.Nj = (int)Nj; ga.K = (int)Kt; ga.ldI = (int)Kt; ga.ldJ = p.ipconv ? (int)Kt : 0; ga.ldD = g.OH * g.OW;
   ga.C = p.rdec ? g.C * g.KH : g.C; ga.H = g.H; ga.W = g.W; ga.OH = g.OH; ga.OW = g.OW;   // (row-decimated patch: the kernel's "channels" are the C * KH row sets)
@@ -1279,7 +1399,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   if (cfg.SPLITK > 1) reduce_splitk(impl, host, ga, Nj * g.OC, true, g.relu, g.OH * g.OW, g.OC);
   last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)ga.tiles_i * ga.tiles_j * cfg.SPLITK; last_launch.block = cfg.threads();
   last_launch.flops = 2.0 * Nj * g.OC * Kt;
-  last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
+  last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * (g.pooled() ? (double)g.UH * g.UW : (double)g.H * g.W) + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
 }
 
 
@@ -1661,6 +1781,7 @@ void native_kernels_t::conv_nhwc(void const *filts, float const *biases, void co
   long const Nj = (long)g.B * g.OH * g.OW, Kt = pool ? (long)g.C : (long)g.C * g.KH * g.KW;
   if (!Nj || !g.OC) return;
   if (Nj > 0x7fffffffl || Kt > 0x7fffffffl) unsup_err("hip_conv_nhwc: dims exceed int32");
+  if (patch_filts && !pool && !out_f32 && rows_auto(g, host->nh_num_cus(), tune_of(impl, "conv_tile"))) { conv_nhwc_rows(filts, biases, in, out, g, post_ops_t(), out_ctot, out_coff); return; }   // (output-bound stems)
   plan_t const p = patch_filts ? plan_conv_nhwc_patch(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), out_f32, pool) : plan_conv_nhwc(g, host->nh_num_cus(), tune_of(impl, "conv_tile"), out_f32);
   tile_cfg_t const &cfg = p.cfg;
   kernel_t &k = get_kernel(impl, host, p);
@@ -1717,6 +1838,18 @@ static bool apply_pool_window(op_base_t const &op, string const &sfx, conv_geom_
   return true;
 }
 
+// fp32 hip_conv with a max pooling fused in front (annotation: uint32 hip_pool = 1, dims pool_sz / pool_stride carried by the op; boda_amd/conv_pipe.py): `in` is the
+// POOLING's input.  g arrives with H / W = that tensor's planes; they become the pooled plane.  Only windows that tile the plane exactly (no pooling pad, no clipped window).
+static bool apply_f32_pool(op_base_t const &op, conv_geom_t &g, char const *what) {
+  if (!op.has("hip_pool") || !op.get_u32("hip_pool")) return false;
+  dims_t const &ks = op.get_dims("pool_sz"), &st = op.get_dims("pool_stride");
+  g.PKH = (int)ks.dsz("y"); g.PKW = (int)ks.dsz("x"); g.PSY = (int)st.dsz("y"); g.PSX = (int)st.dsz("x"); g.UH = g.H; g.UW = g.W;
+  if (g.PKH < 1 || g.PKW < 1 || g.PKH > 3 || g.PKW > 3 || g.PKH * g.PKW < 2 || g.PSY < 1 || g.PSX < 1 || g.UH < g.PKH || g.UW < g.PKW) unsup_err(string(what) + ": fused pooling takes windows of 2..9 positions, at most 3 x 3");
+  if ((g.UH - g.PKH) % g.PSY || (g.UW - g.PKW) % g.PSX) unsup_err(string(what) + ": fused pooling needs windows that tile the plane exactly (no clipped last window)");
+  g.H = (g.UH - g.PKH) / g.PSY + 1; g.W = (g.UW - g.PKW) / g.PSX + 1;
+  return true;
+}
+
 // AOT: compile (into the on-disk code-object cache) the specialisation that run() would pick for `op`.  No device needed.
 // With arch == "" nothing is compiled and *plan_out receives "<kernel> <tile> <-D options>": the planner's decision (host-logic tests).
 size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int num_cus, string const &tile_arg, string *plan_out) {
@@ -1770,6 +1903,7 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
     }
     conv_geom_t g; memset(&g, 0, sizeof(g));
     if (!multi) g = geom_from_dims(op.get_dims("filts"), op.get_dims("in"), op.get_dims(op.has("out") ? "out" : "out_0"), op.get_dims("stride"), op.get_dims("in_pad"), relu);
+    if (!multi) (void)apply_f32_pool(op, g, "prebuild");   // (hip_conv with a pooling fused in front: `in` is the pooling's input)
     conv_geom_t g2; int pry = 0, prx = 0;
     if (multi) {
       int const n = (int)op.get_dims("multi").dsz("n"); std::vector<conv_geom_t> gs;
@@ -1785,7 +1919,10 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
         gp = geom_from_dims(fl, op.get_dims("in"), op.get_dims("out"), op.get_dims("stride"), op.get_dims("in_pad"), relu);
         pool = apply_pool_window(op, string(), gp, "hip_conv_nhwc");
       }
-      p = plan_conv_nhwc_patch(gp, num_cus, tile, op.get_dims("out").tn == "float", pool);
+      post_ops_t post; string why;
+      if (apply_post_ops(op, gp, post, "prebuild")) { if (pool || !plan_conv_nhwc_rows(gp, post, num_cus, p, &why)) unsup_err("hip_conv_nhwc (rolling-rows form): " + (pool ? string("no pooling in front") : why)); }
+      else if (!pool && op.get_dims("out").tn != "float" && rows_auto(gp, num_cus, tile)) plan_conv_nhwc_rows(gp, post_ops_t(), num_cus, p);
+      else p = plan_conv_nhwc_patch(gp, num_cus, tile, op.get_dims("out").tn == "float", pool);
     }
     else if (op.has_func_name() && op.get_func_name() == "hip_conv_k1_chain") {
       if (!plan_k1_chain(g, (int)op.get_dims("filts2").dsz("out_chan"), op.get_u32("conv_has_relu2") != 0, p)) unsup_err("prebuild: hip_conv_k1_chain does not cover this pair of convolutions");
@@ -2049,6 +2186,8 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     if (f.dsz("in_chan") != (uint32_t)g.C) rt_err("hip_conv_nhwc: filts.in_chan != in.chan");
     bool const pool = apply_pool_window(fi.op, string(), g, "hip_conv_nhwc");
     if (pool && !patch_filts) rt_err("hip_conv_nhwc: fused pooling needs the in_grp:y:x:out_chan:in_chan8 form of filts");
+    post_ops_t post; bool const has_post = apply_post_ops(fi.op, g, post, "hip_conv_nhwc");   // (out = the pooled tensor; g.OH x g.OW are the convolution's own planes from here on)
+    if (has_post && (!patch_filts || pool || out.tn != "bfloat16")) rt_err("hip_conv_nhwc: a pooling fused behind the convolution needs the in_grp:y:x:out_chan:in_chan8 form of filts, a bfloat16 out and no pooling in front");
     int out_ctot = 0, out_coff = 0;
     auto oi = am.find("out_chan_off");
     if (oi != am.end()) {
@@ -2059,6 +2198,11 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     if (bi.dsz("out_chan") != (uint32_t)g.OC || (!out_ctot && out.dsz("chan") != (uint32_t)g.OC) || out.dsz("img") != (uint32_t)g.B) rt_err("hip_conv_nhwc: inconsistent biases/out dims");
     if (!g.SY || !g.SX) rt_err("hip_conv_nhwc: zero stride");
     if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW) rt_err("hip_conv_nhwc: out dims do not match in/filts/stride/in_pad");
+    if (has_post) {
+      if ((int)out.dsz("y") != post.POH || (int)out.dsz("x") != post.POW) rt_err("hip_conv_nhwc: out dims do not match the fused pooling");
+      conv_nhwc_rows(host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), host->nh_var_ptr(inm), host->nh_var_ptr(onm), g, post, out_ctot, out_coff);
+      return;
+    }
     tile_override_t const tov(impl, "conv_tile", fi.op);
     conv_nhwc(host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), host->nh_var_ptr(inm), host->nh_var_ptr(onm), g, out.tn == "float", out_ctot, out_coff, patch_filts, pool);
     return;
@@ -2110,6 +2254,7 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     assert_st(f.sz() == 4 && in.sz() == 4 && out.sz() == 4 && bi.sz() == 1);
     conv_geom_t g = geom_from_dims(f, in, out, stride, in_pad, fi.op.get_u32("conv_has_relu") != 0);
     if (f.dsz("in_chan") != (uint32_t)g.C) rt_err("hip_conv: filts.in_chan != in.chan");
+    if (apply_f32_pool(fi.op, g, "hip_conv") && (fn != "hip_conv" || bf16)) unsup_err("fused pooling (hip_pool): the fp32 hip_conv function only");
     // optional by-value arg out_chan_off: `out` is then a wider tensor (an inception module's Concat output) and this conv writes
     // channels [out_chan_off, out_chan_off + out_chan) of it -- the channel-offset copy of src/rtc_fwd.cc:267-280 folded into the store
     int out_ctot = 0, out_coff = 0;

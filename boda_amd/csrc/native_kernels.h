@@ -57,7 +57,15 @@ struct tile_cfg_t {
            (MT != 32 ? ("_m" + std::to_string(MT)) : string()) + (SPLITK > 1 ? ("_s" + std::to_string(SPLITK)) : string()) + (PF != 1 ? ("_p" + std::to_string(PF)) : string()) + (SW ? "_sw" : ""); }
 };
 
-struct conv_geom_t { int B, C, H, W, OC, KH, KW, SY, SX, PY, PX, OH, OW; bool relu; };
+struct conv_geom_t { int B, C, H, W, OC, KH, KW, SY, SX, PY, PX, OH, OW; bool relu;
+  // round 5, fp32 hip_conv only: a max pooling fused in FRONT of the convolution (kernels/gemm_conv_f32.hip, PKH).  H x W are then the POOLED plane -- the convolution's
+  // input --, UH x UW the planes of the tensor actually read (the pooling's input); PKH == PKW == 1: no pooling (UH / UW unused).
+  int PKH = 1, PKW = 1, PSY = 1, PSX = 1, UH = 0, UW = 0;
+  bool pooled() const { return PKH * PKW > 1; } };
+
+// channels-last bf16, rolling-rows kernel (kernels/conv_nhwc_rows_bf16.hip): what follows the convolution INSIDE the launch -- a max pooling of its output (PKH > 0:
+// window, stride, padding; POH x POW = the pooled planes, the tensor the launch writes) and an across-channel LRN of the pooled values (LRN_N > 0: local size, alpha, beta, k)
+struct post_ops_t { int PKH = 0, PKW = 0, PSY = 1, PSX = 1, PPY = 0, PPX = 0, POH = 0, POW = 0, LRN_N = 0; float alpha = 0.f, beta = 0.f, k = 0.f; bool pooled() const { return PKH > 0; } };
 
 struct launch_info_t { string kernel; tile_cfg_t cfg; uint32_t grid = 0, block = 0; double flops = 0, algo_bytes = 0; };
 
@@ -74,6 +82,7 @@ struct native_kernels_t {
             char const *algo = nullptr);
 
   // channels-last bf16 tensors (kernels/conv_nhwc_bf16.hip): filts out_chan:y:x:in_chan, in / out img:y:x:chan; g.C = stored channels (multiple of 8)
+  void conv_nhwc_rows(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, post_ops_t const &post, int out_ctot = 0, int out_coff = 0);   // F' filts; g.OH x g.OW = the convolution's own output planes
   void conv_nhwc(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, bool out_f32, int out_ctot = 0, int out_coff = 0, bool patch_filts = false, bool pool = false);   // pool: g.KH x g.KW / g.PY, g.PX are a max-pooling window fused in front of 1x1 filters (patch form); patch_filts: filts are F'[in_grp][ky][kx][out_chan][8] -> the LDS input-patch kernel
   // horizontally fused channels-last convolutions (same `in`, same kernel geometry; filts / biases stacked along out_chan, members padded to `pad` rows)
   void conv_nhwc_grp(void const *filts, float const *biases, void const *in, conv_geom_t const &g, bool out_f32, int n, int const *noc, void *const *outs,

@@ -153,6 +153,41 @@ def fuse_pool(a: Op, pool_in: Dims, kern: Tuple[int, int], pad: Tuple[int, int])
     a.nda_vals["pool_sz"] = none(*kern); a.nda_vals["pool_pad"] = none(*pad)
 
 
+def post_fusable(a: Op, kern, stride, pad, avg: bool, lrn=None) -> bool:
+    """Can the max pooling that alone reads this convolution's output -- and the across-channel LRN that alone reads the pooling's (lrn = (local_size, alpha, beta, k)) -- run
+    INSIDE the convolution's launch?  The rolling-rows kernel's conditions (csrc/kernels/conv_nhwc_rows_bf16.hip; the planner has the last word: explain_plan): the LDS-patch
+    form of filts, stride 1 (after space-to-depth), at most 64 out_chans in whole 8-channel chunks, a bfloat16 output, a fused ReLU (the caller checks), no pooling in front."""
+    if a.get_func_name() != FUNC or not a.get_dims("filts").has("in_grp") or a.has("nhwc_pool") or a.has("nhwc_post_pool") or a.get_dims("out").tn != "bfloat16":
+        return False
+    st, oc = a.get_dims("stride"), a.get_dims("filts").dsz("out_chan")
+    if (st.dsz("y"), st.dsz("x")) != (1, 1) or oc > 64 or oc % 8:
+        return False
+    if avg or not (1 <= kern[0] <= 7 and 1 <= kern[1] <= 7 and kern[0] * kern[1] >= 2) or min(stride) < 1 or not (0 <= pad[0] < kern[0] and 0 <= pad[1] < kern[1]):
+        return False
+    if lrn is not None:
+        ls, alpha, _, k = lrn
+        if not (ls % 2 == 1 and 1 <= ls // 2 <= 4 and k > 0.0 and alpha >= 0.0):
+            return False
+    return True
+
+
+def fuse_post(a: Op, pool_out: Dims, kern, stride, pad, lrn=None) -> None:
+    """In place: the annotated hip_conv_nhwc function takes the max pooling behind it (post_fusable) and, with lrn = (local_size, alpha, beta, k), the LRN behind that.  Its
+    `out` becomes the POOLED tensor; window and LRN constants travel with the function (uint32 nhwc_post_pool, dims post_pool_sz / post_pool_stride / post_pool_pad, uint32
+    nhwc_post_lrn = local size, floats post_lrn_alpha / post_lrn_beta / post_lrn_k).  The reference runs conv, pool and lrn as three functions (src/rtc_fwd.cc:495-503,
+    545-549, test/rtc/pool.cucl, lrn.cucl); here the convolution's rows are pooled out of an LDS ring and its own output tensor is never written."""
+    none = lambda y, x: Nda(Dims(("y", "x"), (y, x), "none"), "none")
+    a.nda_vals["out_ref"] = Nda(dims=pool_out, tn=pool_out.tn)
+    a.nda_vals["out"] = Nda(dims=nhwc_dims(pool_out, "bfloat16", pad=False), tn="bfloat16")
+    a.set_u32("nhwc_post_pool", 1)
+    a.nda_vals["post_pool_sz"] = none(*kern); a.nda_vals["post_pool_stride"] = none(*stride); a.nda_vals["post_pool_pad"] = none(*pad)
+    if lrn is not None:
+        ls, alpha, beta, k = lrn
+        a.set_u32("nhwc_post_lrn", int(ls))
+        for n, v in (("post_lrn_alpha", alpha), ("post_lrn_beta", beta), ("post_lrn_k", k)):
+            a.nda_vals[n] = Nda(None, "float", (float(v),))
+
+
 GRP_FUNC = "hip_conv_nhwc_grp"
 
 
@@ -199,7 +234,7 @@ _MULTI_MEMBER_ARGS = ("filts", "biases", "in", "stride", "in_pad", "out")
 def multi_eligible(anno: Op) -> bool:
     """A member of a multi-problem launch: a plain hip_conv_nhwc function on the implicit-GEMM kernel (filts out_chan:y:x:in_chan) -- not the input-patch form, not
     space-to-depth (both bind other kernels with another summation order)."""
-    return anno.get_func_name() == FUNC and not anno.has("nhwc_s2d") and not anno.get_dims("filts").has("in_grp") and not anno.has("nhwc_pool")
+    return anno.get_func_name() == FUNC and not anno.has("nhwc_s2d") and not anno.get_dims("filts").has("in_grp") and not anno.has("nhwc_pool") and not anno.has("nhwc_post_pool")
 
 
 def annotate_multi(annos: List[Op]) -> Op:
@@ -232,7 +267,7 @@ SET_FUNC = "hip_conv_nhwc_set"
 def set_eligible(anno: Op) -> bool:
     """A member of a set: any hip_conv_nhwc function -- implicit-GEMM or input-patch form of filts (the member keeps its own specialised kernel code); not the
     space-to-depth conv1 form, whose input layout belongs to the net's first layout pass."""
-    return anno.get_func_name() == FUNC and not anno.has("nhwc_s2d")
+    return anno.get_func_name() == FUNC and not anno.has("nhwc_s2d") and not anno.has("nhwc_post_pool")     # (nor a convolution with a pooling taken into its launch: the rolling-rows kernel)
 
 
 def annotate_set(annos: List[Op]) -> Op:

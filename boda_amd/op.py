@@ -311,6 +311,10 @@ class Op:
                  OC=f.dsz("out_chan"), KH=f.dsz("y"), KW=f.dsz("x"),
                  SY=st.dsz("y"), SX=st.dsz("x"), PY=pad.dsz("y"), PX=pad.dsz("x"),
                  OH=o.dsz("y"), OW=o.dsz("x"))
+        if self.has("hip_pool") and self.get_u32("hip_pool"):   # a max pooling fused in front (cnn_op.fuse_f32_pool): `in` is the POOLING's input, H x W the pooled plane
+            ks, ps = self.get_dims("pool_sz"), self.get_dims("pool_stride")
+            g.update(UH=g["H"], UW=g["W"], PKH=ks.dsz("y"), PKW=ks.dsz("x"), PSY=ps.dsz("y"), PSX=ps.dsz("x"))
+            g["H"] = (g["UH"] - g["PKH"]) // g["PSY"] + 1; g["W"] = (g["UW"] - g["PKW"]) // g["PSX"] + 1
         f_in = f.dsz("in_grp") * f.dsz("in_chan8") if f.has("in_grp") else f.dsz("in_chan")   # (filts in the input-patch kernel's in_grp:y:x:out_chan:in_chan8 form, boda_amd/nhwc.py)
         if f_in != g["C"]:
             raise RtErr("conv: filts.in_chan != in.chan (groups are not on this path)")

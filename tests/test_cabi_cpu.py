@@ -144,7 +144,10 @@ def test_planner_k1_chain_and_the_net_driver_fuses_nin_block_one():
     from boda_amd.conv_pipe import ConvPipeFwd, DryRtc, alexnet_ng_conv, nin_imagenet
     for batch, want in ((128, [("cccp1", "cccp2")]), (2, [])):
         f = ConvPipeFwd(DryRtc()); f.init(nin_imagenet(batch))
-        assert f.k1_chains == want and (not want or [c.tag for c in f.fwd_calls][:3] == ["conv1", "cccp1+cccp2", "pool0"]) and list(f._lazy) == [a_ for a_, _ in want]
+        assert f.k1_chains == want and (not want or [c.tag for c in f.fwd_calls][:3] == ["conv1", "cccp1+cccp2", "pool0"]) and list(f._lazy) == [a_ for a_, _ in want] and not f.fused_pools
+        # (round 5, opt-in: pool0 / pool2 formed inside conv2 / conv3's patch loads -- the third call of the pass is conv2 then, and the pooled nodes are lazy ones too)
+        f = ConvPipeFwd(DryRtc(), fuse_f32_pools=True); f.init(nin_imagenet(batch))
+        assert not want or ([c.tag for c in f.fwd_calls][:3] == ["conv1", "cccp1+cccp2", "conv2"] and f.fused_pools == {"pool0": "conv2", "pool2": "conv3"} and list(f._lazy) == ["cccp1", "pool0", "pool2"])
     f = ConvPipeFwd(DryRtc(), fuse_k1_chains=False); f.init(nin_imagenet(128)); assert not f.k1_chains
     f = ConvPipeFwd(DryRtc()); f.init(alexnet_ng_conv(256)); assert not f.k1_chains       # fc6 -> fc7 -> fc8 are whole-input windows / too wide
 

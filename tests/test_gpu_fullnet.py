@@ -138,6 +138,42 @@ def test_k1_chains_are_bit_identical_to_separate_launches(rtc):
     assert np.array_equal(mid, res[True]["cccp1"]) and np.array_equal(bo.conv_fwd(mid, params["cccp2_filts"], params["cccp2_biases"], (1, 1), (0, 0), True), res[True]["cccp2"])
 
 
+def test_f32_pool_fused_into_the_consuming_convolution_is_bit_identical(rtc, monkeypatch):
+    """fp32 nets (round 5; SURVEY section 8 F2's fusion clause on the path config 4 runs): a max pooling whose only reader is a convolution on the LDS-patch form is taken
+    into that convolution -- a patch element is the window maximum, formed while the patch is staged (kernels/gemm_conv_f32.hip, PKH).  NiN: pool0 -> conv2, pool2 -> conv3
+    (pool3 -> conv4 stays: conv4's tile keeps two K tiles in flight); AlexNet: pool1 -> conv2, pool2 -> conv3 (pool5 -> fc6 is a whole-input window: not a patch).  Every node
+    equals the unfused pass bit for bit -- the poolings' own nodes, which no call of the pass writes any more, are materialised when asked for --, the fused convolution equals
+    the oracle's pooling + convolution, and a graph replay of the fused list writes the same bits.  The fusion is opt-in (fuse_f32_pools / BODAHIP_F32_POOL_FUSION=1): exact, but
+    measured slower than the two launches (profiles/r05_probe_f32_pool_fusion.txt); at 3 images the plans keep two K tiles in flight, BODAHIP_F32_POOL_ALL takes those too."""
+    monkeypatch.setenv("BODAHIP_F32_POOL_ALL", "1")
+    for mk, want in ((nin_imagenet, {"pool0": "conv2", "pool2": "conv3"}), (alexnet_ng_conv, {"pool1": "conv2", "pool2": "conv3"})):
+        cp = mk(3); params = _params(cp); data = bo.gen_conv_in(*cp.nodes["data"].sizes)
+        nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
+        res = {}
+        for fuse in (False, True):
+            fwd = ConvPipeFwd(rtc, fuse_f32_pools=fuse); fwd.init(cp, op_params=params)
+            try:
+                funcs = [c.func for c in fwd.fwd_calls]
+                assert fwd.fused_pools == (want if fuse else {}) and funcs.count("fwd_pool") == sum(o.type == "Pooling" for o in cp.ops) - len(fwd.fused_pools)
+                assert all(cp.ops[[o.tag for o in cp.ops].index(t)].top in fwd._lazy for t in fwd.fused_pools)
+                io = {"data": data}
+                fwd.run_fwd(["data"], io, nodes)
+                res[fuse] = io
+                if fuse:
+                    fwd.capture_graph(); rtc.set_var_to_zero(fwd.var_of(cp.out_node())); fwd.run_graph()
+                    assert np.array_equal(rtc.copy_var_to_nda(fwd.var_of(cp.out_node())), io[cp.out_node()])
+            finally:
+                fwd.release()
+        for n in nodes:
+            assert np.array_equal(res[False][n], res[True][n]), n
+        relu_after = {o.bot for o in cp.ops if o.type == "ReLU" and o.in_place}
+        for ptag, ctag in want.items():
+            pool = next(o for o in cp.ops if o.tag == ptag); conv = next(o for o in cp.ops if o.tag == ctag)
+            pooled = bo.pool_fwd(res[True][pool.bot], pool.kern_sz, pool.stride, pool.in_pad, False)
+            assert np.array_equal(pooled, res[True][pool.top])
+            assert np.array_equal(bo.conv_fwd(pooled, params[ctag + "_filts"], params[ctag + "_biases"], conv.stride, conv.in_pad, relu=(conv.top in relu_after)), res[True][conv.top])
+
+
 def test_graph_replay_equals_call_by_call(rtc):
     """hipGraph capture of a whole forward call list (GoogLeNet: 82 launches): the replay writes the same bits as the
     call-by-call run, can be relaunched, and captured calls have no per-call timing."""
@@ -655,3 +691,55 @@ def test_channels_last_pool_lrn_specialised_kernels(rtc):
             assert close(w, g, 1e-5) and close(w, gen, 1e-5), op.tag
             assert (np.abs(g.astype(np.float64) - gen) <= 2.0 * ulp * np.abs(gen)).all(), op.tag      # (neighbouring bf16 values: at most 2^-7 apart, relative)
             assert float(np.mean(g != gen)) < 0.02, op.tag     # (a different rounding only where the fp32 value sits on a bf16 tie)
+
+
+@pytest.mark.parametrize("chunks", ["", "2", "5"], ids=["chunks-auto", "chunks-2", "chunks-5"])
+def test_pooling_and_lrn_taken_into_the_convolutions_launch_are_bit_identical(rtc, chunks, monkeypatch):
+    """Channels-last bf16 nets, round 5 (csrc/kernels/conv_nhwc_rows_bf16.hip; ConvPipeFwd fuse_post): a convolution on the rolling-rows kernel takes the max pooling
+    that alone reads it -- and the across-channel LRN that alone reads that -- into its launch: the convolution's rows are pooled out of an LDS ring, the pooled row is
+    normalised in LDS, and the convolution's own output never reaches memory (the reference: three functions, src/rtc_fwd.cc:495-503 / 545-549 / lrn.cucl).  Every node
+    equals the pass with the three ops run apart, bit for bit -- the skipped nodes (the convolution's and the pooling's) are materialised on demand -- and a graph
+    replay writes the same bits.  Small stems: a 7x7 / 2 one (space-to-depth) with GoogLeNet's 3x3 / 2 ceil-mode pooling and LRN 5 on odd planes; windows cut by every
+    edge (3x3 / 2 pad 1) + LRN 9 on 40 channels; 2x2 / 2 without an LRN; 3x3 / 1 pad 1 (overlapping windows on every row) + LRN 3; a pooling read by two ops and an
+    average pooling stay apart.  Then GoogLeNet node for node.  Row runs of every length: one pooled row per workgroup (small batches), two and five runs per image."""
+    from boda_amd.cnn_op import OpTune
+    from boda_amd.conv_pipe import pipe_from_spec
+    if chunks:
+        monkeypatch.setenv("BODAHIP_NHWC_ROWS_CHUNKS", chunks)
+    specs = {
+        "stem7": ("input data 3 61 57|conv c1 data c1 64 7 7 2 2 3 3|relu r1 c1 c1|pool p1 c1 p1 3 3 2 2 0 0 0 0|lrn n1 p1 n1 5 0.0001 0.75 1.0|conv c2 n1 c2 24 1 1 1 1 0 0", {"c1": ("p1", "n1")}),
+        "edges": ("input data 8 23 30|conv c1 data c1 40 3 3 1 1 1 1|relu r1 c1 c1|pool p1 c1 p1 3 3 2 2 1 1 0 0|lrn n1 p1 n1 9 0.02 0.75 2.0", {"c1": ("p1", "n1")}),
+        "nolrn": ("input data 16 20 28|conv c1 data c1 24 3 3 1 1 0 0|relu r1 c1 c1|pool p1 c1 p1 2 2 2 2 0 0 0 0|conv c2 p1 c2 16 3 3 1 1 1 1|relu r2 c2 c2", {"c1": ("p1", None)}),
+        "s1": ("input data 8 12 33|conv c1 data c1 64 2 2 1 1 0 0|relu r1 c1 c1|pool p1 c1 p1 3 3 1 1 1 1 0 0|lrn n1 p1 n1 3 0.05 0.75 1.0", {"c1": ("p1", "n1")}),
+        "apart": ("input data 8 14 14|conv c1 data c1 32 3 3 1 1 1 1|relu r1 c1 c1|pool p1 c1 p1 3 3 2 2 0 0 0 0|lrn n1 p1 n1 5 0.0001 0.75 1.0|conv c2 p1 c2 8 1 1 1 1 0 0|"
+                  "conv d1 data d1 32 3 3 1 1 1 1|relu rd d1 d1|pool q1 d1 q1 3 3 2 2 0 0 1 0", {"c1": ("p1", None)}),     # (p1 has two readers: the LRN stays a call; q1 averages)
+    }
+    cases = [(pipe_from_spec(nm, sp.split("|"), 3), want) for nm, (sp, want) in specs.items()] + ([(googlenet_conv(3), {"conv1": ("pool1", "norm1")})] if not chunks else [])
+    for cp, want in cases:
+        params = _params(cp)
+        data = (bo.gen_conv_in(*cp.nodes["data"].sizes) * np.float32(3.0)).astype(np.float32)
+        nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
+        res = {}
+        for fuse in (True, False):
+            fwd = ConvPipeFwd(rtc, OpTune(hip_dtype="bf16", hip_layout="nhwc"), fuse_post=fuse)
+            fwd.init(cp, op_params=params)
+            try:
+                assert fwd.fused_post == (want if fuse else {}), (cp.name, fwd.fused_post)
+                tags = [c.tag for c in fwd.fwd_calls]
+                for ctag, (ptag, ltag) in fwd.fused_post.items():
+                    assert "+".join(t for t in (ctag, ptag, ltag) if t) in tags and not any(t in tags for t in (ctag, ptag, ltag) if t), tags
+                io = {"data": data}
+                fwd.run_fwd(["data"], io, nodes)
+                res[fuse] = io
+                if fuse:
+                    fwd.capture_graph(); out = cp.out_node()
+                    rtc.set_var_to_zero(fwd.var_of(out)); fwd.run_graph()
+                    assert np.array_equal(fwd._fetch(out), io[out])
+            finally:
+                fwd.release()
+        for n in nodes:
+            assert np.array_equal(res[True][n], res[False][n]), (cp.name, n, float(np.mean(res[True][n] != res[False][n])))
+        # (and the pooled node is the oracle's pooling of the convolution's node as the device stored it: the maximum is exact)
+        for ctag, (ptag, _) in want.items():
+            pool = next(o for o in cp.ops if o.tag == ptag)
+            assert np.array_equal(bo.pool_fwd(res[True][pool.bot], pool.kern_sz, pool.stride, pool.in_pad, False), res[True][pool.top]), (cp.name, ptag)

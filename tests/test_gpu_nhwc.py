@@ -490,3 +490,36 @@ def test_k_slices_reduced_inside_the_launch(be, shape, tile):
                 first = dict(first or {}); first[key] = outs["out"].copy()
             else:
                 assert np.array_equal(first[key], outs["out"]), (rep, key)
+
+
+ROWS = [  # B, C, H, W, OC, KH, KW, S, P -- what the rolling-rows kernel takes: stride 1 after space-to-depth, more than one tap, at most 64 out_chans, a short K
+    (3, 3, 61, 57, 64, 7, 7, 2, 3), (2, 3, 224, 224, 64, 7, 7, 2, 3), (5, 16, 19, 23, 40, 3, 3, 1, 1), (2, 8, 30, 20, 24, 3, 3, 1, 0), (7, 24, 9, 300, 64, 1, 3, 1, 1),
+    (4, 8, 12, 12, 37, 5, 5, 1, 2), (300, 8, 6, 6, 16, 3, 3, 1, 1), (1, 32, 40, 9, 8, 2, 2, 1, 0), (3, 3, 35, 35, 33, 6, 6, 2, 2)]
+
+
+@pytest.mark.parametrize("chunks", ["", "1", "3"], ids=["chunks-auto", "chunk-1", "chunks-3"])
+@pytest.mark.parametrize("shape", ROWS, ids=lambda s: "x".join(str(v) for v in s))
+def test_rolling_rows_kernel_vs_oracle_and_patch_kernel(be, shape, chunks, monkeypatch):
+    """Round 5 (kernels/conv_nhwc_rows_bf16.hip): a workgroup walks down a run of output rows of one image with the filters in registers; the rows leave through an LDS
+    ring.  Against the oracle (both bounds of this file); and against the patch kernel run on the same operands: the k-slot order is the same, so with an even tap count
+    -- the space-to-depth stems -- the MFMA chains are the same whatever either planner picks, and the outputs are equal bit for bit.  Row runs of every length (one
+    workgroup per image, three, as many as there are rows; a last run that is shorter), out_chans that do not fill the 64-row tile, padded and unpadded planes, a plane
+    wider than a tile row's 256 positions is refused."""
+    monkeypatch.setenv("BODAHIP_NHWC_ROWS", "1")
+    if chunks:
+        monkeypatch.setenv("BODAHIP_NHWC_ROWS_CHUNKS", chunks)
+    op = _conv_op(*shape)
+    outs, prc = _run(be, op, OpTune(**NHWC))
+    if shape[3] == 300:      # 300 output positions per row: not this kernel's
+        assert prc.launch["kernel"] != "bodahip_conv_nhwc_rows_bf16", prc.launch
+        return
+    assert prc.launch["kernel"] == "bodahip_conv_nhwc_rows_bf16", prc.launch
+    _check_bf16(op, outs, prc)
+    monkeypatch.setenv("BODAHIP_NHWC_ROWS", "0")
+    outs2, prc2 = _run(be, op, OpTune(**NHWC))
+    assert prc2.launch["kernel"] == "bodahip_conv_nhwc_patch_bf16", prc2.launch
+    a = add_codegen_annotations(op, OpTune(**NHWC)); taps = a.get_dims("filts").dsz("y") * a.get_dims("filts").dsz("x")
+    if taps % 2 == 0:
+        assert np.array_equal(outs["out"], outs2["out"]), shape
+    else:     # (an odd tap count pairs a step's last tap with the next group's first one or with a zero slot, by the channel groups per step: same sums, another order)
+        assert float(np.max(np.abs(outs["out"].astype(np.float64) - outs2["out"]) / np.maximum(1.0, np.abs(outs2["out"])))) < 2.0 ** -7

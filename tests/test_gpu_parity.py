@@ -341,6 +341,40 @@ def test_conv_vs_oracle_bit_exact(be, shape):
     assert np.array_equal(want, outs["out"]), sd.basic_str()
 
 
+# (B, C, pooled H, pooled W, OC, KH, KW, conv stride, conv pad, pool window, pool stride): the tensor read is the pooling's input, planes of (H - 1) * ps + pk
+POOLED_CONVS = [(3, 5, 9, 9, 40, 3, 3, 1, 1, 3, 2), (2, 7, 13, 11, 33, 5, 5, 1, 2, 3, 2), (5, 6, 6, 6, 70, 3, 3, 1, 1, 2, 2), (2, 4, 12, 10, 20, 3, 3, 2, 1, 3, 1), (1, 3, 8, 8, 16, 2, 2, 1, 0, 3, 3),
+                (7, 12, 6, 6, 130, 3, 3, 1, 1, 3, 2), (3, 96, 27, 27, 64, 5, 5, 1, 2, 3, 2)]
+
+
+@pytest.mark.parametrize("shape", POOLED_CONVS, ids=lambda s: "x".join(str(v) for v in s))
+@pytest.mark.parametrize("tile", ["", "64x256x16x1x4x2", "32x256x16x1x4x2", "128x128x16x2x2x2", "64x64x16x2x2x2"])
+def test_conv_with_a_max_pooling_fused_in_front_bit_exact(be, shape, tile):
+    """Round 5 (kernels/gemm_conv_f32.hip, PKH; cnn_op.fuse_f32_pool): hip_conv whose `in` is a POOLING's input -- every element of the convolution's LDS input patch is
+    the maximum of its window, formed while the patch is staged.  Equal bit for bit to the oracle's max pooling followed by its convolution (the reference runs the two
+    as two functions: test/rtc/pool.cucl, then the conv): windows 2 x 2 / 3 x 3, pool strides 1 / 2 / 3, convolutions with padding, stride 2 in y, tiles that straddle
+    images, an odd channel count (K tail), every tile of the patch planner."""
+    from boda_amd.cnn_op import f32_pool_fusable, fuse_f32_pool
+    from boda_amd.op import Dims
+    B, C, H, W, OC, KH, KW, S, P, pk, ps = shape
+    if S != 1:   # (the patch form needs stride 1 in x: a strided convolution is not fusable, and says so)
+        op = _conv_op(B, C, H, W, OC, KH, KW, S, P)
+        assert not f32_pool_fusable(add_codegen_annotations(op, OpTune()), Dims(("img", "chan", "y", "x"), (B, C, (H - 1) * ps + pk, (W - 1) * ps + pk), "float"), (pk, pk), (ps, ps), (0, 0), 0)
+        return
+    op = _conv_op(B, C, H, W, OC, KH, KW, S, P)
+    anno = add_codegen_annotations(op, OpTune(hip_tile=tile))
+    uin = Dims(("img", "chan", "y", "x"), (B, C, (H - 1) * ps + pk, (W - 1) * ps + pk), "float")
+    plain = add_codegen_annotations(op, OpTune())
+    assert f32_pool_fusable(plain, uin, (pk, pk), (ps, ps), (0, 0), 0) and not f32_pool_fusable(plain, uin, (pk, pk), (ps, ps), (0, 0), 1) and not f32_pool_fusable(plain, uin, (pk, pk), (ps, ps), (1, 1), 0)
+    fuse_f32_pool(anno, uin, (pk, pk), (ps, ps))
+    assert anno.conv_geom()["H"] == H and anno.conv_geom()["UH"] == (H - 1) * ps + pk
+    outs, prc = profile_rcg_call(be, anno, 5, 0.0, 1, include_ins=True, tile=tile)
+    assert prc.launch["kernel"] == "bodahip_conv_f32"
+    pooled = bo.pool_fwd(outs["in"], (pk, pk), (ps, ps), (0, 0), False)
+    assert pooled.shape == (B, C, H, W)
+    want = bo.conv_fwd(pooled, outs["filts"], outs["biases"], (S, S), (P, P), True)
+    assert np.array_equal(want, outs["out"]), (prc.launch["cfg"], SsdsDiff.of(want, outs["out"]).basic_str())
+
+
 @pytest.mark.parametrize("shape", [s for s in EDGE_CONVS if s[6] >= 2] + [(3, 24, 15, 15, 100, 3, 3, 1, 1), (2, 3, 35, 35, 96, 11, 11, 4, 0)])
 def test_conv_row_gather_all_kernel_widths(be, shape, monkeypatch):
     """The row gather (J_MODE 6) is the default for KW >= 6 only; force it for every KW >= 2 (padding, strides, first-row and
