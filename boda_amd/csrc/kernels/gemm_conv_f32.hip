@@ -56,6 +56,7 @@
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef KNAME
 #define KNAME bodahip_gemm_f32
@@ -100,6 +101,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef PF
 #define PF 1 // K-tiles prefetched ahead in registers: 1 | 2 (two register sets; for workgroups that run alone on their CU) | 4 | 6 | 8 (a ring of register sets: tile-starved long-K shapes)
 #endif
+#ifndef KHO
+#define KHO 0 // 1: SEQUENTIAL K HAND-OFF (round 5) -- an exact cure for launches whose tiles do not deal out evenly over the CUs (288 tiles of 128x128 on 256 CUs run as two
+#endif        // rounds, the second one 12 % full).  A tile's K range is cut into p.splitk SEGMENTS; segment s of a tile CONTINUES the ascending-k fma chains of segment s - 1 from
+              // its stored accumulators (unlike K slices nothing is re-associated: every output is still one fmaf chain over k = 0..K-1, bit-identical to the unsegmented
+              // kernel, to the reference and to the oracle).  Jobs (tile, segment) are numbered segment-major and PULLED by persistent workgroups from one counter, so the
+              // producer of any accumulator tile a workgroup waits for is already running: no assumption on dispatch order, placement or co-residency
+              // (/opt/skills/guides/cdna_hip_programming.md, Guideline 16).  Hand-off = the guide's write-through recipe: 16-byte sc1 slab stores, every wave drains vmcnt,
+              // barrier, one relaxed agent-scope flag store; the consumer polls the flag relaxed (one lane, s_sleep), barrier, 16-byte sc1 loads.  Workspace p.ws: word 0 the
+              // job counter, word 1 the exit counter, words 16.. one flag per tile, slabs from p.ws + p.ws_slab on -- all zero between launches (the last segment of a tile
+              // clears its flag, the last workgroup to leave clears the counters), so a captured graph replays without a memset node.
 #ifndef MT
 #define MT 32 // MFMA tile: 32 -> v_mfma_f32_32x32x2_f32 (default), 16 -> v_mfma_f32_16x16x4_f32 (4x more, smaller wave tiles for
 #endif        // shapes with too few 32x32 tiles to give every SIMD a wave; same fp32 rate, same ascending-k fma chain)
@@ -568,8 +579,19 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
   int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int const wi = wave / WJ, wj = wave % WJ;
 
+#if KHO
+  static_assert(!SPLITK && !SPECW, "K hand-off: an exact form -- no K slices; the staging-wave form returns early");
+  unsigned *const hq = reinterpret_cast<unsigned *>(p.ws);
+  int const n_tiles_all = p.tiles_i * p.tiles_j, n_jobs = n_tiles_all * p.splitk;
+  for (;;) {   // persistent workgroup: one (tile, segment) job per pass
+  if (threadIdx.x == 0) reinterpret_cast<unsigned *>(smem)[0] = __hip_atomic_fetch_add(hq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();   // (every wave is past the previous job's last LDS read: each K step ends with a barrier, the epilogue does not touch the LDS)
+  int const job = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<unsigned *>(smem)[0]);
+  __syncthreads();
+  if (job >= n_jobs) break;
+  int const seg = job / n_tiles_all, bid = job - seg * n_tiles_all;
+#elif SPLITK
   // ---- XCD-aware workgroup -> tile map (bijective for any grid size) ------------------------------------------
-#if SPLITK
   int const bid = blockIdx.x / p.splitk, slice = blockIdx.x % p.splitk;
 #else
   int const bid = blockIdx.x;
@@ -654,16 +676,45 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
 #endif
 
   acc_t acc[kTI][kTJ];
+#if KHO
+  constexpr int kHQ = kNA / 4, kSlabB = kTI * kTJ * kHQ * kNT * 16;   // accumulator quads per MFMA tile; bytes of a tile's slab: the accumulator registers, thread by thread (coalesced 16-byte accesses)
+  rsrc_t const rW = make_rsrc(p.ws + p.ws_slab + (long)bid * (long)(kSlabB / 4), (unsigned)kSlabB);
+  if (seg > 0) {   // continue the chains of segment seg - 1: wait for its accumulators (its workgroup pulled its job before this one was pulled: it is running or done)
+    if (threadIdx.x == 0) {
+      unsigned long long const t0 = __builtin_amdgcn_s_memrealtime();   // (100 MHz)
+      while (__hip_atomic_load(hq + 16 + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)seg) {
+        __builtin_amdgcn_s_sleep(32);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) __builtin_trap();   // 4 s: a broken hand-off aborts the launch instead of hanging the device
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < kTI; ++a)
+#pragma unroll
+      for (int b = 0; b < kTJ; ++b)
+#pragma unroll
+        for (int q = 0; q < kHQ; ++q) {
+          f32x4 const v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, (((a * kTJ + b) * kHQ + q) * kNT + tid) * 16, 0, 16));
+          float const y0 = v[0], y1 = v[1], y2 = v[2], y3 = v[3];
+          acc[a][b][4 * q] = y0; acc[a][b][4 * q + 1] = y1; acc[a][b][4 * q + 2] = y2; acc[a][b][4 * q + 3] = y3;
+        }
+  } else
+#endif
+  {
 #pragma unroll
   for (int a = 0; a < kTI; ++a)
 #pragma unroll
     for (int b = 0; b < kTJ; ++b)
 #pragma unroll
       for (int r = 0; r < kNA; ++r) acc[a][b][r] = 0.f;
+  }
 
   float ri[kNI], rj[kNJ];
   int const nkt_all = (p.K + BK - 1) / BK;
-#if SPLITK
+#if KHO
+  int const kt_begin = seg * p.kt_per;
+  int const nkt = max(0, min(nkt_all, kt_begin + p.kt_per) - kt_begin);
+#elif SPLITK
   int const kt_begin = slice * p.kt_per;
   int const nkt = max(0, min(nkt_all, kt_begin + p.kt_per) - kt_begin);
 #else
@@ -813,6 +864,24 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
   }
 #endif
 
+#if KHO
+  if (seg + 1 < p.splitk) {   // not the tile's last segment: hand the raw accumulators on
+#pragma unroll
+    for (int a = 0; a < kTI; ++a)
+#pragma unroll
+      for (int b = 0; b < kTJ; ++b)
+#pragma unroll
+        for (int q = 0; q < kHQ; ++q) {
+          float const x0 = acc[a][b][4 * q], x1 = acc[a][b][4 * q + 1], x2 = acc[a][b][4 * q + 2], x3 = acc[a][b][4 * q + 3];
+          f32x4 v; v[0] = x0; v[1] = x1; v[2] = x2; v[3] = x3;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rW, (((a * kTJ + b) * kHQ + q) * kNT + tid) * 16, 0, 16);
+        }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_barrier" ::: "memory");   // every wave's share of the slab has left (write-through: acknowledged by the fabric)
+    if (threadIdx.x == 0) __hip_atomic_store(hq + 16 + bid, (unsigned)(seg + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    continue;
+  }
+  if (p.splitk > 1 && threadIdx.x == 0) __hip_atomic_store(hq + 16 + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the tile is complete: its flag is ready for the next launch / graph replay
+#endif
   // ---- epilogue: MFMA C/D layout.  32x32: column j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16
   //                                16x16: column j = lane&15, row i = 4*(lane>>4) + r,               r < 4
 #if !SPLITK
@@ -960,6 +1029,13 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
         }
       }
     }
+  }
+#endif
+#if KHO
+  }   // job loop
+  if (threadIdx.x == 0) {   // the last workgroup to leave clears both counters (every other one has drawn its final, out-of-range job before it counted itself out)
+    unsigned const n = __hip_atomic_fetch_add(hq + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n == gridDim.x - 1) { __hip_atomic_store(hq + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(hq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   }
 #endif
 }

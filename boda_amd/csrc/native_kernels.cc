@@ -32,7 +32,7 @@ struct chain_args_t : gemm_args_t {
 };
 static_assert(sizeof(gemm_args_t) == 176, "gemm_args_t is declared with this size by every kernel source (and by set_kernel_source's text)");
 
-struct kernel_t { hipModule_t mod = nullptr; hipFunction_t func = nullptr; };
+struct kernel_t { hipModule_t mod = nullptr; hipFunction_t func = nullptr; int occ = 0; };   // occ: resident workgroups per CU (queried on first use by the persistent forms)
 
 struct native_kernels_t::impl_t {
   std::map<string, kernel_t> kernels; // key = option string
@@ -78,15 +78,15 @@ void native_kernels_t::set_tune(string const &key, string const &val) {
   if (val.empty()) impl->tune.erase(key); else { impl->tune[key] = val; }
 }
 
-// "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF]]]]"
+// "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF[xSW[xKHO]]]]]]"
 static bool parse_tile(string const &s, tile_cfg_t &c) {
-  int v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int n = 0; string cur;
+  int v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int n = 0; string cur;
   for (size_t i = 0; i <= s.size(); ++i) {
-    if (i == s.size() || s[i] == 'x' || s[i] == ':') { if (cur.empty() || n >= 10) return false; v[n++] = atoi(cur.c_str()); cur.clear(); }
+    if (i == s.size() || s[i] == 'x' || s[i] == ':') { if (cur.empty() || n >= 11) return false; v[n++] = atoi(cur.c_str()); cur.clear(); }
     else if (s[i] >= '0' && s[i] <= '9') cur.push_back(s[i]); else return false;
   }
   if (n < 5) return false;
-  c.BI = v[0]; c.BJ = v[1]; c.BK = v[2]; c.WI = v[3]; c.WJ = v[4]; c.MINW = (n >= 6) ? v[5] : 1; c.SPLITK = (n >= 7) ? v[6] : 1; c.MT = (n >= 8) ? v[7] : 32; c.PF = (n >= 9) ? v[8] : 1; c.SW = (n >= 10) ? v[9] : 0;
+  c.BI = v[0]; c.BJ = v[1]; c.BK = v[2]; c.WI = v[3]; c.WJ = v[4]; c.MINW = (n >= 6) ? v[5] : 1; c.SPLITK = (n >= 7) ? v[6] : 1; c.MT = (n >= 8) ? v[7] : 32; c.PF = (n >= 9) ? v[8] : 1; c.SW = (n >= 10) ? v[9] : 0; c.KHO = (n >= 11) ? v[10] : 0;
   return true;
 }
 // the static_asserts of the kernel, checked on the host so that a bad tune is an unsup_err, not a compile failure
@@ -97,6 +97,7 @@ static void check_cfg(tile_cfg_t const &c, bool gather, bool patch = false) {   
   if (gather) ok = ok && ((c.BK * c.BJ) % nt == 0); // the gathers give every thread whole elements / rows
   if (gather) ok = ok && (nt % c.BJ == 0) && (c.BJ % 64 == 0);
   ok = ok && c.SPLITK >= 1 && c.SPLITK <= 64 && c.MINW >= 1 && (c.PF == 1 || c.PF == 2 || c.PF == 4 || c.PF == 6 || c.PF == 8);
+  ok = ok && c.KHO >= 0 && c.KHO <= 64 && (c.KHO <= 1 || (c.SPLITK == 1 && c.SW == 0));   // K hand-off: an exact form (no K slices), not with staging waves
   if (c.PF > 2) ok = ok && ((long)c.PF * c.BK * (c.BI + c.BJ) / nt <= 192);   // (the ring of register sets: PF x staged elements per thread)
   int const accs = (c.BI / (c.WI * c.MT)) * (c.BJ / (c.WJ * c.MT));
   ok = ok && accs * (c.MT == 32 ? 16 : 4) <= 256;
@@ -160,11 +161,14 @@ static vect_string cfg_defs(tile_cfg_t const &c) {
   if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { // experiment hook: extra -D options for the native kernels
     vect_string r = {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI),
                      "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW), "-DMT=" + std::to_string(c.MT), "-DPF=" + std::to_string(c.PF), "-DSPECW=" + std::to_string(c.SW)};
+    if (c.KHO > 1) r.push_back("-DKHO=1");
     std::istringstream is(e); string tok; while (is >> tok) r.push_back(tok);
     return r;
   }
-  return {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI),
+  vect_string r = {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI),
           "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW), "-DMT=" + std::to_string(c.MT), "-DPF=" + std::to_string(c.PF), "-DSPECW=" + std::to_string(c.SW)};
+  if (c.KHO > 1) r.push_back("-DKHO=1");
+  return r;
 }
 struct plan_t;
 static kernel_t &get_kernel(native_kernels_t::impl_t *impl, native_host_t *host, plan_t const &p);
@@ -314,6 +318,7 @@ static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string
       return p;
     }
   }
+  p.cfg.KHO = 0;   // (K hand-off is a convolution form: the sgemm launches are plain grids)
   check_cfg(p.cfg, false);
   p.defs = cfg_defs(p.cfg);
   p.defs.push_back(string("-DI_MODE=") + ((M % 4 == 0) ? "0" : "1"));
@@ -889,6 +894,11 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
     if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
     return p;
   }
+  if (bf16 || p.cfg.SPLITK > 1 || g.pooled()) p.cfg.KHO = 0;
+  if (p.cfg.KHO > 1) {   // K hand-off: no empty segment
+    long const nkt = (Kt + p.cfg.BK - 1) / p.cfg.BK, per = (nkt + p.cfg.KHO - 1) / p.cfg.KHO;
+    p.cfg.KHO = (int)((nkt + per - 1) / per); if (p.cfg.KHO <= 1) p.cfg.KHO = 0;
+  }
   if (bf16) bf16_cfg(p.cfg, !p.ipconv, g.OC, Nj, Kt, allow_splitk ? num_cus : 0, !tile.empty());
   else check_cfg(p.cfg, !p.ipconv && !p.patch, p.patch);
   p.defs = cfg_defs(p.cfg);
@@ -958,6 +968,41 @@ static void setup_ksl(native_kernels_t::impl_t *impl, native_host_t *host, gemm_
     it = impl->ktabs.emplace(key, dev).first;
   }
   ga.splitk = cfg.SPLITK; ga.kt_per = (int)((nk + cfg.SPLITK - 1) / cfg.SPLITK); ga.ws = (float *)it->second; ga.ws_slab = (long)(tick_b / 4);
+}
+
+// The workspace of a call that runs as (tile, segment) jobs with sequential K hand-off (gemm_conv_f32.hip -DKHO=1): 16 counter words (job counter, exit counter), one flag
+// word per tile, then ONE slab of raw fp32 accumulators per tile (a tile's segments run one after the other).  Like the K-slice workspace it belongs to the call, is
+// allocated and zeroed on the call's first run (not inside a capture) and is left zeroed by every launch.
+static void setup_kho(native_kernels_t::impl_t *impl, native_host_t *host, gemm_args_t &ga, tile_cfg_t const &cfg, void const *key_ptr) {
+  long const tiles = (long)ga.tiles_i * ga.tiles_j, nkt = (ga.K + cfg.BK - 1) / cfg.BK;
+  size_t const tick_b = ((size_t)(16 + tiles) * 4 + 255) & ~size_t(255);
+  size_t const slab_b = (size_t)cfg.BI * cfg.BJ * 4;
+  size_t const total = tick_b + (size_t)tiles * slab_b;
+  string const key = "kho:" + std::to_string((uintptr_t)key_ptr) + ":" + std::to_string((uintptr_t)ga.J) + ":" + std::to_string((uintptr_t)ga.I) + ":" + std::to_string(ga.out_coff) + ":" +
+                     std::to_string(total) + ":" + cfg.str();
+  auto it = impl->ktabs.find(key);
+  if (it == impl->ktabs.end()) {
+    if (host->nh_capturing()) rt_err("graph capture: the K hand-off workspace of this call is not allocated yet -- run the call list once before capturing it");
+    void *dev = nullptr;
+    hip_err_chk(hipMalloc(&dev, total), "hipMalloc(K hand-off workspace)");
+    hip_err_chk(hipMemsetAsync(dev, 0, tick_b, host->nh_stream()), "hipMemsetAsync(K hand-off counters)");
+    it = impl->ktabs.emplace(key, dev).first;
+  }
+  ga.splitk = cfg.KHO; ga.kt_per = (int)((nkt + cfg.KHO - 1) / cfg.KHO); ga.ws = (float *)it->second; ga.ws_slab = (long)(tick_b / 4);
+}
+// persistent launch of a K hand-off call: as many workgroups as are resident at once (more would only find the job queue empty), never more than there are jobs
+static uint32_t launch_kho(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t const &c) {
+  if (!k.occ) {
+    int nb = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k.func, c.threads(), 0) != hipSuccess || nb < 1) nb = 1;
+    k.occ = nb;
+  }
+  if (char const *e = getenv("BODAHIP_KHO_OCC")) k.occ = std::max(1, atoi(e));
+  long const jobs = (long)a.tiles_i * a.tiles_j * a.splitk;
+  uint32_t const grid = (uint32_t)std::min<long>(jobs, (long)host->nh_num_cus() * k.occ);
+  void *params[] = {&a};
+  hip_err_chk(host->nh_launch(k.func, grid, 1, (uint32_t)c.threads(), params), "hipModuleLaunchKernel(native, K hand-off)");
+  return grid;
 }
 
 static kernel_t &get_reduce_kernel(native_kernels_t::impl_t *impl, native_host_t *host, bool epi, bool relu) {
@@ -1394,10 +1439,14 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
     last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
     return;
   }
-  setup_splitk(impl, host, ga, cfg, (size_t)Nj * g.OC);
-  launch(host, k, ga, cfg);
-  if (cfg.SPLITK > 1) reduce_splitk(impl, host, ga, Nj * g.OC, true, g.relu, g.OH * g.OW, g.OC);
-  last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (uint32_t)ga.tiles_i * ga.tiles_j * cfg.SPLITK; last_launch.block = cfg.threads();
+  uint32_t kho_grid = 0;
+  if (cfg.KHO > 1) { setup_kho(impl, host, ga, cfg, out); kho_grid = launch_kho(host, k, ga, cfg); }
+  else {
+    setup_splitk(impl, host, ga, cfg, (size_t)Nj * g.OC);
+    launch(host, k, ga, cfg);
+    if (cfg.SPLITK > 1) reduce_splitk(impl, host, ga, Nj * g.OC, true, g.relu, g.OH * g.OW, g.OC);
+  }
+  last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = kho_grid ? kho_grid : (uint32_t)ga.tiles_i * ga.tiles_j * cfg.SPLITK; last_launch.block = cfg.threads();
   last_launch.flops = 2.0 * Nj * g.OC * Kt;
   last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * (g.pooled() ? (double)g.UH * g.UW : (double)g.H * g.W) + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
 }

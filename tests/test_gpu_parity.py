@@ -375,6 +375,49 @@ def test_conv_with_a_max_pooling_fused_in_front_bit_exact(be, shape, tile):
     assert np.array_equal(want, outs["out"]), (prc.launch["cfg"], SsdsDiff.of(want, outs["out"]).basic_str())
 
 
+KHO_CASES = [   # (shape, tile with an eleventh field = K segments per tile): every operand mode of the kernel, 32x32 and 16x16 MFMA tiles, register rings, more jobs than workgroups fit
+    ((32, 64, 13, 13, 256, 3, 3, 1, 1), "64x64x18x2x2x2x1x32x1x0x3"),     # LDS input patch; 340 tiles x 3 segments on at most 512 resident workgroups
+    ((16, 256, 13, 13, 128, 1, 1, 1, 0), "64x64x16x2x2x2x1x32x2x0x4"),    # 1x1 gather, two K tiles in flight
+    ((8, 32, 27, 27, 96, 3, 3, 2, 0), "32x64x32x2x4x1x1x16x2x0x2"),       # table gather, 16x16x4 MFMA tiles
+    ((4, 3, 67, 67, 96, 11, 11, 4, 0), "32x256x22x1x4x2x1x32x1x0x3"),     # row gather / row-decimated patch (conv1 shapes)
+    ((24, 384, 6, 6, 1000, 3, 3, 1, 1), "128x128x36x2x2x2x1x32x1x0x5"),   # ragged out_chan tile row, tiles that straddle images
+    ((40, 1024, 6, 6, 1000, 1, 1, 1, 0), "128x128x16x2x2x2x1x32x1x0x8"),  # NiN cccp8's shape: 8 x 12 tiles, eight segments
+    ((2, 16, 9, 9, 40, 3, 3, 1, 1), "64x64x16x2x2x2x1x32x1x0x64"),        # more segments asked for than K steps: normalised down
+]
+
+
+@pytest.mark.parametrize("shape,tile", KHO_CASES, ids=lambda v: v if isinstance(v, str) else "x".join(map(str, v)))
+def test_conv_sequential_k_hand_off_bit_exact(be, shape, tile):
+    """Round 5 (kernels/gemm_conv_f32.hip -DKHO=1): a tile's K range runs as SEGMENTS on persistent workgroups that pull (tile, segment) jobs from one counter; segment s
+    continues the fma chains of segment s - 1 from its stored accumulators.  Nothing is re-associated: the result equals the oracle (and the unsegmented kernel) bit for bit.
+    Each case runs twice with DIFFERENT data (gen_data's `vi`) -- vars are freed and re-created at the same addresses, so the second run reuses the call's workspace: a stale
+    slab, flag or counter would show --, and three times in a row on the same tensors (the workspace must be left clean by every launch)."""
+    op = _conv_op(*shape)
+    g = op.conv_geom()
+    anno = add_codegen_annotations(op, OpTune(hip_tile=tile))
+    for vi, iters in ((0.0, 1), (0.375, 3)):
+        outs, prc = profile_rcg_call(be, anno, 5, vi, iters, include_ins=True, tile=tile)
+        assert prc.launch["kernel"] == "bodahip_conv_f32" and "_h" in prc.launch["cfg"], prc.launch
+        want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
+        assert np.array_equal(want, outs["out"]), (vi, prc.launch, SsdsDiff.of(want, outs["out"]).basic_str())
+    nkt = -(-(g["C"] * g["KH"] * g["KW"]) // int(prc.launch["cfg"].split("x")[2].split("_")[0]))
+    assert int(prc.launch["cfg"].split("_h")[1]) <= nkt     # no empty segment
+
+
+@pytest.mark.parametrize("tile", ["64x64x16x2x2x2x1x32x1x0x2", "128x128x16x2x2x2x1x32x1x0x3"])
+def test_conv_k_hand_off_random_shapes_bit_exact(be, tile):
+    """The fuzz sweep of test_conv_random_shapes_bit_exact with every launch cut into K segments (where the K loop has at least two steps)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fuzz_conv import cases
+    for sh in cases(24, 11 + len(tile)):
+        op = _conv_op(*sh)
+        outs, prc = _run(be, op, 5, tune=OpTune(hip_tile=tile), include_ins=True)
+        g = op.conv_geom()
+        want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (g["SY"], g["SX"]), (g["PY"], g["PX"]), True)
+        assert np.array_equal(want, outs["out"]), (sh, prc.launch["cfg"])
+
+
 @pytest.mark.parametrize("shape", [s for s in EDGE_CONVS if s[6] >= 2] + [(3, 24, 15, 15, 100, 3, 3, 1, 1), (2, 3, 35, 35, 96, 11, 11, 4, 0)])
 def test_conv_row_gather_all_kernel_widths(be, shape, monkeypatch):
     """The row gather (J_MODE 6) is the default for KW >= 6 only; force it for every KW >= 2 (padding, strides, first-row and
