@@ -102,15 +102,22 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define PF 1 // K-tiles prefetched ahead in registers: 1 | 2 (two register sets; for workgroups that run alone on their CU) | 4 | 6 | 8 (a ring of register sets: tile-starved long-K shapes)
 #endif
 #ifndef KHO
-#define KHO 0 // 1: SEQUENTIAL K HAND-OFF (round 5) -- an exact cure for launches whose tiles do not deal out evenly over the CUs (288 tiles of 128x128 on 256 CUs run as two
-#endif        // rounds, the second one 12 % full).  A tile's K range is cut into p.splitk SEGMENTS; segment s of a tile CONTINUES the ascending-k fma chains of segment s - 1 from
-              // its stored accumulators (unlike K slices nothing is re-associated: every output is still one fmaf chain over k = 0..K-1, bit-identical to the unsegmented
-              // kernel, to the reference and to the oracle).  Jobs (tile, segment) are numbered segment-major and PULLED by persistent workgroups from one counter, so the
-              // producer of any accumulator tile a workgroup waits for is already running: no assumption on dispatch order, placement or co-residency
+#define KHO 0 // 1: SEQUENTIAL K HAND-OFF (round 5; opt-in: eleventh field of a tile string = segments per tile) -- an EXACT way of evening out launches whose tiles do not deal
+#endif        // out evenly over the CUs.  A tile's K range is cut into p.splitk SEGMENTS; segment s CONTINUES the ascending-k fma chains of segment s - 1 from its stored
+              // accumulators (unlike K slices nothing is re-associated: every output is still one fmaf chain over k = 0..K-1, bit-identical to the unsegmented kernel, to the
+              // reference and to the oracle).  Jobs (tile, segment) are numbered segment-major and PULLED by persistent workgroups from one counter, so the producer of any
+              // accumulator tile a workgroup waits for is already running: no assumption on dispatch order, placement or co-residency
               // (/opt/skills/guides/cdna_hip_programming.md, Guideline 16).  Hand-off = the guide's write-through recipe: 16-byte sc1 slab stores, every wave drains vmcnt,
-              // barrier, one relaxed agent-scope flag store; the consumer polls the flag relaxed (one lane, s_sleep), barrier, 16-byte sc1 loads.  Workspace p.ws: word 0 the
-              // job counter, word 1 the exit counter, words 16.. one flag per tile, slabs from p.ws + p.ws_slab on -- all zero between launches (the last segment of a tile
-              // clears its flag, the last workgroup to leave clears the counters), so a captured graph replays without a memset node.
+              // barrier, one sc1 flag store; the consumer's first wave polls the flag (sc1 load, s_sleep, bounded), barrier, 16-byte sc1 slab loads.  Workspace p.ws: word 0
+              // the job counter, word 1 the exit counter, word 2 "a wait timed out", words 16.. one flag per tile, slabs from p.ws + p.ws_slab on -- counters and flags are
+              // zero between launches (the last segment of a tile clears its flag, the last workgroup to leave clears the counters): a captured graph replays as it is.
+              // What it is worth (profiles/r05_probe_k_hand_off.txt): a tile's segments run one after the other, so never more chains are active than there are tiles --
+              // the gain is only that chains migrate between CUs at segment boundaries.  With one workgroup per CU (no job ever waits) NiN conv4 at 256 images 104.9 ->
+              // 111.2 TF/s on 128x256 tiles in eight segments, AlexNet conv5 100.7 -> 103.5; everything else level or slower (a lone workgroup per CU runs these
+              // kernels at ~0.72 of peak, two co-resident ones at ~0.88 -- and with two per CU half of the persistent workgroups wait on a predecessor).  Not a default plan.
+#ifndef KHO_DBG
+#define KHO_DBG 0 // experiment hook (BODAHIP_EXTRA_DEFS): 1 no slab stores / loads | 2 no flags (no poll, no flag stores) | 4 no exit protocol | 8 static job assignment (no counter)
+#endif
 #ifndef MT
 #define MT 32 // MFMA tile: 32 -> v_mfma_f32_32x32x2_f32 (default), 16 -> v_mfma_f32_16x16x4_f32 (4x more, smaller wave tiles for
 #endif        // shapes with too few 32x32 tiles to give every SIMD a wave; same fp32 rate, same ascending-k fma chain)
@@ -581,15 +588,25 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
 
 #if KHO
   static_assert(!SPLITK && !SPECW, "K hand-off: an exact form -- no K slices; the staging-wave form returns early");
-  unsigned *const hq = reinterpret_cast<unsigned *>(p.ws);
   int const n_tiles_all = p.tiles_i * p.tiles_j, n_jobs = n_tiles_all * p.splitk;
+  // The counters and flags are reached through a buffer descriptor, by the first wave only, with every lane but lane 0 given an out-of-range offset (dropped by the
+  // hardware): no `if (threadIdx.x == 0)` anywhere in the job loop.  (With such divergent branches -- and a poll loop inside one -- this compiler turned the job loop
+  // and the K loop into exec-masked divergent loops and lost the flag address on the way: memory faults.)  Every branch the hand-off adds is wave-uniform.
+  rsrc_t const rQ = make_rsrc(p.ws, (unsigned)(16 + n_tiles_all) * 4u);
+  int const q_l0 = (lane == 0) ? 0 : kOOB;
+  int kho_pass = 0; (void)kho_pass;
   for (;;) {   // persistent workgroup: one (tile, segment) job per pass
-  if (threadIdx.x == 0) reinterpret_cast<unsigned *>(smem)[0] = __hip_atomic_fetch_add(hq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if KHO_DBG & 8
+  int const job = (int)blockIdx.x + (int)gridDim.x * kho_pass; ++kho_pass;
+#else
+  if (wave == 0) reinterpret_cast<int *>(smem)[0] = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rQ, q_l0, 0, 0));
   __syncthreads();   // (every wave is past the previous job's last LDS read: each K step ends with a barrier, the epilogue does not touch the LDS)
   int const job = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<unsigned *>(smem)[0]);
   __syncthreads();
+#endif
   if (job >= n_jobs) break;
   int const seg = job / n_tiles_all, bid = job - seg * n_tiles_all;
+  int const flag_off = (16 + bid) * 4;   // (wave-uniform: job comes out of a readfirstlane)
 #elif SPLITK
   // ---- XCD-aware workgroup -> tile map (bijective for any grid size) ------------------------------------------
   int const bid = blockIdx.x / p.splitk, slice = blockIdx.x % p.splitk;
@@ -679,13 +696,21 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
 #if KHO
   constexpr int kHQ = kNA / 4, kSlabB = kTI * kTJ * kHQ * kNT * 16;   // accumulator quads per MFMA tile; bytes of a tile's slab: the accumulator registers, thread by thread (coalesced 16-byte accesses)
   rsrc_t const rW = make_rsrc(p.ws + p.ws_slab + (long)bid * (long)(kSlabB / 4), (unsigned)kSlabB);
-  if (seg > 0) {   // continue the chains of segment seg - 1: wait for its accumulators (its workgroup pulled its job before this one was pulled: it is running or done)
-    if (threadIdx.x == 0) {
-      unsigned long long const t0 = __builtin_amdgcn_s_memrealtime();   // (100 MHz)
-      while (__hip_atomic_load(hq + 16 + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)seg) {
+  if (seg > 0 && !(KHO_DBG & 1)) {   // continue the chains of segment seg - 1: wait for its accumulators (its workgroup pulled its job before this one was pulled: it is running or done)
+    if (wave == 0 && !(KHO_DBG & 2)) {   // (a scalar branch: `wave` comes out of a readfirstlane)
+      // The first wave polls as a whole, on a wave-uniform value (every lane loads the same word; readfirstlane): a WAVE-UNIFORM loop.  (With the loop inside an
+      // `if (threadIdx.x == 0)` the compiler turned the job loop and the K loop around it into exec-masked divergent loops -- and mis-placed the flag address.)
+      // Bounded: 4 s of the 100 MHz clock; a hand-off that never arrives -- a bug -- then computes on whatever the slab holds and says so in word 2 of the
+      // workspace instead of hanging the device.
+      unsigned const t0 = (unsigned)__builtin_amdgcn_s_memrealtime();   // (32 bits of the 100 MHz clock: differences are good for 42 s)
+      bool timed_out = false;
+      for (;;) {
+        unsigned const have = (unsigned)__builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(rQ, flag_off, 0, 16));   // (sc1: past the L1)
+        if (have >= (unsigned)seg) break;
         __builtin_amdgcn_s_sleep(32);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) __builtin_trap();   // 4 s: a broken hand-off aborts the launch instead of hanging the device
+        if ((unsigned)__builtin_amdgcn_s_memrealtime() - t0 > 400000000u) { timed_out = true; break; }
       }
+      if (timed_out) __builtin_amdgcn_raw_buffer_store_b32(1, rQ, q_l0 + 8, 0, 16);
     }
     __syncthreads();
 #pragma unroll
@@ -867,7 +892,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
 #if KHO
   if (seg + 1 < p.splitk) {   // not the tile's last segment: hand the raw accumulators on
 #pragma unroll
-    for (int a = 0; a < kTI; ++a)
+    for (int a = 0; a < ((KHO_DBG & 1) ? 0 : kTI); ++a)
 #pragma unroll
       for (int b = 0; b < kTJ; ++b)
 #pragma unroll
@@ -877,10 +902,9 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rW, (((a * kTJ + b) * kHQ + q) * kNT + tid) * 16, 0, 16);
         }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_barrier" ::: "memory");   // every wave's share of the slab has left (write-through: acknowledged by the fabric)
-    if (threadIdx.x == 0) __hip_atomic_store(hq + 16 + bid, (unsigned)(seg + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    continue;
-  }
-  if (p.splitk > 1 && threadIdx.x == 0) __hip_atomic_store(hq + 16 + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the tile is complete: its flag is ready for the next launch / graph replay
+    if (wave == 0 && !(KHO_DBG & 2)) __builtin_amdgcn_raw_buffer_store_b32(seg + 1, rQ, q_l0 + flag_off, 0, 16);   // (sc1: write-through, like the slab)
+  } else {
+  if (p.splitk > 1 && wave == 0 && !(KHO_DBG & 2)) __builtin_amdgcn_raw_buffer_store_b32(0, rQ, q_l0 + flag_off, 0, 16);   // the tile is complete: its flag is ready for the next launch / graph replay
 #endif
   // ---- epilogue: MFMA C/D layout.  32x32: column j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5), r < 16
   //                                16x16: column j = lane&15, row i = 4*(lane>>4) + r,               r < 4
@@ -1032,10 +1056,11 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
   }
 #endif
 #if KHO
+  }   // the tile's last segment
   }   // job loop
-  if (threadIdx.x == 0) {   // the last workgroup to leave clears both counters (every other one has drawn its final, out-of-range job before it counted itself out)
-    unsigned const n = __hip_atomic_fetch_add(hq + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (n == gridDim.x - 1) { __hip_atomic_store(hq + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(hq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if (wave == 0 && !(KHO_DBG & 4)) {   // the last workgroup to leave clears both counters (every other one has drawn its final, out-of-range job before it counted itself out)
+    int const n = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rQ, q_l0 + 4, 0, 0));
+    if (n == (int)gridDim.x - 1) { __builtin_amdgcn_raw_buffer_store_b32(0, rQ, q_l0 + 4, 0, 16); __builtin_amdgcn_raw_buffer_store_b32(0, rQ, q_l0, 0, 16); }
   }
 #endif
 }

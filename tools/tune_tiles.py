@@ -28,12 +28,19 @@ for op in ops:
     k = op.to_str()
     if k not in seen:
         auto_ms, auto_cfg = t_of(op, "")
-        best_ms, best_t = auto_ms, ""
+        best_ms, best_t, best_cfg = 1e30, "", ""
         for t in a.tiles.split(","):
+            if not t: continue
             try: ms, cfg = t_of(op, t)
             except Exception: continue
-            if ms < best_ms: best_ms, best_t = ms, t
-        if best_t and best_ms > auto_ms * (1.0 - a.min_gain): best_ms, best_t = auto_ms, ""
+            if ms < best_ms: best_ms, best_t, best_cfg = ms, t, cfg
+        # The planner's choice is timed first, right after the data was generated (clocks not settled): an identical configuration timed later came out 8-12 % "faster".
+        # So: the planner's choice again at the end, and the winner and the planner's choice alternately twice more -- the minimum of each side counts.
+        auto_ms = min(auto_ms, t_of(op, "")[0])
+        if best_t and best_cfg != auto_cfg:
+            for _ in range(2):
+                best_ms = min(best_ms, t_of(op, best_t)[0]); auto_ms = min(auto_ms, t_of(op, "")[0])
+        if (not best_t) or best_cfg == auto_cfg or best_ms > auto_ms * (1.0 - a.min_gain): best_ms, best_t = auto_ms, ""
         seen[k] = (auto_ms, best_ms, best_t, auto_cfg)
         g = op.conv_geom()
         print(f"C{g['C']:4d} {g['H']:3d}x{g['W']:<3d} OC{g['OC']:4d} k{g['KH']}s{g['SY']}  auto {auto_cfg:>22s} {auto_ms*1e3:7.1f} us   best {best_t or '(auto)':>26s} {best_ms*1e3:7.1f} us", flush=True)
