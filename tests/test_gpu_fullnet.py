@@ -216,6 +216,40 @@ def test_graph_replay_equals_call_by_call(rtc):
         fwd.release()
 
 
+def test_k_hand_off_in_a_whole_net_and_its_graph_replay(rtc):
+    """Round 5 (kernels/gemm_conv_f32.hip -DKHO=1): every convolution of GoogLeNet on K hand-off tiles (three segments per tile, persistent workgroups) -- node for node
+    bit-identical to the planner's plain grids, call by call and as a hipGraph replayed on NEW data (the counters, flags and slabs of every call's workspace are left
+    clean by each launch: nothing is reset between replays), also with the graph re-wired to the calls' true dependencies (independent calls overlap)."""
+    from boda_amd.cnn_op import OpTune
+    cp = googlenet_conv(2)
+    data = bo.gen_conv_in(*cp.nodes["data"].sizes)
+    nodes = [cp.out_node(), "icp9_out", "icp3_out", "conv2"]
+    ref = ConvPipeFwd(rtc); ref.init(cp, op_params=_params(cp))
+    try:
+        want = {"data": data}; ref.run_fwd(["data"], want, nodes)
+        want2 = {"data": data[::-1].copy()}; ref.run_fwd(["data"], want2, nodes)
+    finally:
+        ref.release()
+    fwd = ConvPipeFwd(rtc, OpTune(hip_tile="64x64x16x2x2x2x1x32x1x0x3")); fwd.init(cp, op_params=_params(cp))
+    try:
+        io = {"data": data}
+        fwd.run_fwd(["data"], io, nodes)
+        assert "_h" in rtc.last_launch()["cfg"], rtc.last_launch()     # (the classifier's convolution: the tile took effect)
+        for n in nodes:
+            assert np.array_equal(io[n], want[n]), n
+        for parallel in (False, True):
+            fwd.capture_graph(parallel=parallel)
+            for d, w in ((data[::-1].copy(), want2), (data, want), (data[::-1].copy(), want2)):
+                rtc.copy_nda_to_var("data", d)
+                for n in nodes:
+                    rtc.set_var_to_zero(fwd.var_of(n))
+                fwd.run_graph()
+                for n in nodes:
+                    assert np.array_equal(rtc.copy_var_to_nda(fwd.var_of(n)), w[n]), (parallel, n)
+    finally:
+        fwd.release()
+
+
 def test_concat_copies_into_channel_ranges(rtc):
     cp = ConvPipe("c", "data", Dims.make("float", img=3, chan=5, y=6, x=7))
     cp.add(PipeOp("pa", "Pooling", "data", "pa", kern_sz=(3, 3), stride=(1, 1), in_pad=(1, 1)))
