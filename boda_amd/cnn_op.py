@@ -39,7 +39,7 @@ class OpTune:
     hip_out: str = ""  # extension (with hip_layout=nhwc): "f32" = the kernel writes float instead of bfloat16
     hip_exact: int = 1  # extension: 1 = fp32 results bit-identical to the reference's per-thread fma chain (default); 0 = tolerance mode: within the reference's bound for re-associating
     # kernels (mrd < 2e-3, src/rtc_prof.cc:317-319,436; its 2e-4 default, :161, is not met by ANY second association of a K = 9216 sum on its U(-5,5) data) -- deterministic K slices on tile-starved long-K layers, Winograd where it is faster
-    hip_tile: str = ""  # extension: workgroup tile of the native kernels "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF]]]]" ("" = heuristic)
+    hip_tile: str = ""  # extension: workgroup tile of the native kernels "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF[xSW[xKHO]]]]]]" ("" = heuristic)
 
     _ALWAYS = ("MNt", "MNb", "tconv_max_ksz")  # u32_pt_t fields print as "8 8" != default text "8:8": always dumped
 

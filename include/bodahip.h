@@ -123,8 +123,8 @@ int bodahip_graph_destroy(bodahip_ctx *ctx, uint32_t graph_id);
 int bodahip_get_stream(bodahip_ctx *ctx, void **hip_stream_out);   /* the backend's hipStream_t, for event timing / interop */
 int bodahip_get_device_info(bodahip_ctx *ctx, char *arch_buf, size_t arch_buf_sz, int *num_cus_out, int *clock_khz_out);
 /* tile override for the native kernels (the op_tune_t MNt/MNb/Kb analogue): key "sgemm_tile"|"conv_tile",
- * value "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF]]]]" (workgroup tile, K step, waves, min waves per SIMD, K slices, MFMA tile 32|16,
- * K-tiles prefetched 1|2) or "" to restore the heuristic; key "k1_stream" (the streaming kernel for short-K 1x1 / stride-1 convs,
+ * value "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF[xSW[xKHO]]]]]]" (workgroup tile, K step, waves, min waves per SIMD, K slices, MFMA tile 32|16,
+ * K-tiles prefetched 1|2|4|6|8, staging waves 0|1, sequential K segments per tile of an fp32 convolution) or "" to restore the heuristic; key "k1_stream" (the streaming kernel for short-K 1x1 / stride-1 convs,
  * kernels/k1_stream_f32.hip): "" automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row / 32-pel blocks per wave);
  * key "timing": how get_dur attributes stream time to calls -- "" | "call" (markers around every call: the reference's semantics,
  * src/nvrtc_util.cc:355-385) | "kernel" (events bound to the call's own dispatches) | "stream" (end markers only: per-call durations add up to
