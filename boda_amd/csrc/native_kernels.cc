@@ -827,6 +827,13 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   // long-K 1x1 layers on 64x64 tiles: a 32-deep K step (tools/tune_tiles.py over GoogLeNet / ResNet-50 at B=64: every 1x1 layer with
   // >= 480 input channels gains 4-6 % over the 16-deep step; with 256 channels and fewer it does not)
   if (p.k1 && !bf16 && tile.empty() && p.cfg.BI == 64 && p.cfg.BJ == 64 && p.cfg.MT == 32 && p.cfg.BK == 16 && g.C >= 448) p.cfg.BK = 32;
+  // Round 5, in-sequence A/Bs through the tile-wisdom path (tools/wisdom_ab.sh; isolated sweeps mislead here): a 1x1 layer whose 128 x 128 tiles still make >= 3.5 rounds
+  // of the CUs runs 8-9 % faster on them than on the 64 x 64 tiles the short-launch rule prefers (half the operand bytes per flop through the L2) -- NiN cccp5 / cccp6 at
+  // 256 images 128 -> 116 us, cccp3 / cccp4 at 128 images 129 -> 119 us; with fewer tiles (cccp5 at 128 images: 507, cccp7 / cccp8: 288-576) the finer tiles stay ahead.
+  if (p.k1 && !bf16 && tile.empty() && p.cfg.BI == 64 && p.cfg.BJ == 64 && p.cfg.MT == 32 && g.OC % 128 == 0 && getenv("BODAHIP_NO_K1_128") == nullptr) {
+    long const t128 = (long)(g.OC / 128) * ((Nj + 127) / 128);
+    if (t128 * 2 >= 7l * num_cus) { p.cfg.BI = 128; p.cfg.BJ = 128; p.cfg.BK = 16; p.cfg.WI = 2; p.cfg.WJ = 2; p.cfg.MINW = 2; p.cfg.PF = 1; }
+  }
   // SX == 1, more than one tap: LDS input patch (J_MODE 7) -- a K step is CB whole input channels, staged as padded input rows
   // (coalesced, ~KH*KW x fewer loads than an im2col image) and read by the MFMAs in place.  Needs compile-time plane sizes.
   p.patch = false;
