@@ -127,6 +127,29 @@ def test_planner_picks_the_documented_kernel_and_operand_mode_per_shape():
     assert "-DSPLITK" not in ex(_conv(64, 1024, 14, 256, 1, func="hip_conv_bf16"))
 
 
+def test_planner_round5_rules_k1_tiles_and_the_k_hand_off_tile_field():
+    """Round 5, host logic only: (1) a 1x1 fp32 layer whose 128 x 128 tiles still make >= 3.5 rounds of the CUs takes them (in-sequence A/B: NiN cccp5 at 256 images,
+    cccp3 at 128), with fewer tiles the 64 x 64 tiles stay; (2) the eleventh tile field asks for sequential K hand-off (-DKHO=1): segments are lowered until none is
+    empty, it is an fp32 convolution form (ignored by sgemm), and it is refused together with K slices or staging waves."""
+    ex = R.explain_plan
+    assert ex(_conv(256, 384, 13, 384, 1)).startswith("bodahip_conv_f32 128x128x16_w2x2 ")        # cccp5 @256: 3 x 338 = 1014 tiles
+    assert ex(_conv(128, 256, 27, 256, 1)).startswith("bodahip_conv_f32 128x128x16_w2x2 ")        # cccp3 @128: 2 x 729 = 1458 tiles
+    assert ex(_conv(128, 384, 13, 384, 1)).startswith("bodahip_conv_f32 64x64x16_w2x2_p2 ")       # cccp5 @128: 507 tiles
+    assert ex(_conv(256, 1024, 6, 1024, 1)).startswith("bodahip_conv_f32 64x64x32_w2x2_p2 ")      # cccp7 @256: 576 tiles
+    assert ex(_conv(256, 1024, 6, 1000, 1)).startswith("bodahip_conv_f32 64x64x32_w2x2_p2 ")      # cccp8: out_chans not a multiple of 128
+    p = ex(_conv(128, 384, 6, 1024, 3, 1, 1), tile="128x128x36x2x2x2x1x32x1x0x8")
+    assert p.startswith("bodahip_conv_f32 128x128x36_w2x2_h8 ") and "-DKHO=1" in p and "-DJ_MODE=7" in p
+    p = ex(_conv(2, 16, 9, 40, 3, 1, 1), tile="64x64x16x2x2x2x1x32x1x0x64")                       # K = 144 = 8 steps of 18: at most 8 segments
+    assert "_h8 " in p and "-DKHO=1" in p
+    p = ex(_conv(2, 8, 9, 40, 3, 1, 1), tile="64x64x72x2x2x2x1x32x1x0x4")                          # one K step: no hand-off at all
+    assert "_h" not in p.split(" ")[1] and "-DKHO" not in p
+    assert "-DKHO" not in ex(_conv(8, 64, 13, 128, 1), tile="64x64x16x2x2x2x2x32x1x0x3")          # with K slices (a re-associating form): the hand-off is dropped
+    with pytest.raises(UnsupErr, match="unsupported tile configuration"):                         # with staging waves (they leave the kernel early): refused
+        ex(_conv(8, 64, 13, 128, 1), tile="64x64x16x2x2x1x1x32x1x1x3")
+    sg = lambda m, n, k: __import__("boda_amd.op", fromlist=["parse_op"]).parse_op(f"(str_vals=(type=sgemm),nda_vals=(a=(dims=(K={k},M={m})),b=(dims=(K={k},N={n})),c=(dims=(M={m},N={n}))))")
+    assert "-DKHO" not in ex(sg(512, 512, 512), tile="64x64x16x2x2x2x1x32x1x0x4")
+
+
 def test_planner_k1_chain_and_the_net_driver_fuses_nin_block_one():
     """hip_conv_k1_chain (round 4c): two chained 1x1 convolutions plan onto the chain form of the 16-bytes-per-lane streaming kernel (both filter images in LDS, the
     intermediate channels = the rows of one accumulator set), and ConvPipeFwd fuses exactly NiN's cccp1 -> cccp2 at the bench batches (dry init, no device)."""
