@@ -178,7 +178,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(host->nh_launch(k.func, grid, 1, (uint32_t)c.threads(), params), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, fc = false, big = false, rdec = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false, nhwc_rows = false, ksl = false; int rows = 0, cg = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, fc = false, big = false, cbig = false, rdec = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false, nhwc_rows = false, ksl = false; int rows = 0, cg = 0; };
 
 // Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
 //   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
@@ -800,6 +800,57 @@ static bool plan_rdec(conv_geom_t const &g, int num_cus, plan_t &p) {
                           string("-DRELU=") + (g.relu ? "1" : "0")}) p.defs.push_back(d);
   return true;
 }
+// Round 6: kernels/conv_big_f32.hip -- WI x WJ multiplying waves + four staging waves (tile field SW == 2): "TBIxTBJxBKSxWIxWJxMINWx1x32xPFx2".  The pel side takes the
+// cheapest form the geometry allows: the LDS input patch (stride 1 in x, more than one tap: BKS becomes whole channels, the smallest even multiple of KH KW that is >= the
+// tile's BKS), the plain 1x1 form, else the table gather.  The host-side checks are the kernel's static_asserts (a bad tune is an unsup_err, not a compile failure).
+struct conv_big_form_t { int jmode = 2, bks = 16, nstg = 4, ivw = 1; long lds = 0; };
+static bool conv_big_form(conv_geom_t const &g, tile_cfg_t const &c, conv_big_form_t &f, string *why = nullptr) {
+  auto bad = [&](char const *m) { if (why) *why = m; return false; };
+  int const nmw = c.WI * c.WJ;
+  if (!(nmw == 8 || nmw == 4)) return bad("eight (or four) multiplying waves");
+  if (c.BI <= 0 || c.BJ <= 0 || c.BI % (c.WI * 32) || c.BJ % (c.WJ * 32)) return bad("tile not a multiple of the waves' 32 x 32 blocks");
+  int const ti = c.BI / (c.WI * 32), tj = c.BJ / (c.WJ * 32);
+  if (ti > 4 || tj > 4 || ti * tj > 8) return bad("more than 4 x 2 | 2 x 4 blocks per wave");
+  if (c.BK % 2 || c.BK < 4 || c.BK > 64) return bad("BKS: even, 4 .. 64");
+  if (!(c.PF == 1 || c.PF == 2 || c.PF == 4) || c.MT != 32 || c.SPLITK != 1 || c.KHO > 1 || c.MINW < 1 || c.MINW > 2) return bad("PF 1 | 2 | 4, MT 32, no K slices / hand-off, MINW 1 | 2");
+  long const Kt = (long)g.C * g.KH * g.KW;
+  int const ldi = (c.BI / ti) * (ti == 3 ? 4 : ti) + 4, ldj = (c.BJ / tj) * (tj == 3 ? 4 : tj) + 4;
+  long img_j = 0;
+  bool const k1 = g.KH == 1 && g.KW == 1 && g.PY == 0 && g.PX == 0;
+  bool const patch = !k1 && g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && getenv("BODAHIP_CBIG_NO_PATCH") == nullptr;
+  f.bks = c.BK;
+  if (patch) {
+    int const taps = g.KH * g.KW; int cb = 1; while (cb * taps < c.BK || (cb * taps) % 2) ++cb;
+    f.bks = cb * taps; if (f.bks > 128) return bad("patch form: K step above 128");
+    int const wp = g.W + 2 * g.PX, rows_max = (c.BJ - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
+    long const cs = (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp;
+    if (cs > 16 * 256) return bad("patch form: more than 16 patch elements per staging thread and channel");
+    f.jmode = 7; img_j = (cb * cs + 3) / 4 * 4;
+  } else {
+    int const cpt = (c.BJ + 255) / 256; if (c.BJ % cpt) return bad("pel columns per staging thread");
+    int const tw = c.BJ / cpt; if (tw % 64 || 256 / tw < 1 || c.BK % (256 / tw)) return bad("pel staging: whole waves per k row");
+    if (!k1 && (c.BK / (256 / tw)) % 4) return bad("table gather: whole quads of k rows per staging thread");
+    f.jmode = k1 ? 5 : 2; img_j = (long)f.bks * ldj;
+  }
+  f.ivw = (Kt % 4 == 0 && f.bks % 4 == 0) ? 4 : ((Kt % 2 == 0) ? 2 : 1);
+  long const stage = ((long)f.bks * ldi + img_j) * 4, cap = 160l * 1024 / c.MINW;
+  f.nstg = 4; if (char const *e = getenv("BODAHIP_CBIG_NSTG")) f.nstg = atoi(e); else if (4 * stage > cap) f.nstg = 3;
+  if (!(f.nstg == 3 || f.nstg == 4) || f.nstg * stage > cap) return bad("LDS stages exceed the CU's 160 KB");
+  f.lds = f.nstg * stage;
+  return true;
+}
+static plan_t plan_conv_big(conv_geom_t const &g, tile_cfg_t const &c) {
+  string why; conv_big_form_t f;
+  if (!conv_big_form(g, c, f, &why)) unsup_err("native kernel: unsupported staging-wave tile " + c.str() + " (" + why + ")");
+  plan_t p; p.cbig = true; p.k1 = (f.jmode == 5); p.patch = (f.jmode == 7); p.kname = "bodahip_conv_big_f32"; p.cfg = c; p.cfg.BK = f.bks;
+  p.defs = {"-DTBI=" + std::to_string(c.BI), "-DTBJ=" + std::to_string(c.BJ), "-DWI=" + std::to_string(c.WI), "-DWJ=" + std::to_string(c.WJ), "-DBKS=" + std::to_string(f.bks),
+            "-DPF=" + std::to_string(c.PF), "-DNSTG=" + std::to_string(f.nstg), "-DMINW=" + std::to_string(c.MINW), "-DI_VW=" + std::to_string(f.ivw), "-DJ_MODE=" + std::to_string(f.jmode),
+            "-DKH=" + std::to_string(g.KH), "-DKW=" + std::to_string(g.KW), "-DSY=" + std::to_string(g.SY), "-DSX=" + std::to_string(g.SX),
+            "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX), string("-DRELU=") + (g.relu ? "1" : "0")};
+  if (f.jmode == 7) for (auto const &kv : {std::make_pair("CH", g.H), std::make_pair("CW", g.W), std::make_pair("COH", g.OH), std::make_pair("COW", g.OW)}) p.defs.push_back(string("-D") + kv.first + "=" + std::to_string(kv.second));
+  if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return p;
+}
 static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false, string const &k1s = string(), bool allow_splitk = true, bool exact = true) {
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   plan_t p;
@@ -811,6 +862,10 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   p.ipconv = (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W);
   p.cfg = choose_cfg(g.OC, (int)Nj, (int)Kt, num_cus, !p.ipconv, bf16);
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad conv_tile '" + tile + "'"); }
+  if (!bf16 && p.cfg.SW == 2) {   // the staging-wave kernel, asked for by its own tile string
+    if (g.pooled()) unsup_err("hip_conv: fused pooling (hip_pool) is a form of the LDS-patch kernel, not of the staging-wave kernel");
+    return plan_conv_big(g, p.cfg);
+  }
   // wide kernels: row gather (one address + wide loads per (in_chan,ky) row of KW taps): a K step is `rows` whole rows, BK = rows*KW.
   // Measured (MI355X, B=256): 11x11/s4 +8%, 5x5 -3%, 3x3 -9% vs the per-element table gather (unaligned x3 loads cost more than the
   // address arithmetic they save), so the default takes it for KW >= 6 only; BODAHIP_ROW_GATHER_MIN_KW overrides (>= 2).
@@ -926,7 +981,7 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
 }
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
-  return hiprtc_compile(p.nhwc_rows ? k_src_conv_nhwc_rows_bf16 : p.nhwc_multi ? k_src_conv_nhwc_multi_bf16 : p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.big ? k_src_sgemm_big_f32 : p.fc ? k_src_fc_f32 : p.stream ? (p.quad ? k_src_k1_quad_f32 : k_src_k1_stream_f32) : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
+  return hiprtc_compile(p.nhwc_rows ? k_src_conv_nhwc_rows_bf16 : p.nhwc_multi ? k_src_conv_nhwc_multi_bf16 : p.nhwc_patch ? k_src_conv_nhwc_patch_bf16 : p.nhwc ? k_src_conv_nhwc_bf16 : p.patch16 ? k_src_conv_patch_bf16 : (p.cbig ? k_src_conv_big_f32 : p.big ? k_src_sgemm_big_f32 : p.fc ? k_src_fc_f32 : p.stream ? (p.quad ? k_src_k1_quad_f32 : k_src_k1_stream_f32) : (p.bf16 ? k_src_gemm_conv_bf16 : k_src_gemm_conv_f32)), p.kname, arch, opts, log, true);
 }
 
 // grow-only scratch shared by the split-K slabs and the Winograd-domain tensors (like the reference's cudnn scratch var)
@@ -1117,6 +1172,7 @@ static sgemm_split_t plan_sgemm_split(uint32_t M, uint32_t N, uint32_t K, int nu
 // the 256 x 128 form of the staging-wave kernel where its tiles deal out in (nearly) whole rounds -- see sgemm(); "" = not here
 static string sgemm_wide_tile(uint32_t M, uint32_t N, uint32_t K, long cus) {
   if (M % 4 || N % 4 || K < 512 || getenv("BODAHIP_NO_SGEMM_256X128")) return string();
+  if (char const *e = getenv("BODAHIP_SGEMM_BIG")) { if (string(e) == "off") return string(); }   // (the x3x4 tile is a form of the staging-wave kernel only: with the kernel switched off the general kernel's own choice stands)
   long const t256 = (long)((M + 255) / 256) * ((N + 255) / 256), t128 = (long)((M + 255) / 256) * ((N + 127) / 128);
   double const eff = (double)t128 / (double)(((t128 + cus - 1) / cus) * cus);
   return (t256 >= cus && eff >= 0.95) ? string("256x128x8x3x4x1") : string();
@@ -1450,7 +1506,17 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   if (cfg.KHO > 1) { setup_kho(impl, host, ga, cfg, out); kho_grid = launch_kho(host, k, ga, cfg); }
   else {
     setup_splitk(impl, host, ga, cfg, (size_t)Nj * g.OC);
+    char const *const tstamp = p.cbig ? getenv("BODAHIP_CBIG_TSTAMP") : nullptr;   // experiment hook (tools/cbig_timeline.py): kernel built with -DTSTAMP=1 leaves 8 clock stamps per workgroup in the scratch; appended to the named file
+    size_t const ts_bytes = (size_t)ga.tiles_i * ga.tiles_j * 64;
+    if (tstamp) { ensure_ws(impl, host, ts_bytes); ga.ws = (float *)impl->ws; hip_err_chk(hipMemsetAsync(impl->ws, 0, ts_bytes, host->nh_stream()), "hipMemsetAsync(tstamp)"); }
     launch(host, k, ga, cfg);
+    if (tstamp) {
+      std::vector<unsigned long long> h(ts_bytes / 8);
+      hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize(tstamp)");
+      hip_err_chk(hipMemcpy(h.data(), impl->ws, ts_bytes, hipMemcpyDeviceToHost), "hipMemcpy(tstamp)");
+      if (FILE *f = fopen(tstamp, "a")) { fprintf(f, "launch %s grid %d\n", cfg.str().c_str(), ga.tiles_i * ga.tiles_j);
+        for (size_t w = 0; w < h.size() / 8; ++w) { for (int e = 0; e < 8; ++e) fprintf(f, "%llu ", h[w * 8 + e]); fprintf(f, "\n"); } fclose(f); }
+    }
     if (cfg.SPLITK > 1) reduce_splitk(impl, host, ga, Nj * g.OC, true, g.relu, g.OH * g.OW, g.OC);
   }
   last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = kho_grid ? kho_grid : (uint32_t)ga.tiles_i * ga.tiles_j * cfg.SPLITK; last_launch.block = cfg.threads();

@@ -203,6 +203,11 @@ def test_planner_sgemm_tiles_follow_problem_size():
     os.environ["BODAHIP_NO_SGEMM_SPLIT"] = "1"
     try: assert R.explain_plan(sg(7168, 7168, 7168)).startswith("bodahip_sgemm_f32 ")
     finally: del os.environ["BODAHIP_NO_SGEMM_SPLIT"]
+    # the documented switch BODAHIP_SGEMM_BIG=off leaves every size on the general kernel (round-5 advisor finding: the wide-tile rule used to hand it the staging-wave kernel's x3x4 tile)
+    os.environ["BODAHIP_SGEMM_BIG"] = "off"
+    try:
+        for n in (4096, 8192, 12288): assert R.explain_plan(sg(n, n, n)).startswith("bodahip_sgemm_f32 "), R.explain_plan(sg(n, n, n))
+    finally: del os.environ["BODAHIP_SGEMM_BIG"]
     # the tile heuristic balances tiles over the CUs it is told about: a 512^3 problem on 256 CUs takes the thin 16x16-MFMA tiles, on 16 CUs 64x64
     assert R.explain_plan(sg(512, 512, 512), num_cus=256).split()[1] == "32x32x32_w2x2_m16_p8"
     assert R.explain_plan(sg(512, 512, 512), num_cus=16).split()[1] == "64x64x32_w2x2_p2"
