@@ -612,8 +612,8 @@ class ConvPipeFwd:
                 if any(w.top == o.bot and w.tag not in fused for w in cp.ops[op_index[o.tag] + 1:op_index[q.tag]]):
                     continue      # (the fused kernel reads the pooling's input at the convolution's position: nobody may rewrite it in between)
                 plan0 = explain_plan(qa, getattr(self, "_num_cus", 256)).split()
-                if "-DJ_MODE=7" not in plan0 or (("_p" in plan0[1]) and os.environ.get("BODAHIP_F32_POOL_ALL") is None) or "-DRDEC=1" in plan0:
-                    continue      # (not the patch form / a plan with several K tiles in flight)
+                if "-DJ_MODE=7" not in plan0 or (("_p" in plan0[1]) and ("_big" not in plan0[1]) and os.environ.get("BODAHIP_F32_POOL_ALL") is None) or "-DRDEC=1" in plan0:
+                    continue      # (not the patch form / a plan with several K tiles in flight; a staging-wave plan -- round 6 -- gives way to the fused form's own patch kernel)
                 fa = qa.copy(); fuse_f32_pool(fa, cp.nodes[o.bot], tuple(o.kern_sz), tuple(o.stride))
                 try:
                     explain_plan(fa, getattr(self, "_num_cus", 256))

@@ -83,7 +83,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define TSTAMP 0 // experiment hook (BODAHIP_CBIG_TSTAMP, tools/cbig_timeline.py): 1 = every workgroup leaves clock stamps in p.ws: [0] start [1] XCC id [2] stager at the first barrier
 #endif           // [3] first multiplying wave leaves the K loop [4] ... has issued its stores [5] ... has its stores acknowledged (s_memrealtime: 100 MHz, chip-wide)
 #ifndef ABLATE
-#define ABLATE 0 // experiment hook: 1 no output stores | 2 no gather loads | 8 no filter loads
+#define ABLATE 0 // experiment hook: 1 no output stores | 2 no pel loads | 4 no LDS stores in the staging waves | 8 no filter loads
 #endif
 
 struct gemm_args_t { // same layout as gemm_conv_f32.hip (one host-side struct serves all fp32 kernels)
@@ -101,6 +101,7 @@ struct gemm_args_t { // same layout as gemm_conv_f32.hip (one host-side struct s
   long bsI, bsJ, bsD;
 };
 
+#ifndef XPOSE_ONLY
 namespace {
 constexpr int kNMW = WI * WJ;                 // multiplying waves
 constexpr int kNST = 256;                     // staging threads (four waves)
@@ -143,11 +144,23 @@ constexpr int lcm(int a, int b) { int x = a; while (x % b) x += a; return x; }
 constexpr int kU = lcm(lcm(NSTG, PF), 2);     // steps per unrolled round (stage = step % NSTG, register set = step % PF, operand buffer = (step * kKK + kk) % 2: compile-time)
 constexpr int kD = NSTG - 1;                  // a tile is written kD steps ahead of its step
 constexpr int kOOB = (int)0x80000000;
-// filter staging: unit = I_VW consecutive k of one out_chan row
+// filter staging.  I_VW 0 (the default plan): the filters come K-MAJOR -- [k][out_chan padded to a multiple of 4], rows k >= K zero up to a whole number of K steps -- from the
+// call's scratch, where bodahip_conv_big_xpose (below) puts them first; a unit = four out_chans of one k: a 16-byte load whose lanes run along out_chan (whole cache lines,
+// like the sgemm kernel's operands) and one ds_write_b128.  Why: reading OIHW rows directly (I_VW 4 | 2 | 1: a unit = I_VW consecutive k of one out_chan row, transposed on
+// the way into LDS) gives every wave-load 8-16 rows K floats apart -- measured with clock stamps (round 6, AlexNet conv3 on 128 x 512 tiles): the staging waves then sit 94 %
+// of the K loop waiting for those loads (9,600 cycles per step for five loads per thread; 290 for the six pel loads), and the multiplying waves wait for them at the barriers.
+#if I_VW == 0
+constexpr int kUPR = TBI / 4;                 // units per k row
+constexpr int kUnitsI = BKS * kUPR;
+constexpr int kIW = 4;
+static_assert(TBI % 4 == 0, "k-major filter units: four out_chans");
+#else
 constexpr int kUPR = BKS / I_VW;              // units per row and step
 constexpr int kUnitsI = TBI * kUPR;
+constexpr int kIW = I_VW;
+static_assert(BKS % I_VW == 0 && (I_VW == 1 || I_VW == 2 || I_VW == 4), "I_VW: 0 | 1 | 2 | 4");
+#endif
 constexpr int kNUI = (kUnitsI + kNST - 1) / kNST;
-static_assert(BKS % I_VW == 0 && (I_VW == 1 || I_VW == 2 || I_VW == 4), "I_VW: 1 | 2 | 4");
 // pel staging: a thread owns kCPT columns (pels) of the tile and kRPT k rows of every step
 constexpr int kCPT = (TBJ + 255) / 256;       // columns per thread
 constexpr int kTW = TBJ / kCPT;               // threads across the tile's pels
@@ -183,7 +196,7 @@ namespace {
 __device__ __forceinline__ float vget(f32x4 const &v, int i) { return v[i]; }
 __device__ __forceinline__ float vget(f32x2 const &v, int i) { return v[i]; }
 __device__ __forceinline__ float vget(float const &v, int) { return v; }
-struct ivec_t { float v[I_VW]; };
+struct ivec_t { float v[kIW]; };
 } // namespace
 
 extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_args_t const p) {
@@ -204,7 +217,7 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
   int const i0 = tile_i * TBI, j0 = tile_j * TBJ;
   int const nkt = (p.K + BKS - 1) / BKS;
 #if TSTAMP
-  unsigned long long *const ts = reinterpret_cast<unsigned long long *>(p.ws) + (size_t)blockIdx.x * 8;
+  unsigned long long *const ts = reinterpret_cast<unsigned long long *>(p.ws) + (size_t)blockIdx.x * 16;
   auto stamp = [&](int e) { if ((threadIdx.x & 63) == 0) ts[e] = __builtin_amdgcn_s_memrealtime(); };
   if (threadIdx.x == 0) { ts[0] = __builtin_amdgcn_s_memrealtime(); ts[1] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)); }   // HW_REG_XCC_ID, bits 0-3
 #endif
@@ -212,6 +225,34 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
   if (stager) {
     int const tid = threadIdx.x - kNMW * 64;
     rsrc_t const rI = make_rsrc(p.I, p.I_bytes), rJ = make_rsrc(p.J, p.J_bytes);
+#if I_VW == 0
+    // ---- filter units (k-major scratch, p.ldI = padded out_chans per k row): unit c = tid + n * 256 -> k row c / kUPR, out_chans 4 (c % kUPR) .. + 3
+    int goffI[kNUI], loffI[kNUI];
+#pragma unroll
+    for (int n = 0; n < kNUI; ++n) {
+      int const c = tid + n * kNST, kr = c / kUPR, x = 4 * (c % kUPR);
+      goffI[n] = (c < kUnitsI && i0 + x < p.ldI) ? ((kr * p.ldI + i0 + x) * 4) : kOOB;   // (out_chans past the padded end: 0)
+      loffI[n] = (c < kUnitsI) ? (kr * kLDI + colI(x)) : -1;
+    }
+    auto gloadI = [&](int n, int kt) -> ivec_t {   // (tiles fetched past the end re-read the last one: the scratch ends with it)
+      ivec_t r;
+      f32x4 const v = bload4(rI, (ABLATE & 8) ? kOOB : goffI[n], min(kt, nkt - 1) * (BKS * 4) * p.ldI);
+      r.v[0] = v[0]; r.v[1] = v[1]; r.v[2] = v[2]; r.v[3] = v[3];
+      return r;
+    };
+    auto lstoreI = [&](int n, int stage, ivec_t const &v) {
+      if ((loffI[n] >= 0) && !((ABLATE & 4) && v.v[0] != 123.456f)) {
+        if constexpr (kTI == 3) {   // (three row blocks at pitch four: the four out_chans of a unit are not contiguous in the image)
+          int const x = 4 * ((tid + n * kNST) % kUPR), kr = (tid + n * kNST) / kUPR;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sm[stage * kImg2 + kr * kLDI + colI(x + e)] = v.v[e];
+        } else {
+          f32x4 const w = {v.v[0], v.v[1], v.v[2], v.v[3]};
+          *reinterpret_cast<f32x4 *>(sm + stage * kImg2 + loffI[n]) = w;
+        }
+      }
+    };
+#else
     // ---- filter units: unit c = tid + n * 256 -> out_chan row c / kUPR, k offset I_VW * (c % kUPR).  Rows past Mi of an edge tile read whatever lies there (or 0 past
     // the tensor): their outputs are never stored and no other output sees them.
     int goffI[kNUI], loffI[kNUI];
@@ -235,11 +276,12 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
       return r;
     };
     auto lstoreI = [&](int n, int stage, ivec_t const &v) {
-      if (loffI[n] >= 0) {
+      if ((loffI[n] >= 0) && !((ABLATE & 4) && v.v[0] != 123.456f)) {
 #pragma unroll
         for (int e = 0; e < I_VW; ++e) sm[stage * kImg2 + loffI[n] + e * kLDI] = v.v[e];
       }
     };
+#endif
 #if J_MODE == 7
     // ---- input patch: element el = tid + e * 256 of a channel's kCS floats = (slot s, padded column x); its byte offset inside channel 0 is fixed for the whole K loop
     int goffJ[kEPT];
@@ -274,7 +316,7 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
       for (int cc = 0; cc < kCB; ++cc)
 #pragma unroll
         for (int e = 0; e < kEPT; ++e)
-          if (((e + 1) * kNST <= kCS) || (tid + e * kNST < kCS)) sm[stage * kImg2 + kImgI + cc * kCS + e * kNST + tid] = v.v[cc * kEPT + e];
+          if ((((e + 1) * kNST <= kCS) || (tid + e * kNST < kCS)) && !((ABLATE & 4) && v.v[0] != 123.456f)) sm[stage * kImg2 + kImgI + cc * kCS + e * kNST + tid] = v.v[cc * kEPT + e];
     };
 #else
     // ---- pel columns of this thread
@@ -364,16 +406,37 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
     if (wave == kNMW) stamp(2);
 #endif
     asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");
+#if TSTAMP
+    unsigned long long st_a = 0, st_b = 0, st_l = 0, st_w = 0;   // shader cycles of the first staging wave: filter part | pel part | LDS drain | at the barrier
+#define ST_T0 unsigned long long t_ = __builtin_amdgcn_s_memtime(), t2_;
+#define ST_ADD(ACC) t2_ = __builtin_amdgcn_s_memtime(); ACC += t2_ - t_; t_ = t2_;
+#else
+#define ST_T0
+#define ST_ADD(ACC)
+#endif
     for (int kb = 0; kb < nkt; kb += kU) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         if (kb + u >= nkt) break;                                // (wave-uniform; the multiplying waves leave at the same step)
+        ST_T0
 #pragma unroll
         for (int n = 0; n < kNUI; ++n) { lstoreI(n, (u + kD) % NSTG, ringI[(u + kD) % PF][n]); ringI[(u + kD) % PF][n] = gloadI(n, kb + u + kD + PF); }
+        ST_ADD(st_a)
         lstoreJ((u + kD) % NSTG, ringJ[(u + kD) % PF]); ringJ[(u + kD) % PF] = gloadJ(kb + u + kD + PF);
+        ST_ADD(st_b)
+#if TSTAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ST_ADD(st_l)
+        asm volatile("s_barrier" ::: "memory");
+        ST_ADD(st_w)
+#else
         asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory");   // (scalar loads share the counter and return out of order: only 0 is a safe count)
+#endif
       }
     }
+#if TSTAMP
+    if (wave == kNMW && lane == 0) { ts[8] = st_a; ts[9] = st_b; ts[10] = st_l; ts[11] = st_w; }
+#endif
     return;
   }
 
@@ -418,7 +481,13 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
-  asm volatile("s_barrier" ::: "memory");
+ asm volatile("s_barrier" ::: "memory");
+#if TSTAMP
+  if (wave == 0 && lane == 0) ts[6] = __builtin_amdgcn_s_memtime();   // shader clock at the start ...
+#endif
+#if TSTAMP
+  unsigned long long bar_wait = 0;
+#endif
   avec_t a[2]; bop_t b[2];                                // operands of k pair n and n + 1 (n counted across steps: buffer n % 2): the reads run one pair (kTI x kTJ MFMAs) ahead
   a[0] = readA(0, 0); b[0] = readB(0, 0);
   for (int kb = 0; kb < nkt; kb += kU) {
@@ -438,12 +507,21 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
           for (int u = 0; u < kTJ; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(vget(ca, t), BGET(cb, u), acc[t][u], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+#if TSTAMP
+      unsigned long long const tb0 = __builtin_amdgcn_s_memtime();
       asm volatile("s_barrier" ::: "memory");
+      bar_wait += __builtin_amdgcn_s_memtime() - tb0;
+#else
+      asm volatile("s_barrier" ::: "memory");
+#endif
     }
   }
+#if TSTAMP
+  if (wave == 0 && lane == 0) ts[1] = (ts[1] & 15) | (bar_wait << 4);   // shader cycles the first multiplying wave spent at the K loop's barriers
+#endif
 
 #if TSTAMP
-  if (wave == 0) stamp(3);
+  if (wave == 0) { stamp(3); if (lane == 0) ts[7] = __builtin_amdgcn_s_memtime(); }   // ... and at the end of the K loop: cycles / microseconds = the clock the loop ran at
 #endif
   // ---- epilogue: MFMA row rho = 8 * (r / 4) + r % 4 + 4 * (lane / 32) of row block t is tile row kTI rho + t; column kappa = lane % 32 of column block u is tile column
   // kTJ kappa + u: a lane holds kTJ CONSECUTIVE pels of out_chan row (t, r) -- one 4 kTJ-byte store where they lie in one image (NCHW planes are contiguous in pel; the
@@ -553,3 +631,17 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
   if (wave == 0) { stamp(4); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(5); }
 #endif
 }
+#else  // XPOSE_ONLY
+// bodahip_conv_big_xpose: filts[out_chan][k] (OIHW, k = (in_chan, ky, kx) contiguous) -> dst[k][out_chan], out_chans padded to Mi4 (a multiple of 4) and k to Kp (whole K
+// steps) with zeros: the layout the staging waves read with whole-line loads.  32 x 32 tiles through LDS: both sides coalesced.  (The reference runs the same kind of pass in
+// front of its k1conv / tconv variants: xpose_filts, src/cnn_codegen.cc; here it is part of the call, a few microseconds for the megabytes of a layer's filters.)
+extern "C" __global__ __launch_bounds__(256) void KNAME(float const *__restrict__ filts, float *__restrict__ dst, int Mi, int Mi4, int K, int Kp) {
+  __shared__ float t[32][33];
+  int const k0 = blockIdx.x * 32, i0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { int const i = i0 + ty + 8 * r, k = k0 + tx; t[ty + 8 * r][tx] = (i < Mi && k < K) ? filts[(long)i * K + k] : 0.f; }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { int const k = k0 + ty + 8 * r, i = i0 + tx; if (k < Kp && i < Mi4) dst[(long)k * Mi4 + i] = t[tx][ty + 8 * r]; }
+}
+#endif

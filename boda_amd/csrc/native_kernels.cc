@@ -819,20 +819,22 @@ static bool conv_big_form(conv_geom_t const &g, tile_cfg_t const &c, conv_big_fo
   bool const k1 = g.KH == 1 && g.KW == 1 && g.PY == 0 && g.PX == 0;
   bool const patch = !k1 && g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && getenv("BODAHIP_CBIG_NO_PATCH") == nullptr;
   f.bks = c.BK;
-  if (patch) {
+  bool patch_ok = false;
+  if (patch) {   // (a patch that does not fit -- whole-input windows, very wide planes -- gives way to the table gather)
     int const taps = g.KH * g.KW; int cb = 1; while (cb * taps < c.BK || (cb * taps) % 2) ++cb;
-    f.bks = cb * taps; if (f.bks > 128) return bad("patch form: K step above 128");
     int const wp = g.W + 2 * g.PX, rows_max = (c.BJ - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
     long const cs = (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp;
-    if (cs > 16 * 256) return bad("patch form: more than 16 patch elements per staging thread and channel");
-    f.jmode = 7; img_j = (cb * cs + 3) / 4 * 4;
-  } else {
+    long const stage4 = ((long)cb * taps * ldi + (cb * cs + 3) / 4 * 4) * 4;
+    if (cb * taps <= 128 && cs <= 16 * 256 && 3 * stage4 <= 160l * 1024 / c.MINW) { patch_ok = true; f.bks = cb * taps; f.jmode = 7; img_j = (cb * cs + 3) / 4 * 4; }
+  }
+  if (!patch_ok) {
     int const cpt = (c.BJ + 255) / 256; if (c.BJ % cpt) return bad("pel columns per staging thread");
     int const tw = c.BJ / cpt; if (tw % 64 || 256 / tw < 1 || c.BK % (256 / tw)) return bad("pel staging: whole waves per k row");
     if (!k1 && (c.BK / (256 / tw)) % 4) return bad("table gather: whole quads of k rows per staging thread");
     f.jmode = k1 ? 5 : 2; img_j = (long)f.bks * ldj;
   }
-  f.ivw = (Kt % 4 == 0 && f.bks % 4 == 0) ? 4 : ((Kt % 2 == 0) ? 2 : 1);
+  // filters: k-major from the call's scratch (0; bodahip_conv_big_xpose runs first) unless BODAHIP_CBIG_IVW=direct asks for loads straight from OIHW rows (4 | 2 | 1 floats along k)
+  f.ivw = 0; if (char const *e = getenv("BODAHIP_CBIG_IVW")) { if (string(e) == "direct") f.ivw = (Kt % 4 == 0 && f.bks % 4 == 0) ? 4 : ((Kt % 2 == 0 && f.bks % 2 == 0) ? 2 : 1); }
   long const stage = ((long)f.bks * ldi + img_j) * 4, cap = 160l * 1024 / c.MINW;
   f.nstg = 4; if (char const *e = getenv("BODAHIP_CBIG_NSTG")) f.nstg = atoi(e); else if (4 * stage > cap) f.nstg = 3;
   if (!(f.nstg == 3 || f.nstg == 4) || f.nstg * stage > cap) return bad("LDS stages exceed the CU's 160 KB");
@@ -865,6 +867,30 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   if (!bf16 && p.cfg.SW == 2) {   // the staging-wave kernel, asked for by its own tile string
     if (g.pooled()) unsup_err("hip_conv: fused pooling (hip_pool) is a form of the LDS-patch kernel, not of the staging-wave kernel");
     return plan_conv_big(g, p.cfg);
+  }
+  // Round 6: stride-1 KH x KW >= 2 layers (the reference's tconv / conv cases) go to the staging-wave kernel (kernels/conv_big_f32.hip, LDS-patch form) in its
+  // two-workgroups-per-CU tiles when those deal out evenly.  In-sequence A/Bs on MI355X (tools/cbig_ab_sets*.sh, us, old -> new): AlexNet at 256 images conv2 1677 -> 1657,
+  // conv3 571 -> 532, conv4 849 -> 784, conv5 649 -> 585; NiN at 128 images conv2 908 -> 865, conv3 315 -> 285; its one-workgroup tiles (128 x 512, 256 x 256) and every
+  // 1 x 1 layer measured level or slower than the kernels below, tile-starved maps (NiN conv4: 6 x 6) slower.  A lone workgroup of this kernel keeps the matrix pipe as
+  // busy as two co-resident ones (the staging waves hide the loads), so what counts is the deal over CUs, not over workgroup slots: score = padding x (tiles / CUs) /
+  // ceil(tiles / CUs), taken when >= 0.80.  BODAHIP_CBIG = off | force (any score).
+  if (!bf16 && tile.empty() && !g.pooled() && !p.ipconv && g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && !(g.KH == g.H && g.KW == g.W && g.OH == 1)) {
+    char const *e = getenv("BODAHIP_CBIG");
+    if (!(e && string(e) == "off")) {
+      struct cand_t { int bi, bj, wi, wj; double base; };
+      static cand_t const cands[] = {{128, 256, 2, 4, 1.00}, {64, 512, 1, 8, 1.00}, {64, 256, 1, 8, 0.98}, {128, 128, 2, 4, 0.97}};
+      double best = -1; tile_cfg_t best_c;
+      for (cand_t const &cd : cands) {
+        tile_cfg_t c; c.BI = cd.bi; c.BJ = cd.bj; c.BK = 16; c.WI = cd.wi; c.WJ = cd.wj; c.MINW = 2; c.SPLITK = 1; c.MT = 32; c.PF = 2; c.SW = 2; c.KHO = 0;
+        conv_big_form_t f; if (!conv_big_form(g, c, f) || f.jmode != 7) continue;
+        long const ti = (g.OC + c.BI - 1) / c.BI, tj = (Nj + c.BJ - 1) / c.BJ, tiles = ti * tj;
+        double const pad = ((double)g.OC / (double)(ti * c.BI)) * ((double)Nj / (double)(tj * c.BJ));
+        double const deal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
+        double const score = cd.base * pad * deal;
+        if (score > best) { best = score; best_c = c; }
+      }
+      if (best >= ((e && string(e) == "force") ? 0.0 : 0.80)) return plan_conv_big(g, best_c);
+    }
   }
   // wide kernels: row gather (one address + wide loads per (in_chan,ky) row of KW taps): a K step is `rows` whole rows, BK = rows*KW.
   // Measured (MI355X, B=256): 11x11/s4 +8%, 5x5 -3%, 3x3 -9% vs the per-element table gather (unaligned x3 loads cost more than the
@@ -1506,16 +1532,30 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
   if (cfg.KHO > 1) { setup_kho(impl, host, ga, cfg, out); kho_grid = launch_kho(host, k, ga, cfg); }
   else {
     setup_splitk(impl, host, ga, cfg, (size_t)Nj * g.OC);
-    char const *const tstamp = p.cbig ? getenv("BODAHIP_CBIG_TSTAMP") : nullptr;   // experiment hook (tools/cbig_timeline.py): kernel built with -DTSTAMP=1 leaves 8 clock stamps per workgroup in the scratch; appended to the named file
-    size_t const ts_bytes = (size_t)ga.tiles_i * ga.tiles_j * 64;
-    if (tstamp) { ensure_ws(impl, host, ts_bytes); ga.ws = (float *)impl->ws; hip_err_chk(hipMemsetAsync(impl->ws, 0, ts_bytes, host->nh_stream()), "hipMemsetAsync(tstamp)"); }
+    size_t ts_off = 0;
+    if (p.cbig && std::find(p.defs.begin(), p.defs.end(), string("-DI_VW=0")) != p.defs.end()) {   // the staging-wave kernel reads its filters k-major: transposed into the scratch first (part of the call)
+      long const mi4 = ((long)g.OC + 3) / 4 * 4, kp = (Kt + cfg.BK - 1) / cfg.BK * cfg.BK;
+      uint64_t const xb = (uint64_t)kp * mi4 * 4;
+      if (xb >= 0x7ffffff0ull) unsup_err("hip_conv: filts of 2 GiB or more are not supported (32-bit buffer offsets)");
+      ts_off = (xb + 255) & ~size_t(255);
+      ensure_ws(impl, host, ts_off + (getenv("BODAHIP_CBIG_TSTAMP") ? (size_t)ga.tiles_i * ga.tiles_j * 128 : 0));
+      plan_t xp; xp.cbig = true; xp.kname = "bodahip_conv_big_xpose"; xp.defs = {"-DXPOSE_ONLY=1"};
+      kernel_t &xk = get_kernel(impl, host, xp);
+      float const *src = filts; float *dst = (float *)impl->ws; int Mi = g.OC, Mi4 = (int)mi4, Kk = (int)Kt, Kp = (int)kp;
+      void *xparams[] = {&src, &dst, &Mi, &Mi4, &Kk, &Kp};
+      hip_err_chk(host->nh_launch(xk.func, (uint32_t)((kp + 31) / 32), (uint32_t)((mi4 + 31) / 32), 256, xparams), "hipModuleLaunchKernel(conv_big_xpose)");
+      ga.I = (float const *)impl->ws; ga.ldI = (int)mi4; ga.I_bytes = (unsigned)xb;
+    }
+    char const *const tstamp = p.cbig ? getenv("BODAHIP_CBIG_TSTAMP") : nullptr;   // experiment hook (tools/cbig_timeline.py): kernel built with -DTSTAMP=1 leaves 16 clock stamps per workgroup in the scratch; appended to the named file
+    size_t const ts_bytes = (size_t)ga.tiles_i * ga.tiles_j * 128;
+    if (tstamp) { ensure_ws(impl, host, ts_off + ts_bytes); ga.ws = (float *)((char *)impl->ws + ts_off); hip_err_chk(hipMemsetAsync(ga.ws, 0, ts_bytes, host->nh_stream()), "hipMemsetAsync(tstamp)"); }
     launch(host, k, ga, cfg);
     if (tstamp) {
       std::vector<unsigned long long> h(ts_bytes / 8);
       hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize(tstamp)");
-      hip_err_chk(hipMemcpy(h.data(), impl->ws, ts_bytes, hipMemcpyDeviceToHost), "hipMemcpy(tstamp)");
+      hip_err_chk(hipMemcpy(h.data(), ga.ws, ts_bytes, hipMemcpyDeviceToHost), "hipMemcpy(tstamp)");
       if (FILE *f = fopen(tstamp, "a")) { fprintf(f, "launch %s grid %d\n", cfg.str().c_str(), ga.tiles_i * ga.tiles_j);
-        for (size_t w = 0; w < h.size() / 8; ++w) { for (int e = 0; e < 8; ++e) fprintf(f, "%llu ", h[w * 8 + e]); fprintf(f, "\n"); } fclose(f); }
+        for (size_t w = 0; w < h.size() / 16; ++w) { for (int e = 0; e < 16; ++e) fprintf(f, "%llu ", h[w * 16 + e]); fprintf(f, "\n"); } fclose(f); }
     }
     if (cfg.SPLITK > 1) reduce_splitk(impl, host, ga, Nj * g.OC, true, g.relu, g.OH * g.OW, g.OC);
   }
@@ -2071,6 +2111,7 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
   if (plan_out) { *plan_out = s2d + p.kname + " " + p.cfg.str(); for (auto const &d : p.defs) *plan_out += " " + d; }
   if (arch.empty()) return 0;
   size_t const n = compile_plan(p, arch, &log).size();
+  if (p.cbig) { plan_t xp; xp.cbig = true; xp.kname = "bodahip_conv_big_xpose"; xp.defs = {"-DXPOSE_ONLY=1"}; compile_plan(xp, arch, &log); }   // (the filter transposition that runs in front of it)
   if (p.patch16) { plan_t fp; fp.patch16 = true; fp.bf16 = true; fp.kname = "bodahip_filt_bf16"; fp.defs = {"-DFILT_ONLY=1"}; compile_plan(fp, arch, &log); }
   if (p.ksl) {   // (K slices reduced inside the launch: no second kernel)
   } else if (p.cfg.SPLITK > 1 && p.nhwc) {

@@ -88,8 +88,22 @@ def test_planner_picks_the_documented_kernel_and_operand_mode_per_shape():
     without a device through bodahip_explain_plan.  One shape per operand mode of DESIGN.md section 3."""
     ex = R.explain_plan
     def mode(plan, key): return re.search(rf"-D{key}=(\d+)", plan).group(1)
-    p = ex(_conv(256, 96, 27, 256, 5, 1, 2))                      # AlexNet conv2: LDS input patch
-    assert p.startswith("bodahip_conv_f32 ") and mode(p, "J_MODE") == "7" and "-DCH=27" in p and "-DRELU=1" in p
+    p = ex(_conv(256, 96, 27, 256, 5, 1, 2))                      # AlexNet conv2: LDS input patch -- round 6: of the staging-wave kernel (two workgroups per CU, filters k-major from the scratch)
+    assert p.startswith("bodahip_conv_big_f32 64x512x50_w1x8_p2_big") and mode(p, "J_MODE") == "7" and "-DCH=27" in p and "-DRELU=1" in p and "-DMINW=2" in p and "-DI_VW=0" in p
+    assert ex(_conv(256, 256, 13, 384, 3, 1, 1)).startswith("bodahip_conv_big_f32 128x256x18_w2x4_p2_big")      # AlexNet conv3: 507 tiles on 256 CUs
+    assert ex(_conv(256, 384, 13, 256, 3, 1, 1)).startswith("bodahip_conv_big_f32 64x256x18_w1x8_p2_big")       # conv5: 676 tiles (2.64 per CU -> 0.88)
+    os.environ["BODAHIP_CBIG"] = "off"
+    try:
+        q = ex(_conv(256, 96, 27, 256, 5, 1, 2)); assert q.startswith("bodahip_conv_f32 ") and mode(q, "J_MODE") == "7" and "-DCH=27" in q   # the round-3 kernel's patch form
+    finally: del os.environ["BODAHIP_CBIG"]
+    assert ex(_conv(256, 384, 6, 1024, 3, 1, 1)).startswith("bodahip_conv_f32 ")       # NiN conv4 (6 x 6 maps: 576 tiles = 2.25 per CU -> 0.75): stays on the tiled kernel
+    assert ex(_conv(2, 24, 15, 100, 3, 1, 1)).startswith("bodahip_conv_f32 ")          # ... and so do small problems
+    p = ex(_conv(256, 96, 27, 256, 5, 1, 2), tile="128x256x32x2x4x1x1x32x2x2")        # the kernel by its own tile string (tenth field 2): BKS = whole channels >= the tile's
+    assert p.startswith("bodahip_conv_big_f32 128x256x50_w2x4_p2_big") and "-DMINW=1" in p
+    p = ex(_conv(256, 384, 13, 384, 1), tile="128x128x16x2x4x2x1x32x2x2")              # 1 x 1: its plain form
+    assert p.startswith("bodahip_conv_big_f32 128x128x16_w2x4_p2_big") and mode(p, "J_MODE") == "5"
+    p = ex(_conv(256, 96, 27, 256, 3, 2, 1), tile="96x256x16x1x8x1x1x32x2x2")          # strided: the table gather
+    assert p.startswith("bodahip_conv_big_f32 96x256x16_w1x8_p2_big") and mode(p, "J_MODE") == "2"
     p = ex(_conv(256, 3, 227, 96, 11, 4, 0))                      # AlexNet conv1 (strided, unpadded, wide): row-decimated LDS patch (round 4), 33 row sets of 1 x 11 kernels
     assert p.startswith("bodahip_conv_f32 32x256x22_w1x4") and mode(p, "J_MODE") == "7" and "-DRDEC=1" in p and "-DKH0=11" in p and "-DSY0=4" in p and "-DCH=55" in p
     p = ex(_conv(64, 3, 224, 64, 7, 2, 3))                        # GoogLeNet / ResNet conv1 (padded): row gather (KW >= 6)
@@ -220,7 +234,7 @@ def test_prebuild_resolves_the_algorithm_like_conv_does_in_tolerance_mode():
     conv3 = _conv(256, 256, 13, 384, 3, 1, 1); conv3.str_vals.pop("func_name"); conv3.nda_vals.pop("conv_has_relu")
     tol = R.explain_plan(add_codegen_annotations(conv3, OpTune(hip_exact=0)))
     assert tol.startswith("winograd(F2x2,3x3)+bodahip_sgemm_f32 ") and "-DEPI=0" in tol
-    assert R.explain_plan(add_codegen_annotations(conv3, OpTune())).startswith("bodahip_conv_f32 ")                       # bit-exact default: the direct kernel
+    assert R.explain_plan(add_codegen_annotations(conv3, OpTune())).startswith("bodahip_conv_big_f32 ")                   # bit-exact default: the direct (round 6: staging-wave) kernel
     res2 = _conv(64, 64, 56, 64, 3, 1, 1); res2.str_vals.pop("func_name"); res2.nda_vals.pop("conv_has_relu")
     assert R.explain_plan(add_codegen_annotations(res2, OpTune(hip_exact=0))).startswith("bodahip_conv_f32 ")            # too few channels for Winograd to pay
     assert R.prebuild(add_codegen_annotations(conv3, OpTune(hip_exact=0))) > 4000                                          # and it cross-compiles

@@ -458,12 +458,51 @@ def test_conv_without_relu_and_alias(be):
 
 @pytest.mark.parametrize("tile", ["64x64x16x1x1", "128x64x16x2x1", "32x128x16x1x2", "96x128x16x1x2", "128x128x32x2x2", "128x256x16x2x4",
                                   "64x64x16x2x2x2x1x16", "32x64x32x2x2x1x1x16", "64x64x16x2x2x2x1x32x2", "128x128x32x2x2x1x1x32x2", "64x256x16x1x4x2",
-                                  "64x256x16x1x4x2x1x32x1x1", "64x64x16x2x2x2x1x32x1x1"])   # staging waves (LDS input patch staged by waves of their own)
+                                  "64x256x16x1x4x2x1x32x1x1", "64x64x16x2x2x2x1x32x1x1",    # staging waves (LDS input patch staged by waves of their own)
+                                  "128x128x16x2x4x2x1x32x2x2", "64x256x16x1x8x2x1x32x2x2", "96x256x16x1x8x1x1x32x2x2", "256x192x16x4x2x1x1x32x2x2", "128x512x8x2x4x1x1x32x4x2",
+                                  "64x512x32x1x8x1x1x32x1x2", "128x128x16x2x2x1x1x32x2x2"])   # round 6: kernels/conv_big_f32.hip (tenth field 2): eight (four) multiplying + four staging waves
 def test_conv_tiles_agree(be, tile):
     op = _conv_op(3, 24, 15, 15, 100, 3, 3, 1, 1)
     ref, _ = _run(be, op, 5)
     got, _ = _run(be, op, 5, tune=OpTune(hip_tile=tile))
     assert np.array_equal(ref["out"], got["out"])
+
+
+CBIG_SHAPES = [(3, 24, 15, 15, 100, 3, 3, 1, 1), (2, 3, 35, 35, 96, 11, 11, 4, 0), (5, 96, 7, 7, 130, 1, 1, 1, 0), (4, 17, 9, 9, 70, 5, 5, 1, 2), (7, 16, 6, 6, 100, 6, 6, 1, 0),
+               (3, 33, 13, 13, 33, 1, 1, 2, 0), (2, 10, 12, 12, 300, 3, 3, 2, 1), (9, 20, 1, 1, 50, 1, 1, 1, 0), (1, 4, 40, 40, 8, 3, 3, 1, 1), (40, 12, 13, 13, 70, 3, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("filt", ["scratch", "direct"])
+@pytest.mark.parametrize("tile", ["256x256x16x2x4x1x1x32x2x2", "128x256x32x2x4x2x1x32x2x2", "96x512x8x1x8x1x1x32x2x2", "64x256x8x1x8x2x1x32x2x2", "192x256x16x2x4x1x1x32x1x2", "128x384x8x2x4x1x1x32x2x2"])
+def test_conv_staging_wave_kernel_bit_exact(be, tile, filt, monkeypatch):
+    """Round 6, kernels/conv_big_f32.hip (multiplying waves + staging waves): every pel form (LDS input patch read in place / 1x1 / table gather), both filter paths
+    (k-major from the call's scratch behind bodahip_conv_big_xpose / straight from OIHW rows), wave tiles of 1-4 x 1-4 blocks incl. the pitch-four layouts of three blocks,
+    one and two workgroups per CU, 3 and 4 LDS stages, K tails, ragged out_chans / pels, tiles that straddle images: each equals the oracle's fma chain bit for bit."""
+    if filt == "direct": monkeypatch.setenv("BODAHIP_CBIG_IVW", "direct")
+    for sh in CBIG_SHAPES:
+        op = _conv_op(*sh)
+        try:
+            outs, prc = _run(be, op, 5, tune=OpTune(hip_tile=tile), include_ins=True)
+        except UnsupErr:
+            continue   # (a tile whose LDS stages do not fit this geometry)
+        assert prc.launch["kernel"] == "bodahip_conv_big_f32", prc.launch
+        want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (sh[7], sh[7]), (sh[8], sh[8]), True)
+        assert np.array_equal(want, outs["out"]), (sh, prc.launch["cfg"])
+
+
+def test_conv_staging_wave_kernel_is_the_plan_where_its_tiles_deal_out(be, monkeypatch):
+    """The planner's rule (round 6): stride-1 multi-tap layers whose two-workgroups-per-CU tiles deal out over the CUs take the staging-wave kernel -- here forced onto
+    small shapes (BODAHIP_CBIG=force) so that the DEFAULT path (no tile string) is what runs: equal to the oracle and to the round-3 kernel (BODAHIP_CBIG=off)."""
+    for sh in [(40, 12, 13, 13, 70, 3, 3, 1, 1), (6, 20, 27, 27, 40, 5, 5, 1, 2), (3, 8, 9, 9, 260, 2, 2, 1, 0)]:
+        op = _conv_op(*sh)
+        monkeypatch.setenv("BODAHIP_CBIG", "force")
+        outs, prc = _run(be, op, 5, include_ins=True)
+        assert prc.launch["kernel"] == "bodahip_conv_big_f32" and "_big" in prc.launch["cfg"], prc.launch
+        want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (1, 1), (sh[8], sh[8]), True)
+        assert np.array_equal(want, outs["out"]), (sh, prc.launch["cfg"])
+        monkeypatch.setenv("BODAHIP_CBIG", "off")
+        old, prc2 = _run(be, op, 5)
+        assert prc2.launch["kernel"] == "bodahip_conv_f32" and np.array_equal(old["out"], outs["out"])
 
 
 @pytest.mark.parametrize("tile", ["128x128x16x2x2x2x4", "64x64x16x2x2x2x3", "96x128x16x1x2x2x7"])
@@ -679,7 +718,8 @@ def test_conv_writes_channel_slice_of_wider_output(be):
         rtc.release_func("slice_conv"); rtc.release_per_call_id_data()
 
 
-@pytest.mark.parametrize("tile", ["", "64x256x32x1x4x2", "128x128x16x2x2x2", "64x64x32x2x2x1x1x32x4"])   # (the last: a ring of four register-staged K tiles, every operand mode)
+@pytest.mark.parametrize("tile", ["", "64x256x32x1x4x2", "128x128x16x2x2x2", "64x64x32x2x2x1x1x32x4",    # (the fourth: a ring of four register-staged K tiles, every operand mode)
+                                  "128x128x16x2x4x2x1x32x2x2", "96x256x16x1x8x1x1x32x2x2"])              # round 6: the staging-wave kernel (patch / 1x1 / gather form as the shape allows)
 def test_conv_random_shapes_bit_exact(be, tile):
     """Seeded random-shape sweep (tools/fuzz_conv.py; kernel sizes 1..11, strides 1..4, paddings, ragged channel counts): whatever
     operand mode the planner picks, with the default and with two forced workgroup tiles, equals the oracle bit for bit.

@@ -31,9 +31,12 @@ for li, L in enumerate(launches[-2:]):
     T = np.array(L, dtype=np.float64); t0 = T[:, 0].min()
     us = lambda x: x / 100.0   # 100 MHz
     st, pro, loop, iss, drain = us(T[:, 0] - t0), us(T[:, 2] - T[:, 0]), us(T[:, 3] - T[:, 2]), us(T[:, 4] - T[:, 3]), us(T[:, 5] - T[:, 4])
-    end = us(T[:, 5] - t0)
+    end = us(T[:, 5] - t0); cyc = T[:, 7] - T[:, 6]
     q = lambda v: f"min {v.min():7.1f} med {np.median(v):7.1f} max {v.max():7.1f}"
     print(f"launch {li}: {len(L)} workgroups, last stamp at {end.max():.1f} us")
-    print("  start    ", q(st)); print("  prologue ", q(pro)); print("  K loop   ", q(loop)); print("  store iss", q(iss)); print("  drain    ", q(drain)); print("  end      ", q(end))
-    xcc = T[:, 1].astype(int) & 15
+    print("  start    ", q(st)); print("  prologue ", q(pro)); print("  K loop   ", q(loop)); print("  store iss", q(iss)); print("  drain    ", q(drain)); print("  end      ", q(end)); print(f"  K loop shader cycles med {np.median(cyc):.0f} -> clock {np.median(cyc / np.maximum(loop, 1e-9)) / 1e3:.3f} GHz")
+    bw = np.array([int(r[1]) >> 4 for r in L], dtype=np.float64)
+    print(f"  wave 0 at the K loop's barriers: med {np.median(bw):.0f} cycles = {100 * np.median(bw / np.maximum(cyc, 1)):.1f} % of the loop")
+    if T.shape[1] >= 12: print("  first staging wave, shader cycles (med): filter part %.0f | pel part %.0f | LDS drain %.0f | at the barrier %.0f" % tuple(np.median(T[:, e]) for e in (8, 9, 10, 11)))
+    xcc = np.array([int(r[1]) & 15 for r in L])
     for x in sorted(set(xcc)): m = xcc == x; print(f"  xcc {x}: n {m.sum():3d} loop med {np.median(loop[m]):7.1f} end max {end[m].max():7.1f}")
