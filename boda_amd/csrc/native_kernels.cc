@@ -853,7 +853,7 @@ static plan_t plan_conv_big(conv_geom_t const &g, tile_cfg_t const &c) {
   if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
   return p;
 }
-static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false, string const &k1s = string(), bool allow_splitk = true, bool exact = true) {
+static plan_t plan_conv_tiled(conv_geom_t const &g, int num_cus, string const &tile, bool bf16, string const &k1s, bool allow_splitk, bool exact) {
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   plan_t p;
   if (!bf16 && tile.empty() && plan_ipconv_dma(g, num_cus, p)) return p;
@@ -867,30 +867,6 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   if (!bf16 && p.cfg.SW == 2) {   // the staging-wave kernel, asked for by its own tile string
     if (g.pooled()) unsup_err("hip_conv: fused pooling (hip_pool) is a form of the LDS-patch kernel, not of the staging-wave kernel");
     return plan_conv_big(g, p.cfg);
-  }
-  // Round 6: stride-1 KH x KW >= 2 layers (the reference's tconv / conv cases) go to the staging-wave kernel (kernels/conv_big_f32.hip, LDS-patch form) in its
-  // two-workgroups-per-CU tiles when those deal out evenly.  In-sequence A/Bs on MI355X (tools/cbig_ab_sets*.sh, us, old -> new): AlexNet at 256 images conv2 1677 -> 1657,
-  // conv3 571 -> 532, conv4 849 -> 784, conv5 649 -> 585; NiN at 128 images conv2 908 -> 865, conv3 315 -> 285; its one-workgroup tiles (128 x 512, 256 x 256) and every
-  // 1 x 1 layer measured level or slower than the kernels below, tile-starved maps (NiN conv4: 6 x 6) slower.  A lone workgroup of this kernel keeps the matrix pipe as
-  // busy as two co-resident ones (the staging waves hide the loads), so what counts is the deal over CUs, not over workgroup slots: score = padding x (tiles / CUs) /
-  // ceil(tiles / CUs), taken when >= 0.80.  BODAHIP_CBIG = off | force (any score).
-  if (!bf16 && tile.empty() && !g.pooled() && !p.ipconv && g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && !(g.KH == g.H && g.KW == g.W && g.OH == 1)) {
-    char const *e = getenv("BODAHIP_CBIG");
-    if (!(e && string(e) == "off")) {
-      struct cand_t { int bi, bj, wi, wj; double base; };
-      static cand_t const cands[] = {{128, 256, 2, 4, 1.00}, {64, 512, 1, 8, 1.00}, {64, 256, 1, 8, 0.98}, {128, 128, 2, 4, 0.97}};
-      double best = -1; tile_cfg_t best_c;
-      for (cand_t const &cd : cands) {
-        tile_cfg_t c; c.BI = cd.bi; c.BJ = cd.bj; c.BK = 16; c.WI = cd.wi; c.WJ = cd.wj; c.MINW = 2; c.SPLITK = 1; c.MT = 32; c.PF = 2; c.SW = 2; c.KHO = 0;
-        conv_big_form_t f; if (!conv_big_form(g, c, f) || f.jmode != 7) continue;
-        long const ti = (g.OC + c.BI - 1) / c.BI, tj = (Nj + c.BJ - 1) / c.BJ, tiles = ti * tj;
-        double const pad = ((double)g.OC / (double)(ti * c.BI)) * ((double)Nj / (double)(tj * c.BJ));
-        double const deal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
-        double const score = cd.base * pad * deal;
-        if (score > best) { best = score; best_c = c; }
-      }
-      if (best >= ((e && string(e) == "force") ? 0.0 : 0.80)) return plan_conv_big(g, best_c);
-    }
   }
   // wide kernels: row gather (one address + wide loads per (in_chan,ky) row of KW taps): a K step is `rows` whole rows, BK = rows*KW.
   // Measured (MI355X, B=256): 11x11/s4 +8%, 5x5 -3%, 3x3 -9% vs the per-element table gather (unaligned x3 loads cost more than the
@@ -1004,6 +980,41 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
   p.defs.push_back("-DPY=" + std::to_string(g.PY)); p.defs.push_back("-DPX=" + std::to_string(g.PX));
   p.defs.push_back(string("-DRELU=") + (g.relu ? "1" : "0"));
   return p;
+}
+// plan_conv: the planner of hip_conv.  Round 6: stride-1 KH x KW >= 2 layers (the reference's tconv / conv cases) and 1 x 1 / stride-1 layers with K >= 384 (NiN cccp5-8;
+// shorter K belongs to the streaming kernels) go to the staging-wave kernel (kernels/conv_big_f32.hip) in its two-workgroups-per-CU tiles when those deal out evenly.
+// In-sequence A/Bs on MI355X (tools/cbig_ab_sets*.sh, tools/env_ab_ops.sh; us, round-5 plan -> this): AlexNet at 256 images conv2 1677 -> 1657, conv3 571 -> 532, conv4
+// 849 -> 784, conv5 649 -> 585; NiN at 256 images conv4 546 -> 463, cccp7 / cccp8 175 -> 152 (64 x 192 tiles of FOUR multiplying waves: 768 tiles = exactly three per CU),
+// at 128 images conv2 908 -> 850, conv3 315 -> 277, conv4 314 -> 267; its one-workgroup tiles (128 x 512, 256 x 256) measured level or slower.  A lone workgroup of
+// this kernel keeps the matrix pipe as busy as two co-resident ones (the staging waves hide the loads), so what counts is the deal over CUs, not over workgroup slots:
+// score = base x padding x (tiles / CUs) / ceil(tiles / CUs), taken when >= 0.76.  The tiles of one or two 32 x 32 blocks per wave only stand in for the tiled kernel's
+// tile-starvation choice (64 x 64): against its 32 x 256 / 64 x 256 tiles they measured slower (GoogLeNet 3x3 128 -> 192 at 28 x 28: 191 -> 212 us), and strided 1 x 1
+// layers stay where they were (ResNet-50 res4a_branch1 on 32 x 128 tiles: 141 -> 230 us).  BODAHIP_CBIG = off | force (any score).
+static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false, string const &k1s = string(), bool allow_splitk = true, bool exact = true) {
+  plan_t const old = plan_conv_tiled(g, num_cus, tile, bf16, k1s, allow_splitk, exact);
+  char const *e = getenv("BODAHIP_CBIG");
+  if (bf16 || !tile.empty() || g.pooled() || (e && string(e) == "off") || old.kname != "bodahip_conv_f32" || old.ipconv || old.rdec || old.cfg.SPLITK > 1 || old.cfg.KHO > 1) return old;
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  bool const k1big = g.KH == 1 && g.KW == 1 && g.PY == 0 && g.PX == 0 && g.SY == 1 && g.SX == 1 && Kt >= 384;
+  bool const patchy = g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && !(g.KH == g.H && g.KW == g.W && g.OH == 1);
+  if (!k1big && !patchy) return old;
+  bool const force = e && string(e) == "force", old_small = (old.cfg.BI <= 64 && old.cfg.BJ <= 64) || force;
+  struct cand_t { int bi, bj, wi, wj; double base; bool small; };
+  static cand_t const cands[] = {{128, 256, 2, 4, 1.00, false}, {64, 512, 1, 8, 1.00, false}, {64, 256, 1, 8, 0.98, false}, {128, 128, 2, 4, 0.97, false},   // eight multiplying waves: 2 x 2 | 2 x 1 blocks each
+                                 {64, 192, 2, 2, 0.97, false}, {128, 128, 2, 2, 0.96, false},                                                             // four: 1 x 3 | 2 x 2
+                                 {64, 128, 2, 2, 0.92, true}, {32, 128, 1, 4, 0.86, true}, {64, 64, 2, 2, 0.85, true}};                                   // four: 1 x 2 | 1 x 1 | 1 x 1
+  double best = -1; tile_cfg_t best_c;
+  for (cand_t const &cd : cands) {
+    if (cd.small && !old_small) continue;
+    tile_cfg_t c; c.BI = cd.bi; c.BJ = cd.bj; c.BK = 16; c.WI = cd.wi; c.WJ = cd.wj; c.MINW = 2; c.SPLITK = 1; c.MT = 32; c.PF = 2; c.SW = 2; c.KHO = 0;
+    conv_big_form_t f; if (!conv_big_form(g, c, f) || f.jmode != (patchy ? 7 : 5)) continue;
+    long const ti = (g.OC + c.BI - 1) / c.BI, tj = (Nj + c.BJ - 1) / c.BJ, tiles = ti * tj;
+    double const pad = ((double)g.OC / (double)(ti * c.BI)) * ((double)Nj / (double)(tj * c.BJ));
+    double const deal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
+    double const score = cd.base * pad * deal;
+    if (score > best) { best = score; best_c = c; }
+  }
+  return (best >= (force ? 0.0 : 0.76)) ? plan_conv_big(g, best_c) : old;
 }
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);

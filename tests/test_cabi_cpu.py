@@ -96,7 +96,11 @@ def test_planner_picks_the_documented_kernel_and_operand_mode_per_shape():
     try:
         q = ex(_conv(256, 96, 27, 256, 5, 1, 2)); assert q.startswith("bodahip_conv_f32 ") and mode(q, "J_MODE") == "7" and "-DCH=27" in q   # the round-3 kernel's patch form
     finally: del os.environ["BODAHIP_CBIG"]
-    assert ex(_conv(256, 384, 6, 1024, 3, 1, 1)).startswith("bodahip_conv_f32 ")       # NiN conv4 (6 x 6 maps: 576 tiles = 2.25 per CU -> 0.75): stays on the tiled kernel
+    assert ex(_conv(256, 384, 6, 1024, 3, 1, 1)).startswith("bodahip_conv_big_f32 64x192x18_w2x2_p2_big")   # NiN conv4 (6 x 6 maps): four multiplying waves, 768 tiles = three per CU
+    assert ex(_conv(128, 384, 6, 1024, 3, 1, 1)).startswith("bodahip_conv_big_f32 32x128x18_w1x4_p2_big")   # ... at 128 images: one-block wave tiles in place of the tiled kernel's 64 x 64 (1152 tiles = 4.5 per CU)
+    assert ex(_conv(256, 1024, 6, 1024, 1)).startswith("bodahip_conv_big_f32 64x192x16_w2x2_p2_big") and "-DJ_MODE=5" in ex(_conv(256, 1024, 6, 1024, 1))   # cccp7: 1 x 1, K >= 384
+    assert ex(_conv(64, 512, 28, 1024, 1, 2, 0)).startswith("bodahip_conv_f32 ")       # strided 1 x 1 (ResNet-50 res4a_branch1): stays on the tiled kernel
+    assert ex(_conv(64, 128, 28, 192, 3, 1, 1)).startswith("bodahip_conv_f32 32x256")  # GoogLeNet 3x3 at 28 x 28: the tiled kernel's 32 x 256 tile beats the small staging-wave tiles
     assert ex(_conv(2, 24, 15, 100, 3, 1, 1)).startswith("bodahip_conv_f32 ")          # ... and so do small problems
     p = ex(_conv(256, 96, 27, 256, 5, 1, 2), tile="128x256x32x2x4x1x1x32x2x2")        # the kernel by its own tile string (tenth field 2): BKS = whole channels >= the tile's
     assert p.startswith("bodahip_conv_big_f32 128x256x50_w2x4_p2_big") and "-DMINW=1" in p
@@ -146,11 +150,14 @@ def test_planner_round5_rules_k1_tiles_and_the_k_hand_off_tile_field():
     cccp3 at 128), with fewer tiles the 64 x 64 tiles stay; (2) the eleventh tile field asks for sequential K hand-off (-DKHO=1): segments are lowered until none is
     empty, it is an fp32 convolution form (ignored by sgemm), and it is refused together with K slices or staging waves."""
     ex = R.explain_plan
-    assert ex(_conv(256, 384, 13, 384, 1)).startswith("bodahip_conv_f32 128x128x16_w2x2 ")        # cccp5 @256: 3 x 338 = 1014 tiles
-    assert ex(_conv(128, 256, 27, 256, 1)).startswith("bodahip_conv_f32 128x128x16_w2x2 ")        # cccp3 @128: 2 x 729 = 1458 tiles
-    assert ex(_conv(128, 384, 13, 384, 1)).startswith("bodahip_conv_f32 64x64x16_w2x2_p2 ")       # cccp5 @128: 507 tiles
-    assert ex(_conv(256, 1024, 6, 1024, 1)).startswith("bodahip_conv_f32 64x64x32_w2x2_p2 ")      # cccp7 @256: 576 tiles
-    assert ex(_conv(256, 1024, 6, 1000, 1)).startswith("bodahip_conv_f32 64x64x32_w2x2_p2 ")      # cccp8: out_chans not a multiple of 128
+    os.environ["BODAHIP_CBIG"] = "off"   # (the tiled kernel's own rules; round 6 hands most of these layers to the staging-wave kernel: next test)
+    try:
+        assert ex(_conv(256, 384, 13, 384, 1)).startswith("bodahip_conv_f32 128x128x16_w2x2 ")        # cccp5 @256: 3 x 338 = 1014 tiles
+        assert ex(_conv(128, 256, 27, 256, 1)).startswith("bodahip_conv_f32 128x128x16_w2x2 ")        # cccp3 @128: 2 x 729 = 1458 tiles
+        assert ex(_conv(128, 384, 13, 384, 1)).startswith("bodahip_conv_f32 64x64x16_w2x2_p2 ")       # cccp5 @128: 507 tiles
+        assert ex(_conv(256, 1024, 6, 1024, 1)).startswith("bodahip_conv_f32 64x64x32_w2x2_p2 ")      # cccp7 @256: 576 tiles
+        assert ex(_conv(256, 1024, 6, 1000, 1)).startswith("bodahip_conv_f32 64x64x32_w2x2_p2 ")      # cccp8: out_chans not a multiple of 128
+    finally: del os.environ["BODAHIP_CBIG"]
     p = ex(_conv(128, 384, 6, 1024, 3, 1, 1), tile="128x128x36x2x2x2x1x32x1x0x8")
     assert p.startswith("bodahip_conv_f32 128x128x36_w2x2_h8 ") and "-DKHO=1" in p and "-DJ_MODE=7" in p
     p = ex(_conv(2, 16, 9, 40, 3, 1, 1), tile="64x64x16x2x2x2x1x32x1x0x64")                       # K = 144 = 8 steps of 18: at most 8 segments
@@ -236,5 +243,5 @@ def test_prebuild_resolves_the_algorithm_like_conv_does_in_tolerance_mode():
     assert tol.startswith("winograd(F2x2,3x3)+bodahip_sgemm_f32 ") and "-DEPI=0" in tol
     assert R.explain_plan(add_codegen_annotations(conv3, OpTune())).startswith("bodahip_conv_big_f32 ")                   # bit-exact default: the direct (round 6: staging-wave) kernel
     res2 = _conv(64, 64, 56, 64, 3, 1, 1); res2.str_vals.pop("func_name"); res2.nda_vals.pop("conv_has_relu")
-    assert R.explain_plan(add_codegen_annotations(res2, OpTune(hip_exact=0))).startswith("bodahip_conv_f32 ")            # too few channels for Winograd to pay
+    assert R.explain_plan(add_codegen_annotations(res2, OpTune(hip_exact=0))).startswith("bodahip_conv_big_f32 ")        # too few channels for Winograd to pay: a direct kernel
     assert R.prebuild(add_codegen_annotations(conv3, OpTune(hip_exact=0))) > 4000                                          # and it cross-compiles
