@@ -83,7 +83,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define TSTAMP 0 // experiment hook (BODAHIP_CBIG_TSTAMP, tools/cbig_timeline.py): 1 = every workgroup leaves clock stamps in p.ws: [0] start [1] XCC id [2] stager at the first barrier
 #endif           // [3] first multiplying wave leaves the K loop [4] ... has issued its stores [5] ... has its stores acknowledged (s_memrealtime: 100 MHz, chip-wide)
 #ifndef ABLATE
-#define ABLATE 0 // experiment hook: 1 no output stores | 2 no pel loads | 4 no LDS stores in the staging waves | 8 no filter loads
+#define ABLATE 0 // experiment hook: 1 no output stores | 2 no pel loads | 4 no LDS stores in the staging waves | 8 no filter loads | 16 (with 2 | 8) pseudo-random values made in registers instead
 #endif
 
 struct gemm_args_t { // same layout as gemm_conv_f32.hip (one host-side struct serves all fp32 kernels)
@@ -116,21 +116,32 @@ constexpr int kLDI = (TBI / kTI) * kTIp + 4, kLDJ = (TBJ / kTJ) * kTJp + 4; // f
 #endif
 // patch geometry (the arithmetic of gemm_conv_f32.hip's J_MODE 7): output rows of one image share slots (row r + 1 starts SY slots after row r); a tile that crosses into the
 // next image starts a new slot group
-constexpr int kTaps = KH * KW, kCB = BKS / kTaps, kWp = CW + 2 * PX;
-static_assert(BKS % kTaps == 0 && SX == 1 && KH >= SY && kTaps >= 2, "patch mode: whole channels per K step, stride 1 in x");
+#ifndef RDEC
+#define RDEC 0 // 1: ROW-DECIMATED patch for strided convolutions without padding (conv1 layers: 11x11 / 4; the form gemm_conv_f32.hip introduced in round 4).  The convolution is
+#endif         // presented as C0 * KH0 "channels" -- row set (in_chan, kernel row) -- of 1 x KW kernels with stride 1 in y over a plane of COH rows: row r of row set (c, ky) is
+               // input row r * SY0 + ky.  k = (c, ky, kx) keeps its order, a K step is kCB whole row sets, the LDS holds ONE input row per output row and row set (coalesced
+               // row loads).  Here the row is stored PHASE-MAJOR -- input column x at (x % SX) * kWq + x / SX -- so that tap kx of consecutive pels is consecutive LDS words
+               // (no bank conflicts at stride SX).  Needs -DC0 -DH0 -DKH0 -DSY0 and KH = SY = 1, PY = PX = 0, CH = COH; p.C = C0 * KH0.
+constexpr int kTaps = KH * KW, kCB = BKS / kTaps, kWq = (CW + SX - 1) / SX, kWp = RDEC ? SX * kWq : CW + 2 * PX;
+static_assert(BKS % kTaps == 0 && kTaps >= 2 && (RDEC ? (KH == 1 && SY == 1 && PY == 0 && PX == 0 && CH == COH) : (SX == 1 && KH >= SY)), "patch mode: whole channels per K step; stride 1 in x or the row-decimated form");
 constexpr int kRowsMax = (TBJ - 2) / COW + 2;                    // output rows a TBJ-pel tile can touch
 constexpr int kSegFull = (COH - 1) * SY + KH;                    // slots of a whole image
 constexpr int kSegMax0 = (COH - 1 + kRowsMax - 1) / COH + 1;     // images a tile can touch
 constexpr int kSegMax = kSegMax0 < kRowsMax ? kSegMax0 : kRowsMax;
 constexpr int kSlots = (kRowsMax - kSegMax) * SY + kSegMax * KH; // slots per channel (upper bound over tile positions)
-constexpr int kCS = kSlots * kWp;                                // floats per channel
-constexpr int kEPT = (kCS + kNST - 1) / kNST;                    // patch elements per staging thread and channel
+constexpr int kCS = kSlots * kWp;                                // floats per channel in LDS
+constexpr int kCSL = RDEC ? kSlots * CW : kCS;                   // elements per channel the staging waves load (row-decimated: the rows themselves, CW wide)
+constexpr int kEPT = (kCSL + kNST - 1) / kNST;                   // patch elements per staging thread and channel
 constexpr int kImgJ = kCB * kCS;
-constexpr int koff(int k) { return (k / kTaps) * kCS + ((k % kTaps) / KW) * kWp + (k % KW); }
-// k = 2 kk + 1 sits a fixed distance after k = 2 kk: next tap of the row | first tap of the next row | first tap of the next channel.  Lanes 32-63 (odd k) fold that
-// distance into their base address once; the even-k offset koff(2 kk) is then an immediate.
-constexpr int kD0 = 1, kD1 = kWp - KW + 1, kD2 = kCS - (KH - 1) * kWp - (KW - 1);
-constexpr int kdelta_class(int kk) { return ((2 * kk) % KW != KW - 1) ? 0 : ((((2 * kk) % kTaps) != kTaps - 1) ? 1 : 2); }
+constexpr int koffin(int kx) { return RDEC ? (kx % SX) * kWq + kx / SX : kx; }   // tap kx inside a stored row
+constexpr int koff(int k) { return (k / kTaps) * kCS + ((k % kTaps) / KW) * kWp + koffin(k % KW); }
+// k = 2 kk + 1 sits a fixed distance after k = 2 kk: next tap of the row (row-decimated: next phase | first column of the next phase group) | first tap of the next row |
+// first tap of the next channel.  Lanes 32-63 (odd k) fold that distance into their base address once; the even-k offset koff(2 kk) is then an immediate.
+constexpr int kD0 = RDEC ? kWq : 1, kD1 = RDEC ? 1 - (SX - 1) * kWq : kWp - KW + 1, kD2 = kCS - (KH - 1) * kWp - koffin(KW - 1);
+constexpr int kdelta_class(int kk) {
+  if (RDEC) return ((2 * kk) % KW == KW - 1) ? 2 : ((((2 * kk) % KW) % SX == SX - 1) ? 1 : 0);
+  return ((2 * kk) % KW != KW - 1) ? 0 : ((((2 * kk) % kTaps) != kTaps - 1) ? 1 : 2);
+}
 #else
 constexpr int kImgJ = BKS * kLDJ;
 #endif
@@ -238,6 +249,7 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
       ivec_t r;
       f32x4 const v = bload4(rI, (ABLATE & 8) ? kOOB : goffI[n], min(kt, nkt - 1) * (BKS * 4) * p.ldI);
       r.v[0] = v[0]; r.v[1] = v[1]; r.v[2] = v[2]; r.v[3] = v[3];
+      if ((ABLATE & 24) == 24) { unsigned h = ((unsigned)tid * 2654435761u + (unsigned)(kt * 40503 + n * 977)) * 2246822519u; for (int e = 0; e < 4; ++e) { h = h * 1664525u + 1013904223u; r.v[e] = (float)(int)(h >> 8) * (1.f / 1677721.6f) - 5.f; } }
       return r;
     };
     auto lstoreI = [&](int n, int stage, ivec_t const &v) {
@@ -283,20 +295,27 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
     };
 #endif
 #if J_MODE == 7
-    // ---- input patch: element el = tid + e * 256 of a channel's kCS floats = (slot s, padded column x); its byte offset inside channel 0 is fixed for the whole K loop
-    int goffJ[kEPT];
+    // ---- input patch: element el = tid + e * 256 of a channel's kCSL elements = (slot s, column x); its byte offset inside channel 0 is fixed for the whole K loop
+    int goffJ[kEPT], lofsJ[kEPT];
     {
       int const R0 = j0 / COW, img0 = R0 / COH, oy0 = R0 - img0 * COH;       // first output row of the tile (workgroup-uniform)
       int const seg0 = (COH - 1 - oy0) * SY + KH;                            // slots of the first image's part
       int const n_img = p.Nj / (COH * COW);
+      constexpr int kRowW = RDEC ? CW : kWp;
 #pragma unroll
       for (int e = 0; e < kEPT; ++e) {
-        int const el = tid + e * kNST, sl = el / kWp, ix = el - sl * kWp - PX;
+        int const el = tid + e * kNST, sl = el / kRowW, xc = el - sl * kRowW, ix = xc - PX;
         int const s2 = sl - seg0, im2 = s2 / kSegFull;
         int const img = (sl < seg0) ? img0 : (img0 + 1 + im2);
         int const iy = (sl < seg0) ? (oy0 * SY - PY + sl) : (s2 - im2 * kSegFull - PY);
-        bool const ok = (el < kCS) && (img < n_img) && ((unsigned)iy < (unsigned)CH) && ((unsigned)ix < (unsigned)CW);
-        goffJ[e] = ok ? (((img * p.C * CH + iy) * CW + ix) * 4) : kOOB;       // padding / past the end: out of range -> 0
+        bool const ok = (el < kCSL) && (img < n_img) && ((unsigned)iy < (unsigned)CH) && ((unsigned)ix < (unsigned)CW);
+#if RDEC
+        goffJ[e] = ok ? (((img * (C0 * H0) + iy * SY0) * CW + ix) * 4) : kOOB;   // row iy of the decimated plane is input row iy * SY0 (+ the row set's kernel row: in coff)
+        lofsJ[e] = (el < kCSL) ? (sl * kWp + (xc % SX) * kWq + xc / SX) : -1;    // stored phase-major
+#else
+        goffJ[e] = ok ? (((img * p.C * CH + iy) * CW + ix) * 4) : kOOB;          // padding / past the end: out of range -> 0
+        lofsJ[e] = (el < kCSL) ? el : -1;
+#endif
       }
     }
     struct jset_t { float v[kCB * kEPT]; };
@@ -305,9 +324,18 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
       int const c0 = kt * kCB;
 #pragma unroll
       for (int cc = 0; cc < kCB; ++cc) {
-        int const coff = min(c0 + cc, p.C - 1) * (CH * CW * 4);   // scalar.  Channels past the end (K tail, tiles fetched past the end) meet zero filter values: any finite data will do -> the image's last channel again
+        // (scalar.  Channels past the end -- K tail, tiles fetched past the end -- meet zero filter values: any finite data will do -> the image's last channel again)
+        int const cq = min(c0 + cc, p.C - 1);
+#if RDEC
+        int const coff = ((cq / KH0) * H0 + cq % KH0) * (CW * 4);
+#else
+        int const coff = cq * (CH * CW * 4);
+#endif
 #pragma unroll
-        for (int e = 0; e < kEPT; ++e) r.v[cc * kEPT + e] = bload1(rJ, (ABLATE & 2) ? kOOB : goffJ[e], coff);
+        for (int e = 0; e < kEPT; ++e) {
+          r.v[cc * kEPT + e] = bload1(rJ, (ABLATE & 2) ? kOOB : goffJ[e], coff);
+          if ((ABLATE & 18) == 18) { unsigned h = ((unsigned)tid * 2654435761u + (unsigned)(kt * 7919 + cc * 31 + e)) * 2246822519u; h = h * 1664525u + 1013904223u; r.v[cc * kEPT + e] = (float)(int)(h >> 8) * (1.f / 1677721.6f) - 5.f; }
+        }
       }
       return r;
     };
@@ -316,7 +344,7 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
       for (int cc = 0; cc < kCB; ++cc)
 #pragma unroll
         for (int e = 0; e < kEPT; ++e)
-          if ((((e + 1) * kNST <= kCS) || (tid + e * kNST < kCS)) && !((ABLATE & 4) && v.v[0] != 123.456f)) sm[stage * kImg2 + kImgI + cc * kCS + e * kNST + tid] = v.v[cc * kEPT + e];
+          if ((lofsJ[e] >= 0) && !((ABLATE & 4) && v.v[0] != 123.456f)) sm[stage * kImg2 + kImgI + cc * kCS + lofsJ[e]] = v.v[cc * kEPT + e];
     };
 #else
     // ---- pel columns of this thread
@@ -532,6 +560,23 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
     unsigned const S4 = (unsigned)OHW * 4u;
     int const ib = i0 + wi * (kTI * 32) + kTI * 4 * (lane >> 5);                 // this lane's first out_chan; + kTI * ((r & 3) + 8 * (r >> 2)) + t: wave-uniform
     auto rowc = [](int t, int r) { return kTI * ((r & 3) + 8 * (r >> 2)) + t; };
+    // biases and ReLU first, IN PLACE, row block by row block (16 loads in flight, one wait): a bias load issued between the stores would wait for every store before it
+    // (one counter, in order) -- measured with the clock stamps: 27.6 us to issue 48 stores that way (AlexNet conv1, 96 x 256 tile), 4.6 us for 64 with the loads batched
+    constexpr int kBB = (kTI * kTJ >= 8) ? 4 : ((kTI * kTJ >= 6) ? 8 : 16);   // biases in flight at a time (what the registers beside the accumulators allow)
+    constexpr bool kBiasFirst = !(PERMJ && kTI * kTJ >= 8);                   // (the 128-accumulator tiles of the permuted-column forms have no registers to spare: bias per row, as before)
+#pragma unroll
+    for (int t = 0; t < (kBiasFirst ? kTI : 0); ++t)
+#pragma unroll
+      for (int rb = 0; rb < 16; rb += kBB) {
+        float bv[kBB];
+#pragma unroll
+        for (int r = 0; r < kBB; ++r) bv[r] = bload1(rB, ib * 4, rowc(t, rb + r) * 4);   // (rows past Mi read 0)
+#pragma unroll
+        for (int u = 0; u < kTJ; ++u)
+#pragma unroll
+          for (int r = 0; r < kBB; ++r) { float x = acc[t][u][rb + r] + bv[r]; if (RELU) x = (x > 0.f) ? x : 0.f; acc[t][u][rb + r] = x; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #if PERMJ
     int const jg0 = j0 + (wj * 32 + (lane & 31)) * kTJ;
     int const img0 = jg0 / OHW, pel0 = jg0 - img0 * OHW;
@@ -552,11 +597,11 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           int const rc = rowc(t, r);
-          float const bvr = bload1(rB, ib * 4, rc * 4);          // (rows past Mi read 0; the compiler batches these loads as far as the registers allow)
           bool const row_ok = !edge || (ib + rc < p.Mi);
           float v[kTJ];
 #pragma unroll
-          for (int u = 0; u < kTJ; ++u) { float x = acc[t][u][r] + bvr; if (RELU) x = (x > 0.f) ? x : 0.f; v[u] = x; }
+          for (int u = 0; u < kTJ; ++u) v[u] = acc[t][u][r];
+          if constexpr (!kBiasFirst) { float const bvr = bload1(rB, ib * 4, rc * 4); for (int u = 0; u < kTJ; ++u) { float x = v[u] + bvr; if (RELU) x = (x > 0.f) ? x : 0.f; v[u] = x; } }
 #if ABLATE & 1
           if (v[0] == 123.456f)
 #endif
@@ -593,9 +638,7 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             int const rc = rowc(t, r);
-            float const bvr = bload1(rB, ib * 4, rc * 4);
-            float va = acc[t][2 * tp][r] + bvr, vb = acc[t][2 * tp + 1][r] + bvr;
-            if (RELU) { va = (va > 0.f) ? va : 0.f; vb = (vb > 0.f) ? vb : 0.f; }
+            float const va = acc[t][2 * tp][r], vb = acc[t][2 * tp + 1][r];
             auto const sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, va), __builtin_bit_cast(unsigned, vb), false, false);
 #if ABLATE & 1
             if (va == 123.456f)
@@ -615,8 +658,7 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             int const rc = rowc(t, r);
-            float v = acc[t][kTJ - 1][r] + bload1(rB, ib * 4, rc * 4);
-            if (RELU) v = (v > 0.f) ? v : 0.f;
+            float const v = acc[t][kTJ - 1][r];
 #if ABLATE & 1
             if (v == 123.456f)
 #endif

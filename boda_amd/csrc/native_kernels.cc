@@ -40,6 +40,7 @@ struct native_kernels_t::impl_t {
   void *ws = nullptr; size_t ws_bytes = 0; // split-K partial-sum slabs (grow-only scratch, like the reference's cudnn scratch var)
   std::vector<void *> ws_retired;          // outgrown scratch buffers that captured graphs may still point into (freed with the backend)
   std::map<string, void *> ktabs;           // im2col gather tables, one per (C,H,W,KH,KW) (device memory)
+  size_t ts_off = 0, ts_bytes = 0; string ts_hdr;   // experiment hook BODAHIP_CBIG_TSTAMP=<file>:late -- the clock stamps of the LAST staging-wave launch, written out when the backend goes
   hipModule_t wino_mod = nullptr; hipFunction_t wino_filt = nullptr, wino_in = nullptr, wino_out = nullptr, wino_fused = nullptr, wino_filt_t = nullptr; // kernels/winograd_f32.hip
 };
 
@@ -51,6 +52,14 @@ native_kernels_t::native_kernels_t(native_host_t *host_) : impl(new impl_t), hos
   if (char const *e = getenv("BODAHIP_EXACT")) impl->tune["exact"] = e;
 }
 native_kernels_t::~native_kernels_t() {
+  if (impl->ts_bytes && impl->ws) {
+    char const *e = getenv("BODAHIP_CBIG_TSTAMP"); string fn = e ? string(e) : string(); if (fn.size() > 5 && fn.substr(fn.size() - 5) == ":late") fn.resize(fn.size() - 5);
+    std::vector<unsigned long long> h(impl->ts_bytes / 8);
+    if (!fn.empty() && hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), (char *)impl->ws + impl->ts_off, impl->ts_bytes, hipMemcpyDeviceToHost) == hipSuccess) {
+      if (FILE *f = fopen(fn.c_str(), "a")) { fprintf(f, "%s\n", impl->ts_hdr.c_str());
+        for (size_t w = 0; w < h.size() / 16; ++w) { for (int e2 = 0; e2 < 16; ++e2) fprintf(f, "%llu ", h[w * 16 + e2]); fprintf(f, "\n"); } fclose(f); }
+    }
+  }
   for (auto &kv : impl->kernels) { if (kv.second.mod) (void)hipModuleUnload(kv.second.mod); }
   if (impl->wino_mod) (void)hipModuleUnload(impl->wino_mod);
   if (impl->ws) (void)hipFree(impl->ws);
@@ -803,7 +812,7 @@ static bool plan_rdec(conv_geom_t const &g, int num_cus, plan_t &p) {
 // Round 6: kernels/conv_big_f32.hip -- WI x WJ multiplying waves + four staging waves (tile field SW == 2): "TBIxTBJxBKSxWIxWJxMINWx1x32xPFx2".  The pel side takes the
 // cheapest form the geometry allows: the LDS input patch (stride 1 in x, more than one tap: BKS becomes whole channels, the smallest even multiple of KH KW that is >= the
 // tile's BKS), the plain 1x1 form, else the table gather.  The host-side checks are the kernel's static_asserts (a bad tune is an unsup_err, not a compile failure).
-struct conv_big_form_t { int jmode = 2, bks = 16, nstg = 4, ivw = 1; long lds = 0; };
+struct conv_big_form_t { int jmode = 2, bks = 16, nstg = 4, ivw = 1; long lds = 0; bool rdec = false; };
 static bool conv_big_form(conv_geom_t const &g, tile_cfg_t const &c, conv_big_form_t &f, string *why = nullptr) {
   auto bad = [&](char const *m) { if (why) *why = m; return false; };
   int const nmw = c.WI * c.WJ;
@@ -817,15 +826,17 @@ static bool conv_big_form(conv_geom_t const &g, tile_cfg_t const &c, conv_big_fo
   int const ldi = (c.BI / ti) * (ti == 3 ? 4 : ti) + 4, ldj = (c.BJ / tj) * (tj == 3 ? 4 : tj) + 4;
   long img_j = 0;
   bool const k1 = g.KH == 1 && g.KW == 1 && g.PY == 0 && g.PX == 0;
-  bool const patch = !k1 && g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && getenv("BODAHIP_CBIG_NO_PATCH") == nullptr;
+  // strided, unpadded, wide kernels (conv1 layers: 11x11 / 4): the row-decimated patch -- C * KH row sets of 1 x KW kernels over the OH decimated rows (-DRDEC=1)
+  bool const rdec = !k1 && g.PY == 0 && g.PX == 0 && g.SY > 1 && g.KH >= 2 && g.KW >= 6 && g.KW <= 16 && g.OH > 1 && getenv("BODAHIP_CBIG_NO_PATCH") == nullptr;
+  bool const patch = rdec || (!k1 && g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && getenv("BODAHIP_CBIG_NO_PATCH") == nullptr);
   f.bks = c.BK;
   bool patch_ok = false;
   if (patch) {   // (a patch that does not fit -- whole-input windows, very wide planes -- gives way to the table gather)
-    int const taps = g.KH * g.KW; int cb = 1; while (cb * taps < c.BK || (cb * taps) % 2) ++cb;
-    int const wp = g.W + 2 * g.PX, rows_max = (c.BJ - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
-    long const cs = (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp;
+    int const taps = rdec ? g.KW : g.KH * g.KW; int cb = 1; while (cb * taps < c.BK || (cb * taps) % 2) ++cb;
+    int const wp = rdec ? g.SX * ((g.W + g.SX - 1) / g.SX) : g.W + 2 * g.PX, rows_max = (c.BJ - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
+    long const cs = rdec ? (long)rows_max * wp : (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp;
     long const stage4 = ((long)cb * taps * ldi + (cb * cs + 3) / 4 * 4) * 4;
-    if (cb * taps <= 128 && cs <= 16 * 256 && 3 * stage4 <= 160l * 1024 / c.MINW) { patch_ok = true; f.bks = cb * taps; f.jmode = 7; img_j = (cb * cs + 3) / 4 * 4; }
+    if (cb * taps <= 128 && cs <= 16 * 256 && 3 * stage4 <= 160l * 1024 / c.MINW) { patch_ok = true; f.bks = cb * taps; f.jmode = 7; f.rdec = rdec; img_j = (cb * cs + 3) / 4 * 4; }
   }
   if (!patch_ok) {
     int const cpt = (c.BJ + 255) / 256; if (c.BJ % cpt) return bad("pel columns per staging thread");
@@ -841,15 +852,17 @@ static bool conv_big_form(conv_geom_t const &g, tile_cfg_t const &c, conv_big_fo
   f.lds = f.nstg * stage;
   return true;
 }
-static plan_t plan_conv_big(conv_geom_t const &g, tile_cfg_t const &c) {
+static plan_t plan_conv_big(conv_geom_t const &g0, tile_cfg_t const &c) {
   string why; conv_big_form_t f;
-  if (!conv_big_form(g, c, f, &why)) unsup_err("native kernel: unsupported staging-wave tile " + c.str() + " (" + why + ")");
-  plan_t p; p.cbig = true; p.k1 = (f.jmode == 5); p.patch = (f.jmode == 7); p.kname = "bodahip_conv_big_f32"; p.cfg = c; p.cfg.BK = f.bks;
+  if (!conv_big_form(g0, c, f, &why)) unsup_err("native kernel: unsupported staging-wave tile " + c.str() + " (" + why + ")");
+  plan_t p; p.cbig = true; p.k1 = (f.jmode == 5); p.patch = (f.jmode == 7); p.rdec = f.rdec; p.kname = "bodahip_conv_big_f32"; p.cfg = c; p.cfg.BK = f.bks;
+  conv_geom_t g = g0; if (f.rdec) { g.KH = 1; g.SY = 1; g.H = g0.OH; }   // (the decimated presentation: 1 x KW kernels, stride 1 in y, OH rows)
   p.defs = {"-DTBI=" + std::to_string(c.BI), "-DTBJ=" + std::to_string(c.BJ), "-DWI=" + std::to_string(c.WI), "-DWJ=" + std::to_string(c.WJ), "-DBKS=" + std::to_string(f.bks),
             "-DPF=" + std::to_string(c.PF), "-DNSTG=" + std::to_string(f.nstg), "-DMINW=" + std::to_string(c.MINW), "-DI_VW=" + std::to_string(f.ivw), "-DJ_MODE=" + std::to_string(f.jmode),
             "-DKH=" + std::to_string(g.KH), "-DKW=" + std::to_string(g.KW), "-DSY=" + std::to_string(g.SY), "-DSX=" + std::to_string(g.SX),
             "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX), string("-DRELU=") + (g.relu ? "1" : "0")};
   if (f.jmode == 7) for (auto const &kv : {std::make_pair("CH", g.H), std::make_pair("CW", g.W), std::make_pair("COH", g.OH), std::make_pair("COW", g.OW)}) p.defs.push_back(string("-D") + kv.first + "=" + std::to_string(kv.second));
+  if (f.rdec) for (auto const &kv : {std::make_pair("RDEC", 1), std::make_pair("C0", g0.C), std::make_pair("H0", g0.H), std::make_pair("KH0", g0.KH), std::make_pair("SY0", g0.SY)}) p.defs.push_back(string("-D") + kv.first + "=" + std::to_string(kv.second));
   if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
   return p;
 }
@@ -993,8 +1006,16 @@ static plan_t plan_conv_tiled(conv_geom_t const &g, int num_cus, string const &t
 static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16 = false, string const &k1s = string(), bool allow_splitk = true, bool exact = true) {
   plan_t const old = plan_conv_tiled(g, num_cus, tile, bf16, k1s, allow_splitk, exact);
   char const *e = getenv("BODAHIP_CBIG");
-  if (bf16 || !tile.empty() || g.pooled() || (e && string(e) == "off") || old.kname != "bodahip_conv_f32" || old.ipconv || old.rdec || old.cfg.SPLITK > 1 || old.cfg.KHO > 1) return old;
+  if (bf16 || !tile.empty() || g.pooled() || (e && string(e) == "off") || old.kname != "bodahip_conv_f32" || old.ipconv || old.cfg.SPLITK > 1 || old.cfg.KHO > 1) return old;
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  if (old.rdec) {   // conv1 layers (11x11 / 4): the row-decimated patch of the staging-wave kernel on 96 x 256 tiles, one K tile in flight so that two workgroups share a CU (70
+    // registers) and one's prologue / stores hide under the other's 17 K steps: AlexNet / NiN conv1 at 256 images 472 -> 450 us in the layer sequence (round 6)
+    tile_cfg_t c; c.BI = 96; c.BJ = 256; c.BK = 16; c.WI = 1; c.WJ = 8; c.MINW = 2; c.SPLITK = 1; c.MT = 32; c.PF = 1; c.SW = 2; c.KHO = 0;
+    conv_big_form_t f; long const ti = (g.OC + 95) / 96;
+    bool const force_r = e && string(e) == "force";
+    if (conv_big_form(g, c, f) && f.rdec && ((double)g.OC / (double)(ti * 96) >= 0.95 || force_r) && (Nj >= 64l * num_cus || force_r)) return plan_conv_big(g, c);
+    return old;
+  }
   bool const k1big = g.KH == 1 && g.KW == 1 && g.PY == 0 && g.PX == 0 && g.SY == 1 && g.SX == 1 && Kt >= 384;
   bool const patchy = g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && !(g.KH == g.H && g.KW == g.W && g.OH == 1);
   if (!k1big && !patchy) return old;
@@ -1559,9 +1580,11 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
     }
     char const *const tstamp = p.cbig ? getenv("BODAHIP_CBIG_TSTAMP") : nullptr;   // experiment hook (tools/cbig_timeline.py): kernel built with -DTSTAMP=1 leaves 16 clock stamps per workgroup in the scratch; appended to the named file
     size_t const ts_bytes = (size_t)ga.tiles_i * ga.tiles_j * 128;
-    if (tstamp) { ensure_ws(impl, host, ts_off + ts_bytes); ga.ws = (float *)((char *)impl->ws + ts_off); hip_err_chk(hipMemsetAsync(ga.ws, 0, ts_bytes, host->nh_stream()), "hipMemsetAsync(tstamp)"); }
+    bool const ts_late = tstamp && strlen(tstamp) > 5 && !strcmp(tstamp + strlen(tstamp) - 5, ":late");   // no synchronisation, no copy per launch: the sequence runs undisturbed
+    if (tstamp) { ensure_ws(impl, host, ts_off + ts_bytes); ga.ws = (float *)((char *)impl->ws + ts_off); if (!ts_late) hip_err_chk(hipMemsetAsync(ga.ws, 0, ts_bytes, host->nh_stream()), "hipMemsetAsync(tstamp)"); }
     launch(host, k, ga, cfg);
-    if (tstamp) {
+    if (ts_late) { impl->ts_off = ts_off; impl->ts_bytes = ts_bytes; impl->ts_hdr = "launch " + cfg.str() + " grid " + std::to_string(ga.tiles_i * ga.tiles_j); }
+    else if (tstamp) {
       std::vector<unsigned long long> h(ts_bytes / 8);
       hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize(tstamp)");
       hip_err_chk(hipMemcpy(h.data(), ga.ws, ts_bytes, hipMemcpyDeviceToHost), "hipMemcpy(tstamp)");

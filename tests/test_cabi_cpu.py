@@ -109,7 +109,10 @@ def test_planner_picks_the_documented_kernel_and_operand_mode_per_shape():
     p = ex(_conv(256, 96, 27, 256, 3, 2, 1), tile="96x256x16x1x8x1x1x32x2x2")          # strided: the table gather
     assert p.startswith("bodahip_conv_big_f32 96x256x16_w1x8_p2_big") and mode(p, "J_MODE") == "2"
     p = ex(_conv(256, 3, 227, 96, 11, 4, 0))                      # AlexNet conv1 (strided, unpadded, wide): row-decimated LDS patch (round 4), 33 row sets of 1 x 11 kernels
-    assert p.startswith("bodahip_conv_f32 32x256x22_w1x4") and mode(p, "J_MODE") == "7" and "-DRDEC=1" in p and "-DKH0=11" in p and "-DSY0=4" in p and "-DCH=55" in p
+    assert p.startswith("bodahip_conv_big_f32 96x256x22_w1x8_big") and mode(p, "J_MODE") == "7" and "-DRDEC=1" in p and "-DKH0=11" in p and "-DSY0=4" in p and "-DCH=55" in p and "-DPF=1" in p   # (round 6: of the staging-wave kernel)
+    os.environ["BODAHIP_CBIG"] = "off"
+    try: q = ex(_conv(256, 3, 227, 96, 11, 4, 0)); assert q.startswith("bodahip_conv_f32 32x256x22_w1x4") and "-DRDEC=1" in q
+    finally: del os.environ["BODAHIP_CBIG"]
     p = ex(_conv(64, 3, 224, 64, 7, 2, 3))                        # GoogLeNet / ResNet conv1 (padded): row gather (KW >= 6)
     assert mode(p, "J_MODE") == "6" and "-DJROWS=" in p
     p = ex(_conv(128, 256, 27, 256, 1))                           # NiN cccp3 at 128 images: 1x1, tiled kernel (K = 256 is not "short")

@@ -493,12 +493,12 @@ def test_conv_staging_wave_kernel_bit_exact(be, tile, filt, monkeypatch):
 def test_conv_staging_wave_kernel_is_the_plan_where_its_tiles_deal_out(be, monkeypatch):
     """The planner's rule (round 6): stride-1 multi-tap layers whose two-workgroups-per-CU tiles deal out over the CUs take the staging-wave kernel -- here forced onto
     small shapes (BODAHIP_CBIG=force) so that the DEFAULT path (no tile string) is what runs: equal to the oracle and to the round-3 kernel (BODAHIP_CBIG=off)."""
-    for sh in [(40, 12, 13, 13, 70, 3, 3, 1, 1), (6, 20, 27, 27, 40, 5, 5, 1, 2), (3, 8, 9, 9, 260, 2, 2, 1, 0)]:
+    for sh in [(40, 12, 13, 13, 70, 3, 3, 1, 1), (6, 20, 27, 27, 40, 5, 5, 1, 2), (3, 8, 9, 9, 260, 2, 2, 1, 0), (3, 3, 51, 51, 96, 11, 11, 4, 0), (2, 5, 40, 40, 100, 6, 6, 2, 0)]:   # (the last two: row-decimated patch)
         op = _conv_op(*sh)
         monkeypatch.setenv("BODAHIP_CBIG", "force")
         outs, prc = _run(be, op, 5, include_ins=True)
         assert prc.launch["kernel"] == "bodahip_conv_big_f32" and "_big" in prc.launch["cfg"], prc.launch
-        want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (1, 1), (sh[8], sh[8]), True)
+        want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (sh[7], sh[7]), (sh[8], sh[8]), True)
         assert np.array_equal(want, outs["out"]), (sh, prc.launch["cfg"])
         monkeypatch.setenv("BODAHIP_CBIG", "off")
         old, prc2 = _run(be, op, 5)
@@ -987,7 +987,7 @@ def test_row_decimated_patch_bit_exact(be, case, monkeypatch):
     op = _conv_op(B, C, H, W, OC, K, K, S, 0)
     monkeypatch.delenv("BODAHIP_RDEC", raising=False)
     outs, prc = _run(be, op, 5, include_ins=True)
-    assert "_w" in prc.launch["cfg"] and prc.launch["kernel"] == "bodahip_conv_f32"
+    assert "_w" in prc.launch["cfg"] and prc.launch["kernel"] in ("bodahip_conv_f32", "bodahip_conv_big_f32")   # (round 6: at bench-like sizes with 96-multiples of out_chans the staging-wave kernel's row-decimated form)
     from boda_amd.rtc import explain_plan
     assert ("-DRDEC=1" in explain_plan(add_codegen_annotations(op, OpTune()))) == ((H - K) // S + 1 > 1)   # (a single output row stays on the row gather)
     want = bo.conv_fwd(outs["in"], outs["filts"], outs["biases"], (S, S), (0, 0), True)
