@@ -710,7 +710,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
         __builtin_amdgcn_s_sleep(32);
         if ((unsigned)__builtin_amdgcn_s_memrealtime() - t0 > 400000000u) { timed_out = true; break; }
       }
-      if (timed_out) __builtin_amdgcn_raw_buffer_store_b32(1, rQ, q_l0 + 8, 0, 16);
+      if (timed_out) { __builtin_amdgcn_raw_buffer_store_b32(1, rQ, q_l0 + 8, 0, 16); __builtin_trap(); }   // (round 6: a lost hand-off fails the launch loudly -- nobody read word 2, and computing on would have given wrong output silently)
     }
     __syncthreads();
 #pragma unroll

@@ -40,6 +40,8 @@ struct native_kernels_t::impl_t {
   void *ws = nullptr; size_t ws_bytes = 0; // split-K partial-sum slabs (grow-only scratch, like the reference's cudnn scratch var)
   std::vector<void *> ws_retired;          // outgrown scratch buffers that captured graphs may still point into (freed with the backend)
   std::map<string, void *> ktabs;           // im2col gather tables, one per (C,H,W,KH,KW) (device memory)
+  int call_ws_hold = 0;                       // > 0: a launch is collecting several of them (hip_conv_nhwc_set): none may be dropped
+  size_t call_ws_bytes = 0;                   // sum of the per-call workspaces ("ksl:" / "kho:" entries of ktabs): bounded, see call_ws_make_room
   size_t ts_off = 0, ts_bytes = 0; string ts_hdr;   // experiment hook BODAHIP_CBIG_TSTAMP=<file>:late -- the clock stamps of the LAST staging-wave launch, written out when the backend goes
   hipModule_t wino_mod = nullptr; hipFunction_t wino_filt = nullptr, wino_in = nullptr, wino_out = nullptr, wino_fused = nullptr, wino_filt_t = nullptr; // kernels/winograd_f32.hip
 };
@@ -1071,6 +1073,19 @@ static void setup_splitk(native_kernels_t::impl_t *impl, native_host_t *host, ge
 // its ticket), then one slab of raw fp32 accumulators per (tile, slice).  It belongs to the CALL (key: its operands and plan), not to the backend's shared scratch:
 // calls of an edge-free graph and members of a level set run at the same time.  Allocated and zeroed on the call's first run (not inside a capture), kept until the
 // backend goes; `key_ptr` tells calls on the same tensors' shapes apart.
+// Per-call workspaces (K slices, K hand-off) are keyed by the call's operands and plan and used to live until the backend went: every init() / release() cycle at a new
+// batch size and every tile tried in a sweep left another one behind, up to 4 GiB each (round-5 advisor finding).  Now their sum is bounded: before a new one is made that
+// would take the sum past 2 GiB (BODAHIP_CALL_WS_MB), all of them are dropped -- after a stream synchronisation, and only while no captured graph can still point into one;
+// a call finds its workspace missing, makes it again and zeroes its tickets, exactly like a first run.
+static void call_ws_make_room(native_kernels_t::impl_t *impl, native_host_t *host, size_t need) {
+  static size_t const cap = (getenv("BODAHIP_CALL_WS_MB") ? (size_t)atol(getenv("BODAHIP_CALL_WS_MB")) : 2048) << 20;
+  if (impl->call_ws_bytes + need <= cap || impl->call_ws_bytes == 0 || impl->call_ws_hold > 0 || host->nh_capturing() || host->nh_live_graphs() > 0) return;
+  hip_err_chk(hipStreamSynchronize(host->nh_stream()), "hipStreamSynchronize");
+  for (auto it = impl->ktabs.begin(); it != impl->ktabs.end();) {
+    if (it->first.compare(0, 4, "ksl:") == 0 || it->first.compare(0, 4, "kho:") == 0) { (void)hipFree(it->second); it = impl->ktabs.erase(it); } else ++it;
+  }
+  impl->call_ws_bytes = 0;
+}
 static void setup_ksl(native_kernels_t::impl_t *impl, native_host_t *host, gemm_args_t &ga, tile_cfg_t const &cfg, long nk, void const *key_ptr, char const *what) {
   long const tiles = (long)ga.tiles_i * ga.tiles_j;
   size_t const tick_b = ((size_t)tiles * 4 + 255) & ~size_t(255);
@@ -1083,7 +1098,8 @@ static void setup_ksl(native_kernels_t::impl_t *impl, native_host_t *host, gemm_
   if (it == impl->ktabs.end()) {
     if (host->nh_capturing()) rt_err("graph capture: the K-slice workspace of this call is not allocated yet -- run the call list once before capturing it");
     void *dev = nullptr;
-    hip_err_chk(hipMalloc(&dev, total), "hipMalloc(K-slice workspace)");
+    call_ws_make_room(impl, host, total);
+    hip_err_chk(hipMalloc(&dev, total), "hipMalloc(K-slice workspace)"); impl->call_ws_bytes += total;
     hip_err_chk(hipMemsetAsync(dev, 0, tick_b, host->nh_stream()), "hipMemsetAsync(K-slice tickets)");
     it = impl->ktabs.emplace(key, dev).first;
   }
@@ -1104,7 +1120,8 @@ static void setup_kho(native_kernels_t::impl_t *impl, native_host_t *host, gemm_
   if (it == impl->ktabs.end()) {
     if (host->nh_capturing()) rt_err("graph capture: the K hand-off workspace of this call is not allocated yet -- run the call list once before capturing it");
     void *dev = nullptr;
-    hip_err_chk(hipMalloc(&dev, total), "hipMalloc(K hand-off workspace)");
+    call_ws_make_room(impl, host, total);
+    hip_err_chk(hipMalloc(&dev, total), "hipMalloc(K hand-off workspace)"); impl->call_ws_bytes += total;
     hip_err_chk(hipMemsetAsync(dev, 0, tick_b, host->nh_stream()), "hipMemsetAsync(K hand-off counters)");
     it = impl->ktabs.emplace(key, dev).first;
   }
@@ -1844,6 +1861,7 @@ static set_layout_t layout_set(std::vector<plan_t> const &plans, std::vector<dou
 }
 
 void native_kernels_t::conv_nhwc_set(int n, multi_member_t const *ms, bool const *patch_filts, bool out_f32) {
+  impl->call_ws_hold = 0;   // (a hold left behind by an earlier call that threw)
   if (n < 1 || n > 16) unsup_err("hip_conv_nhwc_set: 1..16 members");
   std::vector<set_member_plan_t> mp((size_t)n);
   std::vector<plan_t> plans((size_t)n); std::vector<double> costs((size_t)n);
@@ -1873,12 +1891,14 @@ void native_kernels_t::conv_nhwc_set(int n, multi_member_t const *ms, bool const
     }
     if (q.p.ksl) {   // K slices reduced inside the launch: the member's grid is tiles x slices, its workspace its own
       long const nk = q.p.nhwc_patch ? ((long)(g.C / 8) + q.p.cg - 1) / q.p.cg : ((long)(g.C / 8) * g.KH * g.KW + q.p.cfg.BK / 8 - 1) / (q.p.cfg.BK / 8);
-      setup_ksl(impl, host, q.ga, q.p.cfg, nk, ms[m].grp_n > 0 ? ms[m].grp_out[0] : ms[m].out, "hip_conv_nhwc_set");
+      if (!impl->call_ws_hold) { call_ws_make_room(impl, host, size_t(1) << 30); impl->call_ws_hold = 1; }   // (room for this launch's members first; then none of them may go while the others are set up)
+      try { setup_ksl(impl, host, q.ga, q.p.cfg, nk, ms[m].grp_n > 0 ? ms[m].grp_out[0] : ms[m].out, "hip_conv_nhwc_set"); } catch (...) { impl->call_ws_hold = 0; throw; }
     }
     q.tiles = (long)q.ga.tiles_i * q.ga.tiles_j * std::max(1, q.ga.splitk);
     q.tile_cost = set_tile_cost(mi, q.p);
     plans[(size_t)m] = q.p; costs[(size_t)m] = q.tile_cost;
   }
+  impl->call_ws_hold = 0;
   set_layout_t const L = layout_set(plans, costs);
   std::vector<int> const &in_set = L.in_set, &alone = L.alone;
   for (int m = 0; m < n; ++m) mp[(size_t)m].variant = L.variant_of[(size_t)m];

@@ -67,9 +67,14 @@ def tensor_digest(t) -> int:
     b = t.contiguous().view(torch.uint8).reshape(-1)
     if b.numel() % 2:
         b = torch.cat([b, torch.zeros(1, dtype=torch.uint8, device=b.device)])
-    w = b.view(torch.int16).to(torch.int64) & 0xffff
-    idx = torch.arange(w.numel(), dtype=torch.int64, device=w.device) % 65521 + 1
-    return int((w * idx).sum().item())
+    w16 = b.view(torch.int16)
+    total = 0
+    CH = 1 << 22   # words per chunk: the int64 temporaries stay at ~100 MB whatever the tensor (the one-shot form took ~12x the tensor: 1.8 GB for AlexNet fc6)
+    for o in range(0, w16.numel(), CH):
+        w = w16[o:o + CH].to(torch.int64) & 0xffff
+        idx = (torch.arange(o, o + w.numel(), dtype=torch.int64, device=w.device) % 65521) + 1
+        total = (total + int((w * idx).sum().item())) & 0xffffffffffffffff
+    return total - (1 << 64) if total >= (1 << 63) else total   # (wrapped to int64, as the one-shot sum)
 
 
 def verify_replicated(tensors: Sequence, what: str = "weights") -> bool:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh final'
-# then, back here:  python tools/make_profile_summaries.py gpurun_out/final r05
+# then, back here:  python tools/make_profile_summaries.py gpurun_out/final r06
 # Kernel-trace stats and the PMC passes are separate runs (one --pmc set per run, never combined with other trace domains).
 D=${1:-final}
 R=$PWD
@@ -12,14 +12,14 @@ SQ="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES SQ_WAIT_INS
 [ -z "$BENCH_ONLY" ] && rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/calib -o c -- python $R/tools/fetch_calib.py > $O/calib.log 2>&1
 prof() {   # key, bench args
   k=$1; shift
-  rocprofv3 --kernel-trace --stats -d $O/stats_$k -o p -- python $R/bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_$k.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/stats_$k -o p -- python $R/bench.py "$@" --steps 20 --warmup 5 --no-cpu-baseline > $O/stats_$k.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_$k -o p -- python $R/bench.py "$@" --steps 1 --warmup 0 --settle-ms 0 --no-cpu-baseline > $O/fetch_$k.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_$k -o p -- python $R/bench.py "$@" --steps 1 --warmup 0 --settle-ms 0 --no-cpu-baseline > $O/write_$k.log 2>&1
   rocprofv3 --kernel-trace --pmc $SQ -d $O/sq_$k -o p -- python $R/bench.py "$@" --steps 1 --warmup 0 --settle-ms 0 --no-cpu-baseline > $O/sq_$k.log 2>&1
 }
 profnet() {   # key, bench args: whole nets -- kernel trace of the timed form, and ONE forward pass under each counter set (BENCH_SINGLE_PASS)
   k=$1; shift
-  rocprofv3 --kernel-trace --stats -d $O/stats_$k -o p -- python $R/bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_$k.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/stats_$k -o p -- python $R/bench.py "$@" --steps 20 --warmup 5 --no-cpu-baseline > $O/stats_$k.log 2>&1
   BENCH_SINGLE_PASS=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_$k -o p -- python $R/bench.py "$@" --no-cpu-baseline > $O/fetch_$k.log 2>&1
   BENCH_SINGLE_PASS=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_$k -o p -- python $R/bench.py "$@" --no-cpu-baseline > $O/write_$k.log 2>&1
   BENCH_SINGLE_PASS=1 rocprofv3 --kernel-trace --pmc $SQ -d $O/sq_$k -o p -- python $R/bench.py "$@" --no-cpu-baseline > $O/sq_$k.log 2>&1

@@ -4,7 +4,7 @@ kernel-source hash it was measured with: bench.py reports roofline.traffic only 
 import json, os, sqlite3, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "final")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r06"
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
 summ = os.path.join(ROOT, "tools", "rocprof_summary.py")
@@ -30,7 +30,7 @@ for w, (cmdargs, kern) in WORK.items():
     if not os.path.exists(sdb):
         continue
     with open(os.path.join(out, f"{tag}_{w}_kernel_stats.txt"), "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py {cmdargs} --steps 5 --warmup 2 --no-cpu-baseline\n")
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py {cmdargs} --steps 20 --warmup 5 --no-cpu-baseline\n")
         f.write(subprocess.check_output([sys.executable, summ, sdb, "--by-grid"], text=True))
     rows = {}
     for cn, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
@@ -78,7 +78,7 @@ for w, cmdargs in NETS.items():
     sdb = os.path.join(src, f"stats_{w}", "p_results.db")
     if os.path.exists(sdb):
         with open(os.path.join(out, f"{tag}_{w}_kernel_stats.txt"), "w") as f:
-            f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py {cmdargs} --steps 5 --warmup 2 --no-cpu-baseline\n")
+            f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py {cmdargs} --steps 20 --warmup 5 --no-cpu-baseline\n")
             f.write(subprocess.check_output([sys.executable, summ, sdb, "--by-grid"], text=True))
     fdb, wdb = os.path.join(src, f"fetch_{w}", "p_results.db"), os.path.join(src, f"write_{w}", "p_results.db")
     if os.path.exists(fdb) and os.path.exists(wdb):   # round 5: HBM bytes of ONE forward pass, every kernel of it (convs, pool / LRN / layout passes): the config legs' roofline.traffic

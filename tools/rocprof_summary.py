@@ -21,6 +21,23 @@ def main():
         for r in c.execute("select name, grid_x, workgroup_x, count(*), avg(duration), min(duration), max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size) "
                            "from kernels group by name, grid_x, workgroup_x order by name, grid_x"):
             print(f"{r[0]:36s} grid {r[1]:9d} wg {r[2]:4d} calls {r[3]:4d} avg {r[4]:13.1f} min {r[5]:12.0f} vgpr {r[6]} agpr {r[7]} sgpr {r[8]} lds {r[9]}")
+    if by_grid:
+        # steady state (round 6): per (kernel, grid) the FIRST launch -- module load, cold caches: one pass in the run -- is dropped, the rest averaged; the number of passes
+        # over the op list is the launch count of the rarest (kernel, grid); per-step total = sum over groups of avg x launches per pass
+        rows = list(c.execute("select name, grid_x, start, duration from kernels order by start"))
+        groups = {}
+        for n, g, st, du in rows: groups.setdefault((n, g), []).append(du)
+        big = {k: v for k, v in groups.items() if not k[0].startswith(("gen_data", "bodahip_gen", "calib"))}
+        if big:
+            passes = max(1, min(len(v) for v in big.values()))
+            tot = 0.0
+            print(f"## steady state: first launch of every (kernel, grid) dropped; {passes} passes over the op list  [name, grid, launches, avg_ns of the rest, per pass]")
+            for (n, g), v in sorted(big.items()):
+                rest = v[1:] if len(v) > 1 else v
+                avg = sum(rest) / len(rest); per = len(v) / passes
+                tot += avg * per
+                print(f"{n:44s} grid {g:9d} n {len(v):5d} avg {avg:13.1f} x {per:5.2f}")
+            print(f"## steady-state kernel time per step (one pass over the op list): {tot / 1e6:.4f} ms")
     try:
         pm = list(c.execute("select kernel_name, grid_size, counter_name, count(*), sum(value), avg(value) from counters_collection group by kernel_name, grid_size, counter_name order by kernel_name, grid_size"))
     except sqlite3.Error:
