@@ -76,6 +76,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef RELU
 #define RELU 0
 #endif
+#ifndef MINWAVES
+#define MINWAVES MINW // HIP's second launch bound is WAVES PER SIMD, not workgroups per CU.  MINW workgroups of WI WJ + 4 waves would need MINW (WI WJ + 4) / 4: for the twelve-wave tiles that caps
+#endif                // the kernel at 80 registers, and the spills that follow cost more than the second resident workgroup brings (round 6 A/B, AlexNet conv3 528 -> 583 us): the lax bound stays
 #ifndef PERMJ
 #define PERMJ (J_MODE != 7) // 1: column kappa of column block u is tile column kTJ kappa + u (a lane's B operands of a k contiguous in the im2col image, kTJ consecutive pels per lane in the
 #endif                      // epilogue); 0 (patch form): column block u is tile columns 32 u .. 32 u + 31 -- consecutive lanes read consecutive patch elements (no bank conflicts)
@@ -109,7 +112,7 @@ constexpr int kTI = TBI / (WI * 32), kTJ = TBJ / (WJ * 32);   // 32 x 32 blocks 
 static_assert(kNMW == 8 || kNMW == 4, "eight (or four) multiplying waves");
 static_assert(TBI % (WI * 32) == 0 && TBJ % (WJ * 32) == 0 && kTI >= 1 && kTI <= 4 && kTJ >= 1 && kTJ <= 4 && kTI * kTJ <= 8, "wave tile: up to 4 x 2 | 2 x 4 blocks");
 constexpr int kTIp = (kTI == 3) ? 4 : kTI, kTJp = (kTJ == 3) ? 4 : kTJ;   // pitch of a lane's operand group in the LDS image
-constexpr int kLDI = (TBI / kTI) * kTIp + 4, kLDJ = (TBJ / kTJ) * kTJp + 4; // floats per k row of the filter / pel image
+constexpr int kLDI = (TBI / kTI) * kTIp + 4, kLDJ = (PERMJ ? (TBJ / kTJ) * kTJp : TBJ) + 4; // floats per k row of the filter / pel image
 #if J_MODE == 7
 #if !defined(CH) || !defined(CW) || !defined(COH) || !defined(COW)
 #error "J_MODE 7 needs -DCH -DCW -DCOH -DCOW (input / output plane sizes are compile-time)"
@@ -186,7 +189,7 @@ __device__ __forceinline__ float bload1(rsrc_t r, int voff, int soff) { return _
 __device__ __forceinline__ f32x2 bload2(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)); }
 __device__ __forceinline__ f32x4 bload4(rsrc_t r, int voff, int soff) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); }
 constexpr int colI(int x) { return (x / kTI) * kTIp + x % kTI; }   // LDS column of tile row x (out_chan) ...
-__device__ __forceinline__ int colJ(int x) { return (x / kTJ) * kTJp + x % kTJ; }   // ... and of tile column x (pel)
+__device__ __forceinline__ int colJ(int x) { return PERMJ ? (x / kTJ) * kTJp + x % kTJ : x; }   // ... and of tile column x (pel; natural column blocks: itself)
 } // namespace
 
 #if (TBI / (WI * 32)) >= 3
@@ -210,7 +213,7 @@ __device__ __forceinline__ float vget(float const &v, int) { return v; }
 struct ivec_t { float v[kIW]; };
 } // namespace
 
-extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_args_t const p) {
+extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINWAVES) void KNAME(gemm_args_t const p) {
   __shared__ __attribute__((aligned(16))) float sm[NSTG * kImg2];   // [stage][filter image (MFMA A, out_chans) | pel image (MFMA B)][k][kLDI | kLDJ]
   int const lane = threadIdx.x & 63;
   int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -495,10 +498,20 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
   };
 #define BGET(B, U) ((B).v[U])
 #else
+#if PERMJ
   float const *const b_base = sm + kImgI + (lane >> 5) * kLDJ + (wj * 32 + (lane & 31)) * kTJp;
   typedef bvec_t bop_t;
   auto readB = [&](int stage, int kk) -> bop_t { return *reinterpret_cast<bvec_t const *>(b_base + stage * kImg2 + kk * 2 * kLDJ); };
 #define BGET(B, U) vget(B, U)
+#else   // natural column blocks on an im2col / 1x1 image (-DPERMJ=0): kTJ single reads per k pair, consecutive lanes consecutive words; the epilogue's paired row stores
+  float const *const b_base = sm + kImgI + (lane >> 5) * kLDJ + wj * (kTJ * 32) + (lane & 31);
+  struct bop_t { float v[kTJ]; };
+  auto readB = [&](int stage, int kk) -> bop_t { bop_t r;
+#pragma unroll
+    for (int u = 0; u < kTJ; ++u) r.v[u] = b_base[stage * kImg2 + kk * 2 * kLDJ + u * 32];
+    return r; };
+#define BGET(B, U) ((B).v[U])
+#endif
 #endif
   auto readA = [&](int stage, int kk) -> avec_t { return *reinterpret_cast<avec_t const *>(a_base + stage * kImg2 + kk * 2 * kLDI); };
   f32x16 acc[kTI][kTJ];
