@@ -1578,7 +1578,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
     return;
   }
   uint32_t kho_grid = 0;
-  if (cfg.KHO > 1) { setup_kho(impl, host, ga, cfg, out); kho_grid = launch_kho(host, k, ga, cfg); }
+  if (cfg.KHO > 1 && !p.cbig) { setup_kho(impl, host, ga, cfg, out); kho_grid = launch_kho(host, k, ga, cfg); }
   else {
     setup_splitk(impl, host, ga, cfg, (size_t)Nj * g.OC);
     size_t ts_off = 0;
