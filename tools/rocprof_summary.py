@@ -29,7 +29,11 @@ def main():
         for n, g, st, du in rows: groups.setdefault((n, g), []).append(du)
         big = {k: v for k, v in groups.items() if not k[0].startswith(("gen_data", "bodahip_gen", "calib"))}
         if big:
-            passes = max(1, min(len(v) for v in big.values()))
+            # passes over the op list = the launch count that carries the most kernel time (set-up kernels -- data generation, one-time layout passes -- run once and are left out)
+            by_count = {}
+            for v in big.values(): by_count[len(v)] = by_count.get(len(v), 0) + sum(v)
+            passes = max(by_count, key=by_count.get)
+            big = {k: v for k, v in big.items() if len(v) >= passes}
             tot = 0.0
             print(f"## steady state: first launch of every (kernel, grid) dropped; {passes} passes over the op list  [name, grid, launches, avg_ns of the rest, per pass]")
             for (n, g), v in sorted(big.items()):
