@@ -228,7 +228,7 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINWAVES) void KNAME(ge
     int const gsz = min(p.tiles_i - first_i, GROUP_I), in_g = nid - gid * group_sz;
     tile_i = first_i + in_g % gsz; tile_j = in_g / gsz;
   }
-  int const i0 = tile_i * TBI, j0 = tile_j * TBJ;
+  int const i0 = tile_i * TBI, j0 = tile_j * TBJ + (int)p.bsJ;   // (p.bsJ: first pel of this launch -- the tail launch of a two-level tiling starts behind the main launch's whole rounds)
   int const nkt = (p.K + BKS - 1) / BKS;
 #if TSTAMP
   unsigned long long *const ts = reinterpret_cast<unsigned long long *>(p.ws) + (size_t)blockIdx.x * 16;

@@ -189,7 +189,7 @@ static void launch(native_host_t *host, kernel_t &k, gemm_args_t &a, tile_cfg_t 
   hip_err_chk(host->nh_launch(k.func, grid, 1, (uint32_t)c.threads(), params), "hipModuleLaunchKernel(native)");
 }
 
-struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, fc = false, big = false, cbig = false, rdec = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false, nhwc_rows = false, ksl = false; int rows = 0, cg = 0; };
+struct plan_t { tile_cfg_t cfg; vect_string defs; string kname; long split_pels = 0; tile_cfg_t tail_cfg; vect_string tail_defs;   /* split_pels > 0 (staging-wave convolution, round 6): two-level tiling along the pels -- this plan's tiles over the first split_pels pels (whole rounds of the CUs), tail_cfg's over the rest */ bool ipconv = false, k1 = false, bf16 = false, patch = false, stream = false, quad = false, fc = false, big = false, cbig = false, rdec = false, patch16 = false, nhwc = false, nhwc_patch = false, nhwc_multi = false, nhwc_rows = false, ksl = false; int rows = 0, cg = 0; };
 
 // Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
 //   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
@@ -1037,7 +1037,46 @@ static plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, b
     double const score = cd.base * pad * deal;
     if (score > best) { best = score; best_c = c; }
   }
-  return (best >= (force ? 0.0 : 0.76)) ? plan_conv_big(g, best_c) : old;
+  if (best < (force ? 0.0 : 0.76)) return old;
+  plan_t bp = plan_conv_big(g, best_c);
+  // Two-level tiling along the pels (the sgemm path's idea, plan_sgemm_split): when the tiles leave a mostly idle last round, the main tile takes whole rounds of the CUs and
+  // a launch of smaller tiles the remaining pels -- every output is still one launch's one fma chain.  AlexNet / NiN conv2 at 256 images: 1460 tiles of 64 x 512 = 5.7 rounds
+  // -> 5 rounds + 720 tiles of 64 x 128 (2.8 quarter-size rounds): 6 -> 5.75 tile-times.  Taken when the model says >= 3 % on a launch of >= 50 GFLOP (the second launch
+  // costs ~5 us).  BODAHIP_CBIG_SPLIT=off.
+  char const *se = getenv("BODAHIP_CBIG_SPLIT");
+  static double const split_min = (getenv("BODAHIP_CBIG_SPLIT_MIN_GFLOP") ? atof(getenv("BODAHIP_CBIG_SPLIT_MIN_GFLOP")) : 50.0) * 1e9;   // (tests lower it)
+  if (!(se && string(se) == "off") && 2.0 * g.OC * (double)Nj * Kt >= split_min) {
+    auto t_of = [&](cand_t const &cd, long n_pels, long &tiles_out) {
+      long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (n_pels + cd.bj - 1) / cd.bj; tiles_out = ti * tj;
+      return (double)((tiles_out + num_cus - 1) / num_cus) * cd.bi * cd.bj / cd.base;
+    };
+    cand_t const *bc = nullptr; for (cand_t const &cd : cands) if (cd.bi == best_c.BI && cd.bj == best_c.BJ && cd.wi == best_c.WI && cd.wj == best_c.WJ) bc = &cd;
+    long tl = 0; double const t_single = bc ? t_of(*bc, Nj, tl) : 0;
+    double t_best = t_single * 0.97; long best_n1 = 0; cand_t const *m_best = nullptr, *t_best_c = nullptr;
+    for (cand_t const &m : cands) {
+      if (m.small || m.wi * m.wj != 8) continue;
+      tile_cfg_t c1; c1.BI = m.bi; c1.BJ = m.bj; c1.BK = 16; c1.WI = m.wi; c1.WJ = m.wj; c1.MINW = 2; c1.SPLITK = 1; c1.MT = 32; c1.PF = 2; c1.SW = 2; c1.KHO = 0;
+      conv_big_form_t f1; if (!conv_big_form(g, c1, f1) || f1.jmode != (patchy ? 7 : 5)) continue;
+      long const ti1 = (g.OC + m.bi - 1) / m.bi, tj_all = (Nj + m.bj - 1) / m.bj;
+      long const R = (ti1 * tj_all) / num_cus; if (R < 1) continue;
+      long const tj1 = std::min(tj_all - 1, (R * num_cus) / ti1); if (tj1 < 1) continue;
+      long const n1 = tj1 * m.bj; if (n1 >= Nj) continue;
+      double const t_main = (double)((ti1 * tj1 + num_cus - 1) / num_cus) * m.bi * m.bj / m.base;
+      for (cand_t const &t : cands) {
+        tile_cfg_t c2; c2.BI = t.bi; c2.BJ = t.bj; c2.BK = 16; c2.WI = t.wi; c2.WJ = t.wj; c2.MINW = 2; c2.SPLITK = 1; c2.MT = 32; c2.PF = 2; c2.SW = 2; c2.KHO = 0;
+        conv_big_form_t f2; if (!conv_big_form(g, c2, f2) || f2.jmode != (patchy ? 7 : 5)) continue;
+        long tt = 0; double const tsum = t_main + t_of(t, Nj - n1, tt);
+        if (tsum < t_best) { t_best = tsum; best_n1 = n1; m_best = &m; t_best_c = &t; }
+      }
+    }
+    if (m_best) {
+      tile_cfg_t c1; c1.BI = m_best->bi; c1.BJ = m_best->bj; c1.BK = 16; c1.WI = m_best->wi; c1.WJ = m_best->wj; c1.MINW = 2; c1.SPLITK = 1; c1.MT = 32; c1.PF = 2; c1.SW = 2; c1.KHO = 0;
+      tile_cfg_t c2 = c1; c2.BI = t_best_c->bi; c2.BJ = t_best_c->bj; c2.WI = t_best_c->wi; c2.WJ = t_best_c->wj;
+      bp = plan_conv_big(g, c1); plan_t const tp = plan_conv_big(g, c2);
+      bp.split_pels = best_n1; bp.tail_cfg = tp.cfg; bp.tail_defs = tp.defs;
+    }
+  }
+  return bp;
 }
 static std::vector<char> compile_plan(plan_t const &p, string const &arch, string *log) {
   vect_string opts = p.defs; opts.push_back("-DKNAME=" + p.kname);
@@ -1577,7 +1616,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
     last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
     return;
   }
-  uint32_t kho_grid = 0;
+  uint32_t kho_grid = 0, tail_grid = 0;
   if (cfg.KHO > 1 && !p.cbig) { setup_kho(impl, host, ga, cfg, out); kho_grid = launch_kho(host, k, ga, cfg); }
   else {
     setup_splitk(impl, host, ga, cfg, (size_t)Nj * g.OC);
@@ -1599,6 +1638,15 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
     size_t const ts_bytes = (size_t)ga.tiles_i * ga.tiles_j * 128;
     bool const ts_late = tstamp && strlen(tstamp) > 5 && !strcmp(tstamp + strlen(tstamp) - 5, ":late");   // no synchronisation, no copy per launch: the sequence runs undisturbed
     if (tstamp) { ensure_ws(impl, host, ts_off + ts_bytes); ga.ws = (float *)((char *)impl->ws + ts_off); if (!ts_late) hip_err_chk(hipMemsetAsync(ga.ws, 0, ts_bytes, host->nh_stream()), "hipMemsetAsync(tstamp)"); }
+    if (p.cbig && p.split_pels > 0) {   // two-level tiling along the pels: this plan's tiles over the first split_pels pels, the tail plan's over the rest
+      ga.tiles_j = (int)(p.split_pels / cfg.BJ);
+      launch(host, k, ga, cfg);
+      plan_t tp; tp.cbig = true; tp.kname = p.kname; tp.cfg = p.tail_cfg; tp.defs = p.tail_defs; tp.patch = p.patch; tp.k1 = p.k1; tp.rdec = p.rdec;
+      kernel_t &k2 = get_kernel(impl, host, tp);
+      gemm_args_t g2 = ga; g2.tiles_i = (g.OC + tp.cfg.BI - 1) / tp.cfg.BI; g2.tiles_j = (int)((Nj - p.split_pels + tp.cfg.BJ - 1) / tp.cfg.BJ); g2.bsJ = p.split_pels; g2.ws = nullptr;
+      launch(host, k2, g2, tp.cfg);
+      tail_grid = (uint32_t)g2.tiles_i * g2.tiles_j;
+    } else
     launch(host, k, ga, cfg);
     if (ts_late) { impl->ts_off = ts_off; impl->ts_bytes = ts_bytes; impl->ts_hdr = "launch " + cfg.str() + " grid " + std::to_string(ga.tiles_i * ga.tiles_j); }
     else if (tstamp) {
@@ -1610,7 +1658,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
     }
     if (cfg.SPLITK > 1) reduce_splitk(impl, host, ga, Nj * g.OC, true, g.relu, g.OH * g.OW, g.OC);
   }
-  last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = kho_grid ? kho_grid : (uint32_t)ga.tiles_i * ga.tiles_j * cfg.SPLITK; last_launch.block = cfg.threads();
+  last_launch.kernel = p.kname; last_launch.cfg = cfg; last_launch.grid = (kho_grid ? kho_grid : (uint32_t)ga.tiles_i * ga.tiles_j * cfg.SPLITK) + tail_grid; last_launch.block = cfg.threads();
   last_launch.flops = 2.0 * Nj * g.OC * Kt;
   last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * (g.pooled() ? (double)g.UH * g.UW : (double)g.H * g.W) + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
 }
@@ -2162,9 +2210,11 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
       } else { char const *k1e = getenv("BODAHIP_K1_STREAM"); p = plan_conv(g, num_cus, tile, bf16, k1e ? string(k1e) : string(), true, exact); }   // (the env var a backend instance reads its k1_stream tune from)
     }
   } else rt_err("prebuild: op type '" + t + "' has no native kernel");
-  if (plan_out) { *plan_out = s2d + p.kname + " " + p.cfg.str(); for (auto const &d : p.defs) *plan_out += " " + d; }
+  if (plan_out) { *plan_out = s2d + p.kname + " " + p.cfg.str(); for (auto const &d : p.defs) *plan_out += " " + d;
+    if (p.split_pels > 0) *plan_out += " pels<" + std::to_string(p.split_pels) + "+rest:" + p.tail_cfg.str(); }
   if (arch.empty()) return 0;
   size_t const n = compile_plan(p, arch, &log).size();
+  if (p.cbig && p.split_pels > 0) { plan_t tp; tp.cbig = true; tp.kname = p.kname; tp.cfg = p.tail_cfg; tp.defs = p.tail_defs; compile_plan(tp, arch, &log); }
   if (p.cbig) { plan_t xp; xp.cbig = true; xp.kname = "bodahip_conv_big_xpose"; xp.defs = {"-DXPOSE_ONLY=1"}; compile_plan(xp, arch, &log); }   // (the filter transposition that runs in front of it)
   if (p.patch16) { plan_t fp; fp.patch16 = true; fp.bf16 = true; fp.kname = "bodahip_filt_bf16"; fp.defs = {"-DFILT_ONLY=1"}; compile_plan(fp, arch, &log); }
   if (p.ksl) {   // (K slices reduced inside the launch: no second kernel)

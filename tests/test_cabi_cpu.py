@@ -90,8 +90,12 @@ def test_planner_picks_the_documented_kernel_and_operand_mode_per_shape():
     def mode(plan, key): return re.search(rf"-D{key}=(\d+)", plan).group(1)
     p = ex(_conv(256, 96, 27, 256, 5, 1, 2))                      # AlexNet conv2: LDS input patch -- round 6: of the staging-wave kernel (two workgroups per CU, filters k-major from the scratch)
     assert p.startswith("bodahip_conv_big_f32 64x512x50_w1x8_p2_big") and mode(p, "J_MODE") == "7" and "-DCH=27" in p and "-DRELU=1" in p and "-DMINW=2" in p and "-DI_VW=0" in p
-    assert ex(_conv(256, 256, 13, 384, 3, 1, 1)).startswith("bodahip_conv_big_f32 128x256x18_w2x4_p2_big")      # AlexNet conv3: 507 tiles on 256 CUs
-    assert ex(_conv(256, 384, 13, 256, 3, 1, 1)).startswith("bodahip_conv_big_f32 64x256x18_w1x8_p2_big")       # conv5: 676 tiles (2.64 per CU -> 0.88)
+    assert "pels<163840+rest:64x192x50_w2x2_p2_big" in p                                                          # ... two-level: five whole rounds of 64 x 512 tiles (1280), the last 22 784 pels on 64 x 192
+    os.environ["BODAHIP_CBIG_SPLIT"] = "off"
+    try: assert "pels<" not in ex(_conv(256, 96, 27, 256, 5, 1, 2))
+    finally: del os.environ["BODAHIP_CBIG_SPLIT"]
+    assert ex(_conv(256, 256, 13, 384, 3, 1, 1)).startswith("bodahip_conv_big_f32 128x256x18_w2x4_p2_big") and "pels<" not in ex(_conv(256, 256, 13, 384, 3, 1, 1))   # AlexNet conv3: 507 tiles on 256 CUs: one launch
+    q5 = ex(_conv(256, 384, 13, 256, 3, 1, 1)); assert q5.startswith("bodahip_conv_big_f32 128x256x18_w2x4_p2_big") and "pels<32768+rest:64x192x18_w2x2_p2_big" in q5   # conv5: one round of 128 x 256 + a tail (in one launch: 676 tiles of 64 x 256 = 2.64 per CU)
     os.environ["BODAHIP_CBIG"] = "off"
     try:
         q = ex(_conv(256, 96, 27, 256, 5, 1, 2)); assert q.startswith("bodahip_conv_f32 ") and mode(q, "J_MODE") == "7" and "-DCH=27" in q   # the round-3 kernel's patch form

@@ -505,6 +505,36 @@ def test_conv_staging_wave_kernel_is_the_plan_where_its_tiles_deal_out(be, monke
         assert prc2.launch["kernel"] == "bodahip_conv_f32" and np.array_equal(old["out"], outs["out"])
 
 
+def test_conv_two_level_tiling_along_the_pels_bit_exact():
+    """Round 6: a staging-wave plan whose tiles leave a mostly idle last round runs as a main launch over whole rounds of the CUs plus a tail launch of smaller tiles over the
+    remaining pels (`pels<N+rest:` in the plan; by default only for launches of >= 50 GFLOP -- lowered here, in a process of its own because the threshold is read once).
+    Same bits as the oracle and as the single launch (BODAHIP_CBIG_SPLIT=off)."""
+    import subprocess, sys
+    code = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from boda_amd.cnn_op import OpTune, add_codegen_annotations\n"
+        "from boda_amd.ops_prof import OpsBackend, profile_rcg_call\n"
+        "from boda_amd.rtc import make_rtc, explain_plan\n"
+        "from oracle import boda_oracle as bo\n"
+        "from tools.cbig_probe import conv_op\n"
+        "rtc = make_rtc('(be=hip)', 0); rtc.init(); be = OpsBackend(rtc)\n"
+        "op = conv_op(160, 16, 13, 13, 384, 3, 3, 1, 1)\n"
+        "anno = add_codegen_annotations(op, OpTune())\n"
+        "plan = explain_plan(anno); assert 'pels<' in plan and '+rest:' in plan, plan\n"
+        "outs, prc = profile_rcg_call(be, anno, 5, 0.0, 1, include_ins=True)\n"
+        "want = bo.conv_fwd(outs['in'], outs['filts'], outs['biases'], (1, 1), (1, 1), True)\n"
+        "assert np.array_equal(want, outs['out']), prc.launch\n"
+        "os.environ['BODAHIP_CBIG_SPLIT'] = 'off'\n"
+        "assert 'pels<' not in explain_plan(anno)\n"
+        "one, _ = profile_rcg_call(be, anno, 5, 0.0, 1)\n"
+        "assert np.array_equal(one['out'], outs['out'])\n"
+        "print('OK', prc.launch['grid'])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["BODAHIP_CBIG_SPLIT_MIN_GFLOP"] = "0.1"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("tile", ["128x128x16x2x2x2x4", "64x64x16x2x2x2x3", "96x128x16x1x2x2x7"])
 def test_splitk_sgemm_and_conv_within_reference_tolerance(be, tile):
     op = _sgemm_op(300, 200, 1000)
