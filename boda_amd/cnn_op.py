@@ -167,10 +167,12 @@ NATIVE_ARGS: Dict[str, tuple] = {
     "hip_conv_winograd": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
     "hip_conv_nhwc": (("filts", "IN"), ("biases", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
     "hip_conv_k1_chain": (("filts", "IN"), ("biases", "IN"), ("filts2", "IN"), ("biases2", "IN"), ("in", "IN"), ("stride", "REF"), ("in_pad", "REF"), ("out", "OUT")),
+    "hip_conv_filts_kmajor": (("filts", "IN"), ("filts_km", "OUT")),   # filts as [K + 128][out_chan padded to 4]: what hip_conv's optional filts_km arg takes
 }
 
 
 K1_CHAIN_FUNC = "hip_conv_k1_chain"
+FILTS_KMAJOR_FUNC = "hip_conv_filts_kmajor"
 
 
 def k1_chain_applies(a: Op, b: Op) -> bool:

@@ -23,7 +23,7 @@ import os
 import numpy as np
 
 from . import gen_data as gd
-from .cnn_op import K1_CHAIN_FUNC, NATIVE_ARGS, OpTune, add_codegen_annotations, annotate_k1_chain, f32_pool_fusable, fuse_f32_pool, k1_chain_applies
+from .cnn_op import FILTS_KMAJOR_FUNC, K1_CHAIN_FUNC, NATIVE_ARGS, OpTune, add_codegen_annotations, annotate_k1_chain, f32_pool_fusable, fuse_f32_pool, k1_chain_applies
 from .cucl_template import instantiate, parse_template
 from .op import Dims, Nda, Op, RtErr, UnsupErr
 from .rtc import HipCompute, RtcArg, RtcCompileOpts, RtcFuncCall, RtcFuncInfo
@@ -405,8 +405,12 @@ class ConvPipeFwd:
     mode = "rtc"
 
     def __init__(self, rtc: HipCompute, op_tune: Optional[OpTune] = None, per_call_fn: str = "", enable_double_run: bool = False, fuse_siblings: bool = True, fuse_levels: bool = True, fuse_pools: bool = True, sets_take_groups: bool = True,
-                 spec_fwd: bool = True, fuse_pool_lrn="pool_first", fuse_k1_chains: bool = True, fuse_f32_pools: Optional[bool] = None, fuse_post: bool = True):
+                 spec_fwd: bool = True, fuse_pool_lrn="pool_first", fuse_k1_chains: bool = True, fuse_f32_pools: Optional[bool] = None, fuse_post: bool = True, filts_kmajor_once: bool = True):
         self.rtc, self.op_tune = rtc, op_tune or OpTune()
+        # fp32 nets (round 6): a convolution whose plan reads its filters k-major gets that copy made once per set of weights (hip_conv_filts_kmajor, refresh_group_params())
+        # instead of in front of every call -- seven launches less per NiN pass.  Bit-identical (the same transposition kernel, the same bytes); BODAHIP_FILTS_KM_ONCE=off: per call
+        self.filts_kmajor_once = filts_kmajor_once and os.environ.get("BODAHIP_FILTS_KM_ONCE") != "off"
+        self._km_params: List[RtcFuncCall] = []
         # channels-last bf16 nets (round 5): a convolution on the rolling-rows kernel (csrc/kernels/conv_nhwc_rows_bf16.hip: the 7x7/2 stems) takes the max pooling that alone
         # reads it, and the LRN that alone reads that, into its launch -- its rows are pooled out of an LDS ring, its own output (four times the pooled tensor) is never
         # written or read.  GoogLeNet: conv1 + pool1 + norm1 = one call.  Bit-identical to the calls run apart; the skipped nodes are materialised on demand.
@@ -792,6 +796,16 @@ class ConvPipeFwd:
                         cam["out_chan_off"] = am["out_chan_off"]
                     self.fwd_calls.append(FwdCall(first.tag + "+" + op.tag, RtcFuncCall(cfn, cam), K1_CHAIN_FUNC, cp.conv_op(first).flops() + cop.flops()))
                     continue
+                if fn == "hip_conv" and self.filts_kmajor_once and self._plan_reads_filts_kmajor(anno):
+                    # the plan reads its filters k-major (the staging-wave kernel, csrc/kernels/conv_big_f32.hip): the net holds that copy -- made ONCE, below in
+                    # refresh_group_params(), as the reference transposes its filters at set-up (xpose_filts, src/rtc_fwd.cc:229-243) -- and the call skips its own pass
+                    fd = anno.get_dims("filts"); kmv = op.tag + "_filts_km"
+                    kmd = Dims(("k", "out_chan"), (fd.dsz("in_chan") * fd.dsz("y") * fd.dsz("x") + 128, (fd.dsz("out_chan") + 3) // 4 * 4), "float")
+                    rtc.create_var_with_dims(kmv, kmd); self._vars.append(kmv)
+                    xfn = f"{FILTS_KMAJOR_FUNC}__{cp.name}_{op.tag}"
+                    rtc.compile([RtcFuncInfo(xfn, "", [a for a, _ in NATIVE_ARGS[FILTS_KMAJOR_FUNC]], Op({"type": "Convolution", "func_name": FILTS_KMAJOR_FUNC}, {}))]); self._funcs.append(xfn)
+                    self._km_params.append(RtcFuncCall(xfn, {"filts": am["filts"], "filts_km": RtcArg.var(kmv)}))
+                    am["filts_km"] = RtcArg.var(kmv)
                 self.fwd_calls.append(FwdCall(op.tag, RtcFuncCall(gen_fn, am), fn, cop.flops()))
             elif self.nhwc and op.tag in post_of:                   # taken into its convolution's launch (fuse_post): the pooling's node on demand (from the convolution's, on demand too); the LRN's is what that launch writes
                 if op.type == "Pooling":
@@ -960,6 +974,8 @@ class ConvPipeFwd:
         """Stacked filters / biases of the fused sibling convolutions, from the members' own (already transposed) params: init time only (and again after a
         caller overwrote params, e.g. a weight broadcast)."""
         rtc = self.rtc
+        for call in getattr(self, "_km_params", []):     # k-major filter copies of the staging-wave convolutions (filts_kmajor_once)
+            rtc.run(call)
         for fv, bv, grp, tags in getattr(self, "_grp_params", []):
             from . import nhwc as _nhwc
             offs = _nhwc.group_row_offsets(grp)
@@ -970,6 +986,14 @@ class ConvPipeFwd:
                 F[off:off + f.shape[0]] = f; Bv[off:off + b.shape[0]] = b
             rtc.copy_nda_to_var(fv, F); rtc.copy_nda_to_var(bv, Bv)
         rtc.finish_and_sync()
+
+    def _plan_reads_filts_kmajor(self, anno: Op) -> bool:
+        from .rtc import explain_plan
+        try:
+            plan = explain_plan(anno, getattr(self, "_num_cus", 256)).split()
+        except (UnsupErr, RtErr):
+            return False
+        return plan[0] == "bodahip_conv_big_f32" and "-DI_VW=0" in plan
 
     def var_of(self, node: str) -> str:
         return self._alias.get(node, node)
@@ -1118,5 +1142,6 @@ class ConvPipeFwd:
         for v in self._vars:
             rtc.release_var(v)
         self._funcs, self._vars, self.fwd_calls, self._grp_params, self.groups = [], [], [], [], []
+        self._km_params = []
         self.fused_post, self._lazy_pre = {}, {}
         self.k1_chains, self._lazy, self.fused_pools, self.fused_pool_lrn, self.level_sets, self.lds_pool_lrn = [], {}, {}, {}, [], set()   # (a second init() starts from a clean slate)

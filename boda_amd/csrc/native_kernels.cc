@@ -80,6 +80,7 @@ void native_kernels_t::check_compile_time(rtc_func_info_t const &fi) {
   if (fn == "hip_sgemm" || fn == "cublas_sgemm" || fn == "hip_sgemm_bf16") return;
   if (fn == "hip_conv" || fn == "cudnn_conv" || fn == "hip_conv_bf16" || fn == "hip_conv_winograd" || fn == "hip_conv_nhwc" || fn == "hip_conv_nhwc_grp" || fn == "hip_conv_nhwc_multi" || fn == "hip_conv_nhwc_set") { (void)fi.op.get_u32("conv_has_relu"); return; } // required, as src/culibs-wrap.cc:198
   if (fn == "hip_conv_k1_chain") { (void)fi.op.get_u32("conv_has_relu"); (void)fi.op.get_u32("conv_has_relu2"); return; }
+  if (fn == "hip_conv_filts_kmajor") return;
   rt_err("unknown/unhandled native hip function: " + fn);
 }
 void native_kernels_t::set_tune(string const &key, string const &val) {
@@ -1500,7 +1501,7 @@ void native_kernels_t::conv_winograd(float const *filts, float const *biases, fl
   last_launch.algo_bytes = 4.0 * ((double)g.B * g.C * g.H * g.W + (double)Nj * g.OC + (double)g.OC * Kt + g.OC);
 }
 
-void native_kernels_t::conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16, int out_ctot, int out_coff, char const *algo) {
+void native_kernels_t::conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16, int out_ctot, int out_coff, char const *algo, float const *filts_km) {
   if (out_ctot <= 0) { out_ctot = g.OC; out_coff = 0; }
   long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
   if (!Nj || !g.OC) return;
@@ -1622,9 +1623,13 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
     setup_splitk(impl, host, ga, cfg, (size_t)Nj * g.OC);
     size_t ts_off = 0;
     if (p.cbig && std::find(p.defs.begin(), p.defs.end(), string("-DI_VW=0")) != p.defs.end()) {   // the staging-wave kernel reads its filters k-major: transposed into the scratch first (part of the call)
-      long const mi4 = ((long)g.OC + 3) / 4 * 4, kp = (Kt + cfg.BK - 1) / cfg.BK * cfg.BK;
+      long const mi4 = ((long)g.OC + 3) / 4 * 4, kp = filts_km ? Kt + 128 : (Kt + cfg.BK - 1) / cfg.BK * cfg.BK;
       uint64_t const xb = (uint64_t)kp * mi4 * 4;
       if (xb >= 0x7ffffff0ull) unsup_err("hip_conv: filts of 2 GiB or more are not supported (32-bit buffer offsets)");
+      if (filts_km) {   // the caller holds the k-major copy (hip_conv_filts_kmajor, made once: a net's weights do not change between forward passes -- src/rtc_fwd.cc:229-243 transposes its filters at set-up, too)
+        ga.I = filts_km; ga.ldI = (int)mi4; ga.I_bytes = (unsigned)xb;
+        if (getenv("BODAHIP_CBIG_TSTAMP")) ensure_ws(impl, host, (size_t)ga.tiles_i * ga.tiles_j * 128);
+      } else {
       ts_off = (xb + 255) & ~size_t(255);
       ensure_ws(impl, host, ts_off + (getenv("BODAHIP_CBIG_TSTAMP") ? (size_t)ga.tiles_i * ga.tiles_j * 128 : 0));
       plan_t xp; xp.cbig = true; xp.kname = "bodahip_conv_big_xpose"; xp.defs = {"-DXPOSE_ONLY=1"};
@@ -1633,6 +1638,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
       void *xparams[] = {&src, &dst, &Mi, &Mi4, &Kk, &Kp};
       hip_err_chk(host->nh_launch(xk.func, (uint32_t)((kp + 31) / 32), (uint32_t)((mi4 + 31) / 32), 256, xparams), "hipModuleLaunchKernel(conv_big_xpose)");
       ga.I = (float const *)impl->ws; ga.ldI = (int)mi4; ga.I_bytes = (unsigned)xb;
+      }
     }
     char const *const tstamp = p.cbig ? getenv("BODAHIP_CBIG_TSTAMP") : nullptr;   // experiment hook (tools/cbig_timeline.py): kernel built with -DTSTAMP=1 leaves 16 clock stamps per workgroup in the scratch; appended to the named file
     size_t const ts_bytes = (size_t)ga.tiles_i * ga.tiles_j * 128;
@@ -2535,9 +2541,35 @@ void native_kernels_t::run(rtc_func_info_t const &fi, map_str_rtc_arg_t const &a
     if (!g.SY || !g.SX) rt_err("hip_conv: zero stride");
     // out = (in + 2*pad - k)/stride + 1, floor (src/conv_util.cc:167-173)
     if ((g.H + 2 * g.PY - g.KH) / g.SY + 1 != g.OH || (g.W + 2 * g.PX - g.KW) / g.SX + 1 != g.OW) rt_err("hip_conv: out dims do not match in/filts/stride/in_pad");
+    // optional var arg filts_km (round 6): the k-major copy of filts that hip_conv_filts_kmajor wrote -- [K + 128][out_chan padded to 4], zero rows behind K.  A plan that
+    // reads its filters k-major (the staging-wave kernel) then skips the transposition it would run in front of every call; every other plan ignores it
+    float const *km = nullptr;
+    auto ki = am.find("filts_km");
+    if (ki != am.end() && fn == "hip_conv") {
+      if (!ki->second.is_var()) rt_err("hip_conv: filts_km must be a var");
+      dims_t const kd = host->nh_var_dims(ki->second.n); need_float(kd, "filts_km");
+      long const Ktot = (long)g.C * g.KH * g.KW, mi4 = ((long)g.OC + 3) / 4 * 4;
+      if (kd.sz() != 2 || (long)kd.dims(0) != Ktot + 128 || (long)kd.dims(1) != mi4) rt_err("hip_conv: filts_km must be [K + 128][out_chan padded to a multiple of 4] floats");
+      km = (float const *)host->nh_var_ptr(ki->second.n);
+    }
     tile_override_t const tov(impl, "conv_tile", fi.op);
     conv((float const *)host->nh_var_ptr(fnm), (float const *)host->nh_var_ptr(bnm), (float const *)host->nh_var_ptr(inm), (float *)host->nh_var_ptr(onm), g, bf16, out_ctot, out_coff,
-         (fn == "hip_conv_winograd") ? "winograd_all" : nullptr); // hip_conv_winograd: the F(2x2,3x3) path for this function (3x3 / stride 1; others: direct)
+         (fn == "hip_conv_winograd") ? "winograd_all" : nullptr, km); // hip_conv_winograd: the F(2x2,3x3) path for this function (3x3 / stride 1; others: direct)
+    return;
+  }
+  if (fn == "hip_conv_filts_kmajor") {   // filts (out_chan:in_chan:y:x) -> filts_km ([K + 128][out_chan padded to 4], zeros in the padding): see filts_km above
+    string const fnm = var_of(am, "filts"), knm = var_of(am, "filts_km");
+    dims_t const f = host->nh_var_dims(fnm), kd = host->nh_var_dims(knm);
+    need_float(f, "filts"); need_float(kd, "filts_km"); assert_st(f.sz() == 4);
+    long const OC = f.dims(0), Ktot = (long)f.dims(1) * f.dims(2) * f.dims(3), mi4 = (OC + 3) / 4 * 4, kp = Ktot + 128;
+    if (kd.sz() != 2 || (long)kd.dims(0) != kp || (long)kd.dims(1) != mi4) rt_err("hip_conv_filts_kmajor: filts_km must be [K + 128][out_chan padded to a multiple of 4] floats");
+    if ((uint64_t)kp * mi4 * 4 >= 0x7ffffff0ull) unsup_err("hip_conv_filts_kmajor: filts of 2 GiB or more");
+    plan_t xp; xp.cbig = true; xp.kname = "bodahip_conv_big_xpose"; xp.defs = {"-DXPOSE_ONLY=1"};
+    kernel_t &xk = get_kernel(impl, host, xp);
+    float const *src = (float const *)host->nh_var_ptr(fnm); float *dst = (float *)host->nh_var_ptr(knm); int Mi = (int)OC, Mi4 = (int)mi4, Kk = (int)Ktot, Kp = (int)kp;
+    void *xparams[] = {&src, &dst, &Mi, &Mi4, &Kk, &Kp};
+    hip_err_chk(host->nh_launch(xk.func, (uint32_t)((kp + 31) / 32), (uint32_t)((mi4 + 31) / 32), 256, xparams), "hipModuleLaunchKernel(conv_big_xpose)");
+    last_launch.kernel = "bodahip_conv_big_xpose"; last_launch.grid = (uint32_t)(((kp + 31) / 32) * ((mi4 + 31) / 32)); last_launch.block = 256; last_launch.flops = 0; last_launch.algo_bytes = 8.0 * OC * Ktot;
     return;
   }
   rt_err("unknown/unhandled native hip function: " + fn);

@@ -80,7 +80,7 @@ struct native_kernels_t {
   // direct entry points on raw device pointers (used by run() and by the C ABI's fast paths)
   void sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16 = false, bool half = false);   // half: 2-byte IEEE half elements, fp32 math
   void conv(float const *filts, float const *biases, float const *in, float *out, conv_geom_t const &g, bool bf16 = false, int out_ctot = 0, int out_coff = 0,
-            char const *algo = nullptr);
+            char const *algo = nullptr, float const *filts_km = nullptr);   // filts_km: the caller's k-major copy of filts (hip_conv_filts_kmajor), or null
 
   // channels-last bf16 tensors (kernels/conv_nhwc_bf16.hip): filts out_chan:y:x:in_chan, in / out img:y:x:chan; g.C = stored channels (multiple of 8)
   void conv_nhwc_rows(void const *filts, float const *biases, void const *in, void *out, conv_geom_t const &g, post_ops_t const &post, int out_ctot = 0, int out_coff = 0);   // F' filts; g.OH x g.OW = the convolution's own output planes

@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 
 from boda_amd.conv_pipe import ConvPipe, ConvPipeFwd, PipeOp, alexnet_ng_conv, googlenet_conv, nin_imagenet
 from boda_amd.digest import SsdsDiff
-from boda_amd.op import Dims
-from boda_amd.rtc import make_rtc
+from boda_amd.op import Dims, RtErr
+from boda_amd.rtc import RtcFuncCall, make_rtc
 from oracle import boda_oracle as bo
 from oracle.net_forward import oracle_forward as _oracle_forward
 import hashlib
@@ -136,6 +136,42 @@ def test_k1_chains_are_bit_identical_to_separate_launches(rtc):
         assert np.array_equal(res[False][n], res[True][n]), n
     mid = bo.conv_fwd(res[True]["conv1"], params["cccp1_filts"], params["cccp1_biases"], (1, 1), (0, 0), True)
     assert np.array_equal(mid, res[True]["cccp1"]) and np.array_equal(bo.conv_fwd(mid, params["cccp2_filts"], params["cccp2_biases"], (1, 1), (0, 0), True), res[True]["cccp2"])
+
+
+def test_filters_made_k_major_once_per_net_equal_the_per_call_transposition(rtc, monkeypatch):
+    """fp32 nets, round 6: a convolution whose plan reads its filters k-major (the staging-wave kernel) gets that copy from a var the net fills ONCE (hip_conv_filts_kmajor,
+    in refresh_group_params(): at init and after a caller overwrote the weights) instead of from a transposition in front of every call -- the reference's xpose_filts at
+    set-up, src/rtc_fwd.cc:229-243.  Every node equals the per-call form bit for bit; new weights written into the filter vars show up after the refresh; a wrongly sized
+    filts_km is refused.  (BODAHIP_CBIG=force: at 3 images the planner would not pick the kernel by itself.)"""
+    monkeypatch.setenv("BODAHIP_CBIG", "force")
+    cp = nin_imagenet(3); params = _params(cp); data = bo.gen_conv_in(*cp.nodes["data"].sizes)
+    nodes = [n for n in cp.nodes if n != "data" and n in {o.top for o in cp.ops if o.type != "Dropout"}]
+    res = {}
+    for once in (False, True):
+        fwd = ConvPipeFwd(rtc, filts_kmajor_once=once); fwd.init(cp, op_params=params)
+        try:
+            km = [c.tag for c in fwd.fwd_calls if "filts_km" in c.rfc.arg_map]
+            assert (len(km) >= 4 and len(fwd._km_params) == len(km)) if once else not km, km
+            io = {"data": data}
+            fwd.run_fwd(["data"], io, nodes)
+            res[once] = io
+            if once:
+                fwd.capture_graph(); rtc.set_var_to_zero(fwd.var_of(cp.out_node())); fwd.run_graph()
+                assert np.array_equal(rtc.copy_var_to_nda(fwd.var_of(cp.out_node())), io[cp.out_node()])
+                # new weights for one of those layers: stale until the refresh, then the oracle's result on the new weights
+                tag = km[-1]; op = next(o for o in cp.ops if o.tag == tag)
+                f2 = (params[tag + "_filts"] * np.float32(0.5)).astype(np.float32)
+                rtc.copy_nda_to_var(tag + "_filts", f2); fwd.refresh_group_params()
+                io2 = {"data": data}; fwd.run_fwd(["data"], io2, [op.bot, op.top])
+                want = bo.conv_fwd(io2[op.bot], f2, params[tag + "_biases"], tuple(op.stride), tuple(op.in_pad), True)
+                assert np.array_equal(io2[op.top], want) and not np.array_equal(io2[op.top], io[op.top])
+                bad = dict(fwd.fwd_calls[[c.tag for c in fwd.fwd_calls].index(tag)].rfc.arg_map); bad["filts_km"] = bad["filts"]
+                with pytest.raises(RtErr, match="filts_km must be"):
+                    rtc.run(RtcFuncCall(fwd.fwd_calls[[c.tag for c in fwd.fwd_calls].index(tag)].rfc.rtc_func_name, bad))
+        finally:
+            fwd.release()
+    for n in nodes:
+        assert np.array_equal(res[False][n], res[True][n]), n
 
 
 def test_f32_pool_fused_into_the_consuming_convolution_is_bit_identical(rtc, monkeypatch):
