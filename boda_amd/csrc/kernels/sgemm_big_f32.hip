@@ -16,6 +16,9 @@
 // = TI x TJ blocks of 32 x 32) and four staging waves.  The smaller tiles serve the sizes where 256 x 256 leaves CUs idle (2048^3 = 64 tiles; 3072^3 = 144) and the LAST
 // round of the large ones (10240^3 = 1600 tiles = 6.25 rounds): same data path, same ascending-k chain per output -- bit-identical whatever the tile.  With
 // 128 x 128 tiles two workgroups share a CU (MINW 2: 67 KB of LDS and 24 waves).
+// Round 6: FOUR multiplying waves as well (WI x WJ = 2 x 2 | 1 x 4 | 4 x 1; 512 threads) and wave tiles of one row block -- 128 x 128 (64 x 64 per wave), 64 x 128,
+// 128 x 64, 64 x 64: the tiles of the sizes that give 256 CUs less than a 128 x 128 tile each (1024^3) or whose last round is ragged (the rest launch of the two-level
+// tiling).  Several such workgroups share a CU (MINW = waves per SIMD the register budget is set for).
 // Compile-time parameters (-D): KNAME BKS (k per step: 16) PF (K tiles in flight in registers per staging thread: 2 | 4) GROUP_I [TBI TBJ WI WJ MINW]
 
 #ifndef __HIPCC_RTC__
@@ -69,9 +72,10 @@ struct gemm_args_t { // same layout as gemm_conv_f32.hip (one host-side struct s
 };
 
 namespace {
-static_assert(WI * WJ == 8, "eight multiplying waves");
+constexpr int kNMW = WI * WJ;                 // multiplying waves
+static_assert(kNMW == 8 || kNMW == 4, "eight (or four) multiplying waves");
 constexpr int kTI = TBI / (WI * 32), kTJ = TBJ / (WJ * 32);   // 32 x 32 blocks per wave
-static_assert(TBI % (WI * 32) == 0 && TBJ % (WJ * 32) == 0 && (kTI == 4 || kTI == 2) && (kTJ == 2 || kTJ == 1), "wave tile: 4 | 2 row blocks x 2 | 1 column blocks");
+static_assert(TBI % (WI * 32) == 0 && TBJ % (WJ * 32) == 0 && (kTI == 4 || kTI == 2 || kTI == 1) && (kTJ == 2 || kTJ == 1), "wave tile: 4 | 2 | 1 row blocks x 2 | 1 column blocks");
 constexpr int kLDI = TBI + 4, kLDJ = TBJ + 4; // floats per k row of the a / b image
 constexpr int kImgI = BKS * kLDI, kImgJ = BKS * kLDJ, kImg2 = kImgI + kImgJ;   // floats per operand image; per stage
 constexpr int kNLI = BKS * (TBI / 4) / 256, kNLJ = BKS * (TBJ / 4) / 256;      // float4s per staging thread, operand and step (BKS rows x TB / 4 units over 256 threads)
@@ -89,8 +93,10 @@ __device__ __forceinline__ f32x4 bload4(rsrc_t r, int voff, int soff) { return _
 
 #if (TBI / (WI * 32)) == 4
 typedef f32x4 avec_t;
-#else
+#elif (TBI / (WI * 32)) == 2
 typedef float2 avec_t;
+#else
+typedef float avec_t;
 #endif
 #if (TBJ / (WJ * 32)) == 2
 typedef float2 bvec_t;
@@ -103,11 +109,11 @@ __device__ __forceinline__ float vget(float2 const &v, int i) { return i ? v.y :
 __device__ __forceinline__ float vget(float const &v, int) { return v; }
 } // namespace
 
-extern "C" __global__ __launch_bounds__(768, MINW) void KNAME(gemm_args_t const p) {
+extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_args_t const p) {
   __shared__ __attribute__((aligned(16))) float sm[NSTG * kImg2];   // [stage][operand: a (MFMA A, rows i: kImgI floats), then b (MFMA B, columns j)][k][kLDI | kLDJ]
   int const lane = threadIdx.x & 63;
   int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  bool const stager = wave >= 8;
+  bool const stager = wave >= kNMW;
 
   int tile_i, tile_j;
   {
@@ -123,7 +129,7 @@ extern "C" __global__ __launch_bounds__(768, MINW) void KNAME(gemm_args_t const 
   int const nkt_pad = (nkt + kU - 1) / kU * kU;   // whole rounds, no conditions inside the loops: tiles past the last one read zeros and multiply as +0
 
   if (stager) {
-    int const tid = threadIdx.x - 512;
+    int const tid = threadIdx.x - kNMW * 64;
     rsrc_t const rI = make_rsrc(p.I, p.I_bytes), rJ = make_rsrc(p.J, p.J_bytes);
     // unit c = tid + n * 256 of an operand tile: k row c / (TB / 4), columns 4 (c % (TB / 4)) .. +3
     int goffI[kNLI], goffJ[kNLJ], loffI[kNLI], loffJ[kNLJ], krowI[kNLI], krowJ[kNLJ];

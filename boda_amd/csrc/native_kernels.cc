@@ -295,8 +295,8 @@ static void bf16_cfg(tile_cfg_t &c, bool gather, long Mi = 0, long Nj = 0, long 
   if (!ok) unsup_err("native bf16 kernel: unsupported tile configuration " + c.str());
 }
 
+static char const *const kStg64 = "64x64x16x2x2x4x1x32x2x3";   // the staging-wave kernel's 64 x 64 form (tile field 10 == 3: multiplying waves spelled out)
 static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string const &tile, bool bf16 = false, int batch = 1, bool allow_big = true) {
-  (void)K;
   plan_t p; p.kname = bf16 ? "bodahip_sgemm_bf16" : "bodahip_sgemm_f32"; p.bf16 = bf16;
   p.cfg = choose_cfg((int)M, (int)std::min<uint64_t>((uint64_t)N * batch, 0x7fffffffull), (int)K, num_cus, false, bf16); // (a batch deals batch x the tiles)
   if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad sgemm_tile '" + tile + "'"); }
@@ -309,6 +309,18 @@ static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string
   // Plain fp32 operands on the staging-wave kernel (kernels/sgemm_big_f32.hip: eight multiplying waves + four staging waves, four LDS stages; BODAHIP_SGEMM_BIG = off |
   // BKSxPF): 256 x 256 tiles where they fill the chip, and -- round 5 -- its 128 x 128 (two workgroups per CU), 256 x 128 and 128 x 256 forms.  cfg.WI x WJ = 3 x 4 stands for
   // the twelve waves; an explicit tile asks for the kernel that way ("128x128x16x3x4x2").
+  if (!tile.empty() && p.cfg.SW == 3) {   // round 6: the staging-wave kernel with WI x WJ = 8 | 4 multiplying waves spelled out ("64x128x16x2x2x4x1x32x2x3"): its small forms
+    tile_cfg_t const &c = p.cfg;
+    int const nmw = c.WI * c.WJ, ti = (c.WI > 0 && c.BI % (c.WI * 32) == 0) ? c.BI / (c.WI * 32) : 0, tj = (c.WJ > 0 && c.BJ % (c.WJ * 32) == 0) ? c.BJ / (c.WJ * 32) : 0;
+    bool const ok = (nmw == 8 || nmw == 4) && (ti == 4 || ti == 2 || ti == 1) && (tj == 2 || tj == 1) && c.BK >= 4 && c.BK <= 32 && c.BK % 4 == 0 && (c.BK * (c.BI / 4)) % 256 == 0 &&
+                    (c.BK * (c.BJ / 4)) % 256 == 0 && (c.PF == 2 || c.PF == 4) && c.MT == 32 && c.SPLITK == 1 && c.MINW >= 1 && c.MINW <= 8 && 4l * 4 * c.BK * (c.BI + c.BJ + 8) <= 160 * 1024;
+    if (!ok || batch != 1 || M % 4 || N % 4 || !allow_big) unsup_err("hip_sgemm: unsupported staging-wave tile " + c.str() + " (8 | 4 multiplying waves of 4 | 2 | 1 x 2 | 1 blocks, whole float4 units per staging thread, M and N multiples of 4)");
+    p.big = true; p.kname = "bodahip_sgemm_big_f32"; p.cfg.KHO = 0;
+    p.defs = {"-DBKS=" + std::to_string(c.BK), "-DPF=" + std::to_string(c.PF), "-DTBI=" + std::to_string(c.BI), "-DTBJ=" + std::to_string(c.BJ), "-DWI=" + std::to_string(c.WI),
+              "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW)};
+    if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
+    return p;
+  }
   bool const big_tile = (p.cfg.BI == 256 || p.cfg.BI == 128) && (p.cfg.BJ == 256 || p.cfg.BJ == 128);
   bool const want_big = big_tile && ((p.cfg.WI == 3 && p.cfg.WJ == 4) || (p.cfg.BI == 256 && p.cfg.BJ == 256));
   if (allow_big && batch == 1 && want_big && p.cfg.MT == 32 && p.cfg.SPLITK == 1 && M % 4 == 0 && N % 4 == 0) {
@@ -329,6 +341,14 @@ static plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string
       if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
       return p;
     }
+  }
+  // Round 6: where the general kernel would run 64 x 64 tiles (the sizes that give 256 CUs less than two 128 x 128 tiles each: 768^3 .. 3072^3 of sgemm-ops-full), the
+  // staging-wave kernel's 64 x 64 form -- four multiplying waves of one 32 x 32 block, four staging waves, four workgroups per CU -- runs ahead of it: in the layer sequence
+  // of the list (tools/sgemm_stg_ab.sh, TF/s) 1024^3 75 -> 87, 1536^3 88 -> 93, 2048^3 123.5 -> 127.4, 3072^3 128.1 -> 131.5; its 64 x 128 / 128 x 128 forms measured
+  // level at 2048^3 and behind below.  Bit-identical (the same ascending-k chain per output).
+  if (tile.empty() && allow_big && batch == 1 && p.cfg.BI == 64 && p.cfg.BJ == 64 && p.cfg.MT == 32 && p.cfg.SPLITK == 1 && M % 4 == 0 && N % 4 == 0 && K >= 512 && getenv("BODAHIP_NO_SGEMM_STG64") == nullptr) {
+    char const *e = getenv("BODAHIP_SGEMM_BIG");
+    if (!(e && string(e) == "off")) return plan_sgemm(M, N, K, num_cus, kStg64, false, 1, true);
   }
   p.cfg.KHO = 0;   // (K hand-off is a convolution form: the sgemm launches are plain grids)
   check_cfg(p.cfg, false);
@@ -1259,7 +1279,8 @@ static double launch_model(long n, double a, int s, double r, int cus) {
   return t;
 }
 static char const *const kBigTile = "256x256x16x2x4x1x1x32x2";
-static char const *const kTail64 = getenv("BODAHIP_SGEMM_TAIL64") ? getenv("BODAHIP_SGEMM_TAIL64") : "64x64x32x2x2x2x1x32x2";
+// (the rest launch's 64 x 64 tiles: the staging-wave kernel's form since round 6 -- 5120^3 133.1 -> 133.6, 6144^3 136.7 -> 137.3, 7168^3 139.8 -> 140.4 TF/s in the list)
+static char const *const kTail64 = getenv("BODAHIP_SGEMM_TAIL64") ? getenv("BODAHIP_SGEMM_TAIL64") : ((getenv("BODAHIP_SGEMM_BIG") && string(getenv("BODAHIP_SGEMM_BIG")) == "off") || getenv("BODAHIP_NO_SGEMM_STG64")) ? "64x64x32x2x2x2x1x32x2" : kStg64;
 static sgemm_split_t plan_sgemm_split(uint32_t M, uint32_t N, uint32_t K, int num_cus) {
   sgemm_split_t sp;
   if (getenv("BODAHIP_NO_SGEMM_SPLIT") || M % 4 || N % 4 || K < 512 || M < 1024 || N < 1024) return sp;

@@ -52,10 +52,10 @@ struct native_host_t {
 struct tile_cfg_t {
   int BI = 128, BJ = 128, BK = 16, WI = 2, WJ = 2, MINW = 2, SPLITK = 1, MT = 32, PF = 1, SW = 0;   // SW: 1 = as many staging waves as multiplying waves (gemm_conv_f32.hip -DSPECW)
   int KHO = 0;   // > 1: sequential K hand-off in KHO segments per tile (gemm_conv_f32.hip -DKHO=1: exact, persistent workgroups pulling (tile, segment) jobs)
-  int threads() const { return (SW == 2) ? (WI * WJ * 64 + 256) : (WI * WJ * 64 * (SW ? 2 : 1)); }   // SW 2: kernels/conv_big_f32.hip -- WI x WJ multiplying waves + four staging waves
+  int threads() const { return (SW == 2 || SW == 3) ? (WI * WJ * 64 + 256) : (WI * WJ * 64 * (SW ? 2 : 1)); }   // SW 2: kernels/conv_big_f32.hip -- WI x WJ multiplying waves + four staging waves; 3: kernels/sgemm_big_f32.hip likewise
   string str() const {
     return std::to_string(BI) + "x" + std::to_string(BJ) + "x" + std::to_string(BK) + "_w" + std::to_string(WI) + "x" + std::to_string(WJ) +
-           (MT != 32 ? ("_m" + std::to_string(MT)) : string()) + (SPLITK > 1 ? ("_s" + std::to_string(SPLITK)) : string()) + (PF != 1 ? ("_p" + std::to_string(PF)) : string()) + (SW == 2 ? "_big" : (SW ? "_sw" : "")) + (KHO > 1 ? ("_h" + std::to_string(KHO)) : string()); }
+           (MT != 32 ? ("_m" + std::to_string(MT)) : string()) + (SPLITK > 1 ? ("_s" + std::to_string(SPLITK)) : string()) + (PF != 1 ? ("_p" + std::to_string(PF)) : string()) + (SW == 2 ? "_big" : (SW == 3 ? "_stg" : (SW ? "_sw" : ""))) + (KHO > 1 ? ("_h" + std::to_string(KHO)) : string()); }
 };
 
 struct conv_geom_t { int B, C, H, W, OC, KH, KW, SY, SX, PY, PX, OH, OW; bool relu;

@@ -223,7 +223,7 @@ def test_planner_sgemm_tiles_follow_problem_size():
     # two-level tiling: 7168^3 is 784 tiles of 256x256 = 3 rounds of 256 CUs + 16 -> 27 tile rows (756 tiles) on the large tile, the last 256 rows on small
     # tiles; 8192^3 (1024 = 4 rounds exactly) is not split; an explicit tile or BODAHIP_NO_SGEMM_SPLIT switches it off
     sp = R.explain_plan(sg(7168, 7168, 7168))
-    assert sp.startswith("rows<6912:256x256x8_w3x4_p2+rest:bodahip_sgemm_f32 64x64x32_w2x2_p2"), sp
+    assert sp.startswith("rows<6912:256x256x8_w3x4_p2+rest:bodahip_sgemm_big_f32 64x64x16_w2x2_p2_stg"), sp   # (round 6: the rest on the staging-wave kernel's own 64 x 64 form)
     assert R.explain_plan(sg(6144, 6144, 6144)).startswith("rows<5376:") and not R.explain_plan(sg(12288, 12288, 12288)).startswith("rows<")
     assert R.explain_plan(sg(10240, 10240, 10240)).startswith("bodahip_sgemm_big_f32 256x128x8")     # (round 5: 3200 tiles of 256 x 128 = 12.5 rounds, no tail launch; round 4 split it at row 9728)
     assert R.explain_plan(sg(7168, 7168, 7168), tile="128x128x16x2x2x2").startswith("bodahip_sgemm_f32 128x128")
@@ -231,14 +231,23 @@ def test_planner_sgemm_tiles_follow_problem_size():
     os.environ["BODAHIP_NO_SGEMM_SPLIT"] = "1"
     try: assert R.explain_plan(sg(7168, 7168, 7168)).startswith("bodahip_sgemm_f32 ")
     finally: del os.environ["BODAHIP_NO_SGEMM_SPLIT"]
+    # round 6: the sizes the general kernel would give 64 x 64 tiles (768^3 .. 3072^3 of the list) run the staging-wave kernel's 64 x 64 form -- four multiplying waves of
+    # one block, four staging waves (512 threads), register budget for four workgroups per CU; ragged M / N and short K stay on the general kernel; BODAHIP_NO_SGEMM_STG64
+    for n in (1024, 2048, 3072):
+        q = R.explain_plan(sg(n, n, n)); assert q.startswith("bodahip_sgemm_big_f32 64x64x16_w2x2_p2_stg ") and "-DWI=2 -DWJ=2 -DMINW=4" in q, q
+    assert R.explain_plan(sg(1024, 1026, 1024)).startswith("bodahip_sgemm_f32 ") and R.explain_plan(sg(1024, 1024, 256)).startswith("bodahip_sgemm_f32 ")
+    os.environ["BODAHIP_NO_SGEMM_STG64"] = "1"
+    try: assert R.explain_plan(sg(2048, 2048, 2048)).startswith("bodahip_sgemm_f32 64x64x32_w2x2_p2 ")
+    finally: del os.environ["BODAHIP_NO_SGEMM_STG64"]
+    with pytest.raises(Exception): R.explain_plan(sg(2048, 2048, 2048), tile="64x64x8x2x2x4x1x32x2x3")     # (half a float4 unit per staging thread: refused on the host, not by the compiler)
     # the documented switch BODAHIP_SGEMM_BIG=off leaves every size on the general kernel (round-5 advisor finding: the wide-tile rule used to hand it the staging-wave kernel's x3x4 tile)
     os.environ["BODAHIP_SGEMM_BIG"] = "off"
     try:
-        for n in (4096, 8192, 12288): assert R.explain_plan(sg(n, n, n)).startswith("bodahip_sgemm_f32 "), R.explain_plan(sg(n, n, n))
+        for n in (2048, 4096, 8192, 12288): assert R.explain_plan(sg(n, n, n)).startswith("bodahip_sgemm_f32 "), R.explain_plan(sg(n, n, n))
     finally: del os.environ["BODAHIP_SGEMM_BIG"]
     # the tile heuristic balances tiles over the CUs it is told about: a 512^3 problem on 256 CUs takes the thin 16x16-MFMA tiles, on 16 CUs 64x64
     assert R.explain_plan(sg(512, 512, 512), num_cus=256).split()[1] == "32x32x32_w2x2_m16_p8"
-    assert R.explain_plan(sg(512, 512, 512), num_cus=16).split()[1] == "64x64x32_w2x2_p2"
+    assert R.explain_plan(sg(512, 512, 512), num_cus=16).split()[1] == "64x64x16_w2x2_p2_stg"
 
 
 def test_prebuild_resolves_the_algorithm_like_conv_does_in_tolerance_mode():

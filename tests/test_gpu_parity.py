@@ -205,13 +205,17 @@ def test_sgemm_vs_oracle_bit_exact(be, M, N, K):
                                   "32x32x32x2x2x1x1x16", "64x64x64x4x4x1x1x16", "64x64x16x2x2x2x1x16", "64x64x16x2x2x2x1x32x2", "128x128x16x2x2x1x1x32x2",
                                   "128x128x16x2x2x2x1x32x1x1", "64x64x32x2x2x2x1x16x1x1",   # tenth field 1: as many staging waves as multiplying waves (round 4)
                                   "256x256x16x2x4x1x1x32x2",                                # the 256x256 tile = kernels/sgemm_big_f32.hip (ragged edges, K tail, fewer K tiles than its rounds)
-                                  "128x128x8x3x4x2", "128x128x16x3x4x1", "256x128x8x3x4x1", "128x256x16x3x4x1"])   # round 5: that kernel's 128 x 128 / 256 x 128 / 128 x 256 forms ("x3x4": its twelve waves)
+                                  "128x128x8x3x4x2", "128x128x16x3x4x1", "256x128x8x3x4x1", "128x256x16x3x4x1",    # round 5: that kernel's 128 x 128 / 256 x 128 / 128 x 256 forms ("x3x4": its twelve waves)
+                                  "64x64x16x2x2x4x1x32x2x3", "128x128x8x2x2x3x1x32x2x3", "64x128x16x2x2x4x1x32x2x3", "64x128x16x1x4x4x1x32x4x3", "128x64x16x2x2x4x1x32x2x3", "128x64x16x4x1x4x1x32x2x3",
+                                  "64x256x16x1x8x2x1x32x2x3", "128x128x32x4x2x2x1x32x2x3"])   # round 6 (tenth field 3): the multiplying waves spelled out -- four of them, wave tiles of one row block
 def test_sgemm_tiles_agree(be, tile):
     op = _sgemm_op(320, 448, 200)
     ref, _ = _run(be, op, 5)
     got, prc = _run(be, op, 5, tune=OpTune(hip_tile=tile))
     assert prc.launch["cfg"].startswith("x".join(tile.split("x")[:2]))
-    assert (prc.launch["kernel"] == "bodahip_sgemm_big_f32") == (tile.startswith("256x256") or "x3x4" in tile) and prc.launch["cfg"].endswith("_sw") == (len(tile.split("x")) == 10)
+    stg = len(tile.split("x")) == 10 and tile.endswith("x3")
+    assert (prc.launch["kernel"] == "bodahip_sgemm_big_f32") == (tile.startswith("256x256") or "x3x4" in tile or stg) and prc.launch["cfg"].endswith("_stg" if stg else "_sw") == (len(tile.split("x")) == 10)
+    if stg: assert prc.launch["block"] == int(tile.split("x")[3]) * int(tile.split("x")[4]) * 64 + 256
     assert np.array_equal(ref["c"], got["c"])  # incl. the 16x16x4-MFMA tiles (suffix x16): same ascending-k fma chain
 
 
