@@ -1314,6 +1314,114 @@ static string sgemm_wide_tile(uint32_t M, uint32_t N, uint32_t K, long cus) {
   return (t256 >= cus && eff >= 0.95) ? string("256x128x8x3x4x1") : string();
 }
 
+// Round 6: the two-level tiling generalised to guillotine cuts -- a list of rectangles [m0, m0 + rows) x [n0, n0 + cols) of c, each ONE launch of one tile form (operands
+// and output addressed through pointer offsets: a and b are k-major, a sub-rectangle is a column range of both).  Every output still belongs to exactly one launch and is
+// one ascending-k chain: bit-identical to the single launch.  10240^3: 3200 tiles of 256 x 128 = 12.5 rounds of 256 CUs -> rows < 8192 (10 rounds) + the last 2048 rows'
+// first 8192 columns (2 rounds) + a 2048 x 2048 corner on 64 x 64 tiles (1024 = one round of four per CU).
+struct sgemm_part_t { uint32_t m0 = 0, rows = 0, n0 = 0, cols = 0; string tile; };
+static bool parse_parts_env(uint32_t M, uint32_t N, uint32_t K, std::vector<sgemm_part_t> &out) {   // experiments: BODAHIP_SGEMM_PARTS="<size>:m0,rows,n0,cols,tile/m0,rows,...;<size>:..."
+  char const *e = getenv("BODAHIP_SGEMM_PARTS"); if (!e || M != N || N != K) return false;
+  string const v = e, key = std::to_string(M) + ":"; size_t const at = (";" + v).find(";" + key); if (at == string::npos) return false;
+  size_t const b = at + key.size(), en = v.find(';', b); string const spec = v.substr(b, en == string::npos ? string::npos : en - b);
+  std::istringstream is(spec); string one;
+  while (std::getline(is, one, '/')) {
+    sgemm_part_t q; char tl[128];
+    if (sscanf(one.c_str(), "%u,%u,%u,%u,%127s", &q.m0, &q.rows, &q.n0, &q.cols, tl) != 5) rt_err("bad BODAHIP_SGEMM_PARTS entry '" + one + "'");
+    q.tile = tl; out.push_back(q);
+  }
+  uint64_t area = 0; for (auto const &q : out) { if (q.m0 % 4 || q.n0 % 4 || q.m0 + q.rows > M || q.n0 + q.cols > N || !q.rows || !q.cols) rt_err("bad BODAHIP_SGEMM_PARTS rectangle"); area += (uint64_t)q.rows * q.cols; }
+  if (area != (uint64_t)M * N) rt_err("BODAHIP_SGEMM_PARTS: the rectangles do not add up to c");
+  return true;
+}
+
+// The planner of those rectangles.  What the launches cost was measured (tools/sgemm_rounds_probe.py, MI355X, K = 6144): the 256 x 256 form runs ONE workgroup per CU --
+// n tiles take ceil(n / 256) rounds of 1.434 ms; of the 256 x 128 form TWO share a CU (50 KB of LDS, 6 waves per SIMD) -- ceil(n / 512) double rounds of 1.416 ms, and the
+// dispatcher packs a last partial round two-per-CU onto the CUs that free up first instead of spreading it (768 tiles = three whole rounds of 256 take FOUR rounds' time:
+// 2.90 ms; 1280: 4.29 ms); only a launch that fits the chip at once is spread (256 tiles: 0.883 ms).  The 64 x 64 form runs four per CU (a round of 1024: 0.274 of a
+// 256 x 256 round).  So: a cost per form = rounds of (CUs x workgroups per CU) tiles, a partial round costs a whole one unless the launch has no full round at all; the
+// search tries guillotine cuts (rows | columns, the first part one launch of a large form, the remainder cut again: four launches at most) and takes what the model says
+// is >= 2 % ahead of the single launch / the row split above.  10240^3 140.4 -> 146.0 TF/s, 5120^3 135.2 -> 139.5 in the list (tools/sgemm_parts_ab.sh).
+struct sgemm_form_t { char const *tile; int bi, bj, s; double r, lone; };   // s workgroups per CU, relative rate r, efficiency of ONE workgroup alone on a CU against its share of a full CU
+static sgemm_form_t const kFormQ = {"256x256x16x2x4x1x1x32x2", 256, 256, 1, 1.0, 1.0}, kFormW = {"256x128x8x3x4x1", 256, 128, 2, 1.0127, 0.82}, kFormS = {kStg64, 64, 64, 4, 0.913, 0.5};
+static double form_cost(sgemm_form_t const &f, uint32_t rows, uint32_t cols, int cus) {
+  long const n = (long)((rows + f.bi - 1) / f.bi) * ((cols + f.bj - 1) / f.bj), per = (long)cus * f.s;
+  double const a = (double)f.bi * f.bj / 65536.0, round = f.s * a / f.r;
+  if (n <= per) { long const k = (n + cus - 1) / cus; double const eff = (f.s == 1 || k >= f.s) ? 1.0 : f.lone + (1.0 - f.lone) * (double)(k - 1) / (double)(f.s - 1);
+                  return (double)k * a / (f.r * eff); }   // (a launch the chip takes at once is spread over the CUs)
+  if (f.s >= 4) return (double)n / (double)per * round;    // four staggered workgroups per CU: no rounds to speak of -- 5120^3's rest launch of 2560 tiles (2.5 x 1024) took 2.5 x a 1024-tile launch
+  return (double)((n + per - 1) / per) * round;
+}
+struct sgemm_parts_plan_t { std::vector<sgemm_part_t> parts; double t = 1e30; };
+static sgemm_parts_plan_t plan_parts_rec(uint32_t m0, uint32_t rows, uint32_t n0, uint32_t cols, int cus, double ovh, int depth) {
+  sgemm_parts_plan_t best;
+  for (sgemm_form_t const *f : {&kFormQ, &kFormW, &kFormS}) {
+    double const t = form_cost(*f, rows, cols, cus) + ovh;
+    if (t < best.t) { best.t = t; sgemm_part_t q; q.m0 = m0; q.rows = rows; q.n0 = n0; q.cols = cols; q.tile = f->tile; best.parts = {q}; }
+  }
+  if (depth <= 0) return best;
+  for (sgemm_form_t const *f : {&kFormQ, &kFormW}) {
+    long const per = (long)cus * f->s, tj = (cols + f->bj - 1) / f->bj, ti = (rows + f->bi - 1) / f->bi;
+    for (long R = 1; R < ti; ++R) {     // rows [0, R tile rows) x all columns: one launch of form f -- whole rounds only (anything else is what the remainder's own search covers)
+      if ((R * tj) % per) continue;
+      uint32_t const r1 = (uint32_t)(R * f->bi);
+      sgemm_parts_plan_t rest = plan_parts_rec(m0 + r1, rows - r1, n0, cols, cus, ovh, depth - 1);
+      double const t = form_cost(*f, r1, cols, cus) + ovh + rest.t;
+      if (t < best.t) { best.t = t; sgemm_part_t q; q.m0 = m0; q.rows = r1; q.n0 = n0; q.cols = cols; q.tile = f->tile; best.parts = {q}; best.parts.insert(best.parts.end(), rest.parts.begin(), rest.parts.end()); }
+    }
+    for (long C = 1; C < tj; ++C) {     // all rows x columns [0, C tile columns)
+      if ((C * ti) % per) continue;
+      uint32_t const c1 = (uint32_t)(C * f->bj);
+      sgemm_parts_plan_t rest = plan_parts_rec(m0, rows, n0 + c1, cols - c1, cus, ovh, depth - 1);
+      double const t = form_cost(*f, rows, c1, cus) + ovh + rest.t;
+      if (t < best.t) { best.t = t; sgemm_part_t q; q.m0 = m0; q.rows = rows; q.n0 = n0; q.cols = c1; q.tile = f->tile; best.parts = {q}; best.parts.insert(best.parts.end(), rest.parts.begin(), rest.parts.end()); }
+    }
+  }
+  return best;
+}
+// "" = no decomposition beats what sgemm() would do anyway
+static std::vector<sgemm_part_t> plan_sgemm_parts(uint32_t M, uint32_t N, uint32_t K, int cus) {
+  std::vector<sgemm_part_t> none;
+  if (getenv("BODAHIP_NO_SGEMM_PARTS") || getenv("BODAHIP_NO_SGEMM_SPLIT") || M % 4 || N % 4 || K < 512 || M < 1024 || N < 1024 || (long)((M + 255) / 256) * ((N + 255) / 256) < cus) return none;
+  if (char const *e = getenv("BODAHIP_SGEMM_BIG")) { if (string(e) == "off") return none; }
+  if (M % 64 || N % 64) return none;                      // (cuts at multiples of the forms' tiles; the last parts reach the edges)
+  double const ovh = 25.7 / (double)K;                    // ~6 us per launch in 256 x 256 rounds of this K
+  sgemm_parts_plan_t pp = plan_parts_rec(0, M, 0, N, cus, ovh, 3);
+  // ... and one free cut on top (neither side a launch of its own; coarse positions): 5120^3 = rows < 4096 { 4096 x 4096 on 256 x 256 tiles (256 = one round) | the other
+  // 1024 columns on 64 x 64 } over the last 1024 rows on 64 x 64
+  for (uint32_t R = 1024; R < M; R += 1024) {
+    sgemm_parts_plan_t const t1 = plan_parts_rec(0, R, 0, N, cus, ovh, 2), t2 = plan_parts_rec(R, M - R, 0, N, cus, ovh, 2);
+    if (t1.t + t2.t < pp.t) { pp.t = t1.t + t2.t; pp.parts = t1.parts; pp.parts.insert(pp.parts.end(), t2.parts.begin(), t2.parts.end()); }
+  }
+  for (uint32_t C = 1024; C < N; C += 1024) {
+    sgemm_parts_plan_t const t1 = plan_parts_rec(0, M, 0, C, cus, ovh, 2), t2 = plan_parts_rec(0, M, C, N - C, cus, ovh, 2);
+    if (t1.t + t2.t < pp.t) { pp.t = t1.t + t2.t; pp.parts = t1.parts; pp.parts.insert(pp.parts.end(), t2.parts.begin(), t2.parts.end()); }
+  }
+  if (pp.parts.size() < 2) return none;
+  // what sgemm() does without it: the 256 x 128 single launch where it deals out, else the row split / the single launch (same cost model)
+  double t_now = std::min(form_cost(kFormQ, M, N, cus), form_cost(kFormW, M, N, cus)) + ovh;
+  sgemm_split_t const sp = plan_sgemm_split(M, N, K, cus);
+  if (sp.m_main && sgemm_wide_tile(M, N, K, cus).empty()) t_now = std::min(t_now, form_cost(kFormQ, sp.m_main, N, cus) + form_cost(kFormS, M - sp.m_main, N, cus) + 2 * ovh);
+  return (pp.t < 0.98 * t_now) ? pp.parts : none;
+}
+
+static void sgemm_parts(native_kernels_t *nk, native_kernels_t::impl_t *impl, native_host_t *host, float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, std::vector<sgemm_part_t> const &parts) {
+  if ((uint64_t)K * M * 4 > 0x80000000ull || (uint64_t)K * N * 4 > 0x80000000ull || (uint64_t)M * N * 4 >= 0x7ffffff0ull) unsup_err("hip_sgemm: operands / c of 2 GiB or more are not supported (32-bit buffer offsets)");
+  uint32_t grid = 0; bool first = true;
+  for (sgemm_part_t const &q : parts) {
+    plan_t const p = plan_sgemm(q.rows, q.cols, K, host->nh_num_cus(), q.tile, false);
+    kernel_t &k = get_kernel(impl, host, p);
+    gemm_args_t ga; memset(&ga, 0, sizeof(ga));
+    ga.I = a + q.m0; ga.J = b + q.n0; ga.D = c + (size_t)q.m0 * N + q.n0; ga.bias = nullptr;
+    ga.Mi = (int)q.rows; ga.Nj = (int)q.cols; ga.K = (int)K; ga.ldI = (int)M; ga.ldJ = (int)N; ga.ldD = (int)N;
+    ga.I_bytes = (unsigned)(((uint64_t)K * M - q.m0) * 4); ga.J_bytes = (unsigned)(((uint64_t)K * N - q.n0) * 4); ga.D_bytes = (unsigned)((((uint64_t)q.rows - 1) * N + q.cols) * 4);
+    ga.tiles_i = (int)((q.rows + p.cfg.BI - 1) / p.cfg.BI); ga.tiles_j = (int)((q.cols + p.cfg.BJ - 1) / p.cfg.BJ); ga.splitk = 1;
+    launch(host, k, ga, p.cfg);
+    grid += (uint32_t)ga.tiles_i * ga.tiles_j;
+    if (first) { nk->last_launch.kernel = p.kname; nk->last_launch.cfg = p.cfg; nk->last_launch.block = p.cfg.threads(); first = false; }
+  }
+  nk->last_launch.grid = grid; nk->last_launch.flops = 2.0 * M * N * K; nk->last_launch.algo_bytes = 4.0 * ((double)K * M + (double)K * N + (double)M * N);
+}
+
 void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t M, uint32_t N, uint32_t K, bool bf16, bool half) {
   if (!M || !N) return;
   size_t const esz = half ? 2 : 4;   // half: a / b / c stored as IEEE half, fp32 math (the reference's 16-bit-storage sgemm, src/cnn_codegen.cc:440-449)
@@ -1329,6 +1437,11 @@ void native_kernels_t::sgemm(float const *a, float const *b, float *c, uint32_t 
   // waves of 64 x 64; measured in the layer sequence of sgemm-ops-full, three alternating repetitions on one box (tools/sgemm_policy_ab.sh, TF/s): 4096^3 141.2 -> 142.7,
   // 8192^3 143.6 -> 144.9, 12288^3 144.2 -> 145.5, and 10240^3 (3200 tiles = 12.5 rounds, against 6 rounds of 256 x 256 + a tail launch) 136.5 -> 139.7; the whole list
   // 139.6 -> 141.2.  Where the last round is emptier (5120 / 6144 / 7168: 0.78-0.90 full) the two-level split below stays ahead.  Bit-identical either way.
+  if (!bf16 && !half && tune_of(impl, "sgemm_tile").empty() && tile_for.empty() && M % 4 == 0 && N % 4 == 0) {
+    std::vector<sgemm_part_t> parts;
+    if (!parse_parts_env(M, N, K, parts)) parts = plan_sgemm_parts(M, N, K, host->nh_num_cus());
+    if (!parts.empty()) { sgemm_parts(this, impl, host, a, b, c, M, N, K, parts); return; }
+  }
   if (!bf16 && !half && tune_of(impl, "sgemm_tile").empty() && tile_for.empty()) tile_for = sgemm_wide_tile(M, N, K, host->nh_num_cus());
   if (!bf16 && !half && tune_of(impl, "sgemm_tile").empty() && tile_for.empty()) {
     sgemm_split_t const sp = plan_sgemm_split(M, N, K, host->nh_num_cus());
@@ -2154,7 +2267,16 @@ size_t native_kernels_t::prebuild(op_base_t const &op, string const &arch, int n
     dims_t const &a = op.get_dims("a"), &b = op.get_dims("b");
     string const wide = (!bf16 && tile.empty() && a.tn != "half") ? sgemm_wide_tile(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus) : string();
     sgemm_split_t sp; if (!bf16 && tile.empty() && a.tn != "half" && wide.empty()) sp = plan_sgemm_split(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus);
-    if (!wide.empty()) p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, wide, false);
+    std::vector<sgemm_part_t> parts; if (!bf16 && tile.empty() && a.tn != "half") parts = plan_sgemm_parts(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus);
+    if (!parts.empty()) {   // guillotine decomposition: every part's plan is compiled, the last one reported in full
+      s2d = "parts=" + std::to_string(parts.size());
+      for (size_t i = 0; i < parts.size(); ++i) { sgemm_part_t const &q = parts[i];
+        p = plan_sgemm(q.rows, q.cols, a.dsz("K"), num_cus, q.tile, false);
+        s2d += " [" + std::to_string(q.m0) + "+" + std::to_string(q.rows) + "," + std::to_string(q.n0) + "+" + std::to_string(q.cols) + "]:" + p.cfg.str();
+        if (i + 1 < parts.size() && !arch.empty()) compile_plan(p, arch, &log); }
+      s2d += " last:";
+    }
+    else if (!wide.empty()) p = plan_sgemm(a.dsz("M"), b.dsz("N"), a.dsz("K"), num_cus, wide, false);
     else if (sp.m_main) {   // two-level tiling: the large tile over the first m_main rows (reported), small tiles over the rest
       plan_t const tp = plan_sgemm(a.dsz("M") - sp.m_main, b.dsz("N"), a.dsz("K"), num_cus, sp.tail_tile, false);
       p = plan_sgemm(sp.m_main, b.dsz("N"), a.dsz("K"), num_cus, kBigTile, false);

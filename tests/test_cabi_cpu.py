@@ -225,7 +225,14 @@ def test_planner_sgemm_tiles_follow_problem_size():
     sp = R.explain_plan(sg(7168, 7168, 7168))
     assert sp.startswith("rows<6912:256x256x8_w3x4_p2+rest:bodahip_sgemm_big_f32 64x64x16_w2x2_p2_stg"), sp   # (round 6: the rest on the staging-wave kernel's own 64 x 64 form)
     assert R.explain_plan(sg(6144, 6144, 6144)).startswith("rows<5376:") and not R.explain_plan(sg(12288, 12288, 12288)).startswith("rows<")
-    assert R.explain_plan(sg(10240, 10240, 10240)).startswith("bodahip_sgemm_big_f32 256x128x8")     # (round 5: 3200 tiles of 256 x 128 = 12.5 rounds, no tail launch; round 4 split it at row 9728)
+    # round 6: guillotine cuts into whole rounds -- 10240^3 (3200 tiles of 256 x 128 = 6.25 rounds of 512: two such workgroups share a CU) = rows < 8192 (2560) + the last
+    # 2048 rows' first 8192 columns (512) + a 2048^2 corner on 64 x 64 tiles (1024 = one round of four per CU); 5120^3 = a strip on 64 x 64 + 4096^2 (512) + a strip
+    q10 = R.explain_plan(sg(10240, 10240, 10240))
+    assert q10.startswith("parts=3 [0+8192,0+10240]:256x128x8_w3x4_p2 [8192+2048,0+8192]:256x128x8_w3x4_p2 [8192+2048,8192+2048]:64x64x16_w2x2_p2_stg last:bodahip_sgemm_big_f32 64x64x16_w2x2_p2_stg "), q10
+    assert R.explain_plan(sg(5120, 5120, 5120)).startswith("parts=3 ") and "[1024+4096,0+4096]:256x128x8_w3x4_p2" in R.explain_plan(sg(5120, 5120, 5120))
+    os.environ["BODAHIP_NO_SGEMM_PARTS"] = "1"
+    try: assert R.explain_plan(sg(10240, 10240, 10240)).startswith("bodahip_sgemm_big_f32 256x128x8") and R.explain_plan(sg(5120, 5120, 5120)).startswith("rows<3072:")   # (round 5's plans)
+    finally: del os.environ["BODAHIP_NO_SGEMM_PARTS"]
     assert R.explain_plan(sg(7168, 7168, 7168), tile="128x128x16x2x2x2").startswith("bodahip_sgemm_f32 128x128")
     assert not R.explain_plan(sg(7168, 7170, 7168)).startswith("rows<")        # ragged N: scalar staging, no split
     os.environ["BODAHIP_NO_SGEMM_SPLIT"] = "1"

@@ -799,6 +799,24 @@ def test_sgemm_two_level_tiling_bit_exact(be, shape):
     assert np.array_equal(bo.sgemm(outs["a"], outs["b"]), outs["c"])
 
 
+@pytest.mark.parametrize("shape,grid,oracle", [((5120, 5120, 768), 16 * 80 + 16 * 32 + 64 * 16, True), ((10240, 10240, 512), 32 * 80 + 8 * 64 + 32 * 32, False), ((4096, 10240, 520), 16 * 64 + 64 * 32, True)],
+                         ids=lambda s: "x".join(map(str, s)) if isinstance(s, tuple) else str(s))
+def test_sgemm_guillotine_parts_bit_exact(be, shape, grid, oracle):
+    """Round 6: the two-level tiling generalised -- c cut into rectangles (rows | columns), each one launch of one tile form in whole rounds of the CUs (256 x 128 tiles: two
+    per CU -> rounds of 512; 64 x 64: four per CU): 10240^2 = rows < 8192 on 256 x 128 (2560 tiles) + the last rows' first 8192 columns (512) + a 2048^2 corner on 64 x 64
+    (1024); 5120^2 = a 1024-row strip on 64 x 64 + 4096^2 on 256 x 128 (512) + a 4096 x 1024 strip.  Every output is one launch's one ascending-k chain: equal to the
+    single launch bit for bit, and to the oracle."""
+    M, N, K = shape
+    op = _sgemm_op(M, N, K)
+    outs, prc = _run(be, op, 5, include_ins=True)
+    assert prc.launch["kernel"] == "bodahip_sgemm_big_f32" and prc.launch["grid"] == grid, prc.launch
+    os.environ["BODAHIP_NO_SGEMM_PARTS"] = "1"; os.environ["BODAHIP_NO_SGEMM_SPLIT"] = "1"
+    try: outs1, prc1 = _run(be, op, 5)
+    finally: del os.environ["BODAHIP_NO_SGEMM_PARTS"]; del os.environ["BODAHIP_NO_SGEMM_SPLIT"]
+    assert prc1.launch["grid"] != grid and np.array_equal(outs["c"], outs1["c"])
+    if oracle: assert np.array_equal(bo.sgemm(outs["a"], outs["b"]), outs["c"])
+
+
 def test_cucl_template_dyn_dims_per_call(be):
     """A template with an OUT_DYN argument: one generated function serves any dims; the cai__* arguments and the launch geometry
     come from Instance.call_args per call (the reference's rcg_func_call_t::run flow)."""
