@@ -209,7 +209,7 @@ def annotate_k1_chain(a: Op, b: Op, relu_a: int, relu_b: int) -> Op:
 
 def f32_pool_fusable(conv: Op, pool_in, kern, stride, in_pad, avg_pool) -> bool:
     """Can a max pooling (input dims pool_in, window kern, stride, padding in_pad) be taken into the annotated fp32 hip_conv function that alone reads its output?
-    Mirrors apply_f32_pool / plan_conv (csrc/native_kernels.cc): max, no pooling pad, windows of at most 3 x 3 that tile the plane exactly (no clipped last window),
+    Mirrors apply_f32_pool (csrc/native_run.cc) / plan_conv (csrc/native_plan.cc): max, no pooling pad, windows of at most 3 x 3 that tile the plane exactly (no clipped last window),
     and a convolution that takes the LDS-patch form (stride 1 in x, more than one tap, not output 1 x 1)."""
     if avg_pool or tuple(in_pad) != (0, 0) or conv.get_func_name() != "hip_conv" or "hip_tile" in conv.str_vals or conv.has("hip_pool"):
         return False

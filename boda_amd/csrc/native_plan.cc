@@ -1,0 +1,1120 @@
+// native_plan.cc -- tile / variant selection of the native kernels: host logic only (no device calls), shared by run() and prebuild() / explain_plan.
+#include "native_internal.h"
+
+namespace bodahip {
+
+// "BIxBJxBKxWIxWJ[xMINW[xSPLITK[xMT[xPF[xSW[xKHO]]]]]]"
+bool parse_tile(string const &s, tile_cfg_t &c) {
+  int v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int n = 0; string cur;
+  for (size_t i = 0; i <= s.size(); ++i) {
+    if (i == s.size() || s[i] == 'x' || s[i] == ':') { if (cur.empty() || n >= 11) return false; v[n++] = atoi(cur.c_str()); cur.clear(); }
+    else if (s[i] >= '0' && s[i] <= '9') cur.push_back(s[i]); else return false;
+  }
+  if (n < 5) return false;
+  c.BI = v[0]; c.BJ = v[1]; c.BK = v[2]; c.WI = v[3]; c.WJ = v[4]; c.MINW = (n >= 6) ? v[5] : 1; c.SPLITK = (n >= 7) ? v[6] : 1; c.MT = (n >= 8) ? v[7] : 32; c.PF = (n >= 9) ? v[8] : 1; c.SW = (n >= 10) ? v[9] : 0; c.KHO = (n >= 11) ? v[10] : 0;
+  return true;
+}
+// the static_asserts of the kernel, checked on the host so that a bad tune is an unsup_err, not a compile failure
+static void check_cfg(tile_cfg_t const &c, bool gather, bool patch = false) {   // patch: the J image is an input patch sized (and checked) by the patch planner, not BK x BJ
+  int const nt = c.WI * c.WJ * 64;   // multiplying threads (= staging threads)
+  bool ok = c.BI > 0 && c.BJ > 0 && c.BK > 0 && c.WI > 0 && c.WJ > 0 && nt <= 1024 && c.threads() <= 1024 && (c.MT == 32 || c.MT == 16) && (c.BI % (c.WI * c.MT) == 0) && (c.BJ % (c.WJ * c.MT) == 0) &&
+            (c.BK % 2 == 0) && (c.MT == 32 || c.BK % 4 == 0) && (c.BI % 4 == 0) && (c.BJ % 4 == 0);
+  if (gather) ok = ok && ((c.BK * c.BJ) % nt == 0); // the gathers give every thread whole elements / rows
+  if (gather) ok = ok && (nt % c.BJ == 0) && (c.BJ % 64 == 0);
+  ok = ok && c.SPLITK >= 1 && c.SPLITK <= 64 && c.MINW >= 1 && (c.PF == 1 || c.PF == 2 || c.PF == 4 || c.PF == 6 || c.PF == 8);
+  ok = ok && c.KHO >= 0 && c.KHO <= 64 && (c.KHO <= 1 || (c.SPLITK == 1 && c.SW == 0));   // K hand-off: an exact form (no K slices), not with staging waves
+  if (c.PF > 2) ok = ok && ((long)c.PF * c.BK * (c.BI + c.BJ) / nt <= 192);   // (the ring of register sets: PF x staged elements per thread)
+  int const accs = (c.BI / (c.WI * c.MT)) * (c.BJ / (c.WJ * c.MT));
+  ok = ok && accs * (c.MT == 32 ? 16 : 4) <= 256;
+  uint64_t const lds = 2ull * c.BK * (c.BI + 4 + (patch ? 0 : c.BJ + 4)) * 4;
+  ok = ok && lds <= 160 * 1024;
+  if (!ok) unsup_err("native kernel: unsupported tile configuration " + c.str());
+}
+
+// Tile heuristic: score = measured base rate of the tile shape x fraction of the padded tile grid that is real work x how evenly
+// the workgroups deal out over the CUs (tiles / (num_cus * ceil(tiles / num_cus)); with fewer tiles than CUs this is the fraction
+// of CUs that get one).  Base rates are steady-state MI355X measurements relative to 128x128 (sgemm 4096^3..12288^3, AlexNet /
+// NiN / GoogLeNet layers, tools/tile_sweep.py):
+//   128x128 w2x2 1.00 | 256x256 w2x4 with two K-tiles in flight 1.02 (k-major operands only: halves the HBM re-reads; eight 128x64 waves, 8192^3: 140.7 TF/s vs 135.6 as sixteen 64x64 waves with one; BK32 137.7) | 96x256 w1x4 0.95 (gathers; OC = 96-multiples)
+//   64x64 w2x2 with two K-tiles in flight 0.93 (two-wave 64x128 / 32x128 workgroups measured 1.3-1.8x slower than this and are gone)
+//   32x64 as eight 16x16x4-MFMA waves 0.60 (thin out_chan / tile-starved: 2-2.7x faster than 32x128 there) | 32x32 m16 w2x2 0.45
+// Splitting K would fill the chip for tile-starved shapes too, but it re-associates the fp32 sum: the reference's golden digests
+// (tolerance 2e-4 on max(1,|v|)) are only met robustly by the ascending-k chain, so SPLITK is an explicit tune, never the default.
+static double const kShortTail = getenv("BODAHIP_SHORT_TAIL") ? atof(getenv("BODAHIP_SHORT_TAIL")) : 0.6; // tile-times per CU a short launch loses to ramp-up / tail
+static tile_cfg_t choose_cfg(int Mi, int Nj, int K, int num_cus, bool gather, bool bf16 = false) {
+  struct cand_t { int bi, bj, bk, wi, wj, minw, mt, pf; double base; bool gather_ok, plain_ok; };
+  // bf16 kernel (32x32x16 MFMA only, staging-bound: large tiles matter more; 8192^3: 256x256 624 TF/s vs 128x128 457)
+  static cand_t const cands_bf16[] = {
+    {128, 128, 32, 2, 2, 2, 32, 1, 1.00, true, true}, {256, 256, 32, 4, 4, 1, 32, 1, 1.35, false, true}, {128, 256, 32, 2, 4, 1, 32, 1, 1.15, true, false},
+    {96, 128, 32, 1, 2, 2, 32, 1, 0.85, true, true},  {64, 64, 32, 2, 2, 2, 32, 1, 0.70, true, true}};
+  static cand_t const cands_f32[] = {
+    {128, 128, 16, 2, 2, 2, 32, 1, 1.00, true, true},  {256, 256, 16, 2, 4, 1, 32, 2, 1.02, false, true}, {96, 256, 16, 1, 4, 2, 32, 1, 0.95, true, false},
+    {96, 128, 16, 1, 2, 2, 32, 1, 0.90, false, true},  {64, 64, 16, 2, 2, 2, 32, 2, 0.93, true, true},    {32, 64, 32, 2, 4, 1, 16, 4, 0.60, true, true},
+    {32, 32, 32, 2, 2, 1, 16, 8, 0.45, false, true}}; // (a ring of register-staged K tiles, round 4 -- tools/fc_pf_sweep.py, isolated layers, us: AlexNet fc8 32x32x64 two tiles in
+  // flight 63.6 -> 32x32x32 eight in flight 51.1; GoogLeNet's classifier at 64 images 18.8 -> 16.3; fc6 at 128 images on 32x64x32: two in flight 181 -> four 148.5)
+  tile_cfg_t best_c; double best = -1;
+  // launches shorter than ~200 us at full rate also pay ramp-up / tail: about 0.6 tile-times per CU (measured NiN 1x1 layers at
+  // B=128: 507 128x128 tiles 83 TF/s, 2028 64x64 tiles 88-91), which favours finer tiles there
+  bool const short_kernel = !bf16 && 2.0 * Mi * (double)Nj * K < 2.4e10;
+  cand_t const *cands = bf16 ? cands_bf16 : cands_f32;
+  int const n_cands = bf16 ? (int)(sizeof(cands_bf16) / sizeof(cand_t)) : (int)(sizeof(cands_f32) / sizeof(cand_t));
+  for (int ci = 0; ci < n_cands; ++ci) {
+    cand_t const &cd = cands[ci];
+    if (gather ? !cd.gather_ok : !cd.plain_ok) continue;
+    if (cd.mt == 16 && 2.0 * Mi * (double)Nj * K < 1e8) continue; // tiny problems: launch-bound either way, keep the common kernel
+    long const ti = (Mi + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
+    if (cd.bj == 256 && cd.bi >= 128 && tiles < num_cus) continue;
+    double const pad = ((double)Mi / (double)(ti * cd.bi)) * ((double)Nj / (double)(tj * cd.bj));
+    double const bal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
+    double score = cd.base * pad * bal;
+    if (short_kernel) { double const x = (double)tiles / num_cus; score *= x / (x + kShortTail); }
+    if (score > best) { best = score; best_c.BI = cd.bi; best_c.BJ = cd.bj; best_c.BK = (cd.bi == 64 && cd.bj == 64 && !gather && !bf16) ? 32 : cd.bk; // (k-contiguous / plain operands, usually cold from HBM: twice the bytes in flight; AlexNet fc6/fc7 in sequence 63 -> 78 TF/s)
+      best_c.WI = cd.wi; best_c.WJ = cd.wj; best_c.MINW = cd.minw; best_c.MT = cd.mt; best_c.PF = cd.pf; best_c.SPLITK = 1;
+      // one workgroup per CU and a long K loop (fully-connected layers: 256 tiles, K = 4096 / 9216): four K tiles in flight instead of two (fc6 252.7 -> 237.8 us,
+      // fc7 116.6 -> 111.6; with several workgroups per CU -- sgemm 2048^3 / 3072^3 -- the deeper ring only costs registers: 164 -> 170 us)
+      if (!bf16 && cd.bi == 64 && cd.bj == 64 && cd.mt == 32 && !gather && tiles <= num_cus && K >= 2048) best_c.PF = 4;
+      if (cd.mt == 16 && gather) best_c.PF = 2; }   // (the deeper rings were measured on k-contiguous operands only)
+  }
+  return best_c;
+}
+
+// 64x64 workgroups of four 32x32 wave tiles are what tile-starved shapes get (often a single workgroup per CU): their ~0.5 us
+// MFMA phase per K step cannot cover HBM latency with one K-tile in flight, two can (measured fc6 70 -> 81, fc7 67 -> 76,
+// sgemm 2048^3 95 -> 107 TF/s); larger tiles gain nothing and pay registers.
+static int pf_for(tile_cfg_t const &c) { return (c.BI == 64 && c.BJ == 64 && c.WI == 2 && c.WJ == 2 && c.MT == 32 && c.SPLITK == 1) ? 2 : 1; }
+static vect_string cfg_defs(tile_cfg_t const &c) {
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { // experiment hook: extra -D options for the native kernels
+    vect_string r = {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI),
+                     "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW), "-DMT=" + std::to_string(c.MT), "-DPF=" + std::to_string(c.PF), "-DSPECW=" + std::to_string(c.SW)};
+    if (c.KHO > 1) r.push_back("-DKHO=1");
+    std::istringstream is(e); string tok; while (is >> tok) r.push_back(tok);
+    return r;
+  }
+  vect_string r = {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI),
+          "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW), "-DMT=" + std::to_string(c.MT), "-DPF=" + std::to_string(c.PF), "-DSPECW=" + std::to_string(c.SW)};
+  if (c.KHO > 1) r.push_back("-DKHO=1");
+  return r;
+}
+
+
+// Streaming kernel for short-K 1x1 convolutions (kernels/k1_stream_f32.hip): resident filters, persistent waves, no K tiling.
+//   spec: "" = automatic | "off" | "WIxWJxOCBxCB[xMINW]" (waves along out_chan / pel, 32-row and 32-pel blocks per wave)
+// In the returned plan cfg.BI = out_chans per workgroup, cfg.BJ = pels per super-block, cfg.BK = in_chans.
+static bool plan_k1_stream(conv_geom_t const &g, int num_cus, string const &spec, plan_t &p) {
+  (void)num_cus;
+  if (spec == "off" || getenv("BODAHIP_NO_K1_STREAM")) return false;
+  if (!(g.KH == 1 && g.KW == 1 && g.SY == 1 && g.SX == 1 && g.PY == 0 && g.PX == 0)) return false; // (a spec only applies to the shapes the kernel covers)
+  long const Nj = (long)g.B * g.OH * g.OW;
+  int WI = 0, WJ = 0, OCB = 0, CB = 0, MINW = 0;
+  auto regs = [&](int ocb, int cb) { return (g.C + 1) / 2 * cb + 2 * 16 * ocb * cb + 30; }; // operand ring + two accumulator sets
+  auto lds = [&](int wi, int ocb) { long const oct = wi * ocb * 32; return 4 * ((long)((g.C + 1) / 2 * 2) * (oct | 1) + oct); };
+  // kernels/k1_quad_f32.hip (16 bytes per lane both ways: 128-pel blocks of one image per wave, every wave all of the workgroup's out_chans): spec "qWJxOCBxRING[xMINW]";
+  // automatic for the NiN cccp1/2 class -- at most 96 out_chans (one accumulator set of OCB*64 registers, two waves per SIMD), a short K loop, a long pel axis
+  {
+    int QWJ = 0, QOCB = 0, QRING = 0, QMINW = 0;
+    int const ksteps = (g.C + 1) / 2;
+    if (!spec.empty() && spec[0] == 'q') {
+      int v[4] = {0, 0, 0, 0}, n = 0; size_t i = 1;
+      while (i < spec.size() && n < 4) { size_t j = spec.find('x', i); if (j == string::npos) j = spec.size(); v[n++] = atoi(spec.substr(i, j - i).c_str()); i = j + 1; }
+      if (n < 3) rt_err("bad k1_stream spec '" + spec + "' (qWJxOCBxRING[xMINW])");
+      QWJ = v[0]; QOCB = v[1]; QRING = v[2]; QMINW = v[3];
+      if (QWJ < 1 || QWJ > 16 || QOCB < 1 || QOCB > 4 || QRING < 1 || QRING > 16 || ksteps % QRING || g.OH * g.OW < 4 || lds(1, QOCB) > 160 * 1024)
+        unsup_err("k1_stream: unsupported configuration '" + spec + "' for this shape");
+    } else if (spec.empty() && !getenv("BODAHIP_NO_K1_QUAD") && g.OC > 64 && g.OC <= 96 && g.C <= 128 && g.OH * g.OW >= 512 && Nj >= 150000) {
+      // measured (MI355X, tools/k1s_probe.py, NiN cccp1 at 256 / 128 images, us): tiled kernel 159.5 / 88.6; q4x3x8 two workgroups per CU 156.5 / 95.7; q8x3x8 153.5 / 93.7;
+      // q4x3x8x1 (one workgroup of four waves per CU, six / three blocks per wave) 153.0 / 84.6; rings of 12 / 16 steps 204 / 208 (with the epilogue's 48 stores
+      // they overflow the 6-bit vmcnt and every wait becomes a drain)
+      QWJ = 4; QOCB = (g.OC + 31) / 32; QRING = 8; QMINW = 1; while (ksteps % QRING) --QRING;
+      if (lds(1, QOCB) > 80 * 1024) QWJ = 0;
+    } else if (spec.empty() && !getenv("BODAHIP_NO_K1_QUAD") && g.OC > 96 && g.OC <= 256 && g.OC % 64 == 0 && g.C > 128 && g.C <= 256 && g.OH * g.OW >= 512 && Nj >= 180000) {
+      // NiN cccp3 / cccp4 class (256 -> 256 on 27 x 27) at 256 images, once the filter image was staged with all its loads in flight (round 4c; before, 64 serial round
+      // trips cost this kernel 40 us per launch): eight waves, 64 out_chans per workgroup (four passes over the input, from L2), two workgroups per CU.  Measured
+      // (tools/k1s_probe.py, us): tiled 128x128 219.1 | q8x2x8x2 203.6 | q4x2x8x1 210.5 | q4x4x8x1 211.9 | q4x3x8x1 242.1; at 128 images the tiled kernel leads (116 vs 126)
+      QWJ = 8; QOCB = 2; QRING = 8; QMINW = 2; while (ksteps % QRING) --QRING;
+      if (lds(1, QOCB) > 80 * 1024) QWJ = 0;
+    }
+    if (QWJ) {
+      if (!QMINW) QMINW = (QOCB == 3) ? 2 : ((QOCB == 2) ? 3 : 4);   // registers: OCB*64 accumulators + 4*RING operands + ~30
+      QMINW = (int)std::max(1l, std::min((long)QMINW, std::max(1l, (160l * 1024) / lds(1, QOCB)) * ((QWJ + 3) / 4)));
+      p.stream = true; p.quad = true; p.kname = "bodahip_k1_quad_f32";
+      p.cfg.BI = QOCB * 32; p.cfg.BJ = QWJ * 128; p.cfg.BK = g.C; p.cfg.WI = 1; p.cfg.WJ = QWJ; p.cfg.MINW = QMINW; p.cfg.SPLITK = 1; p.cfg.MT = 32; p.cfg.PF = QRING;
+      p.defs = {"-DKC=" + std::to_string(g.C), "-DHW=" + std::to_string(g.OH * g.OW), "-DWJ=" + std::to_string(QWJ), "-DOCB=" + std::to_string(QOCB),
+                "-DRING=" + std::to_string(QRING), "-DMINW=" + std::to_string(QMINW), string("-DRELU=") + (g.relu ? "1" : "0"), string("-DEDGE_OC=") + ((g.OC % (QOCB * 32)) ? "1" : "0")};
+      if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+      return true;
+    }
+  }
+  if (!spec.empty()) {
+    int v[5] = {0, 0, 0, 0, 0}, n = 0; size_t i = 0;
+    while (i < spec.size() && n < 5) { size_t j = spec.find('x', i); if (j == string::npos) j = spec.size(); v[n++] = atoi(spec.substr(i, j - i).c_str()); i = j + 1; }
+    if (n < 4) rt_err("bad k1_stream spec '" + spec + "' (WIxWJxOCBxCB[xMINW])");
+    WI = v[0]; WJ = v[1]; OCB = v[2]; CB = v[3]; MINW = v[4];
+    if (WI < 1 || WJ < 1 || WI * WJ > 16 || OCB < 1 || OCB > 4 || CB < 1 || CB > 2 || regs(OCB, CB) > 256 || lds(WI, OCB) > 160 * 1024)
+      unsup_err("k1_stream: unsupported configuration '" + spec + "' for this shape");
+  } else {
+    // automatic: only where it measures ahead of the tiled kernel (MI355X, in the layer sequence of the bench): few K steps, a long
+    // pel axis, one out_chan tile (the input is streamed once): ResNet-50 res2 64->256 @56x56 B=64: 89 vs 94 us.  For NiN cccp1/2
+    // (96->96 @55x55) it led by 5-12 % until the tiled kernel got its paired 256-byte stores; now the two tie (B=256: 153 + 178 vs
+    // 157 + 159 us), so those layers stay on the tiled kernel.  The layout's R+W ceiling (tools/mem_pattern_probe.py: 2.8-4.2 TB/s on
+    // planes that are not a multiple of 128 bytes) bounds both.
+    if (g.C <= 64 && g.OC > 128 && g.OC <= 512 && g.OC % 256 == 0 && Nj >= 150000) { WI = 8; WJ = 1; OCB = g.OC / 256; CB = 2; }
+    else return false;
+    if (regs(OCB, CB) > 250 || lds(WI, OCB) > 80 * 1024) return false;
+  }
+  if (!MINW) { int const r = regs(OCB, CB); MINW = std::max(1, std::min(8, 512 / r)); int const wpw = (WI * WJ + 3) / 4; // waves per SIMD of one workgroup
+               long const by_lds = std::max(1l, (160l * 1024) / lds(WI, OCB)); MINW = (int)std::max(1l, std::min((long)MINW, by_lds * wpw)); }
+  p.stream = true; p.kname = "bodahip_k1_stream_f32";
+  p.cfg.BI = WI * OCB * 32; p.cfg.BJ = WJ * CB * 32; p.cfg.BK = g.C; p.cfg.WI = WI; p.cfg.WJ = WJ; p.cfg.MINW = MINW; p.cfg.SPLITK = 1; p.cfg.MT = 32; p.cfg.PF = 1;
+  p.defs = {"-DKC=" + std::to_string(g.C), "-DHW=" + std::to_string(g.OH * g.OW), "-DWI=" + std::to_string(WI), "-DWJ=" + std::to_string(WJ),
+            "-DOCB=" + std::to_string(OCB), "-DCB=" + std::to_string(CB), "-DMINW=" + std::to_string(MINW), string("-DRELU=") + (g.relu ? "1" : "0"),
+            string("-DEDGE_OC=") + ((g.OC % (WI * OCB * 32)) ? "1" : "0")};
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return true;
+}
+
+// bf16 variant (kernels/gemm_conv_bf16.hip): BK = 32, 32x32x16 MFMA only, chunked staging
+static void bf16_cfg(tile_cfg_t &c, bool gather, long Mi = 0, long Nj = 0, long K = 0, int num_cus = 0, bool explicit_tile = false) {
+  if (c.MT != 32) { c.MT = 32; c.BI = 64; c.BJ = 64; c.WI = 2; c.WJ = 2; }
+  if (c.BK != 32 && c.BK != 64) c.BK = 32;
+  c.PF = 1;
+  // split-K by default for tile-starved shapes with a long K loop (fully-connected layers: AlexNet fc6 = 4096 x 256 outputs, K = 9216):
+  // the bf16 path has no order-exactness to lose.  Such shapes take 128x128 tiles (the LDS reuse the bf16 MFMA rate needs) and enough
+  // K slices for ~2 workgroups per CU with >= 8 K steps each.  Measured (AlexNet B=256, us): fc6 / fc7 64x64 unsplit 326 / 145,
+  // 64x64 x4 169 / 90, 128x128 x8 114 / 70; mid-size layers lose (ResNet res4 1x1 1024->256, 196 tiles x 32 steps: 47 split vs 42).
+  if (!explicit_tile) {
+    c.SPLITK = 1;
+    if (Mi > 0 && num_cus > 0 && getenv("BODAHIP_NO_BF16_SPLITK") == nullptr) {
+      long const nkt = (K + c.BK - 1) / c.BK;
+      long const tiles = ((Mi + c.BI - 1) / c.BI) * ((Nj + c.BJ - 1) / c.BJ), tiles128 = ((Mi + 127) / 128) * ((Nj + 127) / 128);
+      if (tiles <= num_cus && nkt >= 64) {
+        long s = std::min<long>(16, (2l * num_cus + tiles128 - 1) / tiles128);
+        s = std::min<long>(s, nkt / 8);
+        if (s >= 2) { c.BI = 128; c.BJ = 128; c.WI = 2; c.WJ = 2; c.MINW = 2; c.SPLITK = (int)s; }
+      }
+    }
+  }
+  int const nt = c.threads();
+  bool ok = (c.BI % (c.WI * 32) == 0) && (c.BJ % (c.WJ * 32) == 0) && ((c.BI * c.BK / 8) % nt == 0) && ((c.BJ * c.BK / 8) % nt == 0) && nt <= 1024 &&
+            (c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) * 16 <= 256 && 4ull * (c.BK + 8) * (c.BI + c.BJ) <= 160 * 1024;
+  if (gather) ok = ok && (c.BJ % 64 == 0) && (nt % c.BJ == 0);
+  if (!ok) unsup_err("native bf16 kernel: unsupported tile configuration " + c.str());
+}
+
+static char const *const kStg64 = "64x64x16x2x2x4x1x32x2x3";   // the staging-wave kernel's 64 x 64 form (tile field 10 == 3: multiplying waves spelled out)
+plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string const &tile, bool bf16, int batch, bool allow_big) {
+  plan_t p; p.kname = bf16 ? "bodahip_sgemm_bf16" : "bodahip_sgemm_f32"; p.bf16 = bf16;
+  p.cfg = choose_cfg((int)M, (int)std::min<uint64_t>((uint64_t)N * batch, 0x7fffffffull), (int)K, num_cus, false, bf16); // (a batch deals batch x the tiles)
+  if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad sgemm_tile '" + tile + "'"); }
+  if (bf16) {
+    bf16_cfg(p.cfg, false, M, N, K, num_cus, !tile.empty());
+    p.defs = cfg_defs(p.cfg); p.defs.push_back("-DI_MODE=0"); p.defs.push_back("-DJ_MODE=0"); p.defs.push_back("-DEPI=0");
+    if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
+    return p;
+  }
+  // Plain fp32 operands on the staging-wave kernel (kernels/sgemm_big_f32.hip: eight multiplying waves + four staging waves, four LDS stages; BODAHIP_SGEMM_BIG = off |
+  // BKSxPF): 256 x 256 tiles where they fill the chip, and -- round 5 -- its 128 x 128 (two workgroups per CU), 256 x 128 and 128 x 256 forms.  cfg.WI x WJ = 3 x 4 stands for
+  // the twelve waves; an explicit tile asks for the kernel that way ("128x128x16x3x4x2").
+  if (!tile.empty() && p.cfg.SW == 3) {   // round 6: the staging-wave kernel with WI x WJ = 8 | 4 multiplying waves spelled out ("64x128x16x2x2x4x1x32x2x3"): its small forms
+    tile_cfg_t const &c = p.cfg;
+    int const nmw = c.WI * c.WJ, ti = (c.WI > 0 && c.BI % (c.WI * 32) == 0) ? c.BI / (c.WI * 32) : 0, tj = (c.WJ > 0 && c.BJ % (c.WJ * 32) == 0) ? c.BJ / (c.WJ * 32) : 0;
+    bool const ok = (nmw == 8 || nmw == 4) && (ti == 4 || ti == 2 || ti == 1) && (tj == 2 || tj == 1) && c.BK >= 4 && c.BK <= 32 && c.BK % 4 == 0 && (c.BK * (c.BI / 4)) % 256 == 0 &&
+                    (c.BK * (c.BJ / 4)) % 256 == 0 && (c.PF == 2 || c.PF == 4) && c.MT == 32 && c.SPLITK == 1 && c.MINW >= 1 && c.MINW <= 8 && 4l * 4 * c.BK * (c.BI + c.BJ + 8) <= 160 * 1024;
+    if (!ok || batch != 1 || M % 4 || N % 4 || !allow_big) unsup_err("hip_sgemm: unsupported staging-wave tile " + c.str() + " (8 | 4 multiplying waves of 4 | 2 | 1 x 2 | 1 blocks, whole float4 units per staging thread, M and N multiples of 4)");
+    p.big = true; p.kname = "bodahip_sgemm_big_f32"; p.cfg.KHO = 0;
+    p.defs = {"-DBKS=" + std::to_string(c.BK), "-DPF=" + std::to_string(c.PF), "-DTBI=" + std::to_string(c.BI), "-DTBJ=" + std::to_string(c.BJ), "-DWI=" + std::to_string(c.WI),
+              "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW)};
+    if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
+    return p;
+  }
+  bool const big_tile = (p.cfg.BI == 256 || p.cfg.BI == 128) && (p.cfg.BJ == 256 || p.cfg.BJ == 128);
+  bool const want_big = big_tile && ((p.cfg.WI == 3 && p.cfg.WJ == 4) || (p.cfg.BI == 256 && p.cfg.BJ == 256));
+  if (allow_big && batch == 1 && want_big && p.cfg.MT == 32 && p.cfg.SPLITK == 1 && M % 4 == 0 && N % 4 == 0) {
+    char const *e = getenv("BODAHIP_SGEMM_BIG");
+    if (!(e && string(e) == "off")) {
+      int bks = 8, pf = 2;   // measured (MI355X, 12288^3 / 8192^3 / 6144^3, TF/s): gemm_conv_f32.hip on the same tile 140.2 / 140.4 / 133.6; 16x2 144.7 / 144.5 / 129.0; 8x2 145.1 / 144.8 / 137.7; 8x4 145.1 / 144.8 / 135.4; 16x4 142.0 / 142.2 / 136.5 (four LDS stages)
+      if (!tile.empty() && p.cfg.WI == 3 && p.cfg.BK >= 4 && p.cfg.BK <= 32 && p.cfg.BK % 4 == 0) bks = p.cfg.BK;   // (asked for by its own tile string: the K step too)
+      if (e && *e) { if (sscanf(e, "%dx%d", &bks, &pf) != 2 || bks < 4 || bks > 32 || bks % 4 || (pf != 2 && pf != 4)) rt_err(string("bad BODAHIP_SGEMM_BIG '") + e + "' (off | BKSxPF)"); }
+      if (bks * (p.cfg.BI / 4) % 256 || bks * (p.cfg.BJ / 4) % 256) bks = 8;   // (whole float4 units per staging thread: BKS x TB / 4 a multiple of 256)
+      int const minw = (p.cfg.BI == 128 && p.cfg.BJ == 128) ? ((!tile.empty() && p.cfg.MINW >= 1) ? std::min(p.cfg.MINW, 2) : 2) : 1;
+      p.big = true; p.kname = "bodahip_sgemm_big_f32"; p.cfg.BK = bks; p.cfg.PF = pf; p.cfg.WI = 3; p.cfg.WJ = 4; p.cfg.MINW = minw;
+      p.defs = {"-DBKS=" + std::to_string(bks), "-DPF=" + std::to_string(pf)};
+      if (!(p.cfg.BI == 256 && p.cfg.BJ == 256)) {   // (the 256 x 256 form keeps its option string: its code objects stay the cached ones)
+        bool const tall = (p.cfg.BI == 256 && p.cfg.BJ == 128);    // 256 x 128: 4 x 2 multiplying waves of 64 x 64; the others 2 x 4 (128 x 128: 64 x 32; 128 x 256: 64 x 64)
+        p.defs.push_back("-DTBI=" + std::to_string(p.cfg.BI)); p.defs.push_back("-DTBJ=" + std::to_string(p.cfg.BJ));
+        p.defs.push_back(string("-DWI=") + (tall ? "4" : "2")); p.defs.push_back(string("-DWJ=") + (tall ? "2" : "4")); p.defs.push_back("-DMINW=" + std::to_string(minw));
+      }
+      if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
+      return p;
+    }
+  }
+  // Round 6: where the general kernel would run 64 x 64 tiles (the sizes that give 256 CUs less than two 128 x 128 tiles each: 768^3 .. 3072^3 of sgemm-ops-full), the
+  // staging-wave kernel's 64 x 64 form -- four multiplying waves of one 32 x 32 block, four staging waves, four workgroups per CU -- runs ahead of it: in the layer sequence
+  // of the list (tools/sgemm_stg_ab.sh, TF/s) 1024^3 75 -> 87, 1536^3 88 -> 93, 2048^3 123.5 -> 127.4, 3072^3 128.1 -> 131.5; its 64 x 128 / 128 x 128 forms measured
+  // level at 2048^3 and behind below.  Bit-identical (the same ascending-k chain per output).
+  if (tile.empty() && allow_big && batch == 1 && p.cfg.BI == 64 && p.cfg.BJ == 64 && p.cfg.MT == 32 && p.cfg.SPLITK == 1 && M % 4 == 0 && N % 4 == 0 && K >= 512 && getenv("BODAHIP_NO_SGEMM_STG64") == nullptr) {
+    char const *e = getenv("BODAHIP_SGEMM_BIG");
+    if (!(e && string(e) == "off")) return plan_sgemm(M, N, K, num_cus, kStg64, false, 1, true);
+  }
+  p.cfg.KHO = 0;   // (K hand-off is a convolution form: the sgemm launches are plain grids)
+  check_cfg(p.cfg, false);
+  p.defs = cfg_defs(p.cfg);
+  p.defs.push_back(string("-DI_MODE=") + ((M % 4 == 0) ? "0" : "1"));
+  p.defs.push_back(string("-DJ_MODE=") + ((N % 4 == 0) ? "0" : "1"));
+  p.defs.push_back("-DEPI=0");
+  if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
+  return p;
+}
+// bf16 convolution from a channel-innermost LDS patch (kernels/conv_patch_bf16.hip): KH x KW kernels, stride 1 in x, in_chan % 8 == 0
+bool plan_patch_bf16(conv_geom_t const &g, int num_cus, plan_t &p) {
+  if (getenv("BODAHIP_NO_PATCH16")) return false;
+  int const taps = g.KH * g.KW;
+  if (!(g.SX == 1 && taps >= 2 && g.KH >= g.SY && g.C % 8 == 0 && g.C >= 16)) return false;
+  if (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W) return false; // ("ipconv" shapes stay on the j-major path)
+  int cg = 1; while (cg * taps < 16) ++cg;                                    // k-slots per K step: >= 16 (an odd count is padded with one zero slot)
+  if (char const *e = getenv("BODAHIP_PATCH16_CG")) { if (atoi(e) > 0) cg = atoi(e); }   // (experiments)
+  if (cg > 8) return false;
+  int const np = cg * taps + ((cg * taps) & 1);
+  long const Nj = (long)g.B * g.OH * g.OW;
+  int const wp = g.W + 2 * g.PX;
+  auto lds = [&](int bi, int bj) {
+    int const rows_max = (bj - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
+    long const cs = (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp;
+    return 16l * ((long)np * bi + cg * cs);
+  };
+  struct cand_t { int bi, bj, wi, wj; };
+  static cand_t const cands[] = {{128, 128, 2, 2}, {96, 128, 1, 4}, {64, 128, 1, 4}, {64, 64, 2, 2}};
+  int pick = -1;
+  for (int ci = 0; ci < 4; ++ci) {
+    if (cands[ci].bi == 96 && !(g.OC % 128 > 64 && g.OC % 128 <= 96)) continue;   // 96-row tiles only where they remove padding (out_chan = 96, 224, ...)
+    if (cands[ci].bi == 128 && g.OC % 128 > 64 && g.OC % 128 <= 96 && g.OC < 256) continue;
+    if (cands[ci].bi > 64 && g.OC <= 64) continue;                                       // (no rows of padding for thin layers)
+    cand_t const &c = cands[ci];
+    if (lds(c.bi, c.bj) > 64 * 1024) continue;
+    long const tiles = (long)((g.OC + c.bi - 1) / c.bi) * ((Nj + c.bj - 1) / c.bj);
+    if (pick < 0) pick = ci;
+    if (tiles >= (long)num_cus * 3 / 2) { pick = ci; break; }                 // the largest tile that still gives every CU work
+    pick = ci;
+  }
+  if (pick < 0) return false;
+  cand_t const &c = cands[pick];
+  p.patch16 = true; p.bf16 = true; p.cg = cg; p.kname = "bodahip_conv_patch_bf16";
+  p.cfg.BI = c.bi; p.cfg.BJ = c.bj; p.cfg.BK = cg * 8 * taps; p.cfg.WI = c.wi; p.cfg.WJ = c.wj; p.cfg.MINW = 2; p.cfg.SPLITK = 1; p.cfg.MT = 32; p.cfg.PF = 1;
+  p.defs = {"-DBI=" + std::to_string(c.bi), "-DBJ=" + std::to_string(c.bj), "-DWI=" + std::to_string(c.wi), "-DWJ=" + std::to_string(c.wj), "-DMINW=2",
+            "-DCG=" + std::to_string(cg), "-DKH=" + std::to_string(g.KH), "-DKW=" + std::to_string(g.KW), "-DSY=" + std::to_string(g.SY),
+            "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX), "-DCH=" + std::to_string(g.H), "-DCW=" + std::to_string(g.W),
+            "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW), string("-DRELU=") + (g.relu ? "1" : "0")};
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return true;
+}
+
+// Channels-last bf16 convolution (kernels/conv_nhwc_bf16.hip): implicit GEMM D[oc][pel], operands straight from HBM into LDS
+// (buffer_load ... lds), 32x32x16 bf16 MFMA.  g.C is the STORED channel count (a multiple of 8).  tile: "BIxBJxBKxWIxWJ[xMINW]" or "".
+// grp_pad > 0: horizontally fused convolutions (-DGROUPS=1): g.OC is the stacked, padded out_chan count, every member starts at a multiple of grp_pad -> tiles
+// may not be taller than grp_pad and must divide it; no K slices.
+// In-launch K slices (KSL of kernels/conv_nhwc_bf16.hip, conv_nhwc_patch_bf16.hip): the count is a compile-time constant of the kernel, every slice runs
+// ceil(nk / slices) K steps -- so the count is lowered until no slice is empty (32 at most).
+static int ksl_normalise(int want, long nk) {
+  int s = (int)std::max<long>(1, std::min<long>(std::min(want, 32), nk));
+  while (s > 1) { long const per = (nk + s - 1) / s; if ((nk + per - 1) / per == s) break; --s; }
+  return s;
+}
+plan_t plan_conv_nhwc(conv_geom_t const &g, int num_cus, string const &tile, bool out_f32, int grp_pad, bool allow_split) {
+  if (g.C % 8) unsup_err("hip_conv_nhwc: in_chan of a channels-last bf16 tensor must be a multiple of 8 (the layout pass pads)");
+  if (g.H >= 32768 || g.W >= 32768) unsup_err("hip_conv_nhwc: planes of 32768 rows / columns or more are not supported");
+  long const Nj = (long)g.B * g.OH * g.OW;
+  int const cg = g.C / 8, kc = cg * g.KH * g.KW;
+  plan_t p; p.nhwc = true; p.bf16 = true; p.kname = "bodahip_conv_nhwc_bf16";
+  tile_cfg_t c; c.MT = 32; c.SPLITK = 1; c.PF = 1;
+  // K step: 64 (8 chunks) when a tap's chunks divide into it -- or when K is long anyway; 32 otherwise
+  // Round 5 (tools/ksl_sweep.py, every 1x1 layer of GoogLeNet at 64 images under ten tiles): on SMALL maps (14 x 14 and 7 x 7 at 64 images: 3-12 k pels, 100-600
+  // tiles) the launches are latency-bound, not HBM-bound, and the 64-deep step with half as many barriers wins by 15-25 % (512 -> 128 channels at 14 x 14: 64x128x32
+  // ring 4 10.5 us, 64x64x64 ring 3 7.9; 480 -> 96: 10.3 -> 8.6), ragged taps included (480 channels = 7.5 steps); the 32-deep rules stay for the large maps.
+  bool const big_map = Nj >= 32768;
+  c.BK = (cg % 8 == 0) ? 64 : ((cg % 4 == 0 && big_map) ? 32 : (kc >= 32 ? 64 : 32));
+  // short K (<= 512) on large maps: a 32-deep step -- half the LDS per ring slot, so a deeper ring and more workgroups per CU for what are HBM-bound
+  // launches (measured at 64 images: 1x1 layers with 64-512 input channels at 28 x 28 / 56 x 56 5-10 % faster, the 7x7 / 2 conv1 on 8 stored channels 93 -> 75 us;
+  // from 1024 channels up and on 3x3 layers the 64-deep step wins)
+  if (kc <= 64 && (big_map || kc <= 32)) c.BK = 32;
+  int nbuf = 0;   // LDS ring depth (the tile string's 9th field; 0 = choose below)
+  if (!tile.empty()) {
+    if (!parse_tile(tile, c)) rt_err("bad conv_tile '" + tile + "'");
+    { int nf = 1; for (char ch : tile) if (ch == 'x' || ch == ':') ++nf; if (nf >= 9) nbuf = c.PF; }
+    c.MT = 32; c.PF = 1;
+    if (c.SPLITK < 1 || c.SPLITK > 64) unsup_err("hip_conv_nhwc: unsupported K split " + std::to_string(c.SPLITK));
+    if (grp_pad && (c.BI > grp_pad || grp_pad % c.BI)) unsup_err("hip_conv_nhwc_grp: tile " + c.str() + " does not fit the members' padding of " + std::to_string(grp_pad) + " out_chans");
+  } else {
+    // score = base rate of the tile x fraction of the padded tile grid that is real work x how evenly the tiles deal out over the CUs
+    // (the rule of choose_cfg); base rates are first MI355X measurements of this kernel relative to 128x128
+    // Tile and K split by a small time model (us), calibrated on MI355X (tools/nhwc_sweep.py, ResNet-50 / GoogLeNet at 64 images):
+    //   * the K loop is bound by the L2 -> LDS operand stream, not by the MFMAs: one K step of a workgroup costs ~0.7 us per 32 KB of
+    //     operand tiles (128x128x64), workgroups that share a CU share that rate -> t_main = ceil(wgs / CUs) * steps * 0.7 * (BI + BJ) * BK / 16384;
+    //   * ~4 us per launch of ramp-up, prologue and epilogue;
+    //   * K slices (tile-starved layers with a long K loop: 7x7-map layers, fully-connected layers; this path has no summation order to
+    //     keep) cost a second launch (~3 us) and the fp32 partial tiles written and read once each at ~5 TB/s.
+    struct cand_t { int bi, bj, wi, wj, minw; };
+    //   * large tiles (8 / 16 waves) move fewer operand bytes per flop but then meet the matrix pipes: a K step is never faster than its flops at
+    //     ~45 % of the CU's bf16 MFMA rate (AlexNet / NiN conv2, 5x5 96->256 at 256 images: 128x128 305, 128x256 254, 256x256 243 us).
+    //   * (round 5) the two-wave 32 x 64 tile is gone from the list: never ahead of 64 x 64 x 64 / 32 x 128 x 64 in the sweep of GoogLeNet's 1x1 layers (16-32 out_chans at
+    //     14 x 14: 8.2-8.5 us against 6.6-7.4), and a 128-thread member cannot share a level set's wrapper kernel
+    static cand_t const cands[] = {{128, 128, 2, 2, 2}, {64, 128, 1, 4, 2}, {64, 64, 2, 2, 2}, {32, 128, 1, 4, 2}, {128, 256, 2, 4, 1}, {256, 256, 4, 4, 1}};
+    long const nk = (kc + c.BK / 8 - 1) / (c.BK / 8);
+    bool const two_kernel = getenv("BODAHIP_NHWC_SPLITK2") != nullptr && !grp_pad;
+    // (no slices for a fused sibling group: its outputs stay bit-identical to its members' own launches, which may slice differently or not at all)
+    bool const may_split = getenv("BODAHIP_NO_NHWC_SPLITK") == nullptr && allow_split && !grp_pad;
+    double best = 1e30;
+    for (cand_t const &cd : cands) {
+      if (grp_pad && (cd.bi > grp_pad || grp_pad % cd.bi)) continue;
+      long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
+      if (cd.bi * cd.bj > 128 * 128 && ((long)(cd.bi + cd.bj) * c.BK * 2 * 2 > 140 * 1024 || !getenv("BODAHIP_NHWC_BIG_TILES"))) continue;   // 128x256 / 256x256 at one workgroup per CU:
+      // opt-in.  Measured (MI355X, same box, A/B): NiN whole net +2 %, ResNet-50 / GoogLeNet lists and AlexNet net within noise, single layers both ways --
+      // the wider tile halves the operand re-reads per MFMA but leaves one workgroup per CU with nothing to hide its barriers behind.
+      double const tau = std::max(0.7 * (double)(cd.bi + cd.bj) * c.BK / 16384.0, 2.0 * cd.bi * cd.bj * c.BK / (0.45 * 2.5e9 / num_cus * 1e3));
+      for (int sk = 1; sk <= 16; sk *= 2) {
+        if (sk > 1 && (!may_split || nk / sk < 4)) break;
+        long const wgs = tiles * sk, steps = (nk + sk - 1) / sk;
+        // (two workgroups share a CU without slowing each other at these sizes -- the launches are latency-bound: 392 tiles of 64 x 64 run like 196 --, so a round is 2 x CUs)
+        double t = (double)((wgs + 2 * num_cus - 1) / (2 * num_cus)) * (double)steps * tau + 4.0;
+        // K slices reduced inside the launch (KSL): no second launch, but the slabs leave write-through and are read back by the last arriver -- measured (tools/ksl_sweep.py,
+        // GoogLeNet's 14 x 14 / 7 x 7 layers at 64 images): ~1.5 us + ~1 us per MB of slabs (slices x out_chans x pels x 4 bytes), whatever the tile
+        if (sk > 1) t += two_kernel ? (3.0 + 2.0 * sk * (double)Nj * g.OC * 4.0 / 5e6) : (1.5 + sk * (double)Nj * g.OC * 4.0 / 1e6);
+        if (t < best) { best = t; c.BI = cd.bi; c.BJ = cd.bj; c.WI = cd.wi; c.WJ = cd.wj; c.MINW = cd.minw; c.SPLITK = sk; }
+      }
+    }
+  }
+  int const cpr = c.BK / 8, nt = c.threads();
+  {
+    // ring depth: 3 (one K step of loads in flight across each barrier) where every wave issues the same number of loads per step and two
+    // workgroups still fit a CU's LDS; 2 otherwise
+    bool const even = c.WI > 0 && c.WJ > 0 && ((c.BI * cpr / 64) % (c.WI * c.WJ) == 0) && ((c.BJ * cpr / 64) % (c.WI * c.WJ) == 0);
+    long const per_buf = (long)(c.BI + c.BJ) * c.BK * 2;
+    // (64-deep steps: a third slot only for the small tiles -- 64 x 128 x 64 and 128 x 128 x 64 measured level or FASTER on a ring of two at 28 x 28 / 14 x 14 / 7 x 7:
+    //  832 -> 384 at 7 x 7 11.3 -> 9.4 us, 192 -> 96 at 28 x 28 on 128 x 128 12.9 -> 10.4)
+    if (!nbuf) nbuf = (even && c.BK == 32 && 4 * per_buf <= 48 * 1024) ? 4 : ((even && 3 * per_buf <= 80 * 1024 && (c.BK == 32 || per_buf <= 20 * 1024)) ? 3 : 2);
+    if (nbuf < 2 || nbuf > 4 || (nbuf > 2 && !even)) unsup_err("hip_conv_nhwc: unsupported LDS ring depth " + std::to_string(nbuf) + " for tile " + c.str());
+    c.PF = nbuf;   // (reported as _pN in the launch info)
+  }
+  bool ok = (c.BK == 32 || c.BK == 64) && c.BI > 0 && c.BJ > 0 && c.WI > 0 && c.WJ > 0 && nt <= 1024 && (c.BI % (c.WI * 32) == 0) && (c.BJ % (c.WJ * 32) == 0) &&
+            ((c.BI * cpr) % 64 == 0) && ((c.BJ * cpr) % 64 == 0) && (c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) * 16 <= 256 && c.MINW >= 1;
+  long const lds = std::max<long>((long)nbuf * (c.BI + c.BJ) * c.BK * 2, out_f32 ? 0 : (long)c.BJ * (c.BI * 2 + 16));
+  ok = ok && lds <= 160 * 1024;
+  if (!ok) unsup_err("hip_conv_nhwc: unsupported tile configuration " + c.str());
+  p.cfg = c;
+  p.defs = {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DBK=" + std::to_string(c.BK), "-DWI=" + std::to_string(c.WI), "-DWJ=" + std::to_string(c.WJ),
+            "-DMINW=" + std::to_string(c.MINW), "-DCIN=" + std::to_string(g.C), "-DKH=" + std::to_string(g.KH), "-DKW=" + std::to_string(g.KW),
+            "-DSY=" + std::to_string(g.SY), "-DSX=" + std::to_string(g.SX), "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX),
+            "-DCH=" + std::to_string(g.H), "-DCW=" + std::to_string(g.W), "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW),
+            string("-DRELU=") + (g.relu ? "1" : "0"), string("-DOUT_F32=") + (out_f32 ? "1" : "0"), "-DNBUF=" + std::to_string(nbuf)};
+  if (c.SPLITK > 1) {   // K slices: reduced inside the launch (KSL, round 5) unless the two-kernel form is asked for (BODAHIP_NHWC_SPLITK2=1: slabs in the shared scratch + bodahip_nhwc_splitk_reduce)
+    long const nk2 = ((long)kc + c.BK / 8 - 1) / (c.BK / 8);
+    if (getenv("BODAHIP_NHWC_SPLITK2") && !grp_pad) p.defs.push_back("-DSPLITK=1");
+    else { c.SPLITK = ksl_normalise(c.SPLITK, nk2); p.cfg = c; if (c.SPLITK > 1) { p.defs.push_back("-DKSL=" + std::to_string(c.SPLITK)); p.ksl = true; } }
+  }
+  if (grp_pad) p.defs.push_back("-DGROUPS=1");
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return p;
+}
+// Channels-last bf16 convolution from an LDS input patch (kernels/conv_nhwc_patch_bf16.hip): KH x KW kernels with more than one tap, stride 1 in x; filters in the
+// F'[in_grp][ky][kx][out_chan][8] form.  A K step is CG groups of 8 channels x all taps.  tile: "BIxBJx0xWIxWJ[xMINW]" or "".
+// pool: g.KH x g.KW / g.PY, g.PX describe a MAX-POOLING window fused in front of a 1x1 convolution (-DPOOL=1: the filters hold one k-slot per channel group).
+// channel groups per K step of the input-patch forms (shared by the patch kernel and the rolling-rows kernel: same k-slot order, same MFMA chain, same bits)
+static int patch_cg(int ncg, int taps) {
+  int cg = 1; long best = -1;
+  for (int c = std::min(ncg, 4); c >= 1; --c) {
+    if (c > 1 && c * taps > 50) continue;
+    long const slots = (long)((ncg + c - 1) / c) * (c * taps + ((c * taps) & 1));
+    if (best < 0 || slots < best) { best = slots; cg = c; }
+  }
+  return cg;
+}
+plan_t plan_conv_nhwc_patch(conv_geom_t const &g, int num_cus, string const &tile_arg, bool out_f32, bool pool) {
+  if (g.C % 8) unsup_err("hip_conv_nhwc: in_chan of a channels-last bf16 tensor must be a multiple of 8");
+  string tile = tile_arg;
+  if (pool && tile.empty()) { if (char const *e = getenv("BODAHIP_NHWC_POOL_TILE")) tile = e; }   // (experiments: the tile of the fused-pooling form)
+  int const taps = g.KH * g.KW, ncg = g.C / 8;
+  if (!(g.SX == 1 && taps >= 2 && g.KH >= g.SY)) unsup_err("hip_conv_nhwc (patch form of filts): needs stride 1 in x and more than one tap");
+  long const Nj = (long)g.B * g.OH * g.OW;
+  // ADIRECT (default): filter fragments straight from global memory, the LDS holds the (double-buffered) patch only.  BODAHIP_NHWC_ADIRECT=0: both operands staged.
+  bool adirect = true; if (char const *e = getenv("BODAHIP_NHWC_ADIRECT")) adirect = atoi(e) != 0;
+  // Channel groups per K step: at most 4, at most 50 k-slots, the count that wastes the fewest zero k-slots over the layer (a ragged last step and the zero slot
+  // of an odd step are MFMAs on zeros: 6 groups of a 3x3 as 4 + 2 cost 72 slots, as 2 + 2 + 2 54 -- AlexNet's space-to-depth conv1 at 256 images 128.7 -> 111.9 us;
+  // 5x5 on 12 groups as 6 x 50 instead of 12 x 26: 209 -> 200 us); ties go to the larger step (fewer barriers).
+  int cg = patch_cg(ncg, taps);
+  if (pool) { if (!adirect) unsup_err("hip_conv_nhwc (fused pooling): needs the direct filter path"); cg = std::min(ncg, 4);    // (one k-slot per group: four groups = two MFMA k-iterations per step)
+    if (char const *e = getenv("BODAHIP_NHWC_POOL_CG")) { if (atoi(e) > 0) cg = std::min(ncg, atoi(e)); } }
+  if (char const *e = getenv("BODAHIP_NHWC_PATCH_CG")) { if (atoi(e) > 0) cg = std::min(ncg, atoi(e)); }   // (experiments)
+  int wp = g.W + 2 * g.PX;                                              // slot pitch: as the kernel's wpitch()
+  for (int p2 = wp; p2 < wp + 16; ++p2) if ((g.SY * p2 - g.OW) % 16 == 0) { wp = p2; break; }
+  auto lds_cg = [&](int bi, int bj, int cgx) {
+    int const npx = cgx * taps + ((cgx * taps) & 1);
+    int const rows_max = (bj - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
+    long const cs = (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp, csp = cs + ((2 - cs % 16) + 16) % 16;
+    long const ops = adirect ? 2l * 16l * cgx * csp : 16l * ((long)npx * bi + cgx * csp);
+    return std::max<long>(ops, out_f32 ? 0 : (long)bj * (bi * 2 + 16));
+  };
+  auto lds = [&](int bi, int bj) { return lds_cg(bi, bj, cg); };
+  struct cand_t { int bi, bj, wi, wj, minw, pf; };
+  static cand_t const cands_staged[] = {{64, 256, 1, 4, 2, 0}, {64, 128, 1, 4, 2, 0}, {32, 256, 1, 4, 2, 0}, {128, 128, 2, 2, 2, 0}, {32, 128, 1, 4, 2, 0}, {64, 64, 2, 2, 2, 0}};
+  // ADIRECT: wave tiles wide in pels first (32 x 128: one 1-KB filter fragment load per four MFMAs), in order of preference on equal cost; last the 64 x 128 wave
+  // tile (half the operand bytes per MFMA; 247 registers with four fragments in flight: still two waves per SIMD) for layers with tiles to spare
+  static cand_t const cands_direct[] = {{128, 128, 4, 1, 2, 0}, {64, 256, 2, 2, 2, 0}, {64, 128, 2, 2, 2, 0}, {128, 64, 4, 1, 2, 0}, {32, 128, 1, 4, 2, 0}, {128, 256, 2, 2, 2, 4}, {256, 128, 4, 1, 2, 4}};
+  cand_t const *const cands = adirect ? cands_direct : cands_staged;
+  int const n_cands = adirect ? (int)(sizeof(cands_direct) / sizeof(cand_t)) : (int)(sizeof(cands_staged) / sizeof(cand_t));
+  plan_t p; p.nhwc = true; p.nhwc_patch = true; p.bf16 = true; p.kname = "bodahip_conv_nhwc_patch_bf16";
+  tile_cfg_t c; c.MT = 32; c.SPLITK = 1; c.PF = 1;
+  int pick_pf = 0;
+  if (!tile.empty()) {
+    if (!parse_tile(tile, c)) rt_err("bad conv_tile '" + tile + "'");
+    c.MT = 32; c.PF = 1;
+    if (c.SPLITK < 1 || c.SPLITK > 32 || (c.SPLITK > 1 && !adirect)) unsup_err("hip_conv_nhwc (patch form of filts): unsupported K slices " + std::to_string(c.SPLITK));
+  } else if (pool && getenv("BODAHIP_NHWC_POOL_R4PLAN") == nullptr) {
+    // The fused-pooling form is bound by its LDS reads: a B fragment is KH x KW patch reads + maxima, and a wave forms it for every pel block of its tile -- so waves
+    // must not SHARE pels (WI = 1: the 4 x 1 and 2 x 2 layouts redo the window maxima four / two times per tile) and the wave tile is one pel block wide.  Round 5,
+    // GoogLeNet's nine pool projections at 64 images, us per launch (tools/pool_tile_ab.sh; round-4 plan | 64x128 as 1 x 4 waves): 24.5 | 15.1 (256 -> 64 at 28 x 28),
+    // 26.0 | 17.1 (528 -> 128 at 14 x 14); level elsewhere.  Tile-starved layers with a long K (832 -> 128 at 7 x 7: 50 tiles, 26 steps -- every workgroup pulls 400 KB
+    // through ONE CU's load path) take 64 x 64 tiles and four K slices reduced inside the launch: 27.5 -> 15.6 us.
+    c.BI = (g.OC <= 32) ? 32 : 64; c.BJ = 128; c.WI = 1; c.WJ = 4; c.MINW = 2;
+    long const tiles = (long)((g.OC + c.BI - 1) / c.BI) * ((Nj + c.BJ - 1) / c.BJ), steps = (ncg + 3) / 4;
+    if (tiles * 4 < num_cus && steps >= 16 && getenv("BODAHIP_NO_NHWC_SPLITK") == nullptr) { c.BI = 64; c.BJ = 64; c.WI = 2; c.WJ = 2; c.SPLITK = 4; }
+    cg = std::min(ncg, 4);
+    while (cg > 1 && lds_cg(c.BI, c.BJ, cg) > 80 * 1024) cg = (cg + 1) / 2;
+    if (cg < 4) { cg = std::min(ncg, 4); while (cg > 1 && lds_cg(c.BI, c.BJ, cg) > 160 * 1024) cg = (cg + 1) / 2; }   // (narrow maps with a padded pitch: one workgroup per CU rather than twice the steps)
+  } else if (!adirect) {
+    // Narrow in out_chan, wide in pels: the filter tile -- the larger operand stream here -- is staged once per BJ pels.  score = padding efficiency x share of
+    // the CUs that get a workgroup / operand bytes per flop (filter stream ~ 1/BJ, patch stream ~ 1/(4 BI)).  Measured on MI355X (tools/patch_sweep.sh, 64
+    // images, us incl. the ~6 us launch floor): ResNet-50 3x3 at 56^2 / 28^2 / 14^2 / 7^2: 64x256 30 / 26 / 27 / 45, 64x128 34 / 29 / 27 / 32.5, 32x128 35 / 29 /
+    // 30 / 34; GoogLeNet 3x3 64->192 at 56^2: 64x256 63-66, 32x128 91.  Two workgroups per CU must fit the LDS (80 KB each): wide planes take 2 channel groups
+    // per K step instead of 4 (level with each other where both fit; 8 groups measured 10-50 % slower).
+    int pick = -1, pick_cg = cg; double best = -1;
+    for (long lim = 80 * 1024; pick < 0 && lim <= 160 * 1024; lim *= 2)
+    for (int ci = 0; ci < n_cands; ++ci) {
+      cand_t const &cd = cands[ci];
+      int cgx = cg; while (cgx > 1 && lds_cg(cd.bi, cd.bj, cgx) > lim) cgx = (cgx + 1) / 2;
+      if (lds_cg(cd.bi, cd.bj, cgx) > lim) continue;
+      if (cd.bi > 64 && g.OC <= 64) continue;
+      long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
+      double const pad = ((double)g.OC / (double)(ti * cd.bi)) * ((double)Nj / (double)(tj * cd.bj));
+      double const fill = std::min(1.0, (double)tiles / (double)num_cus);
+      double const bytes_per_flop = 1.0 / cd.bj + 0.25 / cd.bi;
+      double const score = pad * fill / bytes_per_flop;
+      if (score > best) { best = score; pick = ci; pick_cg = cgx; }
+    }
+    if (pick < 0) unsup_err("hip_conv_nhwc (patch form of filts): no tile fits the LDS for this plane width");
+    c.BI = cands[pick].bi; c.BJ = cands[pick].bj; c.WI = cands[pick].wi; c.WJ = cands[pick].wj; c.MINW = cands[pick].minw; cg = pick_cg;
+  } else {
+    // What a launch costs here (tools/adirect_ablate.sh, ResNet-50 256 -> 256 at 14^2, 64 images, 128 x 128 tiles: 20.6 us = 7.3 without the K loop + 7.7 of MFMA
+    // issue + 5.3 of operand loads, 1.5 us of which overlap): the MFMA work of the busiest SIMD -- rounds of workgroups over the CUs x the wave tile -- inflated by
+    // the filter fragments its waves pull through the CU's 64 B/clk L1 path per MFMA (1 / pel blocks of the wave tile).  tiles <= CUs: one round; <= 2 CUs: the CUs
+    // that hold two workgroups set the pace (1.7: two waves per SIMD overlap better than one); beyond that workgroups are handed out as CUs free up.  Measured on
+    // MI355X (tools/adirect_sweep2.sh, 64 images, us incl. the ~6 us launch floor, staged -> direct): ResNet-50 3x3 at 28^2 / 14^2 / 7^2 25.4 -> 21.3 / 26.8 -> 21.2 /
+    // 32.3 -> 24.4-25.1; GoogLeNet 96->208 / 128->256 / 160->320 at 14^2 14.7 -> 11.8 / 17.1 -> 13.8 / 20.7 -> 16.7, 64->192 at 56^2 64.6 -> 60.5; 4 channel groups
+    // per K step (8: 5-100 % slower, 2: level or 10 % slower); 4 / 8 / 12 fragments in flight: level.
+    int pick = -1, pick_cg = cg; double best = 1e30;
+    for (long lim = 80 * 1024; pick < 0 && lim <= 160 * 1024; lim *= 2)      // two workgroups per CU; one where nothing fits that (maps one or two positions wide)
+    for (int ci = 0; ci < n_cands; ++ci) {
+      cand_t const &cd = cands[ci];
+      int cgx = cg; while (cgx > 1 && lds_cg(cd.bi, cd.bj, cgx) > lim) cgx = (cgx + 1) / 2;
+      if (lds_cg(cd.bi, cd.bj, cgx) > lim) continue;
+      long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (Nj + cd.bj - 1) / cd.bj, tiles = ti * tj;
+      double const rounds = (tiles <= num_cus) ? 1.0 : std::max(1.7, (double)tiles / (double)num_cus + 0.25);
+      int const ktj = cd.bj / (cd.wj * 32), kti = cd.bi / (cd.wi * 32);
+      // (fitted to the sweeps; the 64 x 128 wave tile, as 128 x 256 or 256 x 128 workgroup tiles: AlexNet conv2 at 256 images, 1458 tiles, 201 -> 181 us; the
+      //  space-to-depth conv1, 3025 tiles, 110.6 -> 99.4; conv5, 338 tiles, 72 -> 79-88)
+      double const cost = rounds * (double)(cd.bi * cd.bj) / (double)(cd.wi * cd.wj) * ((kti >= 2 && ktj >= 4) ? 1.02 : (ktj >= 4) ? 1.1 : (ktj >= 2) ? 1.3 : 2.0);
+      if (cost < best * 0.97) { best = cost; pick = ci; pick_cg = cgx; pick_pf = cd.pf; }   // (a later candidate must be clearly cheaper)
+    }
+    if (pick < 0) unsup_err("hip_conv_nhwc (patch form of filts): no tile fits the LDS for this plane width");
+    c.BI = cands[pick].bi; c.BJ = cands[pick].bj; c.WI = cands[pick].wi; c.WJ = cands[pick].wj; c.MINW = cands[pick].minw; cg = pick_cg;
+  }
+  while (cg > 1 && lds(c.BI, c.BJ) > 160 * 1024) cg = (cg + 1) / 2;
+  p.cg = cg; c.BK = pool ? cg * 8 : cg * 8 * taps;
+  bool ok = c.BI > 0 && c.BJ > 0 && c.WI > 0 && c.WJ > 0 && c.threads() <= 1024 && (c.BI % (c.WI * 32) == 0) && (c.BJ % (c.WJ * 32) == 0) &&
+            (c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) * 16 <= 256 && c.MINW >= 1 && lds(c.BI, c.BJ) <= 160 * 1024;
+  if (!ok) unsup_err("hip_conv_nhwc (patch form of filts): unsupported tile configuration " + c.str());
+  p.cfg = c;
+  p.defs = {"-DBI=" + std::to_string(c.BI), "-DBJ=" + std::to_string(c.BJ), "-DWI=" + std::to_string(c.WI), "-DWJ=" + std::to_string(c.WJ), "-DMINW=" + std::to_string(c.MINW),
+            "-DCG=" + std::to_string(cg), "-DCIN=" + std::to_string(g.C), "-DKH=" + std::to_string(g.KH), "-DKW=" + std::to_string(g.KW), "-DSY=" + std::to_string(g.SY),
+            "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX), "-DCH=" + std::to_string(g.H), "-DCW=" + std::to_string(g.W),
+            "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW), string("-DRELU=") + (g.relu ? "1" : "0"), string("-DOUT_F32=") + (out_f32 ? "1" : "0")};
+  if (adirect) p.defs.push_back("-DADIRECT=1");
+  if (pool) p.defs.push_back("-DPOOL=1");
+  if (c.SPLITK > 1) { c.SPLITK = ksl_normalise(c.SPLITK, (ncg + cg - 1) / cg); p.cfg = c; if (c.SPLITK > 1) { p.defs.push_back("-DKSL=" + std::to_string(c.SPLITK)); p.ksl = true; } }
+  if (adirect && (pick_pf || (tile.empty() ? 0 : ((c.BI / (c.WI * 32)) * (c.BJ / (c.WJ * 32)) >= 8)))) p.defs.push_back("-DPF=4");   // (128 accumulators: four fragments in flight)
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return p;
+}
+
+// Rolling-rows form of the channels-last bf16 convolution (kernels/conv_nhwc_rows_bf16.hip): short-K layers of at most 64 out_chans whose time is their output --
+// the 7x7/2 stems after space-to-depth.  A workgroup of eight waves walks down a run of output rows of one image with the filters in registers; the rows land in an LDS
+// ring from which they are stored -- or pooled (+ LRN'd) without ever reaching memory (post).  Same k-slot order as the patch kernel (patch_cg): with an even tap count
+// the MFMA chains are the same for every CG, i.e. the same bits as bodahip_conv_nhwc_patch_bf16 whatever that one's plan.
+// Returns false (why = the reason) where the form does not apply.  cfg: BI x BJ = 64 x 256 positions per tile, BK = K of the layer, WJ waves.
+
+bool plan_conv_nhwc_rows(conv_geom_t const &g, post_ops_t const &post, int num_cus, plan_t &p, string *why) {
+  auto no = [&](char const *w) { if (why) *why = w; return false; };
+  (void)num_cus;
+  int const taps = g.KH * g.KW, ncg = g.C / 8;
+  if (g.C % 8) return no("in_chan must be a multiple of 8");
+  if (!(g.SX == 1 && g.SY == 1 && taps >= 2)) return no("needs stride 1 and more than one tap");
+  if (g.OC > 64) return no("at most 64 out_chans (every wave multiplies all of them)");
+  if (g.OW > 256 || g.OW < 1) return no("output rows of at most 256 positions");
+  int cg = patch_cg(ncg, taps);
+  if (char const *e = getenv("BODAHIP_NHWC_PATCH_CG")) { if (atoi(e) > 0) cg = std::min(ncg, atoi(e)); }
+  int const nkt = (ncg + cg - 1) / cg, npr = cg * taps, kn = (npr + (npr & 1)) / 2, nit = nkt * kn;
+  if (nit * 2 * 4 > 160) return no("the filters do not fit the registers (K too long)");
+  if (post.pooled() && !g.relu) return no("the fused pooling needs the convolution's ReLU (non-negative values)");
+  if (post.LRN_N && !(post.pooled() && (post.LRN_N & 1) && post.LRN_N <= 9)) return no("the fused LRN follows a fused pooling; odd local sizes up to 9");
+  int wj = 8; if (char const *e = getenv("BODAHIP_NHWC_ROWS_WJ")) { int const v = atoi(e); if (v == 2 || v == 4 || v == 8) wj = v; }
+  int tr = std::max(1, std::min(256 / g.OW, 8)); if (char const *e = getenv("BODAHIP_NHWC_ROWS_TR")) { int const v = atoi(e); if (v >= 1 && v * g.OW <= 256) tr = v; }
+  auto lds = [&](int trx) {
+    int const wr = g.W + 2 * g.PX; int wp = wr; for (int q = wr; q < wr + 16; ++q) if ((q - g.OW) % 16 == 0) { wp = q; break; }
+    long const cs = (long)(trx + g.KH - 1) * wp, csp = cs + ((2 - cs % 16) + 16) % 16;
+    return 2l * 16l * ncg * csp + (long)(post.pooled() ? trx + post.PKH - 1 : trx) * g.OW * (64 * 2 + 16) + (post.pooled() ? (long)post.POW * 160 : 0l) + 256l;
+  };
+  while (tr > 1 && lds(tr) > 160 * 1024) --tr;
+  if (lds(tr) > 160 * 1024) return no("the input rows of one output row do not fit the LDS");
+  p = plan_t(); p.nhwc = true; p.nhwc_rows = true; p.bf16 = true; p.kname = "bodahip_conv_nhwc_rows_bf16"; p.cg = cg; p.rows = tr;
+  tile_cfg_t c; c.MT = 32; c.SPLITK = 1; c.PF = 1; c.BI = 64; c.BJ = 256; c.BK = g.C * taps; c.WI = 1; c.WJ = wj; c.MINW = 1;
+  p.cfg = c;
+  p.defs = {"-DCIN=" + std::to_string(g.C), "-DCG=" + std::to_string(cg), "-DKH=" + std::to_string(g.KH), "-DKW=" + std::to_string(g.KW), "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX),
+            "-DCH=" + std::to_string(g.H), "-DCW=" + std::to_string(g.W), "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW), string("-DRELU=") + (g.relu ? "1" : "0"),
+            "-DWJ=" + std::to_string(wj), "-DTR=" + std::to_string(tr)};
+  if (post.pooled()) for (auto const &kv : std::vector<std::pair<char const *, int>>{{"PKH", post.PKH}, {"PKW", post.PKW}, {"PSY", post.PSY}, {"PSX", post.PSX}, {"PPY", post.PPY}, {"PPX", post.PPX}, {"POH", post.POH}, {"POW", post.POW}})
+    p.defs.push_back(string("-D") + kv.first + "=" + std::to_string(kv.second));
+  if (post.LRN_N) { p.defs.push_back("-DLRN_N=" + std::to_string(post.LRN_N)); p.defs.push_back("-ffast-math"); }   // (the LRN expression under the flags of the generated LRN functions: see the kernel)
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return true;
+}
+// Plain convolutions (no post ops) that take the rolling-rows kernel by themselves: output-bound stems -- a short K (the filters in registers), few out_chans, a large
+// output.  BODAHIP_NHWC_ROWS=0: never (the patch kernel, as before round 5); =1: wherever the form applies.
+bool rows_auto(conv_geom_t const &g, int num_cus, string const &tile) {
+  char const *e = getenv("BODAHIP_NHWC_ROWS");
+  if ((e && atoi(e) == 0) || !tile.empty()) return false;
+  plan_t p;
+  if (!plan_conv_nhwc_rows(g, post_ops_t(), num_cus, p)) return false;
+  if (e && atoi(e) == 1) return true;
+  return (long)g.C * g.KH * g.KW <= 512 && (double)g.B * g.OH * g.OW * g.OC * 2.0 >= 32e6 && g.B * 2 >= num_cus / 4;
+}
+
+
+// What follows the convolution inside the rolling-rows launch (annotations of the function's op, boda_amd/nhwc.py fuse_post): uint32 nhwc_post_pool = 1 with dims
+// post_pool_sz / post_pool_stride / post_pool_pad (y, x); uint32 nhwc_post_lrn = local size with floats post_lrn_alpha / post_lrn_beta / post_lrn_k.  The function's
+// `out` is then the POOLED tensor: g arrives with OH x OW read from it; they become post's planes and g gets the convolution's own.
+static float op_f32(op_base_t const &op, string const &an) {
+  p_nda_t const &n = op.get(an); if (n->dims.tn != "float" || n->dims.sz() != 0 || !n->rp) rt_err("op: '" + an + "' is not a float scalar");
+  return *static_cast<float const *>(n->rp);
+}
+bool apply_post_ops(op_base_t const &op, conv_geom_t &g, post_ops_t &post, char const *what) {
+  post = post_ops_t();
+  if (!op.has("nhwc_post_pool") || !op.get_u32("nhwc_post_pool")) return false;
+  dims_t const &ks = op.get_dims("post_pool_sz"), &st = op.get_dims("post_pool_stride"), &pp = op.get_dims("post_pool_pad");
+  post.PKH = (int)ks.dsz("y"); post.PKW = (int)ks.dsz("x"); post.PSY = (int)st.dsz("y"); post.PSX = (int)st.dsz("x"); post.PPY = (int)pp.dsz("y"); post.PPX = (int)pp.dsz("x");
+  post.POH = g.OH; post.POW = g.OW;
+  if (!g.SY || !g.SX) rt_err(string(what) + ": zero stride");
+  g.OH = (g.H + 2 * g.PY - g.KH) / g.SY + 1; g.OW = (g.W + 2 * g.PX - g.KW) / g.SX + 1;
+  if (post.PKH < 1 || post.PKW < 1 || post.PKH > 7 || post.PKW > 7 || post.PSY < 1 || post.PSX < 1 || post.PPY < 0 || post.PPX < 0 || post.PPY >= post.PKH || post.PPX >= post.PKW)
+    unsup_err(string(what) + ": fused pooling behind the convolution takes windows of at most 7 x 7 with a padding smaller than the window");
+  if (post.POH < 1 || post.POW < 1 || (post.POH - 1) * post.PSY - post.PPY >= g.OH || (post.POW - 1) * post.PSX - post.PPX >= g.OW)
+    rt_err(string(what) + ": the pooled planes of `out` have windows outside the convolution's output");
+  if (op.has("nhwc_post_lrn") && op.get_u32("nhwc_post_lrn")) {
+    post.LRN_N = (int)op.get_u32("nhwc_post_lrn"); post.alpha = op_f32(op, "post_lrn_alpha"); post.beta = op_f32(op, "post_lrn_beta"); post.k = op_f32(op, "post_lrn_k");
+  }
+  return true;
+}
+
+// Exact fp32 convolutions whose operands are k-contiguous in the REFERENCE layout -- output 1x1, no padding, kernel == whole input (AlexNet
+// fc6-fc8: in[img][K], filts[out_chan][K]) -- through the LDS-DMA kernel's IN_F32 variant (kernels/conv_nhwc_bf16.hip): 64x64 tiles of four
+// waves, 32-deep K steps, an 8-slot LDS ring (six K steps of loads in flight).  Same ascending-k fma chain: bit-exact (tested).  MEASURED SLOWER
+// than the register-staged gather kernel on MI355X and therefore opt-in (BODAHIP_IPCONV_DMA=1): AlexNet fc6 / fc7 at 256 images 65.5 / 63.8 TF/s
+// with 8 ring slots (37 / 37 with 2 or 4) against 80.5 / 78.6 -- a workgroup alone on its CU streaming 16 KB per K step through LDS-DMA gets
+// ~16 GB/s however many steps are in flight (the per-CU LDS-DMA fill rate from HBM), less than two register-staged K-tiles deliver.
+bool plan_ipconv_dma(conv_geom_t const &g, int num_cus, plan_t &p) {
+  if (!getenv("BODAHIP_IPCONV_DMA")) return false;
+  long const Kt = (long)g.C * g.KH * g.KW;
+  if (!(g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W)) return false;
+  if (Kt % 4 || Kt < 512) return false;
+  long const tiles = (long)((g.OC + 63) / 64) * ((g.B + 63) / 64);
+  if (tiles * 4 < num_cus * 3 && string(getenv("BODAHIP_IPCONV_DMA")) != "force") return false;   // fewer workgroups than 3/4 of the CUs: finer (16x16-MFMA) tiles of the gather kernel do better
+  tile_cfg_t c; c.BI = 64; c.BJ = 64; c.BK = 32; c.WI = 2; c.WJ = 2; c.MINW = 1; c.SPLITK = 1; c.MT = 32; c.PF = 8;
+  if (char const *e = getenv("BODAHIP_IPCONV_DMA_NBUF")) c.PF = std::max(2, std::min(8, atoi(e)));
+  p = plan_t(); p.nhwc = true; p.kname = "bodahip_conv_nhwc_f32"; p.cfg = c;
+  p.defs = {"-DBI=64", "-DBJ=64", "-DBK=32", "-DWI=2", "-DWJ=2", "-DMINW=1", "-DCIN=" + std::to_string(Kt), "-DKH=1", "-DKW=1", "-DSY=1", "-DSX=1", "-DPY=0", "-DPX=0",
+            "-DCH=1", "-DCW=1", "-DCOH=1", "-DCOW=1", string("-DRELU=") + (g.relu ? "1" : "0"), "-DOUT_F32=1", "-DIN_F32=1", "-DNBUF=" + std::to_string(c.PF)};
+  if (char const *e = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(e); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return true;
+}
+// Tolerance mode (tune `exact` = 0, op_tune hip_exact=0): the default fp32 plan keeps every output ONE ascending-k fma chain -- bit-identical to the
+// reference's per-thread loop -- which leaves tile-starved layers with a long K (AlexNet fc6 / fc7 / fc8: 256 / 256 / 64 tiles of 64x64 for 256
+// CUs, 128-288 barrier-separated K steps each) on one workgroup per CU.  The reference's own bar is a tolerance, not bit equality; with exact = 0
+// the planner may cut K into slices (deterministic: slice s owns K-tiles [s*kt_per, (s+1)*kt_per), the slabs are summed in ascending slice
+// order by bodahip_splitk_reduce) when the tiles do not fill the chip and K >= 512 (>= 8 K steps per slice).  That re-associates the sum: on the reference's U(-5,5)
+// data fc6 (K = 9216) then differs from the single chain by mrd 8.6e-4 -- inside the reference's bound for re-associating kernels (2e-3,
+// src/rtc_prof.cc:317-319,436), outside its 2e-4 default (:161), and no farther from the exact fp64 product than the chain itself (tested).
+// Measured (MI355X, AlexNet at 256 images, TF/s): fc6 75 -> 94 alone, 80 -> 106 in the layer sequence (64x64, 4 slices of 72 K steps),
+// fc7 78 -> 94, fc8 33 -> 57.
+static void tolerance_splitk(plan_t &p, conv_geom_t const &g, int num_cus, long Nj, long Kt) {
+  static long const min_k = getenv("BODAHIP_TOL_MIN_K") ? atol(getenv("BODAHIP_TOL_MIN_K")) : 512, min_steps = getenv("BODAHIP_TOL_MIN_STEPS") ? atol(getenv("BODAHIP_TOL_MIN_STEPS")) : 8;
+  // (swept on MI355X, fp32 lists at 64 images, effective TF/s with (min K, min K steps per slice) = (2048, 32) / (1024, 16) / (512, 8): GoogLeNet 76.7 / 78.3 / 79.9, ResNet-50 100.5 / 101.5 /
+  //  101.7, AlexNet at 256 images 139.2 / 141.0 / 139.6)
+  if (p.bf16 || p.stream || p.patch16 || p.patch || p.nhwc || p.rows || p.cfg.SPLITK != 1 || Kt < min_k) return;
+  tile_cfg_t c = p.cfg;
+  long tiles = (long)((g.OC + c.BI - 1) / c.BI) * ((Nj + c.BJ - 1) / c.BJ);
+  if (tiles > num_cus) return;
+  if (c.MT != 32 || c.BI < 64 || c.BJ < 64) {   // the thin tiles tile starvation chose: with K slices the common 64x64 tile fills the chip
+    c.BI = 64; c.BJ = 64; c.BK = 32; c.WI = 2; c.WJ = 2; c.MINW = 2; c.MT = 32; c.PF = 2;
+    tiles = (long)((g.OC + 63) / 64) * ((Nj + 63) / 64);
+  }
+  long const nkt = (Kt + c.BK - 1) / c.BK;
+  int sk = 1;
+  while (sk < 16 && nkt / (sk * 2) >= min_steps && tiles * sk * 2 <= 4l * num_cus) sk *= 2;
+  if (sk < 2) return;
+  c.SPLITK = sk; p.cfg = c;
+}
+// Strided convolutions without padding and with wide kernels (conv1 layers: 11x11 / 4): the row-decimated LDS patch of gemm_conv_f32.hip (-DRDEC=1, J_MODE 7 presented with
+// C*KH row sets of 1 x KW kernels).  BODAHIP_RDEC = off | BIxBJxWIxWJxMINW.  In the returned plan cfg.BK = row sets per K step x KW.
+static bool plan_rdec(conv_geom_t const &g, int num_cus, plan_t &p) {
+  char const *e = getenv("BODAHIP_RDEC");
+  if (e && string(e) == "off") return false;
+  if (!(g.PY == 0 && g.PX == 0 && g.SY > 1 && g.KH >= 2 && g.KW >= 6 && g.KW <= 16 && g.OH > 1)) return false;
+  int cb = 1; while (cb * g.KW < 20 || ((cb * g.KW) & 1)) ++cb;
+  int const bk = cb * g.KW; if (bk > 128) return false;
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  auto fits = [&](tile_cfg_t const &c) {
+    int const rows_max = (c.BJ - 2) / g.OW + 2; long const cs = (long)rows_max * g.W;
+    return 2l * 4 * ((long)bk * (c.BI + 4) + cb * cs) <= 64 * 1024 && cs <= 16l * (c.WI * c.WJ * 64);
+  };
+  struct cand_t { int bi, bj, wi, wj, minw; double base; };
+  // measured (MI355X, AlexNet conv1 at 256 images, isolated, us): row gather 96x256 531 | row-decimated patch 32x256 508, 96x256 546, 96x128 549-562, 64x256 (padded out_chans) 628
+  static cand_t const cands[] = {{32, 256, 1, 4, 2, 1.00}, {96, 256, 1, 4, 2, 0.93}, {64, 256, 1, 4, 2, 0.93}, {128, 256, 2, 4, 1, 0.90}};
+  tile_cfg_t best_c; double best = -1;
+  if (e && *e) { int v[5]; if (sscanf(e, "%dx%dx%dx%dx%d", &v[0], &v[1], &v[2], &v[3], &v[4]) != 5) rt_err(string("bad BODAHIP_RDEC '") + e + "' (off | BIxBJxWIxWJxMINW)");
+    best_c.BI = v[0]; best_c.BJ = v[1]; best_c.WI = v[2]; best_c.WJ = v[3]; best_c.MINW = v[4]; best_c.BK = bk; best_c.MT = 32; best_c.SPLITK = 1; best_c.PF = 1;
+    if (!fits(best_c)) unsup_err(string("BODAHIP_RDEC '") + e + "': the tile does not fit"); best = 1; }
+  else for (cand_t const &cd : cands) {
+    tile_cfg_t c; c.BI = cd.bi; c.BJ = cd.bj; c.WI = cd.wi; c.WJ = cd.wj; c.MINW = cd.minw; c.BK = bk; c.MT = 32; c.SPLITK = 1; c.PF = 1;
+    if (!fits(c)) continue;
+    long const ti = (g.OC + c.BI - 1) / c.BI, tj = (Nj + c.BJ - 1) / c.BJ, tiles = ti * tj;
+    double const pad = ((double)g.OC / (double)(ti * c.BI)) * ((double)Nj / (double)(tj * c.BJ));
+    double const bal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
+    double const score = cd.base * pad * bal;
+    if (score > best) { best = score; best_c = c; }
+  }
+  if (best < 0) return false;
+  check_cfg(best_c, false, true);
+  p = plan_t(); p.kname = "bodahip_conv_f32"; p.patch = true; p.rdec = true; p.cfg = best_c;
+  p.defs = cfg_defs(p.cfg);
+  p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0 && bk % 4 == 0) ? "2" : ((Kt % 2 == 0) ? "4" : "3")));
+  for (string const &d : {string("-DJ_MODE=7"), string("-DRDEC=1"), "-DC0=" + std::to_string(g.C), "-DH0=" + std::to_string(g.H), "-DKH0=" + std::to_string(g.KH), "-DSY0=" + std::to_string(g.SY),
+                          "-DCH=" + std::to_string(g.OH), "-DCW=" + std::to_string(g.W), "-DCOH=" + std::to_string(g.OH), "-DCOW=" + std::to_string(g.OW), string("-DEPI=1"),
+                          string("-DKH=1"), "-DKW=" + std::to_string(g.KW), string("-DSY=1"), "-DSX=" + std::to_string(g.SX), string("-DPY=0"), string("-DPX=0"),
+                          string("-DRELU=") + (g.relu ? "1" : "0")}) p.defs.push_back(d);
+  return true;
+}
+// Round 6: kernels/conv_big_f32.hip -- WI x WJ multiplying waves + four staging waves (tile field SW == 2): "TBIxTBJxBKSxWIxWJxMINWx1x32xPFx2".  The pel side takes the
+// cheapest form the geometry allows: the LDS input patch (stride 1 in x, more than one tap: BKS becomes whole channels, the smallest even multiple of KH KW that is >= the
+// tile's BKS), the plain 1x1 form, else the table gather.  The host-side checks are the kernel's static_asserts (a bad tune is an unsup_err, not a compile failure).
+struct conv_big_form_t { int jmode = 2, bks = 16, nstg = 4, ivw = 1; long lds = 0; bool rdec = false; };
+static bool conv_big_form(conv_geom_t const &g, tile_cfg_t const &c, conv_big_form_t &f, string *why = nullptr) {
+  auto bad = [&](char const *m) { if (why) *why = m; return false; };
+  int const nmw = c.WI * c.WJ;
+  if (!(nmw == 8 || nmw == 4)) return bad("eight (or four) multiplying waves");
+  if (c.BI <= 0 || c.BJ <= 0 || c.BI % (c.WI * 32) || c.BJ % (c.WJ * 32)) return bad("tile not a multiple of the waves' 32 x 32 blocks");
+  int const ti = c.BI / (c.WI * 32), tj = c.BJ / (c.WJ * 32);
+  if (ti > 4 || tj > 4 || ti * tj > 8) return bad("more than 4 x 2 | 2 x 4 blocks per wave");
+  if (c.BK % 2 || c.BK < 4 || c.BK > 64) return bad("BKS: even, 4 .. 64");
+  if (!(c.PF == 1 || c.PF == 2 || c.PF == 4) || c.MT != 32 || c.SPLITK != 1 || c.KHO > 1 || c.MINW < 1 || c.MINW > 2) return bad("PF 1 | 2 | 4, MT 32, no K slices / hand-off, MINW 1 | 2");
+  long const Kt = (long)g.C * g.KH * g.KW;
+  int const ldi = (c.BI / ti) * (ti == 3 ? 4 : ti) + 4, ldj = (c.BJ / tj) * (tj == 3 ? 4 : tj) + 4;
+  long img_j = 0;
+  bool const k1 = g.KH == 1 && g.KW == 1 && g.PY == 0 && g.PX == 0;
+  // strided, unpadded, wide kernels (conv1 layers: 11x11 / 4): the row-decimated patch -- C * KH row sets of 1 x KW kernels over the OH decimated rows (-DRDEC=1)
+  bool const rdec = !k1 && g.PY == 0 && g.PX == 0 && g.SY > 1 && g.KH >= 2 && g.KW >= 6 && g.KW <= 16 && g.OH > 1 && getenv("BODAHIP_CBIG_NO_PATCH") == nullptr;
+  bool const patch = rdec || (!k1 && g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && getenv("BODAHIP_CBIG_NO_PATCH") == nullptr);
+  f.bks = c.BK;
+  bool patch_ok = false;
+  if (patch) {   // (a patch that does not fit -- whole-input windows, very wide planes -- gives way to the table gather)
+    int const taps = rdec ? g.KW : g.KH * g.KW; int cb = 1; while (cb * taps < c.BK || (cb * taps) % 2) ++cb;
+    int const wp = rdec ? g.SX * ((g.W + g.SX - 1) / g.SX) : g.W + 2 * g.PX, rows_max = (c.BJ - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
+    long const cs = rdec ? (long)rows_max * wp : (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp;
+    long const stage4 = ((long)cb * taps * ldi + (cb * cs + 3) / 4 * 4) * 4;
+    if (cb * taps <= 128 && cs <= 16 * 256 && 3 * stage4 <= 160l * 1024 / c.MINW) { patch_ok = true; f.bks = cb * taps; f.jmode = 7; f.rdec = rdec; img_j = (cb * cs + 3) / 4 * 4; }
+  }
+  if (!patch_ok) {
+    int const cpt = (c.BJ + 255) / 256; if (c.BJ % cpt) return bad("pel columns per staging thread");
+    int const tw = c.BJ / cpt; if (tw % 64 || 256 / tw < 1 || c.BK % (256 / tw)) return bad("pel staging: whole waves per k row");
+    if (!k1 && (c.BK / (256 / tw)) % 4) return bad("table gather: whole quads of k rows per staging thread");
+    f.jmode = k1 ? 5 : 2; img_j = (long)f.bks * ldj;
+  }
+  // filters: k-major from the call's scratch (0; bodahip_conv_big_xpose runs first) unless BODAHIP_CBIG_IVW=direct asks for loads straight from OIHW rows (4 | 2 | 1 floats along k)
+  f.ivw = 0; if (char const *e = getenv("BODAHIP_CBIG_IVW")) { if (string(e) == "direct") f.ivw = (Kt % 4 == 0 && f.bks % 4 == 0) ? 4 : ((Kt % 2 == 0 && f.bks % 2 == 0) ? 2 : 1); }
+  long const stage = ((long)f.bks * ldi + img_j) * 4, cap = 160l * 1024 / c.MINW;
+  f.nstg = 4; if (char const *e = getenv("BODAHIP_CBIG_NSTG")) f.nstg = atoi(e); else if (4 * stage > cap) f.nstg = 3;
+  if (!(f.nstg == 3 || f.nstg == 4) || f.nstg * stage > cap) return bad("LDS stages exceed the CU's 160 KB");
+  f.lds = f.nstg * stage;
+  return true;
+}
+static plan_t plan_conv_big(conv_geom_t const &g0, tile_cfg_t const &c) {
+  string why; conv_big_form_t f;
+  if (!conv_big_form(g0, c, f, &why)) unsup_err("native kernel: unsupported staging-wave tile " + c.str() + " (" + why + ")");
+  plan_t p; p.cbig = true; p.k1 = (f.jmode == 5); p.patch = (f.jmode == 7); p.rdec = f.rdec; p.kname = "bodahip_conv_big_f32"; p.cfg = c; p.cfg.BK = f.bks;
+  conv_geom_t g = g0; if (f.rdec) { g.KH = 1; g.SY = 1; g.H = g0.OH; }   // (the decimated presentation: 1 x KW kernels, stride 1 in y, OH rows)
+  p.defs = {"-DTBI=" + std::to_string(c.BI), "-DTBJ=" + std::to_string(c.BJ), "-DWI=" + std::to_string(c.WI), "-DWJ=" + std::to_string(c.WJ), "-DBKS=" + std::to_string(f.bks),
+            "-DPF=" + std::to_string(c.PF), "-DNSTG=" + std::to_string(f.nstg), "-DMINW=" + std::to_string(c.MINW), "-DI_VW=" + std::to_string(f.ivw), "-DJ_MODE=" + std::to_string(f.jmode),
+            "-DKH=" + std::to_string(g.KH), "-DKW=" + std::to_string(g.KW), "-DSY=" + std::to_string(g.SY), "-DSX=" + std::to_string(g.SX),
+            "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX), string("-DRELU=") + (g.relu ? "1" : "0")};
+  if (f.jmode == 7) for (auto const &kv : {std::make_pair("CH", g.H), std::make_pair("CW", g.W), std::make_pair("COH", g.OH), std::make_pair("COW", g.OW)}) p.defs.push_back(string("-D") + kv.first + "=" + std::to_string(kv.second));
+  if (f.rdec) for (auto const &kv : {std::make_pair("RDEC", 1), std::make_pair("C0", g0.C), std::make_pair("H0", g0.H), std::make_pair("KH0", g0.KH), std::make_pair("SY0", g0.SY)}) p.defs.push_back(string("-D") + kv.first + "=" + std::to_string(kv.second));
+  if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
+  return p;
+}
+static plan_t plan_conv_tiled(conv_geom_t const &g, int num_cus, string const &tile, bool bf16, string const &k1s, bool allow_splitk, bool exact) {
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  plan_t p;
+  if (!bf16 && tile.empty() && plan_ipconv_dma(g, num_cus, p)) return p;
+  if (!bf16 && tile.empty() && plan_k1_stream(g, num_cus, k1s, p)) return p;
+  if (!bf16 && tile.empty() && !g.pooled() && plan_rdec(g, num_cus, p)) return p;
+  if (bf16 && tile.empty() && plan_patch_bf16(g, num_cus, p)) return p; p.kname = bf16 ? "bodahip_conv_bf16" : "bodahip_conv_f32"; p.bf16 = bf16;
+  // output 1x1, no padding, kernel == whole input ("ipconv" case): the im2col row of image j is the contiguous image
+  p.ipconv = (g.OH == 1 && g.OW == 1 && g.PY == 0 && g.PX == 0 && g.KH == g.H && g.KW == g.W);
+  p.cfg = choose_cfg(g.OC, (int)Nj, (int)Kt, num_cus, !p.ipconv, bf16);
+  if (!tile.empty()) { if (!parse_tile(tile, p.cfg)) rt_err("bad conv_tile '" + tile + "'"); }
+  if (!bf16 && p.cfg.SW == 2) {   // the staging-wave kernel, asked for by its own tile string
+    if (g.pooled()) unsup_err("hip_conv: fused pooling (hip_pool) is a form of the LDS-patch kernel, not of the staging-wave kernel");
+    return plan_conv_big(g, p.cfg);
+  }
+  // wide kernels: row gather (one address + wide loads per (in_chan,ky) row of KW taps): a K step is `rows` whole rows, BK = rows*KW.
+  // Measured (MI355X, B=256): 11x11/s4 +8%, 5x5 -3%, 3x3 -9% vs the per-element table gather (unaligned x3 loads cost more than the
+  // address arithmetic they save), so the default takes it for KW >= 6 only; BODAHIP_ROW_GATHER_MIN_KW overrides (>= 2).
+  p.rows = 0;
+  int rg_min_kw = 6; if (char const *e = getenv("BODAHIP_ROW_GATHER_MIN_KW")) rg_min_kw = std::max(2, atoi(e));
+  if (!bf16 && !p.ipconv && g.KW >= rg_min_kw && g.KW <= 16 && getenv("BODAHIP_NO_ROW_GATHER") == nullptr) {
+    int const rpp = std::max(1, p.cfg.WI * p.cfg.WJ * 64 / p.cfg.BJ);               // row groups per K step
+    int rows = (g.KW <= 3) ? 8 : (g.KW <= 8 ? 4 : 2);                        // BK = 16..28 (22 for 11x11)
+    while (rows % rpp) rows += 2;
+    if ((rows * g.KW) % 2 == 0 && rows % rpp == 0 && (p.cfg.WI * p.cfg.WJ * 64) % p.cfg.BJ == 0 && p.cfg.BJ % 64 == 0 && p.cfg.MT == 32) { p.rows = rows; p.cfg.BK = rows * g.KW; }
+  }
+  // 1x1 kernel, no padding (any stride): the reference's k1conv case -- one add per gathered element, no table
+  p.k1 = !p.ipconv && g.KH == 1 && g.KW == 1 && g.PY == 0 && g.PX == 0;
+  // long-K 1x1 layers on 64x64 tiles: a 32-deep K step (tools/tune_tiles.py over GoogLeNet / ResNet-50 at B=64: every 1x1 layer with
+  // >= 480 input channels gains 4-6 % over the 16-deep step; with 256 channels and fewer it does not)
+  if (p.k1 && !bf16 && tile.empty() && p.cfg.BI == 64 && p.cfg.BJ == 64 && p.cfg.MT == 32 && p.cfg.BK == 16 && g.C >= 448) p.cfg.BK = 32;
+  // Round 5, in-sequence A/Bs through the tile-wisdom path (tools/wisdom_ab.sh; isolated sweeps mislead here): a 1x1 layer whose 128 x 128 tiles still make >= 3.5 rounds
+  // of the CUs runs 8-9 % faster on them than on the 64 x 64 tiles the short-launch rule prefers (half the operand bytes per flop through the L2) -- NiN cccp5 / cccp6 at
+  // 256 images 128 -> 116 us, cccp3 / cccp4 at 128 images 129 -> 119 us; with fewer tiles (cccp5 at 128 images: 507, cccp7 / cccp8: 288-576) the finer tiles stay ahead.
+  if (p.k1 && !bf16 && tile.empty() && p.cfg.BI == 64 && p.cfg.BJ == 64 && p.cfg.MT == 32 && g.OC % 128 == 0 && getenv("BODAHIP_NO_K1_128") == nullptr) {
+    long const t128 = (long)(g.OC / 128) * ((Nj + 127) / 128);
+    if (t128 * 2 >= 7l * num_cus) { p.cfg.BI = 128; p.cfg.BJ = 128; p.cfg.BK = 16; p.cfg.WI = 2; p.cfg.WJ = 2; p.cfg.MINW = 2; p.cfg.PF = 1; }
+  }
+  // SX == 1, more than one tap: LDS input patch (J_MODE 7) -- a K step is CB whole input channels, staged as padded input rows
+  // (coalesced, ~KH*KW x fewer loads than an im2col image) and read by the MFMAs in place.  Needs compile-time plane sizes.
+  p.patch = false;
+  if (!bf16 && !p.ipconv && !p.k1 && !p.rows && g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && (tile.empty() || (p.cfg.MT == 32 && p.cfg.SPLITK == 1)) &&
+      getenv("BODAHIP_NO_PATCH") == nullptr) { // (an explicit tile keeps its BI/BJ/waves; its BK is replaced by whole channels)
+    int const taps = g.KH * g.KW;
+    int const bk_min = tile.empty() ? 32 : p.cfg.BK;                          // an explicit tile's BK is the lower bound for the K step
+    int cb = 1; while (cb * taps < bk_min || (cb * taps) % 2) ++cb;          // BK = cb*taps: even, >= 32 (3x3 -> 36, 5x5 -> 50, 2x2 -> 32)
+    int const bk = cb * taps, wp = g.W + 2 * g.PX;
+    auto fits = [&](tile_cfg_t const &c, long lds_max) {
+      int const rows_max = (c.BJ - 2) / g.OW + 2, seg_max0 = (g.OH - 1 + rows_max - 1) / g.OH + 1, seg_max = std::min(seg_max0, rows_max);
+      long const cs = (long)((rows_max - seg_max) * g.SY + seg_max * g.KH) * wp;
+      long const lds = 2l * 4 * ((long)bk * (c.BI + 4) + cb * cs);
+      return bk <= 128 && lds <= lds_max && cs <= 16l * (c.WI * c.WJ * 64);
+    };
+    if (!tile.empty()) { if (fits(p.cfg, 160 * 1024)) { p.patch = true; p.cfg.BK = bk; } }
+    else {
+      // Staging the pel side is nearly free here, so the best tiles are narrow in out_chan and wide in pels (the filter tile is
+      // staged once per 256 pels) with few accumulators per wave (<= 128 VGPRs: four waves per SIMD).  Measured steady state on
+      // MI355X (B=256 AlexNet conv2-5, TF/s): 64x256 126-131 | 128x256 125-131 | 32x256 110-129 | 64x64 116-122 | 128x128 109-120;
+      // the score is that base rate x tile padding x how evenly the tiles deal out over the CUs.
+      struct cand_t { int bi, bj, wi, wj, minw; double base; };
+      // tools/tune_tiles.py over every distinct GoogLeNet / ResNet-50 layer at B=64 (ten candidate tiles each) corrected two entries: with a
+      // short K loop (< 2048: 64-192 input channels) the 64x64 tile is worth 0.82, not 0.93, of a 64x256 one (GoogLeNet conv2 3x3 64->192
+      // @56x56: 471 vs 380 us), and the 32x128 tile wants four waves (one 32x32 block each), not two (3x3 / 5x5 layers with 32-224 out_chans:
+      // 13-57 % faster).  What the sweep still finds after that is within a few percent of the planner's choice.
+      static double const k32x256 = getenv("BODAHIP_BASE_32X256") ? atof(getenv("BODAHIP_BASE_32X256")) : 0.97; // (0.90 until the planner A/B of tools/tune_all.sh: AlexNet / NiN conv2 5x5 at B=256 1760 -> 1664 us on 32x256, -2 % on both lists)
+      static cand_t const cands[] = {{64, 256, 1, 4, 2, 1.00}, {128, 256, 2, 4, 1, 0.99}, {32, 256, 1, 4, 2, k32x256}, {64, 64, 2, 2, 2, 0.93}, {128, 128, 2, 2, 2, 0.92}, {32, 128, 1, 4, 2, 0.80}};
+      double best = -1;
+      for (cand_t const &cd : cands) {
+        tile_cfg_t c = p.cfg; c.BI = cd.bi; c.BJ = cd.bj; c.WI = cd.wi; c.WJ = cd.wj; c.MINW = cd.minw; c.BK = bk; c.MT = 32; c.SPLITK = 1;
+        if (!fits(c, 64 * 1024)) continue;
+        long const ti = (g.OC + c.BI - 1) / c.BI, tj = (Nj + c.BJ - 1) / c.BJ, tiles = ti * tj;
+        double const pad = ((double)g.OC / (double)(ti * c.BI)) * ((double)Nj / (double)(tj * c.BJ));
+        double const bal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
+        double score = cd.base * pad * bal * ((cd.bi == 64 && cd.bj == 64 && Kt < 2048) ? (0.82 / 0.93) : 1.0);
+        if (2.0 * g.OC * (double)Nj * Kt < 2.4e10) { double const x = (double)tiles / num_cus; score *= x / (x + kShortTail); } // short launches: see choose_cfg
+        if (score > best) { best = score; p.cfg = c; p.patch = true; }
+      }
+    }
+  }
+  if (p.patch && tile.empty()) p.cfg.PF = pf_for(p.cfg);
+  if (g.pooled()) {   // a max pooling fused in front (round 5): the LDS-patch form only, one K tile in flight (the window rows are gathered under thirds of a step's MFMAs)
+    if (bf16 || !p.patch || p.rdec) unsup_err("hip_conv: fused pooling (hip_pool) needs an fp32 convolution that takes the LDS-patch form (stride 1 in x, more than one tap)");
+    p.cfg.PF = 1; p.cfg.SW = 0; p.cfg.SPLITK = 1;
+  }
+  if (!bf16 && !exact && tile.empty() && allow_splitk && !g.pooled()) tolerance_splitk(p, g, num_cus, Nj, Kt);
+  // fully-connected layers (whole-input windows, both operands k-contiguous): kernels/fc_f32.hip -- four multiplying + four staging waves, three LDS stages, 16x16x4
+  // MFMA chains.  Tile TM images x TN out_chans: the largest of 64x64 / 64x32 / 32x32 that still gives (nearly) every CU a workgroup.  BODAHIP_FC = off | TMxTNxBKFxPF
+  // (an explicit spec forces the kernel onto every layer it covers: tests).  Measured (MI355X, AlexNet at 256 images, layer sequence, us): fc6 223 -> 170, fc7 104 -> 82.
+  char const *fc_env = getenv("BODAHIP_FC");
+  bool const fc_forced = fc_env && *fc_env && string(fc_env) != "off";
+  if (!bf16 && p.ipconv && tile.empty() && Kt % 4 == 0 && p.cfg.SPLITK == 1 && !(fc_env && string(fc_env) == "off") &&
+      (fc_forced || (Kt >= 512 && (long)g.OC * Nj >= 65536))) {
+    int tm = 64, tn = 64, bkf = 64, pf = 2;
+    if (fc_forced) {
+      if (sscanf(fc_env, "%dx%dx%dx%d", &tm, &tn, &bkf, &pf) != 4 || (tm != 32 && tm != 64) || (tn != 32 && tn != 64) || (bkf != 32 && bkf != 64) || (pf != 2 && pf != 4))
+        rt_err(string("bad BODAHIP_FC '") + fc_env + "' (off | TMxTNxBKFxPF: 32|64 x 32|64 x 32|64 x 2|4)");
+    } else {
+      auto tiles = [&](int m, int n) { return (long)((Nj + m - 1) / m) * ((g.OC + n - 1) / n); };
+      if (tiles(64, 64) * 4 < (long)num_cus * 3) { tn = 32; if (tiles(64, 32) * 4 < (long)num_cus * 3) tm = 32; }
+    }
+    p.fc = true; p.kname = "bodahip_fc_f32"; p.cfg.BI = tn; p.cfg.BJ = tm; p.cfg.MT = 16; p.cfg.BK = bkf; p.cfg.PF = pf; p.cfg.MINW = 1; p.cfg.WI = 2; p.cfg.WJ = 4;   // (eight waves)
+    p.defs = {"-DTM=" + std::to_string(tm), "-DTN=" + std::to_string(tn), "-DBKF=" + std::to_string(bkf), "-DPF=" + std::to_string(pf), string("-DRELU=") + (g.relu ? "1" : "0")};
+    if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
+    return p;
+  }
+  if (bf16 || p.cfg.SPLITK > 1 || g.pooled()) p.cfg.KHO = 0;
+  if (p.cfg.KHO > 1) {   // K hand-off: no empty segment
+    long const nkt = (Kt + p.cfg.BK - 1) / p.cfg.BK, per = (nkt + p.cfg.KHO - 1) / p.cfg.KHO;
+    p.cfg.KHO = (int)((nkt + per - 1) / per); if (p.cfg.KHO <= 1) p.cfg.KHO = 0;
+  }
+  if (bf16) bf16_cfg(p.cfg, !p.ipconv, g.OC, Nj, Kt, allow_splitk ? num_cus : 0, !tile.empty());
+  else check_cfg(p.cfg, !p.ipconv && !p.patch, p.patch);
+  p.defs = cfg_defs(p.cfg);
+  p.defs.push_back(string("-DI_MODE=") + ((Kt % 4 == 0 && p.cfg.BK % 4 == 0) ? "2" : ((p.patch && Kt % 2 == 0) ? "4" : "3")));
+  p.defs.push_back(p.ipconv ? (string("-DJ_MODE=") + ((Kt % 4 == 0) ? "3" : "4")) : string(p.k1 ? "-DJ_MODE=5" : (p.patch ? "-DJ_MODE=7" : (p.rows ? "-DJ_MODE=6" : "-DJ_MODE=2"))));
+  if (p.rows) p.defs.push_back("-DJROWS=" + std::to_string(p.rows));
+  if (p.patch) { p.defs.push_back("-DCH=" + std::to_string(g.H)); p.defs.push_back("-DCW=" + std::to_string(g.W));
+                 p.defs.push_back("-DCOH=" + std::to_string(g.OH)); p.defs.push_back("-DCOW=" + std::to_string(g.OW)); }
+  if (g.pooled()) for (auto const &kv : {std::make_pair("PKH", g.PKH), std::make_pair("PKW", g.PKW), std::make_pair("PSY", g.PSY), std::make_pair("PSX", g.PSX), std::make_pair("UH", g.UH), std::make_pair("UW", g.UW)})
+    p.defs.push_back(string("-D") + kv.first + "=" + std::to_string(kv.second));
+  p.defs.push_back("-DEPI=1");
+  if (p.cfg.SPLITK > 1) p.defs.push_back("-DSPLITK=1");
+  p.defs.push_back("-DKH=" + std::to_string(g.KH)); p.defs.push_back("-DKW=" + std::to_string(g.KW));
+  p.defs.push_back("-DSY=" + std::to_string(g.SY)); p.defs.push_back("-DSX=" + std::to_string(g.SX));
+  p.defs.push_back("-DPY=" + std::to_string(g.PY)); p.defs.push_back("-DPX=" + std::to_string(g.PX));
+  p.defs.push_back(string("-DRELU=") + (g.relu ? "1" : "0"));
+  return p;
+}
+// plan_conv: the planner of hip_conv.  Round 6: stride-1 KH x KW >= 2 layers (the reference's tconv / conv cases) and 1 x 1 / stride-1 layers with K >= 384 (NiN cccp5-8;
+// shorter K belongs to the streaming kernels) go to the staging-wave kernel (kernels/conv_big_f32.hip) in its two-workgroups-per-CU tiles when those deal out evenly.
+// In-sequence A/Bs on MI355X (tools/cbig_ab_sets*.sh, tools/env_ab_ops.sh; us, round-5 plan -> this): AlexNet at 256 images conv2 1677 -> 1657, conv3 571 -> 532, conv4
+// 849 -> 784, conv5 649 -> 585; NiN at 256 images conv4 546 -> 463, cccp7 / cccp8 175 -> 152 (64 x 192 tiles of FOUR multiplying waves: 768 tiles = exactly three per CU),
+// at 128 images conv2 908 -> 850, conv3 315 -> 277, conv4 314 -> 267; its one-workgroup tiles (128 x 512, 256 x 256) measured level or slower.  A lone workgroup of
+// this kernel keeps the matrix pipe as busy as two co-resident ones (the staging waves hide the loads), so what counts is the deal over CUs, not over workgroup slots:
+// score = base x padding x (tiles / CUs) / ceil(tiles / CUs), taken when >= 0.76.  The tiles of one or two 32 x 32 blocks per wave only stand in for the tiled kernel's
+// tile-starvation choice (64 x 64): against its 32 x 256 / 64 x 256 tiles they measured slower (GoogLeNet 3x3 128 -> 192 at 28 x 28: 191 -> 212 us), and strided 1 x 1
+// layers stay where they were (ResNet-50 res4a_branch1 on 32 x 128 tiles: 141 -> 230 us).  BODAHIP_CBIG = off | force (any score).
+plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf16, string const &k1s, bool allow_splitk, bool exact) {
+  plan_t const old = plan_conv_tiled(g, num_cus, tile, bf16, k1s, allow_splitk, exact);
+  char const *e = getenv("BODAHIP_CBIG");
+  if (bf16 || !tile.empty() || g.pooled() || (e && string(e) == "off") || old.kname != "bodahip_conv_f32" || old.ipconv || old.cfg.SPLITK > 1 || old.cfg.KHO > 1) return old;
+  long const Nj = (long)g.B * g.OH * g.OW, Kt = (long)g.C * g.KH * g.KW;
+  if (old.rdec) {   // conv1 layers (11x11 / 4): the row-decimated patch of the staging-wave kernel on 96 x 256 tiles, one K tile in flight so that two workgroups share a CU (70
+    // registers) and one's prologue / stores hide under the other's 17 K steps: AlexNet / NiN conv1 at 256 images 472 -> 450 us in the layer sequence (round 6)
+    tile_cfg_t c; c.BI = 96; c.BJ = 256; c.BK = 16; c.WI = 1; c.WJ = 8; c.MINW = 2; c.SPLITK = 1; c.MT = 32; c.PF = 1; c.SW = 2; c.KHO = 0;
+    conv_big_form_t f; long const ti = (g.OC + 95) / 96;
+    bool const force_r = e && string(e) == "force";
+    if (conv_big_form(g, c, f) && f.rdec && ((double)g.OC / (double)(ti * 96) >= 0.95 || force_r) && (Nj >= 64l * num_cus || force_r)) return plan_conv_big(g, c);
+    return old;
+  }
+  bool const k1big = g.KH == 1 && g.KW == 1 && g.PY == 0 && g.PX == 0 && g.SY == 1 && g.SX == 1 && Kt >= 384;
+  bool const patchy = g.SX == 1 && g.KH * g.KW >= 2 && g.KH >= g.SY && !(g.KH == g.H && g.KW == g.W && g.OH == 1);
+  if (!k1big && !patchy) return old;
+  bool const force = e && string(e) == "force", old_small = (old.cfg.BI <= 64 && old.cfg.BJ <= 64) || force;
+  struct cand_t { int bi, bj, wi, wj; double base; bool small; };
+  static cand_t const cands[] = {{128, 256, 2, 4, 1.00, false}, {64, 512, 1, 8, 1.00, false}, {64, 256, 1, 8, 0.98, false}, {128, 128, 2, 4, 0.97, false},   // eight multiplying waves: 2 x 2 | 2 x 1 blocks each
+                                 {64, 192, 2, 2, 0.97, false}, {128, 128, 2, 2, 0.96, false},                                                             // four: 1 x 3 | 2 x 2
+                                 {64, 128, 2, 2, 0.92, true}, {32, 128, 1, 4, 0.86, true}, {64, 64, 2, 2, 0.85, true}};                                   // four: 1 x 2 | 1 x 1 | 1 x 1
+  double best = -1; tile_cfg_t best_c;
+  for (cand_t const &cd : cands) {
+    if (cd.small && !old_small) continue;
+    tile_cfg_t c; c.BI = cd.bi; c.BJ = cd.bj; c.BK = 16; c.WI = cd.wi; c.WJ = cd.wj; c.MINW = 2; c.SPLITK = 1; c.MT = 32; c.PF = 2; c.SW = 2; c.KHO = 0;
+    conv_big_form_t f; if (!conv_big_form(g, c, f) || f.jmode != (patchy ? 7 : 5)) continue;
+    long const ti = (g.OC + c.BI - 1) / c.BI, tj = (Nj + c.BJ - 1) / c.BJ, tiles = ti * tj;
+    double const pad = ((double)g.OC / (double)(ti * c.BI)) * ((double)Nj / (double)(tj * c.BJ));
+    double const deal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
+    double const score = cd.base * pad * deal;
+    if (score > best) { best = score; best_c = c; }
+  }
+  if (best < (force ? 0.0 : 0.76)) return old;
+  plan_t bp = plan_conv_big(g, best_c);
+  // Two-level tiling along the pels (the sgemm path's idea, plan_sgemm_split): when the tiles leave a mostly idle last round, the main tile takes whole rounds of the CUs and
+  // a launch of smaller tiles the remaining pels -- every output is still one launch's one fma chain.  AlexNet / NiN conv2 at 256 images: 1460 tiles of 64 x 512 = 5.7 rounds
+  // -> 5 rounds + 720 tiles of 64 x 128 (2.8 quarter-size rounds): 6 -> 5.75 tile-times.  Taken when the model says >= 3 % on a launch of >= 50 GFLOP (the second launch
+  // costs ~5 us).  BODAHIP_CBIG_SPLIT=off.
+  char const *se = getenv("BODAHIP_CBIG_SPLIT");
+  static double const split_min = (getenv("BODAHIP_CBIG_SPLIT_MIN_GFLOP") ? atof(getenv("BODAHIP_CBIG_SPLIT_MIN_GFLOP")) : 50.0) * 1e9;   // (tests lower it)
+  if (!(se && string(se) == "off") && 2.0 * g.OC * (double)Nj * Kt >= split_min) {
+    auto t_of = [&](cand_t const &cd, long n_pels, long &tiles_out) {
+      long const ti = (g.OC + cd.bi - 1) / cd.bi, tj = (n_pels + cd.bj - 1) / cd.bj; tiles_out = ti * tj;
+      return (double)((tiles_out + num_cus - 1) / num_cus) * cd.bi * cd.bj / cd.base;
+    };
+    cand_t const *bc = nullptr; for (cand_t const &cd : cands) if (cd.bi == best_c.BI && cd.bj == best_c.BJ && cd.wi == best_c.WI && cd.wj == best_c.WJ) bc = &cd;
+    long tl = 0; double const t_single = bc ? t_of(*bc, Nj, tl) : 0;
+    double t_best = t_single * 0.97; long best_n1 = 0; cand_t const *m_best = nullptr, *t_best_c = nullptr;
+    for (cand_t const &m : cands) {
+      if (m.small || m.wi * m.wj != 8) continue;
+      tile_cfg_t c1; c1.BI = m.bi; c1.BJ = m.bj; c1.BK = 16; c1.WI = m.wi; c1.WJ = m.wj; c1.MINW = 2; c1.SPLITK = 1; c1.MT = 32; c1.PF = 2; c1.SW = 2; c1.KHO = 0;
+      conv_big_form_t f1; if (!conv_big_form(g, c1, f1) || f1.jmode != (patchy ? 7 : 5)) continue;
+      long const ti1 = (g.OC + m.bi - 1) / m.bi, tj_all = (Nj + m.bj - 1) / m.bj;
+      long const R = (ti1 * tj_all) / num_cus; if (R < 1) continue;
+      long const tj1 = std::min(tj_all - 1, (R * num_cus) / ti1); if (tj1 < 1) continue;
+      long const n1 = tj1 * m.bj; if (n1 >= Nj) continue;
+      double const t_main = (double)((ti1 * tj1 + num_cus - 1) / num_cus) * m.bi * m.bj / m.base;
+      for (cand_t const &t : cands) {
+        tile_cfg_t c2; c2.BI = t.bi; c2.BJ = t.bj; c2.BK = 16; c2.WI = t.wi; c2.WJ = t.wj; c2.MINW = 2; c2.SPLITK = 1; c2.MT = 32; c2.PF = 2; c2.SW = 2; c2.KHO = 0;
+        conv_big_form_t f2; if (!conv_big_form(g, c2, f2) || f2.jmode != (patchy ? 7 : 5)) continue;
+        long tt = 0; double const tsum = t_main + t_of(t, Nj - n1, tt);
+        if (tsum < t_best) { t_best = tsum; best_n1 = n1; m_best = &m; t_best_c = &t; }
+      }
+    }
+    if (m_best) {
+      tile_cfg_t c1; c1.BI = m_best->bi; c1.BJ = m_best->bj; c1.BK = 16; c1.WI = m_best->wi; c1.WJ = m_best->wj; c1.MINW = 2; c1.SPLITK = 1; c1.MT = 32; c1.PF = 2; c1.SW = 2; c1.KHO = 0;
+      tile_cfg_t c2 = c1; c2.BI = t_best_c->bi; c2.BJ = t_best_c->bj; c2.WI = t_best_c->wi; c2.WJ = t_best_c->wj;
+      bp = plan_conv_big(g, c1); plan_t const tp = plan_conv_big(g, c2);
+      bp.split_pels = best_n1; bp.tail_cfg = tp.cfg; bp.tail_defs = tp.defs;
+    }
+  }
+  return bp;
+}
+
+
+// Two-level tiling for the large fp32 sgemms.  A grid of 256x256 tiles runs one workgroup per CU, so a tile count that is not a
+// multiple of the CU count ends in a mostly idle round (7168^3: 784 tiles = 3 rounds + 16 tiles, measured 102 TF/s against 136 at
+// 8192^3 = 4 rounds exactly); 128x128 tiles quantise finer but run ~8 % slower per flop.  The split gives the first `m_main` rows of c
+// (whole rounds of 256x256 tiles) to the large tile and the remaining rows to a second launch of small tiles that fills the chip for
+// a fraction of a tile-time.  Each output is still ONE ascending-k chain in one thread: results are bit-identical to the unsplit launch.
+// Time model (units: one 256x256 tile on one CU at rate 1): a launch of n tiles of relative area a, s workgroups per CU, relative
+// rate r costs floor(n / (cus*s)) * s*a/r for its full rounds plus k*a/(r*eff) for the last, k = ceil(rest / cus) workgroups on the
+// busiest CU, eff = 0.6 for one of two co-resident workgroups running alone (its MFMAs no longer hide the other's barriers).
+static double launch_model(long n, double a, int s, double r, int cus) {
+  long const per = (long)cus * s, full = n / per, rest = n - full * per;
+  double t = (double)full * s * a / r;
+  if (rest) { long const k = (rest + cus - 1) / cus; double const eff = (k >= s) ? 1.0 : 0.6 + 0.4 * (double)(k - 1) / (double)(s - 1); t += (double)k * a / (r * eff); }
+  return t;
+}
+// (the rest launch's 64 x 64 tiles: the staging-wave kernel's form since round 6 -- 5120^3 133.1 -> 133.6, 6144^3 136.7 -> 137.3, 7168^3 139.8 -> 140.4 TF/s in the list)
+static char const *const kTail64 = getenv("BODAHIP_SGEMM_TAIL64") ? getenv("BODAHIP_SGEMM_TAIL64") : ((getenv("BODAHIP_SGEMM_BIG") && string(getenv("BODAHIP_SGEMM_BIG")) == "off") || getenv("BODAHIP_NO_SGEMM_STG64")) ? "64x64x32x2x2x2x1x32x2" : kStg64;
+sgemm_split_t plan_sgemm_split(uint32_t M, uint32_t N, uint32_t K, int num_cus) {
+  sgemm_split_t sp;
+  if (getenv("BODAHIP_NO_SGEMM_SPLIT") || M % 4 || N % 4 || K < 512 || M < 1024 || N < 1024) return sp;
+  long const ti = (M + 255) / 256, tj = (N + 255) / 256;
+  if (ti * tj < num_cus) return sp;
+  double const r_big = getenv("BODAHIP_SGEMM_RBIG") ? atof(getenv("BODAHIP_SGEMM_RBIG")) : 1.04, r_mid = 1.0, r_small = 0.93;
+  auto small_n = [&](uint32_t rows, int b) { return (long)((rows + b - 1) / b) * (long)((N + b - 1) / b); };
+  sp.t_single = std::min(launch_model(ti * tj, 1.0, 1, r_big, num_cus), launch_model(small_n(M, 128), 0.25, 2, r_mid, num_cus));
+  double best = sp.t_single * 0.975;   // (a split must buy at least 2.5 %)
+  for (long R = 1; R < ti; ++R) {
+    uint32_t const m_main = (uint32_t)(R * 256), rows = M - m_main;
+    double const tm = launch_model(R * tj, 1.0, 1, r_big, num_cus);
+    double const t128 = tm + launch_model(small_n(rows, 128), 0.25, 2, r_mid, num_cus) + 0.004;
+    double const t64 = tm + launch_model(small_n(rows, 64), 0.0625, 2, r_small, num_cus) + 0.004;
+    char const *const force = getenv("BODAHIP_SGEMM_SPLIT_TAIL");   // (experiments: "128" | "64")
+    if (force && atoi(force) == 128) { if (t128 < best) { best = t128; sp.m_main = m_main; sp.tail_tile = "128x128x16x2x2x2"; } continue; }
+    if (force && atoi(force) == 64) { if (t64 < best) { best = t64; sp.m_main = m_main; sp.tail_tile = kTail64; } continue; }
+    if (t128 < best) { best = t128; sp.m_main = m_main; sp.tail_tile = "128x128x16x2x2x2"; }
+    if (t64 < best) { best = t64; sp.m_main = m_main; sp.tail_tile = kTail64; }
+  }
+  sp.t_split = best;
+  return sp;
+}
+
+// the 256 x 128 form of the staging-wave kernel where its tiles deal out in (nearly) whole rounds -- see sgemm(); "" = not here
+string sgemm_wide_tile(uint32_t M, uint32_t N, uint32_t K, long cus) {
+  if (M % 4 || N % 4 || K < 512 || getenv("BODAHIP_NO_SGEMM_256X128")) return string();
+  if (char const *e = getenv("BODAHIP_SGEMM_BIG")) { if (string(e) == "off") return string(); }   // (the x3x4 tile is a form of the staging-wave kernel only: with the kernel switched off the general kernel's own choice stands)
+  long const t256 = (long)((M + 255) / 256) * ((N + 255) / 256), t128 = (long)((M + 255) / 256) * ((N + 127) / 128);
+  double const eff = (double)t128 / (double)(((t128 + cus - 1) / cus) * cus);
+  return (t256 >= cus && eff >= 0.95) ? string("256x128x8x3x4x1") : string();
+}
+
+// Round 6: the two-level tiling generalised to guillotine cuts -- a list of rectangles [m0, m0 + rows) x [n0, n0 + cols) of c, each ONE launch of one tile form (operands
+// and output addressed through pointer offsets: a and b are k-major, a sub-rectangle is a column range of both).  Every output still belongs to exactly one launch and is
+// one ascending-k chain: bit-identical to the single launch.  10240^3: 3200 tiles of 256 x 128 = 12.5 rounds of 256 CUs -> rows < 8192 (10 rounds) + the last 2048 rows'
+// first 8192 columns (2 rounds) + a 2048 x 2048 corner on 64 x 64 tiles (1024 = one round of four per CU).
+bool parse_parts_env(uint32_t M, uint32_t N, uint32_t K, std::vector<sgemm_part_t> &out) {   // experiments: BODAHIP_SGEMM_PARTS="<size>:m0,rows,n0,cols,tile/m0,rows,...;<size>:..."
+  char const *e = getenv("BODAHIP_SGEMM_PARTS"); if (!e || M != N || N != K) return false;
+  string const v = e, key = std::to_string(M) + ":"; size_t const at = (";" + v).find(";" + key); if (at == string::npos) return false;
+  size_t const b = at + key.size(), en = v.find(';', b); string const spec = v.substr(b, en == string::npos ? string::npos : en - b);
+  std::istringstream is(spec); string one;
+  while (std::getline(is, one, '/')) {
+    sgemm_part_t q; char tl[128];
+    if (sscanf(one.c_str(), "%u,%u,%u,%u,%127s", &q.m0, &q.rows, &q.n0, &q.cols, tl) != 5) rt_err("bad BODAHIP_SGEMM_PARTS entry '" + one + "'");
+    q.tile = tl; out.push_back(q);
+  }
+  uint64_t area = 0; for (auto const &q : out) { if (q.m0 % 4 || q.n0 % 4 || q.m0 + q.rows > M || q.n0 + q.cols > N || !q.rows || !q.cols) rt_err("bad BODAHIP_SGEMM_PARTS rectangle"); area += (uint64_t)q.rows * q.cols; }
+  if (area != (uint64_t)M * N) rt_err("BODAHIP_SGEMM_PARTS: the rectangles do not add up to c");
+  return true;
+}
+
+// The planner of those rectangles.  What the launches cost was measured (tools/sgemm_rounds_probe.py, MI355X, K = 6144): the 256 x 256 form runs ONE workgroup per CU --
+// n tiles take ceil(n / 256) rounds of 1.434 ms; of the 256 x 128 form TWO share a CU (50 KB of LDS, 6 waves per SIMD) -- ceil(n / 512) double rounds of 1.416 ms, and the
+// dispatcher packs a last partial round two-per-CU onto the CUs that free up first instead of spreading it (768 tiles = three whole rounds of 256 take FOUR rounds' time:
+// 2.90 ms; 1280: 4.29 ms); only a launch that fits the chip at once is spread (256 tiles: 0.883 ms).  The 64 x 64 form runs four per CU (a round of 1024: 0.274 of a
+// 256 x 256 round).  So: a cost per form = rounds of (CUs x workgroups per CU) tiles, a partial round costs a whole one unless the launch has no full round at all; the
+// search tries guillotine cuts (rows | columns, the first part one launch of a large form, the remainder cut again: four launches at most) and takes what the model says
+// is >= 2 % ahead of the single launch / the row split above.  10240^3 140.4 -> 146.0 TF/s, 5120^3 135.2 -> 139.5 in the list (tools/sgemm_parts_ab.sh).
+struct sgemm_form_t { char const *tile; int bi, bj, s; double r, lone; };   // s workgroups per CU, relative rate r, efficiency of ONE workgroup alone on a CU against its share of a full CU
+static sgemm_form_t const kFormQ = {"256x256x16x2x4x1x1x32x2", 256, 256, 1, 1.0, 1.0}, kFormW = {"256x128x8x3x4x1", 256, 128, 2, 1.0127, 0.82}, kFormS = {kStg64, 64, 64, 4, 0.913, 0.5};
+static double form_cost(sgemm_form_t const &f, uint32_t rows, uint32_t cols, int cus) {
+  long const n = (long)((rows + f.bi - 1) / f.bi) * ((cols + f.bj - 1) / f.bj), per = (long)cus * f.s;
+  double const a = (double)f.bi * f.bj / 65536.0, round = f.s * a / f.r;
+  if (n <= per) { long const k = (n + cus - 1) / cus; double const eff = (f.s == 1 || k >= f.s) ? 1.0 : f.lone + (1.0 - f.lone) * (double)(k - 1) / (double)(f.s - 1);
+                  return (double)k * a / (f.r * eff); }   // (a launch the chip takes at once is spread over the CUs)
+  if (f.s >= 4) return (double)n / (double)per * round;    // four staggered workgroups per CU: no rounds to speak of -- 5120^3's rest launch of 2560 tiles (2.5 x 1024) took 2.5 x a 1024-tile launch
+  return (double)((n + per - 1) / per) * round;
+}
+struct sgemm_parts_plan_t { std::vector<sgemm_part_t> parts; double t = 1e30; };
+static sgemm_parts_plan_t plan_parts_rec(uint32_t m0, uint32_t rows, uint32_t n0, uint32_t cols, int cus, double ovh, int depth) {
+  sgemm_parts_plan_t best;
+  for (sgemm_form_t const *f : {&kFormQ, &kFormW, &kFormS}) {
+    double const t = form_cost(*f, rows, cols, cus) + ovh;
+    if (t < best.t) { best.t = t; sgemm_part_t q; q.m0 = m0; q.rows = rows; q.n0 = n0; q.cols = cols; q.tile = f->tile; best.parts = {q}; }
+  }
+  if (depth <= 0) return best;
+  for (sgemm_form_t const *f : {&kFormQ, &kFormW}) {
+    long const per = (long)cus * f->s, tj = (cols + f->bj - 1) / f->bj, ti = (rows + f->bi - 1) / f->bi;
+    for (long R = 1; R < ti; ++R) {     // rows [0, R tile rows) x all columns: one launch of form f -- whole rounds only (anything else is what the remainder's own search covers)
+      if ((R * tj) % per) continue;
+      uint32_t const r1 = (uint32_t)(R * f->bi);
+      sgemm_parts_plan_t rest = plan_parts_rec(m0 + r1, rows - r1, n0, cols, cus, ovh, depth - 1);
+      double const t = form_cost(*f, r1, cols, cus) + ovh + rest.t;
+      if (t < best.t) { best.t = t; sgemm_part_t q; q.m0 = m0; q.rows = r1; q.n0 = n0; q.cols = cols; q.tile = f->tile; best.parts = {q}; best.parts.insert(best.parts.end(), rest.parts.begin(), rest.parts.end()); }
+    }
+    for (long C = 1; C < tj; ++C) {     // all rows x columns [0, C tile columns)
+      if ((C * ti) % per) continue;
+      uint32_t const c1 = (uint32_t)(C * f->bj);
+      sgemm_parts_plan_t rest = plan_parts_rec(m0, rows, n0 + c1, cols - c1, cus, ovh, depth - 1);
+      double const t = form_cost(*f, rows, c1, cus) + ovh + rest.t;
+      if (t < best.t) { best.t = t; sgemm_part_t q; q.m0 = m0; q.rows = rows; q.n0 = n0; q.cols = c1; q.tile = f->tile; best.parts = {q}; best.parts.insert(best.parts.end(), rest.parts.begin(), rest.parts.end()); }
+    }
+  }
+  return best;
+}
+// "" = no decomposition beats what sgemm() would do anyway
+std::vector<sgemm_part_t> plan_sgemm_parts(uint32_t M, uint32_t N, uint32_t K, int cus) {
+  std::vector<sgemm_part_t> none;
+  if (getenv("BODAHIP_NO_SGEMM_PARTS") || getenv("BODAHIP_NO_SGEMM_SPLIT") || M % 4 || N % 4 || K < 512 || M < 1024 || N < 1024 || (long)((M + 255) / 256) * ((N + 255) / 256) < cus) return none;
+  if (char const *e = getenv("BODAHIP_SGEMM_BIG")) { if (string(e) == "off") return none; }
+  if (M % 64 || N % 64) return none;                      // (cuts at multiples of the forms' tiles; the last parts reach the edges)
+  double const ovh = 25.7 / (double)K;                    // ~6 us per launch in 256 x 256 rounds of this K
+  sgemm_parts_plan_t pp = plan_parts_rec(0, M, 0, N, cus, ovh, 3);
+  // ... and one free cut on top (neither side a launch of its own; coarse positions): 5120^3 = rows < 4096 { 4096 x 4096 on 256 x 256 tiles (256 = one round) | the other
+  // 1024 columns on 64 x 64 } over the last 1024 rows on 64 x 64
+  for (uint32_t R = 1024; R < M; R += 1024) {
+    sgemm_parts_plan_t const t1 = plan_parts_rec(0, R, 0, N, cus, ovh, 2), t2 = plan_parts_rec(R, M - R, 0, N, cus, ovh, 2);
+    if (t1.t + t2.t < pp.t) { pp.t = t1.t + t2.t; pp.parts = t1.parts; pp.parts.insert(pp.parts.end(), t2.parts.begin(), t2.parts.end()); }
+  }
+  for (uint32_t C = 1024; C < N; C += 1024) {
+    sgemm_parts_plan_t const t1 = plan_parts_rec(0, M, 0, C, cus, ovh, 2), t2 = plan_parts_rec(0, M, C, N - C, cus, ovh, 2);
+    if (t1.t + t2.t < pp.t) { pp.t = t1.t + t2.t; pp.parts = t1.parts; pp.parts.insert(pp.parts.end(), t2.parts.begin(), t2.parts.end()); }
+  }
+  if (pp.parts.size() < 2) return none;
+  // what sgemm() does without it: the 256 x 128 single launch where it deals out, else the row split / the single launch (same cost model)
+  double t_now = std::min(form_cost(kFormQ, M, N, cus), form_cost(kFormW, M, N, cus)) + ovh;
+  sgemm_split_t const sp = plan_sgemm_split(M, N, K, cus);
+  if (sp.m_main && sgemm_wide_tile(M, N, K, cus).empty()) t_now = std::min(t_now, form_cost(kFormQ, sp.m_main, N, cus) + form_cost(kFormS, M - sp.m_main, N, cus) + 2 * ovh);
+  return (pp.t < 0.98 * t_now) ? pp.parts : none;
+}
+
+
+} // namespace bodahip

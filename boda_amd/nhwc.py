@@ -61,7 +61,7 @@ _PATCH_TILES = ((128, 128), (64, 256), (64, 128), (128, 64), (32, 128), (128, 25
 
 
 def patch_min_lds(KH: int, SY: int, W: int, PX: int, OH: int, OW: int, out_f32: bool) -> int:
-    """Bytes of LDS the input-patch kernel needs at least for this plane: plan_conv_nhwc_patch's own bound (csrc/native_kernels.cc, `lds_cg`: the double-buffered
+    """Bytes of LDS the input-patch kernel needs at least for this plane: plan_conv_nhwc_patch's own bound (csrc/native_plan.cc, `lds_cg`: the double-buffered
     patch of ONE channel group -- the zero-padded input rows a tile's output positions touch, at the kernel's slot pitch -- or the epilogue's transposed tile),
     minimised over the planner's tiles.  The layout of `filts` is chosen when the op is annotated and binds the kernel at run time, so the annotation must know
     whether any tile fits before it asks for the F' form."""

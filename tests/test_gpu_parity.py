@@ -1408,7 +1408,7 @@ def test_outputs_of_2gib_or_more_are_unsupported(be):
 def test_ipconv_shapes_through_the_lds_dma_kernel_bit_exact(monkeypatch):
     """The exact fp32 variant of the LDS-DMA kernel (kernels/conv_nhwc_bf16.hip, IN_F32: b128 fragment reads feeding two 32x32x2 MFMAs in ascending
     k) on the shapes whose operands are k-contiguous in the reference layout (output 1x1, kernel == whole input).  Opt-in (measured slower than the
-    gather kernel, native_kernels.cc: plan_ipconv_dma) -- forced here and held to bit-exact equality with the oracle like every fp32 kernel."""
+    gather kernel, native_plan.cc: plan_ipconv_dma) -- forced here and held to bit-exact equality with the oracle like every fp32 kernel."""
     monkeypatch.setenv("BODAHIP_IPCONV_DMA", "force")   # (also for shapes with fewer tiles than the planner would send there)
     rtc = make_rtc("(be=hip)", 0); rtc.init()
     b = OpsBackend(rtc)
