@@ -595,7 +595,8 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
       }
     }
     char const *const tstamp = p.cbig ? getenv("BODAHIP_CBIG_TSTAMP") : nullptr;   // experiment hook (tools/cbig_timeline.py): kernel built with -DTSTAMP=1 leaves 16 clock stamps per workgroup in the scratch; appended to the named file
-    size_t const ts_bytes = (size_t)ga.tiles_i * ga.tiles_j * 128;
+    size_t const ts_main = (size_t)ga.tiles_i * ga.tiles_j * 128;   // (with a tail launch: room for its workgroups' stamps behind the main launch's -- its kernel is built with -DTSTAMP=1, too)
+    size_t const ts_bytes = ts_main + ((p.cbig && p.split_pels > 0) ? (size_t)((g.OC + p.tail_cfg.BI - 1) / p.tail_cfg.BI) * (size_t)((Nj - p.split_pels + p.tail_cfg.BJ - 1) / p.tail_cfg.BJ) * 128 : 0);
     bool const ts_late = tstamp && strlen(tstamp) > 5 && !strcmp(tstamp + strlen(tstamp) - 5, ":late");   // no synchronisation, no copy per launch: the sequence runs undisturbed
     if (tstamp) { ensure_ws(impl, host, ts_off + ts_bytes); ga.ws = (float *)((char *)impl->ws + ts_off); if (!ts_late) hip_err_chk(hipMemsetAsync(ga.ws, 0, ts_bytes, host->nh_stream()), "hipMemsetAsync(tstamp)"); }
     if (p.cbig && p.split_pels > 0) {   // two-level tiling along the pels: this plan's tiles over the first split_pels pels, the tail plan's over the rest
@@ -603,7 +604,7 @@ void native_kernels_t::conv(float const *filts, float const *biases, float const
       launch(host, k, ga, cfg);
       plan_t tp; tp.cbig = true; tp.kname = p.kname; tp.cfg = p.tail_cfg; tp.defs = p.tail_defs; tp.patch = p.patch; tp.k1 = p.k1; tp.rdec = p.rdec;
       kernel_t &k2 = get_kernel(impl, host, tp);
-      gemm_args_t g2 = ga; g2.tiles_i = (g.OC + tp.cfg.BI - 1) / tp.cfg.BI; g2.tiles_j = (int)((Nj - p.split_pels + tp.cfg.BJ - 1) / tp.cfg.BJ); g2.bsJ = p.split_pels; g2.ws = nullptr;
+      gemm_args_t g2 = ga; g2.tiles_i = (g.OC + tp.cfg.BI - 1) / tp.cfg.BI; g2.tiles_j = (int)((Nj - p.split_pels + tp.cfg.BJ - 1) / tp.cfg.BJ); g2.bsJ = p.split_pels; g2.ws = tstamp ? (float *)((char *)ga.ws + ts_main) : nullptr;
       launch(host, k2, g2, tp.cfg);
       tail_grid = (uint32_t)g2.tiles_i * g2.tiles_j;
     } else

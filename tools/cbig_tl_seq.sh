@@ -10,5 +10,5 @@ for kv in spec.split(";"):
     i, t = kv.split("="); print(f"{ops[int(i)].to_str()}\t{t}\t0\t0")
 P
 N=$(echo "$SPEC" | tr ';' '\n' | wc -l)
-BODAHIP_TILE_WISDOM=$F BODAHIP_CBIG_TSTAMP=$TS${LATE:+:late} BODAHIP_EXTRA_DEFS="-DTSTAMP=1" python bench.py --workload $W --batch $B --steps ${STEPS:-4} --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+BODAHIP_TILE_WISDOM=$F BODAHIP_CBIG_TSTAMP=$TS${LATE:+:late} BODAHIP_EXTRA_DEFS="-DTSTAMP=1" python bench.py --workload $W --batch $B --steps ${STEPS:-4} --warmup 2 --no-cpu-baseline > /dev/null 2>${TLERR:-/dev/null}
 python tools/cbig_tl_parse.py $TS $N
