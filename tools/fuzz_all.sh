@@ -15,4 +15,5 @@ run nhwc X=1 python tools/fuzz_nhwc.py 300 31
 run pool_lrn X=1 python tools/fuzz_pool_lrn.py 40 32
 run k1_chain X=1 python tools/fuzz_k1_chain.py 120 33
 run lrn_pool_lds X=1 python tools/fuzz_lrn_pool_lds.py 40 34
+run sgemm_parts X=1 python tools/fuzz_sgemm_parts.py 60 5
 cat $O/summary.txt
