@@ -231,7 +231,7 @@ plan_t plan_sgemm(uint32_t M, uint32_t N, uint32_t K, int num_cus, string const 
   if (allow_big && batch == 1 && want_big && p.cfg.MT == 32 && p.cfg.SPLITK == 1 && M % 4 == 0 && N % 4 == 0) {
     char const *e = getenv("BODAHIP_SGEMM_BIG");
     if (!(e && string(e) == "off")) {
-      int bks = 8, pf = 2;   // measured (MI355X, 12288^3 / 8192^3 / 6144^3, TF/s): gemm_conv_f32.hip on the same tile 140.2 / 140.4 / 133.6; 16x2 144.7 / 144.5 / 129.0; 8x2 145.1 / 144.8 / 137.7; 8x4 145.1 / 144.8 / 135.4; 16x4 142.0 / 142.2 / 136.5 (four LDS stages)
+      int bks = 8, pf = 4;   // round 6: four K tiles in flight per staging thread -- in the list, two repetitions each (TF/s): 8x2 143.3, 8x4 144.1 (4096^3 +0.8, 5120^3 +1.0, 8192^3 +0.6, 10240^3 / 12288^3 +0.9), 4x4 143.8, 16x2 136.6 / 16x4 138.8 (the 256 x 128 form no longer shares its CU).  Round 4 measured (MI355X, 12288^3 / 8192^3 / 6144^3, TF/s): gemm_conv_f32.hip on the same tile 140.2 / 140.4 / 133.6; 16x2 144.7 / 144.5 / 129.0; 8x2 145.1 / 144.8 / 137.7; 8x4 145.1 / 144.8 / 135.4; 16x4 142.0 / 142.2 / 136.5 (four LDS stages)
       if (!tile.empty() && p.cfg.WI == 3 && p.cfg.BK >= 4 && p.cfg.BK <= 32 && p.cfg.BK % 4 == 0) bks = p.cfg.BK;   // (asked for by its own tile string: the K step too)
       if (e && *e) { if (sscanf(e, "%dx%d", &bks, &pf) != 2 || bks < 4 || bks > 32 || bks % 4 || (pf != 2 && pf != 4)) rt_err(string("bad BODAHIP_SGEMM_BIG '") + e + "' (off | BKSxPF)"); }
       if (bks * (p.cfg.BI / 4) % 256 || bks * (p.cfg.BJ / 4) % 256) bks = 8;   // (whole float4 units per staging thread: BKS x TB / 4 a multiple of 256)

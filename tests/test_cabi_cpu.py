@@ -209,12 +209,12 @@ def test_planner_sgemm_tiles_follow_problem_size():
         return parse_op(f"(str_vals=(type=sgemm,func_name={fn}),nda_vals=(a=(dims=(K={K},M={M})),b=(dims=(K={K},N={N})),c=(dims=(M={M},N={N}))))")
     big, small = R.explain_plan(sg(8192, 8192, 8192)), R.explain_plan(sg(256, 256, 256))
     # round 4: eight multiplying + four staging waves; round 5: as 256 x 128 tiles (4 x 2 multiplying waves of 64 x 64) where those deal out in whole rounds (2048 tiles = 8 x 256 CUs)
-    assert big.startswith("bodahip_sgemm_big_f32 256x128x8_w3x4_p2") and "-DBKS=8" in big and "-DPF=2" in big and "-DTBJ=128" in big and "-DWI=4" in big
+    assert big.startswith("bodahip_sgemm_big_f32 256x128x8_w3x4_p4") and "-DBKS=8" in big and "-DPF=4" in big and "-DTBJ=128" in big and "-DWI=4" in big
     os.environ["BODAHIP_NO_SGEMM_256X128"] = "1"
-    try: assert R.explain_plan(sg(8192, 8192, 8192)).startswith("bodahip_sgemm_big_f32 256x256x8_w3x4_p2")
+    try: assert R.explain_plan(sg(8192, 8192, 8192)).startswith("bodahip_sgemm_big_f32 256x256x8_w3x4_p4")
     finally: del os.environ["BODAHIP_NO_SGEMM_256X128"]
     # ... and, asked for by their tile strings ("...x3x4": the twelve waves), its 128 x 128 (two workgroups per CU) and 128 x 256 forms
-    assert R.explain_plan(sg(2048, 2048, 2048), tile="128x128x8x3x4x2").startswith("bodahip_sgemm_big_f32 128x128x8_w3x4_p2") and "-DMINW=2" in R.explain_plan(sg(2048, 2048, 2048), tile="128x128x8x3x4x2")
+    assert R.explain_plan(sg(2048, 2048, 2048), tile="128x128x8x3x4x2").startswith("bodahip_sgemm_big_f32 128x128x8_w3x4_p4") and "-DMINW=2" in R.explain_plan(sg(2048, 2048, 2048), tile="128x128x8x3x4x2")
     assert "-DTBI=128 -DTBJ=256 -DWI=2 -DWJ=4" in R.explain_plan(sg(4096, 4096, 4096), tile="128x256x8x3x4x1")
     assert small.startswith("bodahip_sgemm_f32 ") and small.split()[1] != big.split()[1]
     assert "-DI_MODE=1" in R.explain_plan(sg(130, 64, 50)) and "-DJ_MODE=1" in R.explain_plan(sg(128, 66, 50))     # scalar staging for ragged M / N
@@ -223,13 +223,13 @@ def test_planner_sgemm_tiles_follow_problem_size():
     # two-level tiling: 7168^3 is 784 tiles of 256x256 = 3 rounds of 256 CUs + 16 -> 27 tile rows (756 tiles) on the large tile, the last 256 rows on small
     # tiles; 8192^3 (1024 = 4 rounds exactly) is not split; an explicit tile or BODAHIP_NO_SGEMM_SPLIT switches it off
     sp = R.explain_plan(sg(7168, 7168, 7168))
-    assert sp.startswith("rows<6912:256x256x8_w3x4_p2+rest:bodahip_sgemm_big_f32 64x64x16_w2x2_p2_stg"), sp   # (round 6: the rest on the staging-wave kernel's own 64 x 64 form)
+    assert sp.startswith("rows<6912:256x256x8_w3x4_p4+rest:bodahip_sgemm_big_f32 64x64x16_w2x2_p2_stg"), sp   # (round 6: the rest on the staging-wave kernel's own 64 x 64 form)
     assert R.explain_plan(sg(6144, 6144, 6144)).startswith("rows<5376:") and not R.explain_plan(sg(12288, 12288, 12288)).startswith("rows<")
     # round 6: guillotine cuts into whole rounds -- 10240^3 (3200 tiles of 256 x 128 = 6.25 rounds of 512: two such workgroups share a CU) = rows < 8192 (2560) + the last
     # 2048 rows' first 8192 columns (512) + a 2048^2 corner on 64 x 64 tiles (1024 = one round of four per CU); 5120^3 = a strip on 64 x 64 + 4096^2 (512) + a strip
     q10 = R.explain_plan(sg(10240, 10240, 10240))
-    assert q10.startswith("parts=3 [0+8192,0+10240]:256x128x8_w3x4_p2 [8192+2048,0+8192]:256x128x8_w3x4_p2 [8192+2048,8192+2048]:64x64x16_w2x2_p2_stg last:bodahip_sgemm_big_f32 64x64x16_w2x2_p2_stg "), q10
-    assert R.explain_plan(sg(5120, 5120, 5120)).startswith("parts=3 ") and "[1024+4096,0+4096]:256x128x8_w3x4_p2" in R.explain_plan(sg(5120, 5120, 5120))
+    assert q10.startswith("parts=3 [0+8192,0+10240]:256x128x8_w3x4_p4 [8192+2048,0+8192]:256x128x8_w3x4_p4 [8192+2048,8192+2048]:64x64x16_w2x2_p2_stg last:bodahip_sgemm_big_f32 64x64x16_w2x2_p2_stg "), q10
+    assert R.explain_plan(sg(5120, 5120, 5120)).startswith("parts=3 ") and "[1024+4096,0+4096]:256x128x8_w3x4_p4" in R.explain_plan(sg(5120, 5120, 5120))
     os.environ["BODAHIP_NO_SGEMM_PARTS"] = "1"
     try: assert R.explain_plan(sg(10240, 10240, 10240)).startswith("bodahip_sgemm_big_f32 256x128x8") and R.explain_plan(sg(5120, 5120, 5120)).startswith("rows<3072:")   # (round 5's plans)
     finally: del os.environ["BODAHIP_NO_SGEMM_PARTS"]
