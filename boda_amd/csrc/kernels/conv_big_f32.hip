@@ -53,6 +53,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef PF
 #define PF 2
 #endif
+#ifndef STGPRIO
+#define STGPRIO 0
+#endif
 #ifndef NSTG
 #define NSTG 4
 #endif
@@ -237,6 +240,9 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINWAVES) void KNAME(ge
 #endif
 
   if (stager) {
+#if STGPRIO
+    __builtin_amdgcn_s_setprio(STGPRIO);   // the staging waves ahead of the multiplying waves in the SIMD's issue arbitration (priority, then age: a co-resident younger workgroup's staging waves otherwise get the leftover slots)
+#endif
     int const tid = threadIdx.x - kNMW * 64;
     rsrc_t const rI = make_rsrc(p.I, p.I_bytes), rJ = make_rsrc(p.J, p.J_bytes);
 #if I_VW == 0

@@ -52,6 +52,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef MINW
 #define MINW 1
 #endif
+#ifndef STGPRIO
+#define STGPRIO 0
+#endif
 #ifndef NSTG
 #define NSTG 4 // LDS stages: tile t lives in stage t % NSTG and is written during step t - (NSTG - 1).  4: a tile is complete one barrier before its step, so the
 #endif         // multiplying waves fetch its first operands BEFORE the barrier that ends the previous step (nothing but the barrier itself between two steps)
@@ -129,6 +132,9 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
   int const nkt_pad = (nkt + kU - 1) / kU * kU;   // whole rounds, no conditions inside the loops: tiles past the last one read zeros and multiply as +0
 
   if (stager) {
+#if STGPRIO
+    __builtin_amdgcn_s_setprio(STGPRIO);   // the staging waves ahead of the multiplying waves in the SIMD's issue arbitration (priority, then age: a co-resident younger workgroup's staging waves otherwise get the leftover slots)
+#endif
     int const tid = threadIdx.x - kNMW * 64;
     rsrc_t const rI = make_rsrc(p.I, p.I_bytes), rJ = make_rsrc(p.J, p.J_bytes);
     // unit c = tid + n * 256 of an operand tile: k row c / (TB / 4), columns 4 (c % (TB / 4)) .. +3

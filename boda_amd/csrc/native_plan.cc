@@ -762,6 +762,13 @@ static plan_t plan_conv_big(conv_geom_t const &g0, tile_cfg_t const &c) {
             "-DKH=" + std::to_string(g.KH), "-DKW=" + std::to_string(g.KW), "-DSY=" + std::to_string(g.SY), "-DSX=" + std::to_string(g.SX),
             "-DPY=" + std::to_string(g.PY), "-DPX=" + std::to_string(g.PX), string("-DRELU=") + (g.relu ? "1" : "0")};
   if (f.jmode == 7) for (auto const &kv : {std::make_pair("CH", g.H), std::make_pair("CW", g.W), std::make_pair("COH", g.OH), std::make_pair("COW", g.OW)}) p.defs.push_back(string("-D") + kv.first + "=" + std::to_string(kv.second));
+  // Staging waves ahead of the multiplying waves in the SIMD's issue arbitration (s_setprio; priority, then age -- a co-resident younger workgroup's staging waves get the
+  // leftover VALU slots otherwise: clock stamps on conv1 showed the second workgroup of a CU taking 38 us over a 4-us prologue while the first one multiplies).  In place, layer
+  // by layer (tools/stgprio_ab.sh, us, 0 -> 2): conv1 451 -> 439, NiN cccp5 / cccp6 at 256 images 119 -> 113, cccp7 / cccp8 177 / 161 -> 152 / 152; the LDS-patch forms are
+  // mixed (AlexNet conv2 1589 -> 1574, conv4 797 -> 791, but NiN conv4 458 -> 462, conv2 at 128 images 835 -> 840): taken for the 1x1 and the row-decimated forms only.  (The
+  // sgemm kernel's forms lose with it: 3072^3 on 64 x 64 tiles 131.8 -> 112 TF/s.)  BODAHIP_CBIG_STGPRIO = 0..3: every form.
+  { int prio = (f.jmode == 5 || f.rdec) ? 2 : 0; if (char const *e = getenv("BODAHIP_CBIG_STGPRIO")) prio = std::max(0, std::min(3, atoi(e)));
+    if (prio) p.defs.push_back("-DSTGPRIO=" + std::to_string(prio)); }
   if (f.rdec) for (auto const &kv : {std::make_pair("RDEC", 1), std::make_pair("C0", g0.C), std::make_pair("H0", g0.H), std::make_pair("KH0", g0.KH), std::make_pair("SY0", g0.SY)}) p.defs.push_back(string("-D") + kv.first + "=" + std::to_string(kv.second));
   if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
   return p;
