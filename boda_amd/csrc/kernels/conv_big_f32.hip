@@ -53,6 +53,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef PF
 #define PF 2
 #endif
+#ifndef MULPRIO
+#define MULPRIO 0
+#endif
 #ifndef STGPRIO
 #define STGPRIO 0
 #endif
@@ -478,6 +481,9 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINWAVES) void KNAME(ge
   }
 
   // ---- multiplying waves
+#if MULPRIO
+  __builtin_amdgcn_s_setprio(MULPRIO);   // the multiplying waves ahead of whatever else shares the SIMD at priority 0 (STGPRIO, if set, should be higher)
+#endif
   int const wi = wave / WJ, wj = wave % WJ;
   float const *const a_base = sm + (lane >> 5) * kLDI + (wi * 32 + (lane & 31)) * kTIp;            // + stage * kImg2 + kk * 2 * kLDI
 #if J_MODE == 7

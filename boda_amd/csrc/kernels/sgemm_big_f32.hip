@@ -52,6 +52,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #ifndef MINW
 #define MINW 1
 #endif
+#ifndef MULPRIO
+#define MULPRIO 1 // round 6: the multiplying waves at priority 1, the staging waves at 0 -- in the list (tools/stgprio_ab.sh; TF/s) 144.5 -> 145.3: 4096^3 143.0 -> 144.5, 8192^3 145.9 -> 147.0, 12288^3
+#endif          // 146.6 -> 147.5, 2048^3 127.5 -> 129.3; the other way round (STGPRIO) the 64 x 64 form loses 15 %
 #ifndef STGPRIO
 #define STGPRIO 0
 #endif
@@ -191,6 +194,9 @@ extern "C" __global__ __launch_bounds__((kNMW + 4) * 64, MINW) void KNAME(gemm_a
   // operands of a k (and its kTJ B operands) are CONTIGUOUS in the k-major LDS image: one ds_read_b128 + one ds_read_b64 per k pair (256 x 256) instead of six
   // ds_read_b32 (which the compiler pairs into ds_read2_b32 with 8-bit offsets and a base register per (stage, k pair): 48 address registers, spills), and the
   // column blocks of a row leave as one store.
+#if MULPRIO
+  __builtin_amdgcn_s_setprio(MULPRIO);
+#endif
   int const wi = wave / WJ, wj = wave % WJ;
   float const *const a_base = sm + (lane >> 5) * kLDI + wi * (kTI * 32) + kTI * (lane & 31);        // + stage * kImg2 + kk * 2 * kLDI
   float const *const b_base = sm + kImgI + (lane >> 5) * kLDJ + wj * (kTJ * 32) + kTJ * (lane & 31);

@@ -768,7 +768,10 @@ static plan_t plan_conv_big(conv_geom_t const &g0, tile_cfg_t const &c) {
   // mixed (AlexNet conv2 1589 -> 1574, conv4 797 -> 791, but NiN conv4 458 -> 462, conv2 at 128 images 835 -> 840): taken for the 1x1 and the row-decimated forms only.  (The
   // sgemm kernel's forms lose with it: 3072^3 on 64 x 64 tiles 131.8 -> 112 TF/s.)  BODAHIP_CBIG_STGPRIO = 0..3: every form.
   { int prio = (f.jmode == 5 || f.rdec) ? 2 : 0; if (char const *e = getenv("BODAHIP_CBIG_STGPRIO")) prio = std::max(0, std::min(3, atoi(e)));
-    if (prio) p.defs.push_back("-DSTGPRIO=" + std::to_string(prio)); }
+    if (prio) p.defs.push_back("-DSTGPRIO=" + std::to_string(prio));
+    // (the multiplying waves at priority 1, as in the sgemm kernel, measured level in place: AlexNet +0.1 %, NiN at 256 images 0, at 128 -0.3 %.  BODAHIP_CBIG_MULPRIO = 0..3)
+    int mprio = 0; if (char const *e = getenv("BODAHIP_CBIG_MULPRIO")) mprio = std::max(0, std::min(3, atoi(e)));
+    if (mprio) p.defs.push_back("-DMULPRIO=" + std::to_string(mprio)); }
   if (f.rdec) for (auto const &kv : {std::make_pair("RDEC", 1), std::make_pair("C0", g0.C), std::make_pair("H0", g0.H), std::make_pair("KH0", g0.KH), std::make_pair("SY0", g0.SY)}) p.defs.push_back(string("-D") + kv.first + "=" + std::to_string(kv.second));
   if (char const *x = getenv("BODAHIP_EXTRA_DEFS")) { std::istringstream is(x); string tok; while (is >> tok) p.defs.push_back(tok); }
   return p;
