@@ -71,6 +71,12 @@ __device__ __forceinline__ f32x4 bload4(rsrc_t r, int voff, int soff) { return _
 __device__ __forceinline__ float bload1(rsrc_t r, int voff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0)); }
 } // namespace
 
+#ifndef STGPRIO
+#define STGPRIO 0 // experiment hooks: issue priority of the staging / the multiplying waves (s_setprio)
+#endif
+#ifndef MULPRIO
+#define MULPRIO 0
+#endif
 extern "C" __global__ __launch_bounds__(512, 1) void KNAME(gemm_args_t const p) {
   __shared__ __attribute__((aligned(16))) float sm[3 * kStage];   // [stage][image rows TM | filter rows TN][kLDK]
   int const lane = threadIdx.x & 63;
@@ -90,6 +96,9 @@ extern "C" __global__ __launch_bounds__(512, 1) void KNAME(gemm_args_t const p) 
   int const nkt_pad = (nkt + kU - 1) / kU * kU;
 
   if (wave >= 4) {
+#if STGPRIO
+    __builtin_amdgcn_s_setprio(STGPRIO);
+#endif
     // ---- staging waves: tile t lives in stage t % 3.  During step kt they write tile kt + 2 (stage (kt + 2) % 3, last read in step kt - 1) and refill its registers
     // with tile kt + 2 + PF; the barrier that ends the step makes them wait only for the stores of step kt - 1.
     rsrc_t const rI = make_rsrc(p.I, p.I_bytes), rJ = make_rsrc(p.J, p.J_bytes);
@@ -133,6 +142,9 @@ extern "C" __global__ __launch_bounds__(512, 1) void KNAME(gemm_args_t const p) 
     return;
   }
 
+#if MULPRIO
+  __builtin_amdgcn_s_setprio(MULPRIO);
+#endif
   // ---- multiplying waves (2 x 2): wave (wr, wc) owns rows [wr * TM / 2, +TM / 2) x columns [wc * TN / 2, +TN / 2) as kSBM x kSBN sub-blocks of 16 x 16, one
   // v_mfma_f32_16x16x4_f32 chain each.  Lane l supplies row l % 16 and k = 4 q + l / 16 of a k quad: one ds_read_b32 per operand sub-block and quad.
   int const wr = wave >> 1, wc = wave & 1;
