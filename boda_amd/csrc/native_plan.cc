@@ -934,7 +934,7 @@ plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf1
   static cand_t const cands[] = {{128, 256, 2, 4, 1.00, false}, {64, 512, 1, 8, 1.00, false}, {64, 256, 1, 8, 0.98, false}, {128, 128, 2, 4, 0.97, false},   // eight multiplying waves: 2 x 2 | 2 x 1 blocks each
                                  {64, 192, 2, 2, 0.97, false}, {128, 128, 2, 2, 0.96, false},                                                             // four: 1 x 3 | 2 x 2
                                  {64, 128, 2, 2, 0.92, true}, {32, 128, 1, 4, 0.86, true}, {64, 64, 2, 2, 0.85, true}};                                   // four: 1 x 2 | 1 x 1 | 1 x 1
-  double best = -1; tile_cfg_t best_c;
+  double best = -1, best_raw = -1; tile_cfg_t best_c;
   for (cand_t const &cd : cands) {
     if (cd.small && !old_small) continue;
     tile_cfg_t c; c.BI = cd.bi; c.BJ = cd.bj; c.BK = 16; c.WI = cd.wi; c.WJ = cd.wj; c.MINW = 2; c.SPLITK = 1; c.MT = 32; c.PF = 2; c.SW = 2; c.KHO = 0;
@@ -942,10 +942,14 @@ plan_t plan_conv(conv_geom_t const &g, int num_cus, string const &tile, bool bf1
     long const ti = (g.OC + c.BI - 1) / c.BI, tj = (Nj + c.BJ - 1) / c.BJ, tiles = ti * tj;
     double const pad = ((double)g.OC / (double)(ti * c.BI)) * ((double)Nj / (double)(tj * c.BJ));
     double const deal = ((double)tiles / num_cus) / (double)((tiles + num_cus - 1) / num_cus);
-    double const score = cd.base * pad * deal;
-    if (score > best) { best = score; best_c = c; }
+    double score = cd.base * pad * deal;
+    if (score < (force ? 0.0 : 0.76)) continue;   // (the threshold against the tiled kernel)
+    // a launch of at most one workgroup per CU has nothing to hide a tile's prologue and epilogue (~8 us) under; two co-resident tiles of half the size hide about half of it
+    // under each other.  NiN cccp5 / cccp6 at 128 images (255 tiles of 128 x 256, 41 us of multiplying each): 66 -> 62 us on 128 x 128 / 64 x 256 tiles (in-sequence A/B)
+    if (tiles <= num_cus && getenv("BODAHIP_CBIG_NO_ONE_ROUND") == nullptr) { double const tile_us = 2.0 * c.BI * c.BJ * (double)Kt / 0.57e6; score *= 1.0 - 0.5 * 8.0 / std::max(tile_us, 16.0); }
+    if (score > best) { best = score; best_raw = cd.base * pad * deal; best_c = c; }
   }
-  if (best < (force ? 0.0 : 0.76)) return old;
+  if (best_raw < 0) return old;   // (no tile of this kernel passed the threshold; the one-round term only ranks those that did)
   plan_t bp = plan_conv_big(g, best_c);
   // Two-level tiling along the pels (the sgemm path's idea, plan_sgemm_split): when the tiles leave a mostly idle last round, the main tile takes whole rounds of the CUs and
   // a launch of smaller tiles the remaining pels -- every output is still one launch's one fma chain.  AlexNet / NiN conv2 at 256 images: 1460 tiles of 64 x 512 = 5.7 rounds
