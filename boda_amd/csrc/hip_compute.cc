@@ -90,6 +90,8 @@ std::vector<char> hiprtc_compile(string const &src, string const &name, string c
   for (auto const &o : opts) key += " " + o;
   int rtc_major = 0, rtc_minor = 0; hiprtcVersion(&rtc_major, &rtc_minor);
   key += " hiprtc" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor);
+  { // ... and WHICH hiprtc: a process that imported torch first runs the wheel's copy (another ROCm release, the same hiprtcVersion, different code -- boda_amd/rtc.py: _load)
+    Dl_info li; if (dladdr((void *)&hiprtcCompileProgram, &li) && li.dli_fname) key += string(" ") + li.dli_fname; }
   char hbuf[40]; snprintf(hbuf, sizeof(hbuf), "%016llx", (unsigned long long)fnv1a(key));
   string const cdir = default_cache_dir(), cfn = cdir + "/k-" + hbuf + ".hsaco";
   if (use_cache) {

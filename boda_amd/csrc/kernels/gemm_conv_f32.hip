@@ -599,7 +599,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
 #if KHO_DBG & 8
   int const job = (int)blockIdx.x + (int)gridDim.x * kho_pass; ++kho_pass;
 #else
-  if (wave == 0) reinterpret_cast<int *>(smem)[0] = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rQ, q_l0, 0, 0));
+  if (wave == 0) reinterpret_cast<int *>(smem)[0] = __builtin_amdgcn_readfirstlane((lane == 0) ? __hip_atomic_fetch_add(reinterpret_cast<int *>(p.ws), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
   __syncthreads();   // (every wave is past the previous job's last LDS read: each K step ends with a barrier, the epilogue does not touch the LDS)
   int const job = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<unsigned *>(smem)[0]);
   __syncthreads();
@@ -1059,7 +1059,7 @@ extern "C" __global__ __launch_bounds__(WI * WJ * 64 * (SPECW ? 2 : 1), MINW) vo
   }   // the tile's last segment
   }   // job loop
   if (wave == 0 && !(KHO_DBG & 4)) {   // the last workgroup to leave clears both counters (every other one has drawn its final, out-of-range job before it counted itself out)
-    int const n = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rQ, q_l0 + 4, 0, 0));
+    int const n = __builtin_amdgcn_readfirstlane((lane == 0) ? __hip_atomic_fetch_add(reinterpret_cast<int *>(p.ws) + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0);
     if (n == (int)gridDim.x - 1) { __builtin_amdgcn_raw_buffer_store_b32(0, rQ, q_l0 + 4, 0, 16); __builtin_amdgcn_raw_buffer_store_b32(0, rQ, q_l0, 0, 16); }
   }
 #endif
