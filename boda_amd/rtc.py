@@ -22,17 +22,6 @@ def _load() -> C.CDLL:
     if not os.path.exists(SO_PATH):
         raise ImportError(f"boda_amd: HIP extension {SO_PATH} is missing -- run `python -m boda_amd.build` "
                           "(there is no CPU fallback for this backend)")
-    # ONE ROCm stack per process.  The PyTorch wheel bundles its own HIP runtime and hiprtc (ROCm 7.0 in this image; /opt/rocm is 7.2), and whichever copy of a library a process
-    # loads first serves every hip* / hiprtc* symbol afterwards -- libbodahip.so's included.  bench.py imports torch (torch.distributed) before this module, the tests and
-    # __graft_entry__.build() did not: so the code-object cache was filled by one compiler and a cold bench run compiled with the other (both report the same hiprtcVersion).
-    # Round 6 measured the two compilers' code for the SAME kernel sources in place: the wheel's hiprtc gives the staging-wave convolution kernels ~12 more registers and 1.1-1.3 %
-    # more speed (AlexNet list 0.8835 -> 0.897, NiN net 124.0 -> 125.3 TF/s; sgemm level).  So: torch first, everywhere (BODAHIP_NO_TORCH_FIRST=1: the image's own ROCm), and
-    # the cache key names the hiprtc library that compiled the object (csrc/hip_compute.cc).
-    if os.environ.get("BODAHIP_NO_TORCH_FIRST") != "1":
-        try:
-            import torch  # noqa: F401
-        except Exception:
-            pass
     return C.CDLL(SO_PATH)
 
 
